@@ -1,0 +1,213 @@
+"""Benchmark of the north-star metric: img/s (640x640) of CPR ResNet-50 + FPN forward + loss on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path (BasicLocator.forward_train: backbone -> neck -> CPRHead towers -> point
+extraction / scoring / MIL + gfocal losses) over one batch of synthetic 640x640 tiles already resident in HBM.
+Images shard data-parallel with a fixed per-GPU batch (weak scaling); forward + loss has no data-path collective.
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel (conv_mfma_kernel<128,0>, the fp32-MFMA implicit-GEMM conv): algorithmic FLOPs
+                of its launches in the timed region / their summed HIP-event durations, vs the 157.3 TF fp32 MFMA peak
+  cpu_baseline  the CPU oracle (torch-CPU restatement that executes the reference's op sequence bit for bit) timed on
+                this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+GN = dict(type='GN', num_groups=32, requires_grad=True)
+
+
+def model_cfg(depth=50, num_classes=1):
+    """Key/values of T/configs2/TinyPersonV2/coarsepointv2/coarse_point_refine_r50_fpns4_1x_TinyPersonV2_640.py."""
+    alpha = 0.25
+    from pointtinybenchmark_amd import synthetic
+    return dict(
+        type='BasicLocator',
+        backbone=dict(type='ResNet', depth=depth, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                      norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'),
+        neck=dict(type='FPN', in_channels=synthetic.backbone_out_channels(depth), out_channels=256, start_level=0,
+                  add_extra_convs='on_input', num_outs=1, norm_cfg=GN),
+        bbox_head=dict(
+            type='CPRHead', norm_cfg=GN, num_classes=num_classes, in_channels=256, feat_channels=256, stacked_convs=4,
+            num_cls_fcs=0, strides=[4], loss_mil=dict(type='MILLoss', binary_ins=False, loss_weight=alpha),
+            loss_type=0,
+            loss_cfg=dict(with_neg=True, neg_loss_weight=1 - alpha, refine_bag_policy='independent_with_gt_bag',
+                          random_remove_rate=0.4, with_gt_loss=True, gt_loss_weight=alpha, with_mil_loss=True),
+            normal_cfg=dict(prob_cls_type='sigmoid', out_bg_cls=False),
+            train_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=5),
+                                     neg_generator=dict(type='OutCirclePtFeatGenerator', radius=5, class_wise=True)),
+            refine_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=5),
+                                      neg_generator=dict(type='OutCirclePtFeatGenerator', radius=5, keep_wh=True,
+                                                         class_wise=True)),
+            point_refiner=dict(merge_th=0.1, refine_th=0.1, classify_filter=True)))
+
+
+class ConvProbe:
+    """HIP-event brackets around every conv launch of the timed region (events are recorded on the stream the
+    kernels are launched on: torch's current stream)."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from pointtinybenchmark_amd import ops
+        self._orig = ops.conv2d
+        probe = self
+
+        def conv2d(x, pc, *a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = probe._orig(x, pc, *a, **k)
+            e.record()
+            N, H, W, _ = x.shape
+            OH, OW = pc.out_hw(H, W)
+            variant = '%d,%d' % (64 if pc.Cout <= 64 else 128, 1 if pc.Cin == 4 else 0)
+            kreal = pc.KH * pc.KW * (3 if pc.Cin == 4 else pc.Cin)
+            probe.records.append((variant, 2.0 * N * OH * OW * pc.Cout * kreal, s, e))
+            return out
+        ops.conv2d = conv2d   # callers use ``ops.conv2d(...)`` through the module object, so they see the probe
+
+    def remove(self):
+        from pointtinybenchmark_amd import ops
+        ops.conv2d = self._orig
+
+    def summary(self):
+        agg = {}
+        for variant, flops, s, e in self.records:
+            d = agg.setdefault(variant, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += s.elapsed_time(e) * 1e-3
+            d[2] += 1
+        return {v: dict(flops=d[0], seconds=d[1], launches=d[2], tflops=d[0] / d[1] / 1e12 if d[1] > 0 else 0.0)
+                for v, d in agg.items()}
+
+
+def cpu_baseline(batch_size, num_gts, seconds_budget=25.0):
+    """The CPU oracle on this box's host cores: same synthetic workload, bounded sample."""
+    from oracle import cpr_oracle as O
+    from pointtinybenchmark_amd import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synthetic.locator_state_dict(50, 1, 0, 'cpr', 0)
+    batch = synthetic.synthetic_batch(batch_size, 640, 640, num_gts, 1, 0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.locator_forward_train(sd, batch, 50, 0, 4, 5, 1)          # warm-up (also bounds the sample)
+        warm = time.perf_counter() - t0
+        iters = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.locator_forward_train(sd, batch, 50, 0, 4, 5, 1)
+        dt = (time.perf_counter() - t0) / iters
+    return dict(value=batch_size / dt, unit='img/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d timed step(s) of B=%d 640x640 tiles after 1 warm-up (%.1f s/step), oracle = torch-CPU '
+                       'restatement executing the reference op sequence' % (iters, batch_size, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('CPR_BENCH_BATCH', 8)), help='images per GPU')
+    ap.add_argument('--num-gts', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-probe', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)  # backend "nccl" is RCCL on ROCm
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    import pointtinybenchmark_amd as P
+    from pointtinybenchmark_amd import synthetic
+    model = P.build_detector(model_cfg()).cuda()
+    model.load_state_dict(synthetic.locator_state_dict(50, 1, 0, 'cpr', 0), strict=True)
+    model.train()
+    batch = synthetic.synthetic_batch(args.batch, 640, 640, args.num_gts, 1, seed=rank)   # each rank its own shard
+    img = batch['img'].cuda()
+    gtb = [b.cuda() for b in batch['gt_bboxes']]
+    gtl = [l.cuda() for l in batch['gt_labels']]
+    metas = batch['img_metas']
+
+    def step():
+        with torch.no_grad():
+            return model.forward_train(img, metas, gtb, gtl)
+
+    for _ in range(args.warmup):
+        losses = step()
+    probe = None
+    if not args.no_probe:
+        probe = ConvProbe()
+        probe.install()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if probe:
+        probe.remove()
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_vals = {k: float(v) for k, v in losses.items()}
+
+    if rank == 0:
+        total_imgs = args.batch * world * args.steps
+        out = {
+            'metric': 'img/s (640x640) CPR R50-FPN fwd+loss',
+            'value': total_imgs / elapsed, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+            'config': {'workload': 'CPR ResNet-50 + FPN(num_outs=1, stride 4) + CPRHead, 640x640, forward + loss '
+                                   '(configs[1])', 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
+                       'gts_per_image': args.num_gts, 'parallelism': 'dp%d' % world,
+                       'weights': 'random init (synthetic.locator_state_dict seed 0)'},
+            'losses': loss_vals,
+        }
+        if probe:
+            summ = probe.summary()
+            dom = summ.get('128,0')
+            if dom:
+                ach = dom['tflops']
+                out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                                   'kernel': 'conv_mfma_kernel<128,0>', 'launches': dom['launches'],
+                                   'avg_launch_ms': dom['seconds'] / dom['launches'] * 1e3,
+                                   'all_conv_variants': {k: round(v['tflops'], 2) for k, v in summ.items()}}
+            conv_s = sum(v['seconds'] for v in summ.values())
+            out['conv_time_frac'] = conv_s / elapsed
+            out['end_to_end_tflops'] = 224.0e9 * total_imgs / world / elapsed / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(2, args.num_gts)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,73 @@
+"""ctypes binding of libcprhip.so (the C-ABI declared in include/cpr_hip.h).
+
+The product path fails loudly when the library is missing or a symbol is absent: there is no
+eager/PyTorch fallback for any op (a silent fallback would void every parity claim).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libcprhip.so')
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes (restype is always int: 0 ok, <0 error).  Mirrors include/cpr_hip.h one to one.
+SIGNATURES = {
+    'cpr_version': [],
+    'cpr_conv2d_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'cpr_nchw_to_nhwc4': [_p, _p, _i, _i, _i, _i, _p],
+    'cpr_nhwc_to_nchw': [_p, _p, _i, _i, _i, _i, _p],
+    'cpr_maxpool3x3s2': [_p, _p, _i, _i, _i, _i, _p],
+    'cpr_gn_stats': [_p, _p, _i, _i, _i, _i, _p],
+    'cpr_gn_finalize': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    'cpr_gn_apply': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'cpr_box_centers': [_p, _p, _i, _p],
+    'cpr_neg_mask_loss': [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _p, _p],
+    'cpr_bag_sample': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    'cpr_mil_loss': [_p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p],
+    'cpr_refine': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _i, _i, _p],
+    'cpr_point_assign': [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p],
+    'cpr_hungarian_cost': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p],
+    'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+}
+
+_lib = None
+
+
+class CprHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it was not built -- build with
+    ``python -m pointtinybenchmark_amd.build`` (hipcc cross-compiles for gfx950 without a GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CprHipError('%s not found: run `python -m pointtinybenchmark_amd.build` (no CPU fallback exists)'
+                          % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise CprHipError('symbol %s missing from %s (stale build?)' % (name, LIB_PATH))
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point; non-zero status -> RuntimeError (the reference raises Python
+    exceptions / asserts on bad inputs; this is the same contract across the boundary)."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        if rc == -1001:
+            raise CprHipError('%s: invalid argument' % name)
+        if rc == -1002:
+            raise CprHipError('%s: unsupported configuration' % name)
+        raise CprHipError('%s failed with hipError %d' % (name, -rc))
+    return rc

@@ -1,0 +1,122 @@
+"""ResNet backbone on the fp32-MFMA implicit-GEMM conv kernel.
+
+Interface of T/mmdet/models/backbones/resnet.py:305-657 (ctor kwargs, ``forward(x) -> tuple`` of the
+``out_indices`` stage outputs, ``frozen_stages`` / ``norm_eval`` train() semantics, state-dict keys).
+BatchNorm is always evaluated with running statistics on this path (norm_eval=True in every CPR/P2P config)
+and is folded into the conv epilogue; the bottleneck shortcut add + ReLU are fused into conv3's epilogue.
+Forward only: backward is SURVEY.md §8(f) rank 1 ("next")."""
+import torch.nn as nn
+
+from .. import ops
+from ..layers import _PackCache, folded_bn, packed_conv
+from ..registry import BACKBONES
+
+
+class _Block(nn.Module):
+    def __init__(self, kind, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.kind = kind
+        if kind == 'bottleneck':  # style='pytorch': the stride sits on the 3x3 (resnet.py:153-158)
+            self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+            self.bn3 = nn.BatchNorm2d(planes * 4)
+        else:
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def run(self, cache, x):
+        identity = x
+        if self.downsample is not None:
+            s, b = folded_bn(cache, self.downsample[1])
+            identity = ops.conv2d(x, packed_conv(cache, self.downsample[0]), scale=s, bias=b)
+        s1, b1 = folded_bn(cache, self.bn1)
+        o = ops.conv2d(x, packed_conv(cache, self.conv1), scale=s1, bias=b1, relu=True)
+        s2, b2 = folded_bn(cache, self.bn2)
+        if self.kind == 'bottleneck':
+            o = ops.conv2d(o, packed_conv(cache, self.conv2), scale=s2, bias=b2, relu=True)
+            s3, b3 = folded_bn(cache, self.bn3)
+            return ops.conv2d(o, packed_conv(cache, self.conv3), scale=s3, bias=b3, residual=identity, relu=True)
+        return ops.conv2d(o, packed_conv(cache, self.conv2), scale=s2, bias=b2, residual=identity, relu=True)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch_settings = {18: ('basic', (2, 2, 2, 2)), 34: ('basic', (3, 4, 6, 3)), 50: ('bottleneck', (3, 4, 6, 3)),
+                     101: ('bottleneck', (3, 4, 23, 3)), 152: ('bottleneck', (3, 8, 36, 3))}
+
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style='pytorch',
+                 deep_stem=False, avg_down=False, frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None, stage_with_dcn=None,
+                 plugins=None, with_cp=False, zero_init_residual=True, pretrained=None, init_cfg=None):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError('invalid depth %s for resnet' % depth)
+        assert style == 'pytorch' and not deep_stem and not avg_down and dcn is None and plugins is None, \
+            'only the options used by the CPR/P2P configs are built (SURVEY.md §2a row 5)'
+        assert tuple(dilations[:num_stages]) == (1,) * num_stages and norm_cfg.get('type') == 'BN'
+        assert norm_eval, 'BatchNorm batch statistics are not on this path (every CPR/P2P config sets norm_eval=True)'
+        self.depth, self.num_stages, self.out_indices = depth, num_stages, tuple(out_indices)
+        self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
+        kind, blocks = self.arch_settings[depth]
+        exp = 4 if kind == 'bottleneck' else 1
+        stem = stem_channels or base_channels
+        self.conv1 = nn.Conv2d(in_channels, stem, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(stem)
+        inplanes = stem
+        self.res_layers = []
+        for i in range(num_stages):
+            planes = base_channels * 2 ** i
+            layer = []
+            for bi in range(blocks[i]):
+                stride = strides[i] if bi == 0 else 1
+                ds = None
+                if bi == 0 and (stride != 1 or inplanes != planes * exp):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * exp, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * exp))
+                layer.append(_Block(kind, inplanes, planes, stride, ds))
+                inplanes = planes * exp
+            name = 'layer%d' % (i + 1)
+            self.add_module(name, nn.Sequential(*layer))
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+        self._cache = _PackCache()
+        self._freeze_stages()
+
+    def _freeze_stages(self):  # resnet.py:612-628
+        if self.frozen_stages >= 0:
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            for p in getattr(self, 'layer%d' % i).parameters():
+                p.requires_grad = False
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        return self
+
+    def init_weights(self):
+        pass
+
+    def forward(self, x):
+        """x: (N,3,H,W) -> tuple of NCHW-shaped (channels_last) stage outputs."""
+        c = self._cache
+        x = ops.nchw_to_nhwc(x) if x.shape[1] <= 4 else ops.from_nchw(x)
+        s, b = folded_bn(c, self.bn1)
+        x = ops.conv2d(x, packed_conv(c, self.conv1), scale=s, bias=b, relu=True)
+        x = ops.maxpool3x3s2(x)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            for blk in getattr(self, name):
+                x = blk.run(c, x)
+            if i in self.out_indices:
+                outs.append(ops.as_nchw(x))
+        return tuple(outs)

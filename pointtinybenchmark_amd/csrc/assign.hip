@@ -1,0 +1,294 @@
+// Point <-> gt assignment kernels (integer outputs: bit-exact bar against the reference's CPU path).
+//   cpr_point_assign     PointAssigner.assign          T/mmdet/core/bbox/assigners/point_assigner.py:23-133
+//   cpr_hungarian_cost   FocalLossCost + DisCostV2     T/mmdet/core/bbox/match_costs/match_cost.py:84-100,197-214
+//   cpr_lsa_topk         HungarianAssignerV2's LSA loop T/mmdet/core/bbox/assigners/hungarian_assigner.py:229-268
+//                        (replaces scipy.optimize.linear_sum_assignment + the GPU->CPU->GPU round trip)
+#include <limits.h>
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// block-wide argmin over (value, index): smaller value first, then smaller index.  1024 threads max.
+struct MinIdx {
+    float v;
+    int i;
+};
+__device__ __forceinline__ MinIdx min_idx(MinIdx a, MinIdx b) {
+    return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ MinIdx block_argmin(MinIdx x, MinIdx* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MinIdx y;
+        y.v = __shfl_xor(x.v, o, 64);
+        y.i = __shfl_xor(x.i, o, 64);
+        x = min_idx(x, y);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    MinIdx r = sh[0];
+    for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) r = min_idx(r, sh[w]);
+    return r;
+}
+
+// One workgroup walks the gts in order (the reference's sequential "closer gt wins" overwrite semantics).
+__global__ void point_assign_kernel(const float* __restrict__ points, const float* __restrict__ gtb, int n, int k,
+                                    float scale, int pos_num, long long* __restrict__ gt_inds,
+                                    float* __restrict__ best, int* __restrict__ plvl) {
+    __shared__ MinIdx sh[16];
+    __shared__ int s_lmin, s_lmax;
+    __shared__ int chosen[16];
+    __shared__ float chosen_d[16];
+    const int tid = threadIdx.x;
+    int lmin = INT_MAX, lmax = INT_MIN;
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int l = (int)log2f(points[i * 3 + 2]);  // torch.log2(stride).int(): truncation
+        plvl[i] = l;
+        gt_inds[i] = 0;
+        best[i] = INFINITY;
+        lmin = min(lmin, l);
+        lmax = max(lmax, l);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lmin = min(lmin, __shfl_xor(lmin, o, 64));
+        lmax = max(lmax, __shfl_xor(lmax, o, 64));
+    }
+    if (tid == 0) { s_lmin = INT_MAX; s_lmax = INT_MIN; }
+    __syncthreads();
+    if ((tid & 63) == 0) { atomicMin(&s_lmin, lmin); atomicMax(&s_lmax, lmax); }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        const float x1 = gtb[j * 4], y1 = gtb[j * 4 + 1], x2 = gtb[j * 4 + 2], y2 = gtb[j * 4 + 3];
+        const float gx = __fadd_rn(x1, x2) * 0.5f, gy = __fadd_rn(y1, y2) * 0.5f;
+        const float gw = fmaxf(__fsub_rn(x2, x1), 1e-6f), gh = fmaxf(__fsub_rn(y2, y1), 1e-6f);
+        int glvl = (int)(__fadd_rn(log2f(__fdiv_rn(gw, scale)), log2f(__fdiv_rn(gh, scale))) * 0.5f);
+        glvl = min(max(glvl, s_lmin), s_lmax);
+        for (int r = 0; r < pos_num; ++r) {
+            MinIdx m;
+            m.v = INFINITY;
+            m.i = INT_MAX;
+            for (int i = tid; i < n; i += blockDim.x) {
+                if (plvl[i] != glvl) continue;
+                bool taken = false;
+                for (int q = 0; q < r; ++q) taken |= (chosen[q] == i);
+                if (taken) continue;
+                const float dx = __fdiv_rn(__fsub_rn(points[i * 3], gx), gw);
+                const float dy = __fdiv_rn(__fsub_rn(points[i * 3 + 1], gy), gh);
+                const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+                MinIdx c;
+                c.v = d;
+                c.i = i;
+                m = min_idx(m, c);
+            }
+            m = block_argmin(m, sh);
+            if (tid == 0) { chosen[r] = m.i; chosen_d[r] = m.v; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            for (int r = 0; r < pos_num; ++r) {
+                const int p = chosen[r];
+                if (p == INT_MAX) continue;
+                if (chosen_d[r] < best[p]) { gt_inds[p] = j + 1; best[p] = chosen_d[r]; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int cpr_point_assign(const float* points, const float* gt_bboxes, int n, int k, float scale, int pos_num,
+                                long long* gt_inds, float* ws_best, int* ws_lvl, hipStream_t stream) {
+    CPR_CHECK_ARG(n >= 0 && k >= 0 && pos_num > 0 && pos_num <= 16 && scale > 0);
+    if (n == 0) return CPR_OK;
+    CPR_CHECK_ARG(points && gt_inds && ws_best && ws_lvl && (k == 0 || gt_bboxes));
+    hipLaunchKernelGGL(point_assign_kernel, dim3(1), dim3(1024), 0, stream, points, gt_bboxes, n, k, scale, pos_num,
+                       gt_inds, ws_best, ws_lvl);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// cost^T[g][m] = w_cls * (pos - neg)[m, label_g] + w_dis * L1(pred_m / f, gt_g / f), fp32, evaluation order
+// of the reference expressions kept.
+__global__ void hungarian_cost_kernel(const float* __restrict__ pred, int pred_stride,
+                                      const float* __restrict__ logits, int C, const float* __restrict__ gt,
+                                      const int* __restrict__ labels, float* __restrict__ costT, int M, int G,
+                                      float w_cls, float alpha, float gamma, float eps, float w_dis, float fx,
+                                      float fy) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (m >= M) return;
+    const int l = labels[g];
+    const float x = logits[(size_t)m * C + l];
+    const float p = 1.f / (1.f + expf(-x));
+    const float pg = (gamma == 2.f) ? p * p : powf(p, gamma);
+    const float qg = (gamma == 2.f) ? (1.f - p) * (1.f - p) : powf(1.f - p, gamma);
+    const float neg = __fmul_rn(__fmul_rn(-logf(__fadd_rn(__fsub_rn(1.f, p), eps)), 1.f - alpha), pg);
+    const float pos = __fmul_rn(__fmul_rn(-logf(__fadd_rn(p, eps)), alpha), qg);
+    const float cls = __fmul_rn(__fsub_rn(pos, neg), w_cls);
+    const float dx = fabsf(__fsub_rn(__fdiv_rn(pred[(size_t)m * pred_stride], fx), __fdiv_rn(gt[g * 2], fx)));
+    const float dy = fabsf(__fsub_rn(__fdiv_rn(pred[(size_t)m * pred_stride + 1], fy), __fdiv_rn(gt[g * 2 + 1], fy)));
+    const float dis = __fmul_rn(__fadd_rn(dx, dy), w_dis);
+    costT[(size_t)g * M + m] = __fadd_rn(cls, dis);
+}
+
+extern "C" int cpr_hungarian_cost(const float* pred, int pred_stride, const float* logits, int C, const float* gt,
+                                  const int* labels, float* costT, int M, int G, float w_cls, float alpha,
+                                  float gamma, float eps, float w_dis, float fx, float fy, hipStream_t stream) {
+    CPR_CHECK_ARG(M >= 0 && G >= 0 && C > 0 && pred_stride >= 2);
+    if (M == 0 || G == 0) return CPR_OK;
+    CPR_CHECK_ARG(pred && logits && gt && labels && costT);
+    hipLaunchKernelGGL(hungarian_cost_kernel, dim3(cdiv(M, 256), G), dim3(256), 0, stream, pred, pred_stride, logits,
+                       C, gt, labels, costT, M, G, w_cls, alpha, gamma, eps, w_dis, fx, fy);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rectangular linear sum assignment, shortest augmenting path (the algorithm scipy's
+// linear_sum_assignment implements: Crouse 2016), float64 duals like scipy, one workgroup per problem.
+// Rows of the LSA are the G gts, columns the M proposals (M >= G).  `topk` rounds: after each round the
+// matched proposals are retired and the problem is solved again on the rest (hungarian_assigner.py:248-268).
+struct ArgD {
+    double v;
+    int unassigned;  // scipy prefers an unassigned column among equal shortest paths
+    int j;
+};
+__device__ __forceinline__ ArgD argd_min(ArgD a, ArgD b) {
+    if (b.v < a.v) return b;
+    if (b.v > a.v) return a;
+    if (b.unassigned != a.unassigned) return b.unassigned > a.unassigned ? b : a;
+    return b.j < a.j ? b : a;
+}
+
+__global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* __restrict__ m_of, const int* __restrict__ g_of,
+                                const long long* __restrict__ cost_off, const long long* __restrict__ col_off,
+                                const long long* __restrict__ row_off, int topk, long long* __restrict__ gt_inds_all,
+                                double* __restrict__ v_all, double* __restrict__ spc_all, int* __restrict__ path_all,
+                                int* __restrict__ row4col_all, unsigned char* __restrict__ sc_all,
+                                unsigned char* __restrict__ active_all, double* __restrict__ u_all,
+                                int* __restrict__ col4row_all, unsigned char* __restrict__ sr_all,
+                                int* __restrict__ status) {
+    __shared__ ArgD sh[16];
+    __shared__ int s_i, s_sink, s_j, s_fail, s_nactive;
+    __shared__ double s_minval;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int M = m_of[b], G = g_of[b];
+    const float* costT = costT_all + cost_off[b];
+    long long* gt_inds = gt_inds_all + col_off[b];
+    double* v = v_all + col_off[b];
+    double* spc = spc_all + col_off[b];
+    int* path = path_all + col_off[b];
+    int* row4col = row4col_all + col_off[b];
+    unsigned char* SC = sc_all + col_off[b];
+    unsigned char* active = active_all + col_off[b];
+    double* u = u_all + row_off[b];
+    int* col4row = col4row_all + row_off[b];
+    unsigned char* SR = sr_all + row_off[b];
+
+    for (int j = tid; j < M; j += nt) { gt_inds[j] = 0; active[j] = 1; }
+    if (tid == 0) { s_fail = 0; s_nactive = M; }
+    __syncthreads();
+    if (G == 0 || M == 0) return;
+
+    for (int round = 0; round < topk; ++round) {
+        if (s_nactive / G == 0) break;  // cost_new.shape[0] // num_gts != 0
+        for (int j = tid; j < M; j += nt) { v[j] = 0.0; row4col[j] = -1; }
+        for (int i = tid; i < G; i += nt) { u[i] = 0.0; col4row[i] = -1; }
+        __syncthreads();
+        for (int cur = 0; cur < G; ++cur) {
+            for (int j = tid; j < M; j += nt) { spc[j] = INFINITY; SC[j] = active[j] ? 0 : 1; path[j] = -1; }
+            for (int i = tid; i < G; i += nt) SR[i] = 0;
+            if (tid == 0) { s_i = cur; s_sink = -1; s_minval = 0.0; }
+            __syncthreads();
+            while (true) {
+                const int i = s_i;
+                const double minval = s_minval, ui = u[i];
+                ArgD best;
+                best.v = INFINITY; best.unassigned = 0; best.j = INT_MAX;
+                for (int j = tid; j < M; j += nt) {
+                    if (SC[j]) continue;
+                    const double r = minval + (double)costT[(size_t)i * M + j] - ui - v[j];
+                    double s = spc[j];
+                    if (r < s) { path[j] = i; spc[j] = r; s = r; }
+                    ArgD c;
+                    c.v = s; c.unassigned = (row4col[j] == -1) ? 1 : 0; c.j = j;
+                    best = argd_min(best, c);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    ArgD y;
+                    y.v = __shfl_xor(best.v, o, 64);
+                    y.unassigned = __shfl_xor(best.unassigned, o, 64);
+                    y.j = __shfl_xor(best.j, o, 64);
+                    best = argd_min(best, y);
+                }
+                __syncthreads();
+                if ((tid & 63) == 0) sh[tid >> 6] = best;
+                __syncthreads();
+                if (tid == 0) {
+                    ArgD r = sh[0];
+                    for (int w = 1; w < (nt + 63) / 64; ++w) r = argd_min(r, sh[w]);
+                    SR[i] = 1;
+                    if (r.j == INT_MAX || r.v == INFINITY) {
+                        s_fail = 1; s_sink = -2;
+                    } else {
+                        s_minval = r.v;
+                        s_j = r.j;
+                        SC[r.j] = 1;
+                        if (row4col[r.j] == -1) s_sink = r.j; else s_i = row4col[r.j];
+                    }
+                }
+                __syncthreads();
+                if (s_sink != -1) break;
+            }
+            if (s_fail) break;
+            const double minval = s_minval;
+            // dual updates (rows in SR other than cur use their matched column's path cost)
+            for (int i = tid; i < G; i += nt) {
+                if (i == cur) u[i] += minval;
+                else if (SR[i]) u[i] += minval - spc[col4row[i]];
+            }
+            __syncthreads();
+            for (int j = tid; j < M; j += nt)
+                if (SC[j] && active[j]) v[j] -= minval - spc[j];
+            __syncthreads();
+            if (tid == 0) {  // augment along the path
+                int j = s_sink;
+                while (true) {
+                    const int i = path[j];
+                    row4col[j] = i;
+                    const int t = col4row[i];
+                    col4row[i] = j;
+                    j = t;
+                    if (i == cur) break;
+                }
+            }
+            __syncthreads();
+        }
+        if (s_fail) break;
+        for (int i = tid; i < G; i += nt) {
+            const int j = col4row[i];
+            gt_inds[j] = i + 1;
+            active[j] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) s_nactive -= G;
+        __syncthreads();
+    }
+    if (tid == 0 && status) status[b] = s_fail;
+}
+
+extern "C" int cpr_lsa_topk(const float* costT, const int* m_of, const int* g_of, const long long* cost_off,
+                            const long long* col_off, const long long* row_off, int num_problems, int topk,
+                            long long* gt_inds, double* ws_v, double* ws_spc, int* ws_path, int* ws_row4col,
+                            unsigned char* ws_sc, unsigned char* ws_active, double* ws_u, int* ws_col4row,
+                            unsigned char* ws_sr, int* status, hipStream_t stream) {
+    CPR_CHECK_ARG(num_problems >= 0 && topk >= 1);
+    if (num_problems == 0) return CPR_OK;
+    CPR_CHECK_ARG(costT && m_of && g_of && cost_off && col_off && row_off && gt_inds && ws_v && ws_spc && ws_path &&
+                  ws_row4col && ws_sc && ws_active && ws_u && ws_col4row && ws_sr);
+    hipLaunchKernelGGL(lsa_topk_kernel, dim3(num_problems), dim3(1024), 0, stream, costT, m_of, g_of, cost_off,
+                       col_off, row_off, topk, gt_inds, ws_v, ws_spc, ws_path, ws_row4col, ws_sc, ws_active, ws_u,
+                       ws_col4row, ws_sr, status);
+    CPR_LAUNCH_STATUS();
+}
+
+extern "C" int cpr_version(void) { return 1; }

@@ -1,0 +1,302 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the cuDNN/ATen conv2d the reference reaches through torch for every conv on the hot path
+// (T/mmdet/models/backbones/resnet.py:630-645, T/mmdet/models/necks/fpn.py:172-194,
+//  T/mmdet/models/point/dense_heads/cpr_head.py:1033-1043, .../p2p_head.py:113-123).
+//
+// Layout (chosen for MI355X, not inherited from the reference's NCHW):
+//   activations  NHWC fp32          -> the GEMM K dimension (kh, kw, cin) is contiguous per tap, so one
+//                                      128-byte line = 32 input channels of one pixel = one row of a K-chunk
+//   weights      [Cout][KH][KW][Cin] fp32, row stride Kpad (multiple of 32, zero padded)
+//   GEMM         D[m = (n,oy,ox)][c = cout] = sum_k A[m][k] * Wt[c][k],  M = N*OH*OW
+//
+// Block = 256 threads = 4 waves (2x2), tile 128(M) x BN(cout) x 32(K) per step, double-buffered LDS,
+// register-staged global loads (the A operand needs per-pixel zero padding and, optionally, the fused
+// GroupNorm-apply+ReLU of the producing layer, so it cannot be a raw LDS-DMA copy).
+// LDS rows are padded to 36 floats: ds_read_b128 of 32 consecutive rows at one k-offset is conflict free
+// (slot = 9*row mod 16 is a bijection over each 16-lane service group).
+// MFMA operand mapping (one f32 per lane): A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31];
+// a lane reads 4 consecutive k (one ds_read_b128) and feeds 4 MFMAs: lanes <32 cover k0..k0+3 and lanes
+// >=32 cover k0+4..k0+7 of every 8-wide k group -- the reduction order inside a K-chunk is permuted,
+// which is immaterial for the fp32 sum.
+// Epilogue (fused): y = acc*scale[c] + bias[c] (+ residual[m][c]) (ReLU)  -- eval-mode BatchNorm folded
+// to a per-channel affine, the bottleneck shortcut add and the activation never touch HBM separately.
+// Optional fused GroupNorm statistics: per (image, group) sum / sum-of-squares partials of the raw conv
+// output (one slot per M-tile, reduced by gn_finalize -- deterministic, no float atomics).
+#include "common.h"
+
+struct ConvParams {
+    const float* in;
+    const float* wgt;
+    float* out;
+    const float* scale;     // [Cout] or null
+    const float* bias;      // [Cout] or null
+    const float* residual;  // [M][Cout] or null
+    const float* in_a;      // [N][Cin] or null: input transform x*a+b then ReLU (fused GN apply of the producer)
+    const float* in_b;
+    float* gn_part;         // [tilesM][Cout][2] per-M-tile per-channel (sum, sumsq) of the output, or null
+    int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, in_relu;
+    int tilesM, tilesN;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDSW = 36;  // padded row (floats)
+
+template <int BN, int MODE>  // MODE 0: Cin % 32 == 0 ; MODE 1: Cin == 4 (stem, one tap per float4)
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
+    constexpr int WN = BN / 2;
+    constexpr int NI = WN / 32;
+    constexpr int MI = 2;
+    constexpr int BL = BN * 8 / 256;  // float4 B loads per thread
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDSW];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDSW;
+
+    // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles (cout tiles
+    // fastest) so the activations' 3x3 halo rows and the two cout tiles of one pixel tile share one L2.
+    const int T = p.tilesM * p.tilesN;
+    const int per = (T + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= T) return;
+    const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 7, r0 = tid >> 3;
+
+    // ---- per-thread A row descriptors (4 rows: r0 + 32 j)
+    int iy0[4], ix0[4], nimg[4];
+    bool mok[4];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int m = m0 + r0 + 32 * j;
+        mok[j] = m < p.M;
+        int mm = mok[j] ? m : 0;
+        int n = mm / ohw;
+        int rem = mm - n * ohw;
+        int oy = rem / p.OW, ox = rem - oy * p.OW;
+        nimg[j] = n;
+        iy0[j] = oy * p.stride - p.pad;
+        ix0[j] = ox * p.stride - p.pad;
+    }
+    // ---- B row pointers
+    const float* wrow[BL];
+    bool wok[BL];
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+        int c = n0 + r0 + 32 * j;
+        wok[j] = c < p.Cout;
+        wrow[j] = p.wgt + (size_t)(wok[j] ? c : 0) * p.Kpad + c4 * 4;
+    }
+
+    f32x4 ra[4], rb[BL], xa, xb;
+    unsigned okmask = 0;         // bit j: row j of the tile in flight is a real (not padded) pixel
+    int kh = 0, kw = 0, c0 = 0;  // MODE 0 running tap state
+    const bool xform = p.in_a != nullptr;  // host guarantees OH*OW % BM == 0 then: one image per M-tile
+    const int nblk = (m0 < p.M ? m0 : 0) / ohw;
+
+    // Loads are issued raw (from clamped, always-valid addresses) and stay in flight during the MFMA phase;
+    // zero padding and the fused GN-apply+ReLU are applied when the registers are written to LDS.
+    auto load_tile = [&](int kt) {
+        okmask = 0;
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = iy0[j] + kh, ix = ix0[j] + kw;
+                const bool ok = mok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                okmask |= (ok ? 1u : 0u) << j;
+                const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+                const float* src = p.in + ((size_t)(nimg[j] * p.H + iyc) * p.W + ixc) * p.Cin + c0 + c4 * 4;
+                ra[j] = *reinterpret_cast<const f32x4*>(src);
+            }
+            if (xform) {
+                const int ci = nblk * p.Cin + c0 + c4 * 4;
+                xa = *reinterpret_cast<const f32x4*>(p.in_a + ci);
+                xb = *reinterpret_cast<const f32x4*>(p.in_b + ci);
+            }
+            c0 += BK;
+            if (c0 == p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+        } else {
+            const int tap = kt * 8 + c4;
+            const int th = tap / p.KW, tw = tap - th * p.KW;
+            const bool tok = tap < p.KH * p.KW;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = iy0[j] + th, ix = ix0[j] + tw;
+                const bool ok = tok && mok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                okmask |= (ok ? 1u : 0u) << j;
+                const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+                ra[j] = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(nimg[j] * p.H + iyc) * p.W + ixc) * 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + kt * BK);
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * LDSW;
+        float* b = Bs + buf * BN * LDSW;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = ra[j];
+            if (MODE == 0 && xform) {
+                v = v * xa + xb;
+                if (p.in_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            if (!((okmask >> j) & 1u)) v = zero;
+            *reinterpret_cast<f32x4*>(a + (r0 + 32 * j) * LDSW + c4 * 4) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j)
+            *reinterpret_cast<f32x4*>(b + (r0 + 32 * j) * LDSW + c4 * 4) = wok[j] ? rb[j] : zero;
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = wave & 1, wn = wave >> 1;
+    const int arow = wm * 64 + (lane & 31);
+    const int brow = wn * WN + (lane & 31);
+    const int koff = 4 * (lane >> 5);
+
+    const int KT = p.Kpad / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float* a = As + buf * BM * LDSW + arow * LDSW + koff;
+        const float* b = Bs + buf * BN * LDSW + brow * LDSW + koff;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSW + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSW + kk * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  D layout: col j = lane&31 (cout), row i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).
+    // Branch-free: residual values are fetched in one batch from clamped addresses, stores are predicated.
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int c = n0 + wn * WN + j * 32 + (lane & 31);
+        const bool cok = c < p.Cout;
+        const int cc = cok ? c : p.Cout - 1;
+        const float sc = p.scale ? p.scale[cc] : 1.f;
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        float gsum = 0.f, gsq = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rbase = m0 + wm * 64 + i * 32 + 4 * half;
+            float res[16];
+            if (p.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    res[r] = p.residual[(size_t)m * p.Cout + cc];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] * sc + bi + res[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                const bool ok = cok && m < p.M;
+                if (ok) p.out[(size_t)m * p.Cout + c] = v;
+                v = ok ? v : 0.f;
+                gsum += v;
+                gsq += v * v;
+            }
+        }
+        if (p.gn_part) {
+            // per-channel partials of this block's 128 pixels: combine the two half-waves, then the two
+            // M-waves through LDS (the A region is free: every wave is past the K loop's final barrier).
+            gsum += __shfl_xor(gsum, 32, 64);
+            gsq += __shfl_xor(gsq, 32, 64);
+            const int cl = wn * WN + j * 32 + (lane & 31);
+            if (half == 0) {
+                smem[(wm * BN + cl) * 2 + 0] = gsum;
+                smem[(wm * BN + cl) * 2 + 1] = gsq;
+            }
+        }
+    }
+    if (p.gn_part) {
+        __syncthreads();
+        if (tid < BN) {
+            const int c = n0 + tid;
+            if (c < p.Cout) {
+                float s = smem[tid * 2] + smem[(BN + tid) * 2];
+                float q = smem[tid * 2 + 1] + smem[(BN + tid) * 2 + 1];
+                p.gn_part[((size_t)tm * p.Cout + c) * 2 + 0] = s;
+                p.gn_part[((size_t)tm * p.Cout + c) * 2 + 1] = q;
+            }
+        }
+    }
+}
+
+// C-ABI ------------------------------------------------------------------------------------------
+extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
+                              const float* residual, const float* in_a, const float* in_b, float* gn_part, int N,
+                              int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad,
+                              int relu, int in_relu, hipStream_t stream) {
+    CPR_CHECK_ARG(in && wgt && out);
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    CPR_CHECK_ARG(Kpad % BK == 0);
+    ConvParams p;
+    p.in = in; p.wgt = wgt; p.out = out; p.scale = scale; p.bias = bias; p.residual = residual;
+    p.in_a = in_a; p.in_b = in_b; p.gn_part = gn_part;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Kpad = Kpad; p.relu = relu; p.in_relu = in_relu;
+    p.OH = (H + 2 * pad - KH) / stride + 1;
+    p.OW = (W + 2 * pad - KW) / stride + 1;
+    CPR_CHECK_ARG(p.OH > 0 && p.OW > 0);
+    long long M = (long long)N * p.OH * p.OW;
+    CPR_CHECK_ARG(M < (1ll << 31) && (long long)N * H * W * Cin < (1ll << 40));
+    p.M = (int)M;
+    const bool mode1 = (Cin == 4);
+    if (!mode1) {
+        CPR_CHECK_ARG(Cin % BK == 0 && Kpad == KH * KW * Cin);
+    } else {
+        CPR_CHECK_ARG(Kpad >= KH * KW * 4 && in_a == nullptr);
+    }
+    const int bn = (Cout <= 64) ? 64 : 128;
+    p.tilesM = (p.M + BM - 1) / BM;
+    p.tilesN = (Cout + bn - 1) / bn;
+    const int T = p.tilesM * p.tilesN;
+    const int grid = ((T + 7) / 8) * 8;
+    if (gn_part || in_a) CPR_CHECK_ARG((p.OH * p.OW) % BM == 0);
+    if (in_a) CPR_CHECK_ARG(in_b && p.OH == H && p.OW == W);
+    if (bn == 64) {
+        if (mode1) hipLaunchKernelGGL((conv_mfma_kernel<64, 1>), dim3(grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<64, 0>), dim3(grid), dim3(256), 0, stream, p);
+    } else {
+        if (mode1) hipLaunchKernelGGL((conv_mfma_kernel<128, 1>), dim3(grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<128, 0>), dim3(grid), dim3(256), 0, stream, p);
+    }
+    CPR_LAUNCH_STATUS();
+}

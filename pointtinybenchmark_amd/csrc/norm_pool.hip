@@ -1,0 +1,235 @@
+// HBM-bound helper kernels around the conv stack (all NHWC fp32, float4 = 4 channels per lane):
+//   cpr_nchw_to_nhwc4     network input (N,3,H,W) -> (N,H,W,4) zero-padded 4th channel (stem conv K-order)
+//   cpr_maxpool3x3s2      ResNet stem pool            (T/mmdet/models/backbones/resnet.py:610,637)
+//   cpr_gn_stats          GroupNorm partial sums      (mmcv ConvModule norm in fpn.py:124-144, cpr_head.py:990)
+//   cpr_gn_finalize       partials -> per (image, channel) affine a = rstd*gamma, b = beta - mean*a
+//   cpr_gn_apply          y = x*a + b [ReLU] [+ nearest-upsampled coarser level]   (fpn.py:179-188 fused)
+//   cpr_nhwc_to_nchw      optional export of a feature map in the reference's dense NCHW layout
+// Each is a single streaming pass: 16 B per lane, fully coalesced, no LDS except the block reductions.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
+    const long long total = (long long)N * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW, p = i - n * HW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* src = in + n * C * HW + p;
+        v.x = src[0];
+        if (C > 1) v.y = src[HW];
+        if (C > 2) v.z = src[2ll * HW];
+        if (C > 3) v.w = src[3ll * HW];
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
+extern "C" int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, hipStream_t stream) {
+    CPR_CHECK_ARG(in && out && N > 0 && C >= 1 && C <= 4 && H > 0 && W > 0);
+    const long long total = (long long)N * H * W;
+    const int grid = (int)(cdivll(total, 256) < 8192 ? cdivll(total, 256) : 8192);
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid), dim3(256), 0, stream, in, out, N, C, H * W);
+    CPR_LAUNCH_STATUS();
+}
+
+// NHWC -> NCHW through a 32x32 LDS tile (both sides coalesced)
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
+    __shared__ float t[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        t[r][tx] = (p < HW && c < C) ? in[((size_t)n * HW + p) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (p < HW && c < C) out[((size_t)n * C + c) * HW + p] = t[tx][r];
+    }
+}
+
+extern "C" int cpr_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, hipStream_t stream) {
+    CPR_CHECK_ARG(in && out && N > 0 && C > 0 && H > 0 && W > 0);
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, stream, in, out, C, HW);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W,
+                                    int C4, int OH, int OW) {
+    const long long total = (long long)N * OH * OW * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int n = (int)(r / OH);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)n * H + iy) * W + ix) * C4 * 4 + c * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = m;
+    }
+}
+
+extern "C" int cpr_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, hipStream_t stream) {
+    CPR_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * OH * OW * (C / 4);
+    const int grid = (int)(cdivll(total, 256) < 16384 ? cdivll(total, 256) : 16384);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, stream, in, out, N, H, W, C / 4, OH, OW);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics, stage 1: per (image, slot) per-channel (sum, sumsq) over a slab of pixels.
+// part layout [N][P][C][2] -- the same layout the conv epilogue emits (P = OH*OW/128 there).
+// Block = 256 threads; Q = C/4 lanes cover one pixel's channels, 256/Q pixels per pass.
+__global__ void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C, int P) {
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, slot = blockIdx.x;
+    const int Q = C >> 2;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q, PP = 256 / Q;
+    const int per = (HW + P - 1) / P;
+    const int p0 = slot * per, p1 = min(HW, p0 + per);
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (int p = p0 + pl; p < p1; p += PP) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)n * HW + p) * C + q * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[threadIdx.x * 8 + k] = s[k];
+        red[threadIdx.x * 8 + 4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < PP; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += red[(r * Q + q) * 8 + k];
+        float* dst = part + (((size_t)n * P + slot) * C + q * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[k * 2] = a[k];
+            dst[k * 2 + 1] = a[4 + k];
+        }
+    }
+}
+
+extern "C" int cpr_gn_stats(const float* x, float* part, int N, int HW, int C, int P, hipStream_t stream) {
+    CPR_CHECK_ARG(x && part && N > 0 && HW > 0 && P > 0);
+    CPR_CHECK_ARG(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(P, N), dim3(256), 0, stream, x, part, HW, C, P);
+    CPR_LAUNCH_STATUS();
+}
+
+// stage 2: one block per image; thread c reduces its channel over the P slots in double, groups are
+// combined through LDS, and the per (image, channel) affine of torch's GroupNorm is emitted:
+//   a = rstd*gamma, b = beta - mean*a      (y = x*a + b)
+__global__ void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ a_out,
+                                   float* __restrict__ b_out, float* __restrict__ mean_out,
+                                   float* __restrict__ rstd_out, int P, int C, int G, double count, float eps) {
+    extern __shared__ double sh[];  // [C][2] then [G][2]
+    const int n = blockIdx.x;
+    const int cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0, q = 0;
+        for (int t = 0; t < P; ++t) {
+            const float* src = part + (((size_t)n * P + t) * C + c) * 2;
+            s += (double)src[0];
+            q += (double)src[1];
+        }
+        sh[c * 2] = s;
+        sh[c * 2 + 1] = q;
+    }
+    __syncthreads();
+    double* gs = sh + 2 * C;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double s = 0, q = 0;
+        for (int k = 0; k < cpg; ++k) {
+            s += sh[(g * cpg + k) * 2];
+            q += sh[(g * cpg + k) * 2 + 1];
+        }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0) var = 0;
+        gs[g * 2] = mean;
+        gs[g * 2 + 1] = 1.0 / sqrt(var + (double)eps);
+        if (mean_out) mean_out[n * G + g] = (float)mean;
+        if (rstd_out) rstd_out[n * G + g] = (float)gs[g * 2 + 1];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float mean = (float)gs[g * 2], rstd = (float)gs[g * 2 + 1];
+        const float a = rstd * gamma[c];
+        a_out[n * C + c] = a;
+        b_out[n * C + c] = beta[c] - mean * a;
+    }
+}
+
+extern "C" int cpr_gn_finalize(const float* part, const float* gamma, const float* beta, float* a_out, float* b_out,
+                               float* mean_out, float* rstd_out, int N, int P, int C, int G, int HW, float eps,
+                               hipStream_t stream) {
+    CPR_CHECK_ARG(part && gamma && beta && a_out && b_out && N > 0 && P > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0);
+    const size_t shmem = (size_t)(2 * C + 2 * G) * sizeof(double);
+    CPR_CHECK_ARG(shmem <= 60000);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), shmem, stream, part, gamma, beta, a_out, b_out,
+                       mean_out, rstd_out, P, C, G, (double)HW * (C / G), eps);
+    CPR_LAUNCH_STATUS();
+}
+
+// apply: y[n,p,c] = x*a[n,c] + b[n,c]; optional ReLU; optional += up[n, sy(p), sx(p), c] (nearest, the
+// index rule of F.interpolate(mode='nearest'): src = min(floor(dst * in/out), in-1)).  In-place safe.
+__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
+                                const float* __restrict__ up, float* __restrict__ y, int N, int H, int W, int C4,
+                                int UH, int UW, int relu) {
+    const long long total = (long long)N * H * W * C4;
+    const float sy = (float)UH / (float)H, sx = (float)UW / (float)W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int px = (int)(r % W);
+        r /= W;
+        const int py = (int)(r % H);
+        const int n = (int)(r / H);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + ((size_t)n * C4 + c) * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + ((size_t)n * C4 + c) * 4);
+        v = v * av + bv;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (up) {
+            const int uy = min((int)floorf(py * sy), UH - 1), ux = min((int)floorf(px * sx), UW - 1);
+            const f32x4 u = *reinterpret_cast<const f32x4*>(up + ((((size_t)n * UH + uy) * UW + ux) * C4 + c) * 4);
+            v = v + u;
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
+extern "C" int cpr_gn_apply(const float* x, const float* a, const float* b, const float* up, float* y, int N, int H,
+                            int W, int C, int UH, int UW, int relu, hipStream_t stream) {
+    CPR_CHECK_ARG(x && a && b && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    if (up) CPR_CHECK_ARG(UH > 0 && UW > 0);
+    const long long total = (long long)N * H * W * (C / 4);
+    const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, stream, x, a, b, up, y, N, H, W, C / 4, UH, UW, relu);
+    CPR_LAUNCH_STATUS();
+}

@@ -1,0 +1,304 @@
+"""CPRHead -- Coarse Point Refinement head (T/mmdet/models/point/dense_heads/cpr_head.py:898-1309).
+
+Same registry name, constructor keys and method signatures as the reference; the work is done by HIP kernels:
+  forward        4 x [conv3x3 -> GN32 -> ReLU] on the MFMA conv kernel; GN statistics ride in the conv epilogue
+                 and GN-apply+ReLU is folded into the NEXT conv's input load (only the last layer materialises)
+  loss           ONE 1x1 conv projects the head features to a (N,H,W,2C) logit map ([cls ++ ins]); the negative
+                 grid mask + sigmoid + gfocal run on that map, positive bags are bilinear-sampled from it
+                 (valid because num_cls_fcs == 0: Linear and bilinear sampling commute), MIL + gt loss in one
+                 wave per bag; no host sync, the four scalars stay on the device
+  get_bboxes     same extraction, then PointRefiner as one wave per gt.
+Single FPN level and num_refine == 1, like every shipped config (the reference asserts the single level itself:
+cpr_head.py:799,1152)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..layers import ConvModule, _PackCache, conv_gn
+from ..registry import HEADS, build_loss
+
+_GENERATORS = ('CirclePtFeatGenerator', 'OutCirclePtFeatGenerator', 'OutGridCirclesPtFeatGenerator',
+               'AnchorPtFeatGenerator')
+
+
+def circle_offsets(radius, stride, base_num_point=8, start_angle=0, same_num_all_radius=False):
+    """Ring offsets of CirclePtFeatGenerator.get_point_neighbours (cpr_head.py:474-497), computed on the HOST
+    with torch's CPU cos/sin so the bag coordinates are the reference's bit for bit."""
+    out = []
+    for i in range(radius):
+        r = (i + 1) * stride
+        n = base_num_point if same_num_all_radius else base_num_point * (i + 1)
+        ang = torch.arange(n).float() / n * 360 + start_angle
+        ang = ang / 360 * np.pi * 2
+        out.append(torch.stack([r * torch.cos(ang), r * torch.sin(ang)], dim=-1))
+    return torch.cat(out).float().contiguous()
+
+
+def sqrt_threshold(thr):
+    """Smallest fp32 t with torch.sqrt(t) >= thr on the host CPU.  The reference compares
+    ``cdist(...).min() >= stride*radius`` (cpr_head.py:278); cdist = sqrt(d2) and torch's CPU sqrt is monotone
+    but not correctly rounded, so the exact d2-space threshold is read off the host implementation instead of
+    being assumed to be thr*thr."""
+    thr = np.float32(thr)
+    c = np.float32(thr * thr)
+    cand = [c]
+    lo = hi = c
+    for _ in range(64):
+        lo = np.nextafter(lo, np.float32(-np.inf), dtype=np.float32)
+        hi = np.nextafter(hi, np.float32(np.inf), dtype=np.float32)
+        cand += [lo, hi]
+    cand = np.sort(np.array(cand, dtype=np.float32))
+    ok = (torch.sqrt(torch.from_numpy(cand)) >= float(thr)).numpy()
+    first = int(np.argmax(ok))
+    assert ok[first:].all() and not ok[:first].any(), 'host sqrt is not monotone around the threshold'
+    return float(cand[first])
+
+
+class _Extractor:
+    """Parsed ``train_pts_extractor`` / ``refine_pts_extractor`` config (PointExtractor, cpr_head.py:602-662)."""
+
+    def __init__(self, pos_generator, neg_generator, strides, num_classes):
+        pg, ng = dict(pos_generator), dict(neg_generator)
+        assert pg.pop('type') == 'CirclePtFeatGenerator', 'pos generator: only CirclePtFeatGenerator is built'
+        ntype = ng.pop('type')
+        assert ntype in _GENERATORS, ntype
+        self.pos_radius = pg.pop('radius')
+        self.pos_kw = dict(start_angle=pg.pop('start_angle', 0), base_num_point=pg.pop('base_num_point', 8),
+                           same_num_all_radius=pg.pop('same_num_all_radius', False))
+        assert pg.pop('append_center', True) and not pg, pg
+        self.neg_is_anchor = ntype == 'AnchorPtFeatGenerator'
+        self.neg_radius = ng.get('radius', 0)
+        self.neg_class_wise = ng.get('class_wise', False)
+        self.strides, self.num_classes = strides, num_classes
+        self._off = {}
+
+    def offsets(self, stride, device):
+        key = (stride, str(device))
+        if key not in self._off:
+            self._off[key] = circle_offsets(self.pos_radius, stride, **self.pos_kw).to(device)
+        return self._off[key]
+
+
+@HEADS.register_module()
+class CPRHead(nn.Module):
+    def __init__(self, num_classes, in_channels, num_cls_fcs=0, fc_out_channels=1024,
+                 train_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=5),
+                                          neg_generator=dict(type='OutCirclePtFeatGenerator', radius=3)),
+                 refine_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=5),
+                                           neg_generator=dict(type='AnchorPtFeatGenerator', scale_factor=1.0)),
+                 point_refiner=dict(), ins_share_head_feat=True, ins_share_head_classifier=False,
+                 loss_mil=dict(type='MILLoss', binary_ins=False, loss_weight=1.0), loss_type=0,
+                 loss_cfg=dict(with_neg=True, neg_loss_weight=1.0, refine_bag_policy='independent_with_gt_bag',
+                               random_remove_rate=0.4, with_gt_loss=False, gt_loss_weight=1.0, with_mil_loss=True),
+                 normal_cfg=dict(prob_cls_type='sigmoid', out_bg_cls=False), init_cfg=None, debug=False,
+                 debug_info=dict(), other_info=dict(),
+                 # AnchorFreeHead kwargs (T/mmdet/models/dense_heads/anchor_free_head.py:40-87)
+                 feat_channels=256, stacked_convs=4, strides=(4, 8, 16, 32, 64), dcn_on_last_conv=False,
+                 conv_bias='auto', loss_cls=None, loss_bbox=None, conv_cfg=None, norm_cfg=None, train_cfg=None,
+                 test_cfg=None):
+        super().__init__()
+        assert num_cls_fcs == 0 and ins_share_head_feat and not loss_mil.get('binary_ins', False) and loss_type == 0, \
+            'options outside the shipped configs are SURVEY.md §8f rank 4 ("next")'
+        assert normal_cfg.get('prob_cls_type', 'sigmoid') == 'sigmoid' and not normal_cfg.get('out_bg_cls', False)
+        assert norm_cfg is not None and norm_cfg['type'] == 'GN' and not dcn_on_last_conv and not debug
+        self.num_classes = self.cls_out_channels = self.num_cls_out = num_classes
+        self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
+        self.strides = list(strides)
+        self.ins_share_head_feat, self.ins_share_head_classifier = ins_share_head_feat, ins_share_head_classifier
+        self.loss_cfg, self.loss_type, self.normal_cfg = dict(loss_cfg), loss_type, dict(normal_cfg)
+        self.train_cfg, self.test_cfg, self.other_info = train_cfg, test_cfg, dict(other_info)
+        self.cls_convs = nn.ModuleList()
+        self.ins_convs = nn.ModuleList()
+        chn = in_channels
+        for _ in range(stacked_convs):
+            self.cls_convs.append(ConvModule(chn, feat_channels, 3, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg))
+            chn = feat_channels
+        self.cls_fcs = nn.ModuleList()
+        self.ins_fcs = nn.ModuleList()
+        self.cls_out = nn.Linear(chn, num_classes)
+        self.ins_out = self.cls_out if ins_share_head_classifier else nn.Linear(chn, num_classes)
+        self.loss_mil = build_loss(loss_mil)
+        self.loss_cls = self.loss_mil
+        self.train_pts_extractor = _Extractor(**train_pts_extractor, strides=self.strides, num_classes=num_classes)
+        self.refine_pts_extractor = _Extractor(**refine_pts_extractor, strides=self.strides, num_classes=num_classes)
+        pr = dict(gt_alpha=0.5, merge_th=0.05, refine_th=0.05, classify_filter=False, return_score_type='mean',
+                  nearest_filter=True)
+        pr.update(point_refiner)
+        assert pr['return_score_type'] == 'mean'
+        self.point_refiner = pr
+        self._cache = _PackCache()
+        self._thr = {}
+        self.init_weights()
+
+    # ------------------------------------------------------------------ init (cpr_head.py:939-948)
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.normal_(m.weight, 0, 0.01)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        nn.init.constant_(self.cls_out.bias, float(-math.log((1 - 0.01) / 0.01)))
+
+    # ------------------------------------------------------------------ forward (cpr_head.py:1030-1043)
+    def forward(self, feats):
+        cls, ins = [], []
+        for x in feats:
+            f = self.forward_single(x)
+            cls.append(f[0])
+            ins.append(f[1])
+        return cls, ins
+
+    def forward_single(self, x):
+        x = ops.from_nchw(x)
+        ab, n = None, len(self.cls_convs)
+        for i, m in enumerate(self.cls_convs):
+            last = i == n - 1
+            if last:
+                x = conv_gn(self._cache, m, x, in_ab=ab, in_relu=True, materialize=True)
+            else:
+                x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=True, materialize=False)
+        out = ops.as_nchw(x)
+        return out, out
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, gt_true_bboxes=None,
+                      proposal_cfg=None, **kwargs):
+        outs = self(x)
+        losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
+                           gt_true_bboxes=gt_true_bboxes)
+        if proposal_cfg is None:
+            return losses
+        return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
+
+    # ------------------------------------------------------------------ shared extraction
+    def _logit_map(self, feat_nhwc):
+        """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C)] (or C when the classifier is shared)."""
+        def make():
+            w = [self.cls_out.weight] + ([] if self.ins_share_head_classifier else [self.ins_out.weight])
+            b = [self.cls_out.bias] + ([] if self.ins_share_head_classifier else [self.ins_out.bias])
+            wt = torch.cat(w, 0).detach()[:, :, None, None]
+            return ops.PackedConv(wt, 1, 0), torch.cat(b, 0).detach().float().contiguous()
+        srcs = [self.cls_out.weight, self.cls_out.bias, self.ins_out.weight, self.ins_out.bias]
+        pc, bias = self._cache.get('proj', srcs, make)
+        return ops.conv2d(feat_nhwc, pc, bias=bias)
+
+    def _gt_tensors(self, gt_bboxes, gt_labels, img_metas, device, shape_key):
+        counts = [int(len(l)) for l in gt_labels]
+        assert len(counts) > 0 and all(c > 0 for c in counts), 'CPRHead does not support empty-gt images ' \
+            '(the reference asserts too: cpr_head.py:1102,1242)'
+        for b, c in zip(gt_bboxes, counts):
+            assert b.shape[0] == c, 'num_refine > 1 inputs are not built (SURVEY.md §8f rank 4)'
+        boxes = torch.cat([b.float() for b in gt_bboxes]).contiguous()
+        labels = torch.cat(list(gt_labels)).to(torch.int32).contiguous()
+        start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        gt_img = np.repeat(np.arange(len(counts), dtype=np.int32), counts)
+        hw = np.array([[m[shape_key][0], m[shape_key][1]] for m in img_metas], dtype=np.int32).reshape(-1)
+        meta = torch.from_numpy(np.concatenate([start, gt_img, hw])).to(device)
+        nb = len(counts)
+        gt_start, gt_img_t, hw_t = meta[:nb + 1], meta[nb + 1:nb + 1 + len(gt_img)], meta[nb + 1 + len(gt_img):]
+        centers = ops.box_centers(boxes.to(device))
+        return centers, labels.to(device), gt_start, gt_img_t, hw_t, counts
+
+    def _d2_threshold(self, stride, radius):
+        key = (stride, radius)
+        if key not in self._thr:
+            self._thr[key] = sqrt_threshold(stride * radius)
+        return self._thr[key]
+
+    # ------------------------------------------------------------------ loss (cpr_head.py:1101-1229)
+    def loss(self, cls_feat, ins_feat, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None, gt_true_bboxes=None,
+             gt_weights=None):
+        assert len(gt_labels) > 0
+        assert len(cls_feat) == 1, 'single FPN level (the reference asserts the same: cpr_head.py:1152)'
+        ex, C, stride = self.train_pts_extractor, self.num_classes, self.strides[0]
+        feat = ops.from_nchw(cls_feat[0])
+        dev = feat.device
+        lmap = self._logit_map(feat)
+        centers, labels, gt_start, gt_img, pad_hw, _ = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev,
+                                                                        'pad_shape')
+        _, valid, bag_logits = ops.bag_sample(lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
+        cfg = self.loss_cfg
+        partial = None
+        if cfg.get('with_neg', True):
+            assert not ex.neg_is_anchor
+            _, partial = ops.neg_mask_loss(lmap, centers, labels, gt_start, pad_hw, C, stride,
+                                           self._d2_threshold(stride, ex.neg_radius), self.loss_mil.eps,
+                                           ex.neg_class_wise)
+        w = None if gt_weights is None else torch.cat(list(gt_weights)).float().to(dev).contiguous()
+        ins_off = 0 if self.ins_share_head_classifier else C
+        out = self.loss_mil.forward_logits(bag_logits, ins_off, valid, labels, C, w, partial,
+                                           cfg.get('gt_loss_weight', 1.0), cfg.get('neg_loss_weight', 1.0))
+        losses = {}
+        if cfg.get('with_gt_loss', False):
+            losses['gt_loss'] = out[0]
+        if cfg.get('with_mil_loss', True):
+            losses['pos_loss'], losses['bag_acc'] = out[1], out[2]
+        if cfg.get('with_neg', True):
+            losses['neg_loss'] = out[3]
+        return losses
+
+    # ------------------------------------------------------------------ refine (cpr_head.py:1231-1283)
+    def get_bboxes(self, cls_feat, ins_feat, img_metas, cfg=None, rescale=False, with_nms=True, gt_bboxes=None,
+                   gt_labels=None, gt_bboxes_ignore=None, gt_true_bboxes=None, gt_anns_id=None, not_refine=None,
+                   cascade_out_fmt=False):
+        assert gt_labels is not None and len(gt_labels) > 0 and gt_anns_id is not None
+        assert len(cls_feat) == 1
+        ex, C, stride, pr = self.refine_pts_extractor, self.num_classes, self.strides[0], self.point_refiner
+        feat = ops.from_nchw(cls_feat[0])
+        dev = feat.device
+        lmap = self._logit_map(feat)
+        centers, labels, gt_start, gt_img, pad_hw, counts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev,
+                                                                             'pad_shape')
+        img_hw = torch.tensor([[m['img_shape'][0], m['img_shape'][1]] for m in img_metas], dtype=torch.int32,
+                              device=dev).reshape(-1)
+        pts, valid, bag_logits = ops.bag_sample(lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
+        # the grid (negative) branch is computed but unused by the reference at refine time (cpr_head.py:794-804)
+        nr_in = None if not_refine is None else torch.cat(list(not_refine)).to(torch.uint8).to(dev).contiguous()
+        rp, sc, nr, chosen = ops.refine(bag_logits, pts, valid, centers, labels, gt_img, gt_start, img_hw, C,
+                                        pr['gt_alpha'], pr['merge_th'], pr['refine_th'], pr['nearest_filter'],
+                                        pr['classify_filter'], nr_in)
+        boxes = torch.cat([rp - 8.0, rp + 8.0], dim=-1)          # center_to_pseudo_bbox, 16x16 (:1303-1309)
+        out, nr_list, s = [], [], 0
+        for b, n in enumerate(counts):
+            bx = boxes[s:s + n]
+            if rescale:
+                bx = bx / bx.new_tensor(img_metas[b]['scale_factor'])
+            ann = gt_anns_id[b].to(dev).unsqueeze(-1).type_as(sc)
+            cols = [bx, sc[s:s + n, None], ann]
+            if self.other_info.get('out_geo', False):
+                cols.append(self._geo(pts[s:s + n], chosen[s:s + n], rp[s:s + n], img_metas[b], rescale))
+            out.append((torch.cat(cols, dim=-1), gt_labels[b]))
+            nr_list.append(nr[s:s + n].bool())
+            s += n
+        if cascade_out_fmt:
+            return out, nr_list
+        if not with_nms:
+            raise NotImplementedError
+        return out
+
+    @staticmethod
+    def _geo(pts, chosen, rp, img_meta, rescale):
+        """get_geo_output (cpr_head.py:852-864): [refined pt, chosen pts...] padded with -1."""
+        G, K, _ = pts.shape
+        m = int(chosen.sum(dim=1).max().item()) if G else 0
+        geo = pts.new_full((G, m + 1, 2), -1.0)
+        geo[:, 0] = rp
+        order = torch.argsort(chosen.to(torch.int16), dim=1, descending=True, stable=True)[:, :m]
+        sel = torch.gather(pts, 1, order[..., None].expand(-1, -1, 2))
+        keep = torch.gather(chosen, 1, order).bool()
+        geo[:, 1:][keep] = sel[keep]
+        if rescale:
+            sf = geo.new_tensor(img_meta['scale_factor'][:2])
+            geo = torch.where(geo >= 0, geo / sf, geo)
+        return geo.reshape(G, -1)
+
+    def simple_test(self, feats, img_metas, rescale=False, **gt_kwargs):
+        """dense_test_mixins.simple_test_bboxes (T/mmdet/models/dense_heads/dense_test_mixins.py:15-36)."""
+        outs = self(feats)
+        return self.get_bboxes(*outs, img_metas, rescale=rescale, **gt_kwargs)
+
+    @staticmethod
+    def pseudo_bbox_to_center(gt_bboxes):
+        return [ops.box_centers(b.float().contiguous()) for b in gt_bboxes]

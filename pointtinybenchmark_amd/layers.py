@@ -1,0 +1,105 @@
+"""Parameter containers + the fused conv/norm building blocks used by backbone, neck and heads.
+
+nn.Conv2d / nn.BatchNorm2d / nn.GroupNorm objects are used ONLY as parameter holders so the state-dict
+keys match the reference checkpoint layout; their ``forward`` is never called -- all
+compute goes through ``ops`` (HIP kernels)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _PackCache:
+    """Repacked weights / folded norms, rebuilt when the source parameter is modified in place."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, key, tensors, make):
+        ver = tuple((t.data_ptr(), t._version) for t in tensors)
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = make()
+        self._d[key] = (ver, val)
+        return val
+
+
+def packed_conv(cache, conv):
+    return cache.get(('pc', id(conv)), [conv.weight],
+                     lambda: ops.PackedConv(conv.weight, conv.stride[0], conv.padding[0]))
+
+
+def folded_bn(cache, bn):
+    """Eval-mode BatchNorm as a per-channel affine for the conv epilogue:
+    scale = gamma / sqrt(var + eps), shift = beta - mean * scale."""
+    def make():
+        with torch.no_grad():
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+            shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        return scale, shift
+    return cache.get(('bn', id(bn)), [bn.weight, bn.bias, bn.running_mean, bn.running_var], make)
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> act container with mmcv's attribute names (``conv``, ``gn``/``bn``), bias='auto'."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias='auto', conv_cfg=None,
+                 norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True):
+        super().__init__()
+        assert conv_cfg is None or conv_cfg.get('type') in (None, 'Conv2d'), 'only plain Conv2d is on this path'
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+        self.norm_name = None
+        if self.with_norm:
+            cfg = dict(norm_cfg)
+            t = cfg.pop('type')
+            rg = cfg.pop('requires_grad', True)
+            if t == 'GN':
+                self.norm_name = 'gn'
+                norm = nn.GroupNorm(num_channels=out_channels, **cfg)
+            elif t == 'BN':
+                self.norm_name = 'bn'
+                norm = nn.BatchNorm2d(out_channels, **cfg)
+            else:
+                raise KeyError(t)
+            for p in norm.parameters():
+                p.requires_grad = rg
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            assert act_cfg.get('type', 'ReLU') == 'ReLU'
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name) if self.norm_name else None
+
+
+def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None):
+    """Run a ConvModule(conv, GN[, ReLU]) on an NHWC tensor.
+
+    The GroupNorm statistics come out of the conv epilogue when the map is tile-aligned (no extra pass);
+    with ``materialize=False`` the raw conv output and the per-(image, channel) affine (a, b) are returned so
+    the CONSUMER conv applies normalisation + ReLU while loading its input tile (no apply pass either).
+    """
+    pc = packed_conv(cache, m.conv)
+    gn = m.norm
+    N, H, W, _ = x.shape
+    OH, OW = pc.out_hw(H, W)
+    fused_stats = (OH * OW) % 128 == 0
+    fuse_in = in_ab is not None and (H * W) % 128 == 0 and pc.stride == 1 and (OH, OW) == (H, W)
+    if in_ab is not None and not fuse_in:
+        x = ops.gn_apply(x, in_ab[0], in_ab[1], relu=in_relu)
+        in_ab = None
+    bias = m.conv.bias
+    if fused_stats:
+        raw, part = ops.conv2d(x, pc, bias=bias, in_ab=in_ab, in_relu=in_relu, gn_part=True)
+    else:
+        raw = ops.conv2d(x, pc, bias=bias, in_ab=in_ab, in_relu=in_relu)
+        part = ops.gn_stats(raw)
+    a, b = ops.gn_finalize(part, gn.weight, gn.bias, N, OH * OW, gn.num_groups, gn.eps)
+    if not materialize:
+        return raw, (a, b)
+    return ops.gn_apply(raw, a, b, relu=m.with_activation, up=up, out=raw)

@@ -1,0 +1,275 @@
+"""Thin tensor -> C-ABI wrappers.  PyTorch here is plumbing only: it owns the device memory
+(caller-allocated outputs and workspaces) and the stream; every op runs in a
+hand-written HIP kernel from libcprhip.so on the current HIP stream.
+
+Activations are NHWC fp32 (see csrc/conv_mfma.hip for why).  ``as_nchw`` / ``from_nchw`` expose them as
+NCHW-shaped (channels_last-strided) tensors, which is what crosses the reference's module boundaries.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(t, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.CprHipError('HIP op called with a CPU tensor: the product path has no CPU fallback')
+    assert t.dtype == dtype and t.is_contiguous(), (t.dtype, t.stride())
+    return t
+
+
+def as_nchw(x_nhwc):
+    """(N,H,W,C) buffer -> NCHW-shaped view (channels_last strides, no copy)."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def from_nchw(x):
+    """NCHW-shaped tensor -> contiguous (N,H,W,C) buffer; free when x is already channels_last."""
+    y = x.permute(0, 2, 3, 1)
+    if y.is_contiguous():
+        return y
+    return nchw_to_nhwc(x)
+
+
+def nchw_to_nhwc(x):
+    N, C, H, W = x.shape
+    if C <= 4:  # network input: pad to 4 channels for the stem's float4 taps
+        x = _check(x.contiguous())
+        out = torch.empty((N, H, W, 4), device=x.device, dtype=torch.float32)
+        _lib.call('cpr_nchw_to_nhwc4', _ptr(x), _ptr(out), N, C, H, W, _stream())
+        return out
+    return x.permute(0, 2, 3, 1).contiguous()  # layout copy only (not on the benchmarked path)
+
+
+def nhwc_to_nchw_dense(x_nhwc):
+    N, H, W, C = x_nhwc.shape
+    out = torch.empty((N, C, H, W), device=x_nhwc.device, dtype=torch.float32)
+    _lib.call('cpr_nhwc_to_nchw', _ptr(_check(x_nhwc)), _ptr(out), N, C, H, W, _stream())
+    return out
+
+
+class PackedConv:
+    """Conv weight repacked for the implicit-GEMM kernel: [Cout][KH][KW][Cin'] fp32, rows padded to a
+    multiple of 32 floats.  Cin' = 4 for the 3-channel stem (zero 4th channel)."""
+
+    def __init__(self, weight, stride=1, padding=0):
+        Cout, Cin, KH, KW = weight.shape
+        w = weight.detach().to(torch.float32).permute(0, 2, 3, 1)  # OHWI
+        if Cin <= 4:
+            wp = torch.zeros((Cout, KH, KW, 4), device=weight.device, dtype=torch.float32)
+            wp[..., :Cin] = w
+            w, cin_p = wp, 4
+        else:
+            assert Cin % 32 == 0, 'input channels must be a multiple of 32 (or <= 4 for the stem)'
+            cin_p = Cin
+        K = KH * KW * cin_p
+        Kpad = (K + 31) // 32 * 32
+        packed = torch.zeros((Cout, Kpad), device=weight.device, dtype=torch.float32)
+        packed[:, :K] = w.reshape(Cout, K)
+        self.w = packed.contiguous()
+        self.Cout, self.Cin, self.KH, self.KW, self.Kpad = Cout, cin_p, KH, KW, Kpad
+        self.stride, self.padding = stride, padding
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.padding - self.KH) // self.stride + 1,
+                (W + 2 * self.padding - self.KW) // self.stride + 1)
+
+
+def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, in_relu=False, gn_part=False,
+           out=None):
+    """x (N,H,W,Cin) -> (N,OH,OW,Cout).  Epilogue: *scale[c] + bias[c] (+residual) (ReLU).
+    in_ab=(a,b) applies x*a[n,c]+b[n,c] (+ReLU) to the input on load (fused GroupNorm of the producer).
+    gn_part=True also returns per-128-pixel-tile per-channel (sum, sumsq) partials of the output."""
+    _check(x)
+    N, H, W, Cin = x.shape
+    assert Cin == pc.Cin, (Cin, pc.Cin)
+    OH, OW = pc.out_hw(H, W)
+    if out is None:
+        out = torch.empty((N, OH, OW, pc.Cout), device=x.device, dtype=torch.float32)
+    part = None
+    if gn_part:
+        assert (OH * OW) % 128 == 0
+        part = torch.empty((N * OH * OW // 128, pc.Cout, 2), device=x.device, dtype=torch.float32)
+    a = b = None
+    if in_ab is not None:
+        a, b = in_ab
+    _lib.call('cpr_conv2d_fwd', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias),
+              _ptr(residual), _ptr(a), _ptr(b), _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride,
+              pc.padding, pc.Kpad, int(relu), int(in_relu), _stream())
+    return (out, part) if gn_part else out
+
+
+def maxpool3x3s2(x):
+    N, H, W, C = _check(x).shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), device=x.device, dtype=torch.float32)
+    _lib.call('cpr_maxpool3x3s2', _ptr(x), _ptr(out), N, H, W, C, _stream())
+    return out
+
+
+def gn_stats(x, slots=None):
+    """Per (image, slot, channel) (sum, sumsq) partials of an NHWC tensor."""
+    N, H, W, C = _check(x).shape
+    HW = H * W
+    if slots is None:
+        slots = max(1, min(256, HW // 256))
+    part = torch.empty((N * slots, C, 2), device=x.device, dtype=torch.float32)
+    _lib.call('cpr_gn_stats', _ptr(x), _ptr(part), N, HW, C, slots, _stream())
+    return part
+
+
+def gn_finalize(part, gamma, beta, N, HW, groups=32, eps=1e-5, want_stats=False):
+    """partials -> per (image, channel) affine (a, b) with y = x*a + b == GroupNorm(x)."""
+    C = part.shape[1]
+    P = part.shape[0] // N
+    a = torch.empty((N, C), device=part.device, dtype=torch.float32)
+    b = torch.empty((N, C), device=part.device, dtype=torch.float32)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty((N, groups), device=part.device, dtype=torch.float32)
+        rstd = torch.empty((N, groups), device=part.device, dtype=torch.float32)
+    _lib.call('cpr_gn_finalize', _ptr(part), _ptr(_check(gamma)), _ptr(_check(beta)), _ptr(a), _ptr(b), _ptr(mean),
+              _ptr(rstd), N, P, C, groups, HW, float(eps), _stream())
+    return (a, b, mean, rstd) if want_stats else (a, b)
+
+
+def gn_apply(x, a, b, relu=False, up=None, out=None):
+    """y = x*a[n,c] + b[n,c] (ReLU) (+ nearest-upsampled ``up``).  In place when out is x."""
+    N, H, W, C = _check(x).shape
+    if out is None:
+        out = torch.empty_like(x)
+    UH = UW = 0
+    if up is not None:
+        UH, UW = up.shape[1], up.shape[2]
+    _lib.call('cpr_gn_apply', _ptr(x), _ptr(a), _ptr(b), _ptr(up), _ptr(out), N, H, W, C, UH, UW, int(relu),
+              _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ CPR points
+def box_centers(boxes):
+    n = boxes.shape[0]
+    out = torch.empty((n, 2), device=boxes.device, dtype=torch.float32)
+    _lib.call('cpr_box_centers', _ptr(_check(boxes)), _ptr(out), n, _stream())
+    return out
+
+
+def neg_mask_loss(logit_map, centers, labels, gt_start, pad_hw, num_classes, stride, d2_thr, eps=1e-6,
+                  class_wise=True):
+    """logit_map (N,H,W,J) -> mask (N*H*W, C) uint8, partial sums (double)."""
+    N, H, W, J = _check(logit_map).shape
+    C = num_classes
+    mask = torch.empty((N * H * W, C), device=logit_map.device, dtype=torch.uint8)
+    nblk = (H * W * C + 255) // 256
+    partial = torch.empty((N * nblk,), device=logit_map.device, dtype=torch.float64)
+    _lib.call('cpr_neg_mask_loss', _ptr(logit_map), J, _ptr(centers), _ptr(labels), _ptr(gt_start), _ptr(pad_hw),
+              _ptr(mask), _ptr(partial), N, H, W, C, float(stride), float(d2_thr), float(eps), int(class_wise), None,
+              _stream())
+    return mask, partial
+
+
+def bag_sample(fmap, centers, gt_img, pad_hw, offsets, stride):
+    """fmap (N,H,W,J); returns pts (G,K,2), valid (G,K) uint8, sampled (G,K,J)."""
+    N, H, W, J = _check(fmap).shape
+    G = centers.shape[0]
+    K = (offsets.shape[0] if offsets is not None else 0) + 1
+    pts = torch.empty((G, K, 2), device=fmap.device, dtype=torch.float32)
+    valid = torch.empty((G, K), device=fmap.device, dtype=torch.uint8)
+    out = torch.empty((G, K, J), device=fmap.device, dtype=torch.float32)
+    _lib.call('cpr_bag_sample', _ptr(fmap), J, _ptr(centers), _ptr(gt_img), _ptr(pad_hw), _ptr(offsets), _ptr(pts),
+              _ptr(valid), _ptr(out), G, K, H, W, float(stride), _stream())
+    return pts, valid, out
+
+
+def mil_loss(logits, ins_off, valid, labels, num_classes, neg_partial, w_mil, w_gt, w_neg, gt_weight=None, eps=1e-6):
+    """-> (5,) tensor {gt_loss, pos_loss, bag_acc, neg_loss, num_pos} and the per-bag workspace (G,5)."""
+    G, K, J = _check(logits).shape
+    bag = torch.empty((G, 5), device=logits.device, dtype=torch.float32)
+    out = torch.empty((5,), device=logits.device, dtype=torch.float32)
+    npart = 0 if neg_partial is None else neg_partial.numel()
+    _lib.call('cpr_mil_loss', _ptr(logits), J, ins_off, _ptr(valid), _ptr(labels), _ptr(gt_weight), _ptr(bag),
+              _ptr(neg_partial), npart, G, K, num_classes, float(eps), float(w_mil), float(w_gt), float(w_neg),
+              _ptr(out), _stream())
+    return out, bag
+
+
+def refine(logits, pts, valid, centers, labels, gt_img, gt_start, img_hw, num_classes, gt_alpha, merge_th, refine_th,
+           use_nearest=True, use_classify=False, not_refine_in=None):
+    G, K, J = _check(logits).shape
+    dev = logits.device
+    rp = torch.empty((G, 2), device=dev, dtype=torch.float32)
+    sc = torch.empty((G,), device=dev, dtype=torch.float32)
+    nr = torch.empty((G,), device=dev, dtype=torch.uint8)
+    chosen = torch.empty((G, K), device=dev, dtype=torch.uint8)
+    _lib.call('cpr_refine', _ptr(logits), J, _ptr(pts), _ptr(valid), _ptr(centers), _ptr(labels), _ptr(gt_img),
+              _ptr(gt_start), _ptr(img_hw), _ptr(not_refine_in), _ptr(rp), _ptr(sc), _ptr(nr), _ptr(chosen), G, K,
+              num_classes, float(gt_alpha), float(merge_th), float(refine_th), int(use_nearest), int(use_classify),
+              _stream())
+    return rp, sc, nr, chosen
+
+
+# ------------------------------------------------------------------------------------------------ assigners
+def point_assign(points, gt_bboxes, scale=4, pos_num=3):
+    n, k = points.shape[0], gt_bboxes.shape[0]
+    dev = points.device
+    inds = torch.zeros((n,), device=dev, dtype=torch.int64)
+    if n == 0 or k == 0:
+        return inds
+    best = torch.empty((n,), device=dev, dtype=torch.float32)
+    lvl = torch.empty((n,), device=dev, dtype=torch.int32)
+    _lib.call('cpr_point_assign', _ptr(_check(points)), _ptr(_check(gt_bboxes)), n, k, float(scale), pos_num,
+              _ptr(inds), _ptr(best), _ptr(lvl), _stream())
+    return inds
+
+
+def hungarian_cost(pred, logits, gt, labels, w_cls=2.0, alpha=0.25, gamma=2.0, eps=1e-12, w_dis=0.1, fx=1.0,
+                   fy=1.0):
+    """-> cost^T (G, M) fp32 (column-major view of the reference's (M, G) cost)."""
+    M, G = pred.shape[0], gt.shape[0]
+    costT = torch.empty((G, M), device=pred.device, dtype=torch.float32)
+    _lib.call('cpr_hungarian_cost', _ptr(_check(pred)), pred.shape[1], _ptr(_check(logits)), logits.shape[1],
+              _ptr(_check(gt)), _ptr(labels), _ptr(costT), M, G, float(w_cls), float(alpha), float(gamma),
+              float(eps), float(w_dis), float(fx), float(fy), _stream())
+    return costT
+
+
+def lsa_topk(costT_list, topk):
+    """Solve a batch of independent assignment problems (one workgroup each).  costT_list: list of (G_b, M_b)
+    fp32 tensors with M_b >= G_b.  Returns list of gt_inds (M_b,) int64 (0 = background, j+1 = gt j)."""
+    dev = costT_list[0].device
+    Ms = [c.shape[1] for c in costT_list]
+    Gs = [c.shape[0] for c in costT_list]
+    nb = len(costT_list)
+    flat = torch.cat([c.reshape(-1) for c in costT_list]) if nb > 1 else costT_list[0].reshape(-1)
+    cost_off, col_off, row_off = [0], [0], [0]
+    for m, g in zip(Ms, Gs):
+        cost_off.append(cost_off[-1] + m * g)
+        col_off.append(col_off[-1] + m)
+        row_off.append(row_off[-1] + g)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)
+    tm, tg = col_off[-1], max(row_off[-1], 1)
+    gt_inds = torch.zeros((tm,), device=dev, dtype=torch.int64)
+    ws_v = torch.empty((tm,), device=dev, dtype=torch.float64)
+    ws_spc = torch.empty((tm,), device=dev, dtype=torch.float64)
+    ws_path = torch.empty((tm,), device=dev, dtype=torch.int32)
+    ws_r4c = torch.empty((tm,), device=dev, dtype=torch.int32)
+    ws_sc = torch.empty((tm,), device=dev, dtype=torch.uint8)
+    ws_act = torch.empty((tm,), device=dev, dtype=torch.uint8)
+    ws_u = torch.empty((tg,), device=dev, dtype=torch.float64)
+    ws_c4r = torch.empty((tg,), device=dev, dtype=torch.int32)
+    ws_sr = torch.empty((tg,), device=dev, dtype=torch.uint8)
+    status = torch.zeros((nb,), device=dev, dtype=torch.int32)
+    _lib.call('cpr_lsa_topk', _ptr(flat), _ptr(i32(Ms)), _ptr(i32(Gs)), _ptr(i64(cost_off[:-1])),
+              _ptr(i64(col_off[:-1])), _ptr(i64(row_off[:-1])), nb, int(topk), _ptr(gt_inds), _ptr(ws_v), _ptr(ws_spc),
+              _ptr(ws_path), _ptr(ws_r4c), _ptr(ws_sc), _ptr(ws_act), _ptr(ws_u), _ptr(ws_c4r), _ptr(ws_sr),
+              _ptr(status), _stream())
+    return [gt_inds[col_off[i]:col_off[i + 1]] for i in range(nb)], status

@@ -1,0 +1,81 @@
+"""-m gpu: assigner indices bit-exact against the reference fixtures, the reference's own known-answer
+vectors (T/tests/test_utils/test_assigner.py:155-194) and the CPU oracle on extra seeds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpr_oracle as O
+from oracle.gen_golden import assigner_inputs
+from tests.test_oracle_golden import _pa_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_point_assigner_reference_known_answers():
+    from pointtinybenchmark_amd import PointAssigner
+    a = PointAssigner()
+    pts = torch.FloatTensor([[0, 0, 1], [10, 10, 1], [5, 5, 1], [32, 32, 1]]).cuda()
+    gtb = torch.FloatTensor([[0, 0, 10, 9], [0, 10, 10, 19]]).cuda()
+    res = a.assign(pts, gtb)
+    assert res.gt_inds.cpu().tolist() == [1, 2, 1, 0]
+    res = a.assign(pts, torch.zeros((0, 4)).cuda())          # empty gt -> all background
+    assert res.gt_inds.cpu().tolist() == [0, 0, 0, 0]
+    res = a.assign(torch.zeros((0, 3)).cuda(), torch.zeros((0, 4)).cuda())
+    assert len(res.gt_inds) == 0
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_point_assigner_vs_reference_fixture(golden_dir, seed):
+    from pointtinybenchmark_amd import PointAssigner
+    g = np.load(os.path.join(golden_dir, 'assigners.npz'))
+    pts, gtb, gl = _pa_inputs(seed)
+    res = PointAssigner(scale=4, pos_num=3).assign(pts.cuda(), gtb.cuda(), None, gl.cuda())
+    assert np.array_equal(res.gt_inds.cpu().numpy(), g['pa%d_gt_inds' % seed])
+    assert np.array_equal(res.labels.cpu().numpy(), g['pa%d_labels' % seed])
+
+
+def _ha(k):
+    from pointtinybenchmark_amd import HungarianAssignerV2
+    return HungarianAssignerV2(cls_costs=dict(type='FocalLossCost', weight=2.0),
+                               reg_costs=dict(type='DisCostV2', weight=0.1, norm_with_img_wh=False), topk_k=k)
+
+
+@pytest.mark.parametrize('case', range(5))
+def test_hungarian_v2_vs_reference_fixture(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, 'assigners.npz'))
+    n_side, G, C, k = [int(v) for v in g['ha%d_cfg' % case]]
+    pred, logits, gt, labels, shp = assigner_inputs(200 + case, n_side, 4, G, C)
+    res = _ha(k).assign(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
+    got = res.gt_inds.cpu().numpy()
+    nbad = int((got != g['ha%d_gt_inds' % case]).sum())
+    assert nbad == 0, '%d of %d assignment indices differ from the reference' % (nbad, got.size)
+    assert np.array_equal(res.labels.cpu().numpy(), g['ha%d_labels' % case])
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_hungarian_v2_vs_oracle_seeds(seed):
+    n_side, G, C, k = [(48, 12, 1, 5), (64, 30, 1, 5), (40, 5, 2, 3), (30, 64, 1, 5), (100, 40, 1, 5),
+                       (20, 3, 1, 1), (160, 100, 1, 5), (56, 17, 5, 4)][seed]
+    pred, logits, gt, labels, shp = assigner_inputs(900 + seed, n_side, 4, G, C)
+    ha = _ha(k)
+    costT = ha.cost_t(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
+    inds, lab, cost = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=k)
+    cerr = float((costT.t().cpu() - cost).abs().max())
+    assert cerr <= 1e-5, 'cost matrix max abs err %.3e' % cerr
+    res = ha.assign(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
+    got = res.gt_inds.cpu()
+    assert int((got > 0).sum()) == int((inds > 0).sum())
+    nbad = int((got != inds).sum())
+    assert nbad == 0, '%d of %d indices differ from scipy' % (nbad, got.numel())
+
+
+def test_hungarian_edge_cases():
+    ha = _ha(5)
+    pred, logits, gt, labels, shp = assigner_inputs(1, 8, 4, 3, 1)
+    res = ha.assign(pred.cuda(), logits.cuda(), torch.zeros((0, 2)).cuda(), torch.zeros((0,), dtype=torch.long).cuda(),
+                    dict(img_shape=shp))
+    assert bool((res.gt_inds == 0).all()) and bool((res.labels == -1).all())
+    res = ha.assign(pred[:0].cuda(), logits[:0].cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
+    assert len(res.gt_inds) == 0

@@ -1,0 +1,138 @@
+"""-m gpu: each HIP kernel through the C-ABI against a torch-CPU fp32 reference of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from pointtinybenchmark_amd import ops
+    return ops
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _cmp(name, got, ref, atol, rtol=1e-5):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    assert bool((err <= tol).all()), '%s: max abs err %.3e (ref max %.3e), %d/%d over tol' % (
+        name, float(err.max()), float(ref.abs().max()), int((err > tol).sum()), err.numel())
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, flags
+    (2, 64, 40, 40, 64, 3, 1, 1, ''),
+    (2, 256, 24, 20, 64, 1, 1, 0, 'bn relu'),
+    (1, 128, 33, 29, 128, 3, 2, 1, 'bn relu'),
+    (2, 256, 20, 20, 512, 1, 2, 0, 'bn'),
+    (2, 3, 64, 96, 64, 7, 2, 3, 'bn relu'),
+    (2, 64, 25, 21, 256, 1, 1, 0, 'bn res relu'),
+    (1, 256, 32, 32, 256, 3, 1, 1, 'bias'),
+    (3, 512, 7, 9, 2048, 1, 1, 0, 'bn res relu'),
+    (2, 256, 16, 16, 2, 1, 1, 0, 'bias'),
+    (1, 2048, 5, 5, 256, 1, 1, 0, ''),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'n%d_c%d_%dx%d_o%d_k%d_s%d_%s' % (c[:7] + (c[8].replace(' ', '-'),)))
+def test_conv2d_vs_torch(case):
+    ops = _ops()
+    N, Cin, H, W, Cout, k, stride, pad, flags = case
+    g = torch.Generator().manual_seed(hash(case[:8]) % 1000)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    ref = F.conv2d(x, w, None, stride, pad)
+    scale = bias = res = None
+    if 'bn' in flags:
+        scale = torch.rand(Cout, generator=g) + 0.5
+        bias = torch.randn(Cout, generator=g)
+        ref = ref * scale[None, :, None, None] + bias[None, :, None, None]
+    elif 'bias' in flags:
+        bias = torch.randn(Cout, generator=g)
+        ref = ref + bias[None, :, None, None]
+    if 'res' in flags:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res
+    if 'relu' in flags:
+        ref = F.relu(ref)
+    pc = ops.PackedConv(w.cuda(), stride, pad)
+    xin = ops.nchw_to_nhwc(x.cuda()) if Cin <= 4 else _nhwc(x)
+    out = ops.conv2d(xin, pc, scale=None if scale is None else scale.cuda(), bias=None if bias is None else bias.cuda(),
+                     residual=None if res is None else _nhwc(res), relu='relu' in flags)
+    torch.cuda.synchronize()
+    _cmp('conv', out.permute(0, 3, 1, 2), ref, atol=2e-5, rtol=2e-5)
+
+
+def test_conv_fused_groupnorm_chain():
+    """conv -> GN stats in the epilogue -> finalize -> next conv applies GN+ReLU on load, vs the unfused torch ops."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 256, 16, 24), generator=g)
+    w1 = torch.randn((256, 256, 3, 3), generator=g) * 0.02
+    w2 = torch.randn((256, 256, 3, 3), generator=g) * 0.02
+    gam = torch.rand(256, generator=g) + 0.5
+    bet = torch.randn(256, generator=g) * 0.1
+    y1 = F.conv2d(x, w1, None, 1, 1)
+    n1 = F.relu(F.group_norm(y1, 32, gam, bet, 1e-5))
+    y2 = F.conv2d(n1, w2, None, 1, 1)
+    pc1, pc2 = ops.PackedConv(w1.cuda(), 1, 1), ops.PackedConv(w2.cuda(), 1, 1)
+    raw, part = ops.conv2d(_nhwc(x), pc1, gn_part=True)
+    a, b, mean, rstd = ops.gn_finalize(part, gam.cuda(), bet.cuda(), 2, 16 * 24, 32, 1e-5, want_stats=True)
+    out2 = ops.conv2d(raw, pc2, in_ab=(a, b), in_relu=True)
+    torch.cuda.synchronize()
+    _cmp('conv1 raw', raw.permute(0, 3, 1, 2), y1, 2e-5)
+    yg = y1.reshape(2, 32, -1)
+    _cmp('gn mean', mean, yg.mean(-1), 1e-5)
+    _cmp('gn rstd', rstd, 1.0 / torch.sqrt(yg.var(-1, unbiased=False) + 1e-5), 1e-4, 1e-5)
+    _cmp('conv2 on fused GN input', out2.permute(0, 3, 1, 2), y2, 5e-5, 5e-5)
+    # unfused statistics kernel agrees with the fused partials
+    part2 = ops.gn_stats(raw)
+    a2, b2 = ops.gn_finalize(part2, gam.cuda(), bet.cuda(), 2, 16 * 24, 32, 1e-5)
+    _cmp('stats kernel a', a2, a, 1e-6, 1e-5)
+    _cmp('stats kernel b', b2, b, 1e-5, 1e-5)
+    mat = ops.gn_apply(raw, a, b, relu=True)
+    _cmp('gn apply', mat.permute(0, 3, 1, 2), n1, 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 32, 48), (1, 64, 33, 31)])
+def test_maxpool(shape):
+    ops = _ops()
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(1))
+    out = ops.maxpool3x3s2(_nhwc(x))
+    assert torch.equal(out.permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 3, 2, 1))
+
+
+@pytest.mark.parametrize('shape,up', [((2, 256, 20, 28), (10, 14)), ((1, 256, 25, 21), (13, 11))])
+def test_gn_apply_with_nearest_upsample_add(shape, up):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(shape, generator=g)
+    u = torch.randn((shape[0], shape[1]) + up, generator=g)
+    gam, bet = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    ref = F.group_norm(x, 32, gam, bet, 1e-5) + F.interpolate(u, size=shape[2:], mode='nearest')
+    xn = _nhwc(x)
+    part = ops.gn_stats(xn)
+    a, b = ops.gn_finalize(part, gam.cuda(), bet.cuda(), shape[0], shape[2] * shape[3], 32, 1e-5)
+    out = ops.gn_apply(xn, a, b, relu=False, up=_nhwc(u))
+    _cmp('gn+up', out.permute(0, 3, 1, 2), ref, 2e-5, 2e-5)
+
+
+def test_layout_kernels():
+    ops = _ops()
+    x = torch.randn((2, 3, 17, 23), generator=torch.Generator().manual_seed(3))
+    y = ops.nchw_to_nhwc(x.cuda()).cpu()
+    assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1)) and bool((y[..., 3] == 0).all())
+    z = torch.randn((2, 19, 21, 70), generator=torch.Generator().manual_seed(4))
+    assert torch.equal(ops.nhwc_to_nchw_dense(z.cuda()).cpu(), z.permute(0, 3, 1, 2).contiguous())
+
+
+def test_missing_gpu_tensor_is_an_error():
+    ops = _ops()
+    from pointtinybenchmark_amd._lib import CprHipError
+    with pytest.raises(CprHipError):
+        ops.maxpool3x3s2(torch.zeros((1, 4, 4, 4)))

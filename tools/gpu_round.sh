@@ -1,0 +1,21 @@
+#!/bin/bash
+# One GPU-box visit: parity tests (all, not fail-fast), a short bench, and a rocprofv3 kernel trace.
+# Everything lands in gpurun_out/ (merged back by gpurun).
+set -u
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=${1:-r1}
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/${TAG}_gpu.txt
+nproc >> gpurun_out/${TAG}_gpu.txt; lscpu | grep -i "model name" >> gpurun_out/${TAG}_gpu.txt
+timeout 900 python -m pytest tests -q -m gpu --tb=short -p no:cacheprovider 2>&1 | tail -150 > gpurun_out/${TAG}_pytest.log
+echo "pytest exit: $?" >> gpurun_out/${TAG}_pytest.log
+tail -5 gpurun_out/${TAG}_pytest.log
+timeout 600 python bench.py --steps 5 --warmup 2 --batch ${BATCH:-8} > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+echo "bench exit: $?"; cat gpurun_out/${TAG}_bench.json; tail -5 gpurun_out/${TAG}_bench.err
+if [ "${PROFILE:-1}" = "1" ]; then
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG} -o ${TAG} -- python $OLDPWD/bench.py --steps 3 --warmup 1 --batch ${BATCH:-8} --no-cpu-baseline --no-probe > /tmp/prof_${TAG}.log 2>&1 )
+  find /tmp/prof_${TAG} -name "*kernel_stats*" -exec cp {} gpurun_out/ \; 2>/dev/null
+  find /tmp/prof_${TAG} -name "*stats*.csv" | head; tail -3 /tmp/prof_${TAG}.log
+fi
+ls -la gpurun_out | tail -20
