@@ -1,0 +1,140 @@
+/* cpr_hip.h -- C ABI of libcprhip.so: the MI355X (gfx950) kernels of the CPR / P2PNet point-localization hot path.
+ *
+ * Conventions:
+ *   - every function returns 0, CPR_ERR_ARG (-1001, shape/pointer check failed), CPR_ERR_UNSUPPORTED (-1002) or
+ *     -(hipError_t); nothing is thrown; the Python host raises RuntimeError on non-zero
+ *   - all pointers are DEVICE pointers unless marked [host]; the caller allocates every output and workspace
+ *     (no hidden allocation, no ownership transfer); functions are stateless and re-entrant
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no host synchronisation inside
+ *   - activations are NHWC fp32; index outputs are int64 (torch long) where the reference returns long
+ * Each entry cites the reference interface it replaces (T/ = TOV_mmdetection/).
+ */
+#ifndef CPR_HIP_H
+#define CPR_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPR_ERR_ARG (-1001)
+#define CPR_ERR_UNSUPPORTED (-1002)
+
+int cpr_version(void);
+
+/* ---- conv stack ------------------------------------------------------------------------------------------------
+ * Replaces ATen/cuDNN conv2d + eval BatchNorm + ReLU + residual add as used by
+ *   ResNet.forward / Bottleneck.forward  T/mmdet/models/backbones/resnet.py:262-302,630-645
+ *   FPN.forward                          T/mmdet/models/necks/fpn.py:166-194
+ *   CPRHead.forward_single               T/mmdet/models/point/dense_heads/cpr_head.py:1033-1043
+ *   P2PHead.forward_single               T/mmdet/models/point/dense_heads/p2p_head.py:113-123
+ * in  (N,H,W,Cin)  wgt [Cout][KH][KW][Cin] rows padded to Kpad  out (N,OH,OW,Cout)
+ * epilogue  y = acc*scale[c] + bias[c] (+ residual[m][c]) (ReLU);   scale/bias/residual may be NULL
+ * in_a/in_b (N,Cin) optional: input is read as relu?(x*a+b) (fused GroupNorm-apply of the producer; needs H*W%128==0)
+ * gn_part optional [N*OH*OW/128][Cout][2]: per-tile per-channel (sum, sumsq) of the output (needs OH*OW%128==0)
+ * Cin must be a multiple of 32, or 4 (3-channel stem padded with a zero channel). */
+int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
+                   const float* residual, const float* in_a, const float* in_b, float* gn_part, int N, int H, int W,
+                   int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int relu, int in_relu,
+                   void* stream);
+
+/* network input (N,C<=4,H,W) NCHW -> (N,H,W,4) NHWC, missing channels zero */
+int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, void* stream);
+/* (N,H,W,C) -> dense (N,C,H,W) (export in the reference's layout) */
+int cpr_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, void* stream);
+/* nn.MaxPool2d(3, 2, 1) of the ResNet stem (resnet.py:610,637); NHWC */
+int cpr_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, void* stream);
+
+/* GroupNorm of mmcv ConvModule (fpn.py:124-144, cpr_head.py:990-991) as three streaming steps:
+ *   stats    part [N][P][C][2] per-slot per-channel (sum, sumsq)
+ *   finalize per (image, channel) affine a = rstd*gamma, b = beta - mean*a   (y = x*a + b); mean/rstd optional (N,G)
+ *   apply    y = x*a + b (ReLU) (+ nearest-upsampled `up` (N,UH,UW,C): the FPN top-down add, fpn.py:179-188) */
+int cpr_gn_stats(const float* x, float* part, int N, int HW, int C, int P, void* stream);
+int cpr_gn_finalize(const float* part, const float* gamma, const float* beta, float* a_out, float* b_out,
+                    float* mean_out, float* rstd_out, int N, int P, int C, int G, int HW, float eps, void* stream);
+int cpr_gn_apply(const float* x, const float* a, const float* b, const float* up, float* y, int N, int H, int W,
+                 int C, int UH, int UW, int relu, void* stream);
+
+/* ---- CPR point kernels -----------------------------------------------------------------------------------------
+ * pseudo_bbox_to_center (cpr_head.py:1293-1301): boxes (n,4) -> centers (n,2) */
+int cpr_box_centers(const float* boxes, float* centers, int n, void* stream);
+
+/* OutCirclePtFeatGenerator.generate + neg branch of CPRHead.loss0 (cpr_head.py:254-290,1219-1228):
+ * logit (N,H,W,J) (class logits in channels [0,C)); gts in CSR form (centers (G,2), labels (G), gt_start (N+1));
+ * pad_hw (N,2) int32.  mask (N*H*W, C) uint8 = the reference's neg `valid`; partial[] (double, N*ceil(H*W*C/256))
+ * = block partial sums of gfocal(sigmoid(logit), 0, valid).  d2_thr = smallest fp32 whose torch-CPU sqrt is
+ * >= stride*radius (the reference thresholds cdist, i.e. a sqrt).  n_partial [host, may be NULL] receives the count. */
+int cpr_neg_mask_loss(const float* logit, int J, const float* centers, const int* labels, const int* gt_start,
+                      const int* pad_hw, unsigned char* mask, double* partial, int N, int H, int W, int C,
+                      float stride, float d2_thr, float eps, int class_wise, int* n_partial, void* stream);
+
+/* CirclePtFeatGenerator.generate (cpr_head.py:453-497,172-199): bag points (rings + centre last), validity and
+ * bilinear samples of a J-channel NHWC map.  offsets (K-1,2) from the host.  pts (G,K,2) valid (G,K) out (G,K,J) */
+int cpr_bag_sample(const float* map, int J, const float* centers, const int* gt_img, const int* pad_hw,
+                   const float* offsets, float* pts, unsigned char* valid, float* out, int G, int K, int H, int W,
+                   float stride, void* stream);
+
+/* MILLoss.forward + gt loss + neg normalisation (multi_instance_learning_loss.py:153-203, cpr_head.py:1159-1228).
+ * logits (G,K,J): cls in [0,C), ins in [ins_off, ins_off+C).  bag_ws (G,5) workspace.
+ * out5 = {gt_loss, pos_loss, bag_acc, neg_loss, num_pos} (device scalars, no host sync). */
+int cpr_mil_loss(const float* logits, int J, int ins_off, const unsigned char* valid, const int* labels,
+                 const float* gt_weight, float* bag_ws, const double* neg_partial, int n_partial, int G, int K, int C,
+                 float eps, float w_mil, float w_gt, float w_neg, float* out5, void* stream);
+
+/* PointRefiner.refine_single (cpr_head.py:711-850): refine_pts (G,2), scores (G), not_refine (G) u8, chosen (G,K) u8 */
+int cpr_refine(const float* logits, int J, const float* pts, const unsigned char* valid, const float* centers,
+               const int* labels, const int* gt_img, const int* gt_start, const int* img_hw,
+               const unsigned char* not_refine_in, float* refine_pts, float* scores, unsigned char* not_refine,
+               unsigned char* chosen, int G, int K, int C, float gt_alpha, float merge_th, float refine_th,
+               int use_nearest, int use_classify, void* stream);
+
+/* ---- assigners -------------------------------------------------------------------------------------------------
+ * PointAssigner.assign (T/mmdet/core/bbox/assigners/point_assigner.py:23-133): points (n,3)=(x,y,stride),
+ * gt_bboxes (k,4) -> gt_inds (n) int64 (0 bg, j+1 = gt j).  ws_best (n) float, ws_lvl (n) int32 workspaces. */
+int cpr_point_assign(const float* points, const float* gt_bboxes, int n, int k, float scale, int pos_num,
+                     long long* gt_inds, float* ws_best, int* ws_lvl, void* stream);
+
+/* FocalLossCost + DisCostV2 (T/mmdet/core/bbox/match_costs/match_cost.py:84-100,197-214):
+ * costT (G,M) = transpose of the reference's (M,G) cost; pred (M,pred_stride>=2), logits (M,C), gt (G,2) */
+int cpr_hungarian_cost(const float* pred, int pred_stride, const float* logits, int C, const float* gt,
+                       const int* labels, float* costT, int M, int G, float w_cls, float alpha, float gamma,
+                       float eps, float w_dis, float fx, float fy, void* stream);
+
+/* The linear_sum_assignment loop of HungarianAssignerV2.assign (hungarian_assigner.py:229-268; replaces scipy and
+ * the device->host->device round trip).  A batch of problems, one workgroup each: problem b has costT at
+ * cost_off[b] (G_b x M_b, M_b >= G_b), column arrays at col_off[b], row arrays at row_off[b].
+ * gt_inds (sum M) int64: 0 background, j+1 = gt j.  status[b] != 0: infeasible. */
+int cpr_lsa_topk(const float* costT, const int* m_of, const int* g_of, const long long* cost_off,
+                 const long long* col_off, const long long* row_off, int num_problems, int topk, long long* gt_inds,
+                 double* ws_v, double* ws_spc, int* ws_path, int* ws_row4col, unsigned char* ws_sc,
+                 unsigned char* ws_active, double* ws_u, int* ws_col4row, unsigned char* ws_sr, int* status,
+                 void* stream);
+
+/* ---- P2P inference ---------------------------------------------------------------------------------------------
+ * per-level top-k of P2PHead._get_bboxes_single (p2p_head.py:367-373): scores (n) -> k largest, sorted descending
+ * (ties: lower index first).  k <= 4096.  out_vals (k) float, out_idx (k) int64. */
+int cpr_topk_desc(const float* scores, int n, int k, float* out_vals, long long* out_idx, void* stream);
+
+/* mmcv.ops.nms.batched_nms as called by multiclass_nms (T/mmdet/core/post_processing/bbox_nms.py:85; mmcv-full
+ * 1.3.x, third-party): class-offset trick, sort by score (descending, ties by index), greedy IoU > thr suppression.
+ * boxes (n,4), scores (n), labels (n) int32, n <= 16384.  keep_idx (n) int64: indices of kept boxes in descending
+ * score order; num_keep (1) int32.  ws_order (n) int32, ws_boxes (n,4) float, ws_mask (n*ceil(n/64)) uint64. */
+int cpr_nms(const float* boxes, const float* scores, const int* labels, int n, float iou_thr, long long* keep_idx,
+            int* num_keep, int* ws_order, float* ws_boxes, unsigned long long* ws_mask, void* stream);
+
+/* P2PHead.get_pred_points (p2p_head.py:125-170): reg (N,H,W,2k) -> pred (N,H*W*k,3) = anchor + point_anchor*stride +
+ * reg*gamma*stride, third column = stride; anchor (same shape) optional.  point_anchor (k,2). */
+int cpr_p2p_decode(const float* reg, const float* point_anchor, float* pred, float* anchor, int N, int H, int W, int k,
+                   float stride, float gamma, void* stream);
+/* max_c sigmoid(logits[m][c]) -> out (M): the score P2PHead._get_bboxes_single ranks with (p2p_head.py:362-369) */
+int cpr_rowmax_sigmoid(const float* logits, float* out, long long M, int C, void* stream);
+/* P2PHead.loss_single + sample_result_to_target (p2p_head.py:220-248,308-328): sigmoid focal loss
+ * (T/mmdet/models/losses/focal_loss.py:11-56) + SmoothL1 (smooth_l1_loss.py:11-28) straight from gt_inds (B,M) int64.
+ * ws_partial (B*ceil(M/256)*3) double; out (B,2) = per image {loss_cls, loss_pts}, averaged by the batch's positives. */
+int cpr_p2p_loss(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
+                 const int* gt_labels, const int* gt_start, double* ws_partial, float* out, int B, int M, int C,
+                 float alpha, float gamma, float beta, float pos_w, float neg_w, float reg_norm, float w_cls,
+                 float w_reg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPR_HIP_H */

@@ -31,6 +31,11 @@ SIGNATURES = {
     'cpr_point_assign': [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p],
     'cpr_hungarian_cost': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p],
     'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'cpr_topk_desc': [_p, _i, _i, _p, _p, _p],
+    'cpr_nms': [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
+    'cpr_p2p_decode': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    'cpr_rowmax_sigmoid': [_p, _p, ctypes.c_longlong, _i, _p],
+    'cpr_p2p_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p],
 }
 
 _lib = None

@@ -1,0 +1,337 @@
+// P2P inference post-processing (T/mmdet/models/point/dense_heads/p2p_head.py:345-405):
+//   cpr_topk_desc  per-level top-k of the max class score (p2p_head.py:367-373, torch.topk)
+//   cpr_nms        mmcv.ops.nms.batched_nms as used by multiclass_nms (bbox_nms.py:85; third-party mmcv-full 1.3.x):
+//                  class-offset boxes, score sort, 64x64 bitmask IoU tiles (one wavefront = one 64-bit mask row),
+//                  serial keep scan by a single wave.
+#include <limits.h>
+#include "common.h"
+
+__device__ __forceinline__ unsigned f2key(float f) {  // monotone: larger float -> larger key
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// in-place bitonic sort, DESCENDING, of P (power of two) 64-bit words by one workgroup
+__device__ void block_bitonic_desc(unsigned long long* a, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = a[i], y = a[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix-select the k-th largest key (4 x 8-bit passes), gather, bitonic-sort the k survivors in LDS.
+__global__ void topk_desc_kernel(const float* __restrict__ scores, int n, int k, float* __restrict__ out_vals,
+                                 long long* __restrict__ out_idx) {
+    __shared__ unsigned long long sel[4096];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_remaining, s_count, s_base, s_wcnt[16];
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)k; s_count = 0; s_base = 0; }
+    unsigned mask = 0;
+    __syncthreads();
+    for (int pass = 3; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        for (int b = tid; b < 256; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (int i = tid; i < n; i += blockDim.x) {
+            const unsigned key = f2key(scores[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0, rem = s_remaining;
+            for (int b = 255; b >= 0; --b) {
+                if (cum + hist[b] >= rem) { s_prefix = prefix | ((unsigned)b << shift); s_remaining = rem - cum; break; }
+                cum += hist[b];
+            }
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned T = s_prefix, take_eq = s_remaining;
+    // keys > T: any order (sorted below); keys == T: the `take_eq` lowest indices (ordered scan)
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + tid;
+        const unsigned key = i < n ? f2key(scores[i]) : 0u;
+        const bool gt = i < n && key > T, eq = i < n && key == T;
+        if (gt) sel[atomicAdd(&s_count, 1u)] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)i);
+        const unsigned long long bal = __ballot(eq);
+        const int lane = tid & 63, w = tid >> 6;
+        if (lane == 0) s_wcnt[w] = __popcll(bal);
+        __syncthreads();
+        unsigned off = s_base;
+        for (int q = 0; q < w; ++q) off += s_wcnt[q];
+        const unsigned rank = off + __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (tid == 0) {
+            unsigned tot = 0;
+            for (int q = 0; q < (int)(blockDim.x >> 6); ++q) tot += s_wcnt[q];
+            s_base += tot;
+        }
+        if (eq && rank < take_eq) sel[(k - take_eq) + rank] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)i);
+        __syncthreads();
+    }
+    int P = 1;
+    while (P < k) P <<= 1;
+    for (int i = k + tid; i < P; i += blockDim.x) sel[i] = 0ull;
+    __syncthreads();
+    block_bitonic_desc(sel, P);
+    for (int i = tid; i < k; i += blockDim.x) {
+        out_vals[i] = key2f((unsigned)(sel[i] >> 32));
+        out_idx[i] = (long long)(~(unsigned)(sel[i] & 0xffffffffull));
+    }
+}
+
+extern "C" int cpr_topk_desc(const float* scores, int n, int k, float* out_vals, long long* out_idx,
+                             hipStream_t stream) {
+    CPR_CHECK_ARG(n >= 0 && k >= 0 && k <= n && k <= 4096);
+    if (k == 0) return CPR_OK;
+    CPR_CHECK_ARG(scores && out_vals && out_idx);
+    hipLaunchKernelGGL(topk_desc_kernel, dim3(1), dim3(1024), 0, stream, scores, n, k, out_vals, out_idx);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void nms_prepare_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                   const int* __restrict__ labels, int n, int* __restrict__ order,
+                                   float* __restrict__ sboxes, unsigned long long* __restrict__ ws) {
+    __shared__ float red[16];
+    __shared__ float s_max;
+    const int tid = threadIdx.x;
+    float m = -INFINITY;
+    for (int i = tid; i < n * 4; i += blockDim.x) m = fmaxf(m, boxes[i]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        float r = red[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, red[w]);
+        s_max = r;
+    }
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += blockDim.x)
+        ws[i] = i < n ? (((unsigned long long)f2key(scores[i]) << 32) | (unsigned)(~(unsigned)i)) : 0ull;
+    __syncthreads();
+    block_bitonic_desc(ws, P);
+    const float off1 = __fadd_rn(s_max, 1.f);  // max_coordinate + 1
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int src = (int)(~(unsigned)(ws[i] & 0xffffffffull));
+        order[i] = src;
+        const float o = __fmul_rn((float)labels[src], off1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sboxes[i * 4 + c] = __fadd_rn(boxes[src * 4 + c], o);
+    }
+}
+
+__global__ void nms_mask_kernel(const float* __restrict__ b, int n, float thr, unsigned long long* __restrict__ mask,
+                                int nblk) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;  // only j > i matters
+    __shared__ float cbx[64 * 4];
+    const int lane = threadIdx.x;
+    const int cj = cb * 64 + lane;
+    if (cj < n) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cbx[lane * 4 + c] = b[cj * 4 + c];
+    }
+    __syncthreads();
+    const int i = rb * 64 + lane;
+    if (i >= n) return;
+    const float x1 = b[i * 4], y1 = b[i * 4 + 1], x2 = b[i * 4 + 2], y2 = b[i * 4 + 3];
+    const float ai = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    unsigned long long bits = 0;
+    const int cnt = min(64, n - cb * 64);
+    for (int t = 0; t < cnt; ++t) {
+        const int j = cb * 64 + t;
+        if (j <= i) continue;
+        const float u1 = cbx[t * 4], v1 = cbx[t * 4 + 1], u2 = cbx[t * 4 + 2], v2 = cbx[t * 4 + 3];
+        const float aj = __fmul_rn(__fsub_rn(u2, u1), __fsub_rn(v2, v1));
+        const float w = fmaxf(0.f, __fsub_rn(fminf(x2, u2), fmaxf(x1, u1)));
+        const float h = fmaxf(0.f, __fsub_rn(fminf(y2, v2), fmaxf(y1, v1)));
+        const float inter = __fmul_rn(w, h);
+        const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, aj), inter));
+        if (ovr > thr) bits |= 1ull << t;
+    }
+    mask[(size_t)i * nblk + cb] = bits;
+}
+
+__global__ void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order, int n,
+                                int nblk, long long* __restrict__ keep_idx, int* __restrict__ num_keep) {
+    __shared__ unsigned long long removed[256];
+    const int lane = threadIdx.x;
+    for (int c = lane; c < nblk; c += 64) removed[c] = 0ull;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long w = removed[i >> 6];
+        if (!((w >> (i & 63)) & 1ull)) {
+            if (lane == 0) keep_idx[cnt] = order[i];
+            ++cnt;
+            const int c0 = i >> 6;  // columns before c0 hold only j <= i: nothing left to suppress there
+            for (int c = c0 + lane; c < nblk; c += 64) removed[c] |= mask[(size_t)i * nblk + c];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) *num_keep = cnt;
+}
+
+extern "C" int cpr_nms(const float* boxes, const float* scores, const int* labels, int n, float iou_thr,
+                       long long* keep_idx, int* num_keep, int* ws_order, float* ws_boxes,
+                       unsigned long long* ws_mask, hipStream_t stream) {
+    CPR_CHECK_ARG(n >= 0 && n <= 16384 && num_keep);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int), stream);
+        return e == hipSuccess ? CPR_OK : -(int)e;
+    }
+    CPR_CHECK_ARG(boxes && scores && labels && keep_idx && ws_order && ws_boxes && ws_mask);
+    const int nblk = cdiv(n, 64);
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(1), dim3(1024), 0, stream, boxes, scores, labels, n, ws_order, ws_boxes,
+                       ws_mask);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, stream, ws_boxes, n, iou_thr, ws_mask, nblk);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, ws_mask, ws_order, n, nblk, keep_idx, num_keep);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// P2PHead.get_pred_points (p2p_head.py:125-170): pred = anchor + point_anchor*stride + reg*gamma*stride.
+// reg (N,H,W,2k) NHWC -> pred (N, H*W*k, 3) = (x, y, stride); anchors are PointGenerator.grid_points
+// (x*stride, y*stride) with NO half-stride offset (T/mmdet/core/anchor/point_generator.py:17-25).
+__global__ void p2p_decode_kernel(const float* __restrict__ reg, const float* __restrict__ point_anchor,
+                                  float* __restrict__ pred, float* __restrict__ anchor, int N, int H, int W, int k,
+                                  float stride, float gamma) {
+    const long long total = (long long)N * H * W * k;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int a = (int)(i % k);
+    const long long pix = i / k;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const float ax = __fadd_rn((float)x * stride, __fmul_rn(point_anchor[a * 2], stride));
+    const float ay = __fadd_rn((float)y * stride, __fmul_rn(point_anchor[a * 2 + 1], stride));
+    const float rx = reg[i * 2], ry = reg[i * 2 + 1];
+    pred[i * 3 + 0] = __fadd_rn(ax, __fmul_rn(__fmul_rn(rx, gamma), stride));
+    pred[i * 3 + 1] = __fadd_rn(ay, __fmul_rn(__fmul_rn(ry, gamma), stride));
+    pred[i * 3 + 2] = stride;
+    if (anchor) { anchor[i * 3] = ax; anchor[i * 3 + 1] = ay; anchor[i * 3 + 2] = stride; }
+}
+
+extern "C" int cpr_p2p_decode(const float* reg, const float* point_anchor, float* pred, float* anchor, int N, int H,
+                              int W, int k, float stride, float gamma, hipStream_t stream) {
+    CPR_CHECK_ARG(reg && point_anchor && pred && N > 0 && H > 0 && W > 0 && k > 0);
+    const long long total = (long long)N * H * W * k;
+    hipLaunchKernelGGL(p2p_decode_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, reg, point_anchor,
+                       pred, anchor, N, H, W, k, stride, gamma);
+    CPR_LAUNCH_STATUS();
+}
+
+// max over classes of sigmoid(logit): the per-proposal score fed to topk (p2p_head.py:362-369)
+__global__ void rowmax_sigmoid_kernel(const float* __restrict__ logits, float* __restrict__ out, long long M, int C) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, 1.f / (1.f + expf(-logits[i * C + c])));
+    out[i] = m;
+}
+extern "C" int cpr_rowmax_sigmoid(const float* logits, float* out, long long M, int C, hipStream_t stream) {
+    CPR_CHECK_ARG(M >= 0 && C > 0);
+    if (M == 0) return CPR_OK;
+    CPR_CHECK_ARG(logits && out);
+    hipLaunchKernelGGL(rowmax_sigmoid_kernel, dim3((unsigned)cdivll(M, 256)), dim3(256), 0, stream, logits, out, M, C);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
+// P2PHead.loss_single (p2p_head.py:220-248) fused with sample_result_to_target (:308-328): sigmoid focal loss
+// (py_sigmoid_focal_loss, T/mmdet/models/losses/focal_loss.py:11-56) + SmoothL1 (smooth_l1_loss.py:11-28) straight
+// from the assignment.  One image per blockIdx.y; per-block partial sums in double, reduced by p2p_loss_finalize.
+__global__ void p2p_loss_kernel(const float* __restrict__ logits, const float* __restrict__ pred,
+                                const long long* __restrict__ gt_inds, const float* __restrict__ gt_pts,
+                                const int* __restrict__ gt_labels, const int* __restrict__ gt_start,
+                                double* __restrict__ partial, int M, int C, float alpha, float gamma, float beta,
+                                float pos_w, float neg_w, float reg_norm) {
+    __shared__ double red[3][4];
+    const int b = blockIdx.y;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    double lc = 0, lp = 0, np_ = 0;
+    if (m < M) {
+        const size_t r = (size_t)b * M + m;
+        const long long gi = gt_inds[r];
+        const bool pos = gi > 0;
+        const int g = pos ? gt_start[b] + (int)gi - 1 : 0;
+        const int label = pos ? gt_labels[g] : C;
+        const float w = pos ? pos_w : (neg_w <= 0.f ? 1.f : neg_w);
+        for (int c = 0; c < C; ++c) {
+            const float x = logits[r * C + c];
+            const float p = 1.f / (1.f + expf(-x));
+            const float t = (c == label) ? 1.f : 0.f;
+            const float pt = (1.f - p) * t + p * (1.f - t);
+            const float fw = (alpha * t + (1.f - alpha) * (1.f - t)) * ((gamma == 2.f) ? pt * pt : powf(pt, gamma));
+            // binary_cross_entropy_with_logits: max(x,0) - x*t + log(1 + exp(-|x|))
+            const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            lc += (double)(bce * fw * w);
+        }
+        if (pos) {
+            np_ = 1.0;
+            const float s = pred[r * 3 + 2];
+            for (int d = 0; d < 2; ++d) {
+                const float a = pred[r * 3 + d] / s / reg_norm, t = gt_pts[g * 2 + d] / s / reg_norm;
+                const float diff = fabsf(a - t);
+                lp += (double)((diff < beta) ? 0.5f * diff * diff / beta : diff - 0.5f * beta);
+            }
+        }
+    }
+    lc = wave_sum_d(lc); lp = wave_sum_d(lp); np_ = wave_sum_d(np_);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lc; red[1][threadIdx.x >> 6] = lp; red[2][threadIdx.x >> 6] = np_; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * 3;
+        for (int k = 0; k < 3; ++k) o[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+    }
+}
+
+// out (B,2): per image {loss_cls, loss_pts}; avg factor = total positives over the batch (p2p_head.py:199-200)
+__global__ void p2p_loss_finalize_kernel(const double* __restrict__ partial, int B, int nblk, float w_cls, float w_reg,
+                                         float* __restrict__ out) {
+    __shared__ double s_np;
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int i = 0; i < B * nblk; ++i) t += partial[(size_t)i * 3 + 2];
+        s_np = t;
+    }
+    __syncthreads();
+    const int b = threadIdx.x;
+    if (b < B) {
+        double lc = 0, lp = 0;
+        for (int i = 0; i < nblk; ++i) { lc += partial[((size_t)b * nblk + i) * 3]; lp += partial[((size_t)b * nblk + i) * 3 + 1]; }
+        out[b * 2] = (float)(lc / s_np * w_cls);
+        out[b * 2 + 1] = (float)(lp / s_np * w_reg);
+    }
+}
+
+extern "C" int cpr_p2p_loss(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
+                            const int* gt_labels, const int* gt_start, double* ws_partial, float* out, int B, int M,
+                            int C, float alpha, float gamma, float beta, float pos_w, float neg_w, float reg_norm,
+                            float w_cls, float w_reg, hipStream_t stream) {
+    CPR_CHECK_ARG(B > 0 && B <= 1024 && M > 0 && C > 0 && beta > 0);
+    CPR_CHECK_ARG(logits && pred && gt_inds && gt_pts && gt_labels && gt_start && ws_partial && out);
+    const int nblk = cdiv(M, 256);
+    hipLaunchKernelGGL(p2p_loss_kernel, dim3(nblk, B), dim3(256), 0, stream, logits, pred, gt_inds, gt_pts, gt_labels,
+                       gt_start, ws_partial, M, C, alpha, gamma, beta, pos_w, neg_w, reg_norm);
+    hipLaunchKernelGGL(p2p_loss_finalize_kernel, dim3(1), dim3(1024), 0, stream, ws_partial, B, nblk, w_cls, w_reg,
+                       out);
+    CPR_LAUNCH_STATUS();
+}

@@ -254,8 +254,11 @@ def lsa_topk(costT_list, topk):
         cost_off.append(cost_off[-1] + m * g)
         col_off.append(col_off[-1] + m)
         row_off.append(row_off[-1] + g)
-    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
-    i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)
+    # index tables: keep them alive in locals until after the launch (a temporary would be freed -- and its block
+    # recycled by the caching allocator -- before the kernel reads it)
+    t_m = torch.tensor(Ms, dtype=torch.int32, device=dev)
+    t_g = torch.tensor(Gs, dtype=torch.int32, device=dev)
+    t_off = torch.tensor([cost_off[:-1], col_off[:-1], row_off[:-1]], dtype=torch.int64, device=dev)
     tm, tg = col_off[-1], max(row_off[-1], 1)
     gt_inds = torch.zeros((tm,), device=dev, dtype=torch.int64)
     ws_v = torch.empty((tm,), device=dev, dtype=torch.float64)
@@ -268,8 +271,71 @@ def lsa_topk(costT_list, topk):
     ws_c4r = torch.empty((tg,), device=dev, dtype=torch.int32)
     ws_sr = torch.empty((tg,), device=dev, dtype=torch.uint8)
     status = torch.zeros((nb,), device=dev, dtype=torch.int32)
-    _lib.call('cpr_lsa_topk', _ptr(flat), _ptr(i32(Ms)), _ptr(i32(Gs)), _ptr(i64(cost_off[:-1])),
-              _ptr(i64(col_off[:-1])), _ptr(i64(row_off[:-1])), nb, int(topk), _ptr(gt_inds), _ptr(ws_v), _ptr(ws_spc),
+    _lib.call('cpr_lsa_topk', _ptr(flat), _ptr(t_m), _ptr(t_g), _ptr(t_off[0]), _ptr(t_off[1]), _ptr(t_off[2]), nb,
+              int(topk), _ptr(gt_inds), _ptr(ws_v), _ptr(ws_spc),
               _ptr(ws_path), _ptr(ws_r4c), _ptr(ws_sc), _ptr(ws_act), _ptr(ws_u), _ptr(ws_c4r), _ptr(ws_sr),
               _ptr(status), _stream())
     return [gt_inds[col_off[i]:col_off[i + 1]] for i in range(nb)], status
+
+
+# ------------------------------------------------------------------------------------------------ P2P inference
+def topk_desc(scores, k):
+    """k largest of a 1-D fp32 tensor, sorted descending, ties by lower index.  -> (values, indices int64)"""
+    n = _check(scores).numel()
+    vals = torch.empty((k,), device=scores.device, dtype=torch.float32)
+    idx = torch.empty((k,), device=scores.device, dtype=torch.int64)
+    _lib.call('cpr_topk_desc', _ptr(scores), n, int(k), _ptr(vals), _ptr(idx), _stream())
+    return vals, idx
+
+
+def nms(boxes, scores, labels, iou_thr):
+    """Class-aware greedy NMS (batched_nms semantics).  -> keep indices (int64, descending score).
+    One host read of the keep count (the reference's NMS output is variable-length too)."""
+    n = boxes.shape[0]
+    dev = boxes.device
+    if n == 0:
+        return torch.zeros((0,), device=dev, dtype=torch.int64)
+    nblk = (n + 63) // 64
+    P = 1
+    while P < n:
+        P <<= 1
+    keep = torch.empty((n,), device=dev, dtype=torch.int64)
+    num = torch.zeros((1,), device=dev, dtype=torch.int32)
+    order = torch.empty((n,), device=dev, dtype=torch.int32)
+    sboxes = torch.empty((n, 4), device=dev, dtype=torch.float32)
+    mask = torch.empty((max(n * nblk, P),), device=dev, dtype=torch.int64)
+    _lib.call('cpr_nms', _ptr(_check(boxes)), _ptr(_check(scores)), _ptr(_check(labels, torch.int32)), n,
+              float(iou_thr), _ptr(keep), _ptr(num), _ptr(order), _ptr(sboxes), _ptr(mask), _stream())
+    return keep[:int(num.item())]
+
+
+def p2p_decode(reg_nhwc, point_anchor, stride, gamma, want_anchor=False):
+    """reg (N,H,W,2k) -> pred (N, H*W*k, 3) = (x, y, stride) [, anchor pts]."""
+    N, H, W, C2 = _check(reg_nhwc).shape
+    k = C2 // 2
+    pred = torch.empty((N, H * W * k, 3), device=reg_nhwc.device, dtype=torch.float32)
+    anchor = torch.empty_like(pred) if want_anchor else None
+    _lib.call('cpr_p2p_decode', _ptr(reg_nhwc), _ptr(_check(point_anchor)), _ptr(pred), _ptr(anchor), N, H, W, k,
+              float(stride), float(gamma), _stream())
+    return (pred, anchor) if want_anchor else pred
+
+
+def rowmax_sigmoid(logits):
+    M, C = _check(logits).shape
+    out = torch.empty((M,), device=logits.device, dtype=torch.float32)
+    _lib.call('cpr_rowmax_sigmoid', _ptr(logits), _ptr(out), M, C, _stream())
+    return out
+
+
+def p2p_loss(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, beta, pos_w, neg_w, reg_norm, w_cls,
+             w_reg):
+    """logits (B,M,C), pred (B,M,3), gt_inds (B,M) int64 -> (B,2) {loss_cls, loss_pts} per image."""
+    B, M, C = _check(logits).shape
+    nblk = (M + 255) // 256
+    ws = torch.empty((B * nblk * 3,), device=logits.device, dtype=torch.float64)
+    out = torch.empty((B, 2), device=logits.device, dtype=torch.float32)
+    _lib.call('cpr_p2p_loss', _ptr(logits), _ptr(_check(pred)), _ptr(_check(gt_inds, torch.int64)), _ptr(_check(gt_pts)),
+              _ptr(_check(gt_labels, torch.int32)), _ptr(_check(gt_start, torch.int32)), _ptr(ws), _ptr(out), B, M, C,
+              float(alpha), float(gamma), float(beta), float(pos_w), float(neg_w), float(reg_norm), float(w_cls),
+              float(w_reg), _stream())
+    return out

@@ -1,0 +1,79 @@
+"""Per-layer timing of every distinct conv launch of the CPR R50-FPN forward (HIP events, 20 launches each).
+Prints flops, minimum HBM bytes, time, TFLOP/s, GB/s and the fraction of min(MFMA roof, HBM roof)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import pointtinybenchmark_amd as P  # noqa: E402
+from pointtinybenchmark_amd import ops, synthetic  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    model = P.build_detector(bench.model_cfg()).cuda()
+    model.load_state_dict(synthetic.locator_state_dict(50, 1, 0, 'cpr', 0), strict=True)
+    batch = synthetic.synthetic_batch(args.batch, 640, 640, 32, 1, 0)
+    img = batch['img'].cuda()
+    gtb = [b.cuda() for b in batch['gt_bboxes']]
+    gtl = [l.cuda() for l in batch['gt_labels']]
+    calls = []
+    orig = ops.conv2d
+
+    def rec(x, pc, *a, **k):
+        calls.append((x, pc, a, dict(k)))
+        return orig(x, pc, *a, **k)
+    ops.conv2d = rec
+    with torch.no_grad():
+        model.forward_train(img, batch['img_metas'], gtb, gtl)
+    ops.conv2d = orig
+    torch.cuda.synchronize()
+    uniq = {}
+    for x, pc, a, k in calls:
+        N, H, W, Cin = x.shape
+        key = (N, H, W, Cin, pc.Cout, pc.KH, pc.stride, k.get('residual') is not None, k.get('in_ab') is not None,
+               bool(k.get('gn_part')))
+        uniq.setdefault(key, [0, x, pc, a, k])[0] += 1
+    rows = []
+    tot_t = tot_f = 0.0
+    for key, (cnt, x, pc, a, k) in uniq.items():
+        N, H, W, Cin, Cout, KH, stride, res, xform, gnp = key
+        OH, OW = pc.out_hw(H, W)
+        creal = 3 if Cin == 4 else Cin
+        flops = 2.0 * N * OH * OW * Cout * KH * KH * creal
+        byts = 4.0 * (N * H * W * Cin + N * OH * OW * Cout * (2 if res else 1) + Cout * KH * KH * Cin)
+        for _ in range(3):
+            orig(x, pc, *a, **k)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.iters):
+            orig(x, pc, *a, **k)
+        e.record()
+        torch.cuda.synchronize()
+        t = s.elapsed_time(e) / args.iters * 1e-3
+        roof = max(flops / 157.3e12, byts / 6.3e12)
+        rows.append(dict(key=str(key), count=cnt, ms=t * 1e3, tflops=flops / t / 1e12, gbs=byts / t / 1e9,
+                         roof_frac=roof / t, gflop=flops / 1e9, mb=byts / 1e6))
+        tot_t += cnt * t
+        tot_f += cnt * flops
+    rows.sort(key=lambda r: -r['ms'] * r['count'])
+    print('%-62s %3s %8s %8s %8s %6s %7s' % ('N,H,W,Cin,Cout,K,s,res,xf,gn', 'cnt', 'ms', 'TF/s', 'GB/s', 'roof', 'tot ms'))
+    for r in rows:
+        print('%-62s %3d %8.3f %8.1f %8.0f %6.2f %7.2f' % (r['key'], r['count'], r['ms'], r['tflops'], r['gbs'],
+                                                          r['roof_frac'], r['ms'] * r['count']))
+    print('conv total per step: %.2f ms, %.1f TF/s aggregate (B=%d)' % (tot_t * 1e3, tot_f / tot_t / 1e12, args.batch))
+    if args.out:
+        json.dump(rows, open(args.out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
