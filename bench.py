@@ -140,7 +140,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('CPR_BENCH_BATCH', 8)), help='images per GPU')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('CPR_BENCH_BATCH', 16)), help='images per GPU')
     ap.add_argument('--num-gts', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')

@@ -36,6 +36,9 @@ int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* s
                    int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int relu, int in_relu,
                    void* stream);
 
+/* test / benchmark hook: force the conv output tile (bm, bn in {0 = heuristic, 64, 128}) */
+int cpr_conv_force_tile(int bm, int bn);
+
 /* network input (N,C<=4,H,W) NCHW -> (N,H,W,4) NHWC, missing channels zero */
 int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, void* stream);
 /* (N,H,W,C) -> dense (N,C,H,W) (export in the reference's layout) */
@@ -99,14 +102,16 @@ int cpr_hungarian_cost(const float* pred, int pred_stride, const float* logits, 
                        float eps, float w_dis, float fx, float fy, void* stream);
 
 /* The linear_sum_assignment loop of HungarianAssignerV2.assign (hungarian_assigner.py:229-268; replaces scipy and
- * the device->host->device round trip).  A batch of problems, one workgroup each: problem b has costT at
- * cost_off[b] (G_b x M_b, M_b >= G_b), column arrays at col_off[b], row arrays at row_off[b].
- * gt_inds (sum M) int64: 0 background, j+1 = gt j.  status[b] != 0: infeasible. */
+ * the device->host->device round trip), including scipy's tie-breaking order.  A batch of problems, one workgroup
+ * each: problem b has costT at cost_off[b] (G_b x M_b, M_b >= G_b), column arrays at col_off[b], row arrays at
+ * row_off[b].  gt_inds (sum M) int64: 0 background, j+1 = gt j.  status[b] != 0: infeasible.
+ * Workspaces: per column ws_v/ws_spc (double), ws_path/ws_row4col/ws_cols/ws_remaining/ws_pos (int32), ws_sc/ws_active
+ * (uint8); per row ws_u (double), ws_col4row (int32), ws_sr (uint8). */
 int cpr_lsa_topk(const float* costT, const int* m_of, const int* g_of, const long long* cost_off,
                  const long long* col_off, const long long* row_off, int num_problems, int topk, long long* gt_inds,
                  double* ws_v, double* ws_spc, int* ws_path, int* ws_row4col, unsigned char* ws_sc,
-                 unsigned char* ws_active, double* ws_u, int* ws_col4row, unsigned char* ws_sr, int* status,
-                 void* stream);
+                 unsigned char* ws_active, int* ws_cols, int* ws_remaining, int* ws_pos, double* ws_u,
+                 int* ws_col4row, unsigned char* ws_sr, int* status, void* stream);
 
 /* ---- P2P inference ---------------------------------------------------------------------------------------------
  * per-level top-k of P2PHead._get_bboxes_single (p2p_head.py:367-373): scores (n) -> k largest, sorted descending

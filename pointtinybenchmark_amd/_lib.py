@@ -17,6 +17,7 @@ _f = ctypes.c_float
 SIGNATURES = {
     'cpr_version': [],
     'cpr_conv2d_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'cpr_conv_force_tile': [_i, _i],
     'cpr_nchw_to_nhwc4': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_nhwc_to_nchw': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_maxpool3x3s2': [_p, _p, _i, _i, _i, _i, _p],
@@ -30,7 +31,7 @@ SIGNATURES = {
     'cpr_refine': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _i, _i, _p],
     'cpr_point_assign': [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p],
     'cpr_hungarian_cost': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p],
-    'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i] + [_p] * 15,
     'cpr_topk_desc': [_p, _i, _i, _p, _p, _p],
     'cpr_nms': [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
     'cpr_p2p_decode': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

@@ -142,32 +142,40 @@ extern "C" int cpr_hungarian_cost(const float* pred, int pred_stride, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
-// Rectangular linear sum assignment, shortest augmenting path (the algorithm scipy's
-// linear_sum_assignment implements: Crouse 2016), float64 duals like scipy, one workgroup per problem.
-// Rows of the LSA are the G gts, columns the M proposals (M >= G).  `topk` rounds: after each round the
-// matched proposals are retired and the problem is solved again on the rest (hungarian_assigner.py:248-268).
+// Rectangular linear sum assignment, shortest augmenting path with float64 duals: an operation-for-operation
+// parallelisation of scipy's linear_sum_assignment (rectangular_lsap.cpp, Crouse 2016), INCLUDING its tie-breaking.
+// The L1 distance term makes exactly tied optima common (swapping two matches often leaves the total unchanged), so
+// matching scipy's indices needs its scan order: columns are visited in the order of its `remaining` array
+// (initialised nc-1..0, swap-with-last on removal); among equal shortest-path values the LAST unassigned column in scan
+// order wins, otherwise the FIRST assigned one.  `remaining` / `pos` reproduce that order; the parallel arg-min carries
+// (value, unassigned, scan position).  One workgroup per problem.  Rows are the G gts, columns the M proposals (M >= G).
+// `topk` rounds: matched proposals are retired and the problem is re-solved on the order-preserving compaction of the
+// rest, exactly as ``cost[cost_assign == 0]`` does (hungarian_assigner.py:248-268).
 struct ArgD {
     double v;
-    int unassigned;  // scipy prefers an unassigned column among equal shortest paths
-    int j;
+    int unassigned;
+    int it;  // position in scipy's `remaining` array
+    int c;   // compact column id
 };
 __device__ __forceinline__ ArgD argd_min(ArgD a, ArgD b) {
     if (b.v < a.v) return b;
     if (b.v > a.v) return a;
     if (b.unassigned != a.unassigned) return b.unassigned > a.unassigned ? b : a;
-    return b.j < a.j ? b : a;
+    if (a.unassigned) return b.it > a.it ? b : a;  // last unassigned in scan order
+    return b.it < a.it ? b : a;                    // first assigned in scan order
 }
 
-__global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* __restrict__ m_of, const int* __restrict__ g_of,
-                                const long long* __restrict__ cost_off, const long long* __restrict__ col_off,
-                                const long long* __restrict__ row_off, int topk, long long* __restrict__ gt_inds_all,
-                                double* __restrict__ v_all, double* __restrict__ spc_all, int* __restrict__ path_all,
-                                int* __restrict__ row4col_all, unsigned char* __restrict__ sc_all,
-                                unsigned char* __restrict__ active_all, double* __restrict__ u_all,
-                                int* __restrict__ col4row_all, unsigned char* __restrict__ sr_all,
-                                int* __restrict__ status) {
+__global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* __restrict__ m_of,
+                                const int* __restrict__ g_of, const long long* __restrict__ cost_off,
+                                const long long* __restrict__ col_off, const long long* __restrict__ row_off, int topk,
+                                long long* __restrict__ gt_inds_all, double* __restrict__ v_all,
+                                double* __restrict__ spc_all, int* __restrict__ path_all, int* __restrict__ row4col_all,
+                                unsigned char* __restrict__ sc_all, unsigned char* __restrict__ active_all,
+                                int* __restrict__ cols_all, int* __restrict__ remaining_all, int* __restrict__ pos_all,
+                                double* __restrict__ u_all, int* __restrict__ col4row_all,
+                                unsigned char* __restrict__ sr_all, int* __restrict__ status) {
     __shared__ ArgD sh[16];
-    __shared__ int s_i, s_sink, s_j, s_fail, s_nactive;
+    __shared__ int s_i, s_sink, s_fail, s_nact, s_nrem, s_base, s_wcnt[16];
     __shared__ double s_minval;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int M = m_of[b], G = g_of[b];
@@ -179,61 +187,98 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
     int* row4col = row4col_all + col_off[b];
     unsigned char* SC = sc_all + col_off[b];
     unsigned char* active = active_all + col_off[b];
+    int* cols = cols_all + col_off[b];
+    int* remaining = remaining_all + col_off[b];
+    int* pos = pos_all + col_off[b];
     double* u = u_all + row_off[b];
     int* col4row = col4row_all + row_off[b];
     unsigned char* SR = sr_all + row_off[b];
 
     for (int j = tid; j < M; j += nt) { gt_inds[j] = 0; active[j] = 1; }
-    if (tid == 0) { s_fail = 0; s_nactive = M; }
+    if (tid == 0) s_fail = 0;
     __syncthreads();
     if (G == 0 || M == 0) return;
 
     for (int round = 0; round < topk; ++round) {
-        if (s_nactive / G == 0) break;  // cost_new.shape[0] // num_gts != 0
-        for (int j = tid; j < M; j += nt) { v[j] = 0.0; row4col[j] = -1; }
+        // ordered compaction of the still-active proposals: cols[c] = original index of the c-th active one
+        if (tid == 0) s_base = 0;
+        __syncthreads();
+        for (int base = 0; base < M; base += nt) {
+            const int j = base + tid;
+            const bool a = j < M && active[j];
+            const unsigned long long bal = __ballot(a);
+            const int lane = tid & 63, w = tid >> 6;
+            if (lane == 0) s_wcnt[w] = __popcll(bal);
+            __syncthreads();
+            int off = s_base;
+            for (int q = 0; q < w; ++q) off += s_wcnt[q];
+            if (a) cols[off + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int q = 0; q < (nt >> 6); ++q) tot += s_wcnt[q];
+                s_base += tot;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_nact = s_base;
+        __syncthreads();
+        const int Mc = s_nact;
+        if (Mc / G == 0) break;  // cost_new.shape[0] // num_gts != 0
+        for (int c = tid; c < Mc; c += nt) { v[c] = 0.0; row4col[c] = -1; }
         for (int i = tid; i < G; i += nt) { u[i] = 0.0; col4row[i] = -1; }
         __syncthreads();
         for (int cur = 0; cur < G; ++cur) {
-            for (int j = tid; j < M; j += nt) { spc[j] = INFINITY; SC[j] = active[j] ? 0 : 1; path[j] = -1; }
+            for (int c = tid; c < Mc; c += nt) {
+                spc[c] = INFINITY; SC[c] = 0; path[c] = -1;
+                remaining[c] = Mc - 1 - c;  // remaining[it] = nc - it - 1
+                pos[c] = Mc - 1 - c;
+            }
             for (int i = tid; i < G; i += nt) SR[i] = 0;
-            if (tid == 0) { s_i = cur; s_sink = -1; s_minval = 0.0; }
+            if (tid == 0) { s_i = cur; s_sink = -1; s_minval = 0.0; s_nrem = Mc; }
             __syncthreads();
             while (true) {
                 const int i = s_i;
                 const double minval = s_minval, ui = u[i];
+                const float* crow = costT + (size_t)i * M;
                 ArgD best;
-                best.v = INFINITY; best.unassigned = 0; best.j = INT_MAX;
-                for (int j = tid; j < M; j += nt) {
-                    if (SC[j]) continue;
-                    const double r = minval + (double)costT[(size_t)i * M + j] - ui - v[j];
-                    double s = spc[j];
-                    if (r < s) { path[j] = i; spc[j] = r; s = r; }
-                    ArgD c;
-                    c.v = s; c.unassigned = (row4col[j] == -1) ? 1 : 0; c.j = j;
-                    best = argd_min(best, c);
+                best.v = INFINITY; best.unassigned = 0; best.it = INT_MAX; best.c = -1;
+                for (int c = tid; c < Mc; c += nt) {
+                    if (SC[c]) continue;
+                    const double r = ((minval + (double)crow[cols[c]]) - ui) - v[c];
+                    double s = spc[c];
+                    if (r < s) { path[c] = i; spc[c] = r; s = r; }
+                    ArgD x;
+                    x.v = s; x.unassigned = (row4col[c] == -1) ? 1 : 0; x.it = pos[c]; x.c = c;
+                    best = (best.c < 0) ? x : argd_min(best, x);
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     ArgD y;
                     y.v = __shfl_xor(best.v, o, 64);
                     y.unassigned = __shfl_xor(best.unassigned, o, 64);
-                    y.j = __shfl_xor(best.j, o, 64);
-                    best = argd_min(best, y);
+                    y.it = __shfl_xor(best.it, o, 64);
+                    y.c = __shfl_xor(best.c, o, 64);
+                    if (y.c >= 0) best = (best.c < 0) ? y : argd_min(best, y);
                 }
                 __syncthreads();
                 if ((tid & 63) == 0) sh[tid >> 6] = best;
                 __syncthreads();
                 if (tid == 0) {
                     ArgD r = sh[0];
-                    for (int w = 1; w < (nt + 63) / 64; ++w) r = argd_min(r, sh[w]);
+                    for (int w = 1; w < (nt + 63) / 64; ++w)
+                        if (sh[w].c >= 0) r = (r.c < 0) ? sh[w] : argd_min(r, sh[w]);
                     SR[i] = 1;
-                    if (r.j == INT_MAX || r.v == INFINITY) {
+                    if (r.c < 0 || r.v == INFINITY) {
                         s_fail = 1; s_sink = -2;
                     } else {
                         s_minval = r.v;
-                        s_j = r.j;
-                        SC[r.j] = 1;
-                        if (row4col[r.j] == -1) s_sink = r.j; else s_i = row4col[r.j];
+                        SC[r.c] = 1;
+                        const int idx = pos[r.c], last = remaining[s_nrem - 1];  // remaining[index] = remaining[--n]
+                        remaining[idx] = last;
+                        pos[last] = idx;
+                        s_nrem -= 1;
+                        if (row4col[r.c] == -1) s_sink = r.c; else s_i = row4col[r.c];
                     }
                 }
                 __syncthreads();
@@ -241,14 +286,13 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
             }
             if (s_fail) break;
             const double minval = s_minval;
-            // dual updates (rows in SR other than cur use their matched column's path cost)
             for (int i = tid; i < G; i += nt) {
                 if (i == cur) u[i] += minval;
                 else if (SR[i]) u[i] += minval - spc[col4row[i]];
             }
             __syncthreads();
-            for (int j = tid; j < M; j += nt)
-                if (SC[j] && active[j]) v[j] -= minval - spc[j];
+            for (int c = tid; c < Mc; c += nt)
+                if (SC[c]) v[c] -= minval - spc[c];
             __syncthreads();
             if (tid == 0) {  // augment along the path
                 int j = s_sink;
@@ -265,12 +309,10 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
         }
         if (s_fail) break;
         for (int i = tid; i < G; i += nt) {
-            const int j = col4row[i];
+            const int j = cols[col4row[i]];
             gt_inds[j] = i + 1;
             active[j] = 0;
         }
-        __syncthreads();
-        if (tid == 0) s_nactive -= G;
         __syncthreads();
     }
     if (tid == 0 && status) status[b] = s_fail;
@@ -279,15 +321,16 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
 extern "C" int cpr_lsa_topk(const float* costT, const int* m_of, const int* g_of, const long long* cost_off,
                             const long long* col_off, const long long* row_off, int num_problems, int topk,
                             long long* gt_inds, double* ws_v, double* ws_spc, int* ws_path, int* ws_row4col,
-                            unsigned char* ws_sc, unsigned char* ws_active, double* ws_u, int* ws_col4row,
-                            unsigned char* ws_sr, int* status, hipStream_t stream) {
+                            unsigned char* ws_sc, unsigned char* ws_active, int* ws_cols, int* ws_remaining,
+                            int* ws_pos, double* ws_u, int* ws_col4row, unsigned char* ws_sr, int* status,
+                            hipStream_t stream) {
     CPR_CHECK_ARG(num_problems >= 0 && topk >= 1);
     if (num_problems == 0) return CPR_OK;
     CPR_CHECK_ARG(costT && m_of && g_of && cost_off && col_off && row_off && gt_inds && ws_v && ws_spc && ws_path &&
-                  ws_row4col && ws_sc && ws_active && ws_u && ws_col4row && ws_sr);
+                  ws_row4col && ws_sc && ws_active && ws_cols && ws_remaining && ws_pos && ws_u && ws_col4row && ws_sr);
     hipLaunchKernelGGL(lsa_topk_kernel, dim3(num_problems), dim3(1024), 0, stream, costT, m_of, g_of, cost_off,
-                       col_off, row_off, topk, gt_inds, ws_v, ws_spc, ws_path, ws_row4col, ws_sc, ws_active, ws_u,
-                       ws_col4row, ws_sr, status);
+                       col_off, row_off, topk, gt_inds, ws_v, ws_spc, ws_path, ws_row4col, ws_sc, ws_active, ws_cols,
+                       ws_remaining, ws_pos, ws_u, ws_col4row, ws_sr, status);
     CPR_LAUNCH_STATUS();
 }
 

@@ -39,15 +39,18 @@ struct ConvParams {
     int tilesM, tilesN;
 };
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDSW = 36;  // padded row (floats)
 
-template <int BN, int MODE>  // MODE 0: Cin % 32 == 0 ; MODE 1: Cin == 4 (stem, one tap per float4)
+// BM x BN output tile (BM, BN in {64, 128}); MODE 0: Cin % 32 == 0, MODE 1: Cin == 4 (stem, one tap per float4);
+// XF: fused per-(image, channel) affine (+ReLU) on the input = GroupNorm-apply of the producing layer.
+template <int BM, int BN, int MODE, bool XF>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
+    constexpr int WM = BM / 2;
     constexpr int WN = BN / 2;
+    constexpr int MI = WM / 32;
     constexpr int NI = WN / 32;
-    constexpr int MI = 2;
+    constexpr int AL = BM * 8 / 256;  // float4 A loads per thread
     constexpr int BL = BN * 8 / 256;  // float4 B loads per thread
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDSW];
     float* As = smem;
@@ -65,12 +68,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;
 
-    // ---- per-thread A row descriptors (4 rows: r0 + 32 j)
-    int iy0[4], ix0[4], nimg[4];
-    bool mok[4];
+    // ---- per-thread A row descriptors (AL rows: r0 + 32 j)
+    int iy0[AL], ix0[AL], nimg[AL];
+    bool mok[AL];
     const int ohw = p.OH * p.OW;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AL; ++j) {
         int m = m0 + r0 + 32 * j;
         mok[j] = m < p.M;
         int mm = mok[j] ? m : 0;
@@ -91,10 +94,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         wrow[j] = p.wgt + (size_t)(wok[j] ? c : 0) * p.Kpad + c4 * 4;
     }
 
-    f32x4 ra[4], rb[BL], xa, xb;
+    f32x4 ra[AL], rb[BL], xa, xb;
     unsigned okmask = 0;         // bit j: row j of the tile in flight is a real (not padded) pixel
     int kh = 0, kw = 0, c0 = 0;  // MODE 0 running tap state
-    const bool xform = p.in_a != nullptr;  // host guarantees OH*OW % BM == 0 then: one image per M-tile
+    constexpr bool xform = XF;   // host guarantees OH*OW % BM == 0 then: one image per M-tile
     const int nblk = (m0 < p.M ? m0 : 0) / ohw;
 
     // Loads are issued raw (from clamped, always-valid addresses) and stay in flight during the MFMA phase;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         okmask = 0;
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < AL; ++j) {
                 const int iy = iy0[j] + kh, ix = ix0[j] + kw;
                 const bool ok = mok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 okmask |= (ok ? 1u : 0u) << j;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             const int th = tap / p.KW, tw = tap - th * p.KW;
             const bool tok = tap < p.KH * p.KW;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < AL; ++j) {
                 const int iy = iy0[j] + th, ix = ix0[j] + tw;
                 const bool ok = tok && mok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 okmask |= (ok ? 1u : 0u) << j;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         float* b = Bs + buf * BN * LDSW;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < AL; ++j) {
             f32x4 v = ra[j];
             if (MODE == 0 && xform) {
                 v = v * xa + xb;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int wm = wave & 1, wn = wave >> 1;
-    const int arow = wm * 64 + (lane & 31);
+    const int arow = wm * WM + (lane & 31);
     const int brow = wn * WN + (lane & 31);
     const int koff = 4 * (lane >> 5);
 
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         float gsum = 0.f, gsq = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * half;
+            const int rbase = m0 + wm * WM + i * 32 + 4 * half;
             float res[16];
             if (p.residual) {
 #pragma unroll
@@ -260,6 +263,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 }
 
 // C-ABI ------------------------------------------------------------------------------------------
+static int force_tile_bm = 0, force_tile_bn = 0;  // test/bench hook (cpr_conv_force_tile), 0 = heuristic
+extern "C" int cpr_conv_force_tile(int bm, int bn) {
+    CPR_CHECK_ARG((bm == 0 || bm == 64 || bm == 128) && (bn == 0 || bn == 64 || bn == 128));
+    force_tile_bm = bm;
+    force_tile_bn = bn;
+    return CPR_OK;
+}
+
 extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
                               const float* residual, const float* in_a, const float* in_b, float* gn_part, int N,
                               int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad,
@@ -284,19 +295,33 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     } else {
         CPR_CHECK_ARG(Kpad >= KH * KW * 4 && in_a == nullptr);
     }
-    const int bn = (Cout <= 64) ? 64 : 128;
-    p.tilesM = (p.M + BM - 1) / BM;
+    if (gn_part || in_a) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
+    if (in_a) CPR_CHECK_ARG(in_b && p.OH == H && p.OW == W);
+    // tile selection: 128x128 when it fills the chip (>= one round of 2 blocks/CU); smaller tiles for the small-M
+    // deep layers so that 256 CUs all get work; GN-fused launches keep 128-pixel tiles (one stats slot per tile).
+    int bm = 128, bn = (Cout <= 64) ? 64 : 128;
+    auto ntiles = [&](int a, int b) { return (long long)((p.M + a - 1) / a) * ((Cout + b - 1) / b); };
+    if (!gn_part && !in_a && !mode1) {
+        if (ntiles(bm, bn) < 512) bm = 64;
+        if (ntiles(bm, bn) < 384 && bn == 128) bn = 64;
+    }
+    if (force_tile_bm > 0 && !gn_part && !in_a && !mode1) { bm = force_tile_bm; }
+    if (force_tile_bn > 0 && Cout > 64 && !mode1) { bn = force_tile_bn; }
+    p.tilesM = (p.M + bm - 1) / bm;
     p.tilesN = (Cout + bn - 1) / bn;
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
-    if (gn_part || in_a) CPR_CHECK_ARG((p.OH * p.OW) % BM == 0);
-    if (in_a) CPR_CHECK_ARG(in_b && p.OH == H && p.OW == W);
-    if (bn == 64) {
-        if (mode1) hipLaunchKernelGGL((conv_mfma_kernel<64, 1>), dim3(grid), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_mfma_kernel<64, 0>), dim3(grid), dim3(256), 0, stream, p);
+#define LAUNCH(BM_, BN_, MODE_, XF_) \
+    hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_>), dim3(grid), dim3(256), 0, stream, p)
+    if (mode1) {
+        if (bn == 64) LAUNCH(128, 64, 1, false); else LAUNCH(128, 128, 1, false);
+    } else if (in_a) {
+        if (bn == 64) LAUNCH(128, 64, 0, true); else LAUNCH(128, 128, 0, true);
+    } else if (bm == 128) {
+        if (bn == 64) LAUNCH(128, 64, 0, false); else LAUNCH(128, 128, 0, false);
     } else {
-        if (mode1) hipLaunchKernelGGL((conv_mfma_kernel<128, 1>), dim3(grid), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_mfma_kernel<128, 0>), dim3(grid), dim3(256), 0, stream, p);
+        if (bn == 64) LAUNCH(64, 64, 0, false); else LAUNCH(64, 128, 0, false);
     }
+#undef LAUNCH
     CPR_LAUNCH_STATUS();
 }

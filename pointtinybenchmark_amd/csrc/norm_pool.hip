@@ -138,49 +138,44 @@ extern "C" int cpr_gn_stats(const float* x, float* part, int N, int HW, int C, i
     CPR_LAUNCH_STATUS();
 }
 
-// stage 2: one block per image; thread c reduces its channel over the P slots in double, groups are
-// combined through LDS, and the per (image, channel) affine of torch's GroupNorm is emitted:
-//   a = rstd*gamma, b = beta - mean*a      (y = x*a + b)
+// stage 2: one block per (image, group): 256 threads reduce the group's P x cpg partials in double, then emit the
+// per (image, channel) affine of torch's GroupNorm:  a = rstd*gamma, b = beta - mean*a   (y = x*a + b)
 __global__ void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ a_out,
                                    float* __restrict__ b_out, float* __restrict__ mean_out,
                                    float* __restrict__ rstd_out, int P, int C, int G, double count, float eps) {
-    extern __shared__ double sh[];  // [C][2] then [G][2]
-    const int n = blockIdx.x;
+    __shared__ double red[2][4];
+    __shared__ double s_mean, s_rstd;
+    const int n = blockIdx.y, g = blockIdx.x;
     const int cpg = C / G;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0, q = 0;
-        for (int t = 0; t < P; ++t) {
-            const float* src = part + (((size_t)n * P + t) * C + c) * 2;
-            s += (double)src[0];
-            q += (double)src[1];
-        }
-        sh[c * 2] = s;
-        sh[c * 2 + 1] = q;
+    double s = 0, q = 0;
+    for (int i = threadIdx.x; i < P * cpg; i += blockDim.x) {
+        const int t = i / cpg, k = i - t * cpg;
+        const float* src = part + (((size_t)n * P + t) * C + g * cpg + k) * 2;
+        s += (double)src[0];
+        q += (double)src[1];
     }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
     __syncthreads();
-    double* gs = sh + 2 * C;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        double s = 0, q = 0;
-        for (int k = 0; k < cpg; ++k) {
-            s += sh[(g * cpg + k) * 2];
-            q += sh[(g * cpg + k) * 2 + 1];
-        }
-        const double mean = s / count;
-        double var = q / count - mean * mean;
+    if (threadIdx.x == 0) {
+        const double ts = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const double tq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double mean = ts / count;
+        double var = tq / count - mean * mean;
         if (var < 0) var = 0;
-        gs[g * 2] = mean;
-        gs[g * 2 + 1] = 1.0 / sqrt(var + (double)eps);
+        s_mean = mean;
+        s_rstd = 1.0 / sqrt(var + (double)eps);
         if (mean_out) mean_out[n * G + g] = (float)mean;
-        if (rstd_out) rstd_out[n * G + g] = (float)gs[g * 2 + 1];
+        if (rstd_out) rstd_out[n * G + g] = (float)s_rstd;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
-        const float mean = (float)gs[g * 2], rstd = (float)gs[g * 2 + 1];
-        const float a = rstd * gamma[c];
+    if (threadIdx.x < cpg) {
+        const int c = g * cpg + threadIdx.x;
+        const float a = (float)s_rstd * gamma[c];
         a_out[n * C + c] = a;
-        b_out[n * C + c] = beta[c] - mean * a;
+        b_out[n * C + c] = beta[c] - (float)s_mean * a;
     }
 }
 
@@ -188,10 +183,9 @@ extern "C" int cpr_gn_finalize(const float* part, const float* gamma, const floa
                                float* mean_out, float* rstd_out, int N, int P, int C, int G, int HW, float eps,
                                hipStream_t stream) {
     CPR_CHECK_ARG(part && gamma && beta && a_out && b_out && N > 0 && P > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0);
-    const size_t shmem = (size_t)(2 * C + 2 * G) * sizeof(double);
-    CPR_CHECK_ARG(shmem <= 60000);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), shmem, stream, part, gamma, beta, a_out, b_out,
-                       mean_out, rstd_out, P, C, G, (double)HW * (C / G), eps);
+    CPR_CHECK_ARG(C / G <= 256);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(256), 0, stream, part, gamma, beta, a_out, b_out, mean_out,
+                       rstd_out, P, C, G, (double)HW * (C / G), eps);
     CPR_LAUNCH_STATUS();
 }
 

@@ -267,14 +267,15 @@ def lsa_topk(costT_list, topk):
     ws_r4c = torch.empty((tm,), device=dev, dtype=torch.int32)
     ws_sc = torch.empty((tm,), device=dev, dtype=torch.uint8)
     ws_act = torch.empty((tm,), device=dev, dtype=torch.uint8)
+    ws_cols = torch.empty((3, tm), device=dev, dtype=torch.int32)   # cols / remaining / pos
     ws_u = torch.empty((tg,), device=dev, dtype=torch.float64)
     ws_c4r = torch.empty((tg,), device=dev, dtype=torch.int32)
     ws_sr = torch.empty((tg,), device=dev, dtype=torch.uint8)
     status = torch.zeros((nb,), device=dev, dtype=torch.int32)
     _lib.call('cpr_lsa_topk', _ptr(flat), _ptr(t_m), _ptr(t_g), _ptr(t_off[0]), _ptr(t_off[1]), _ptr(t_off[2]), nb,
               int(topk), _ptr(gt_inds), _ptr(ws_v), _ptr(ws_spc),
-              _ptr(ws_path), _ptr(ws_r4c), _ptr(ws_sc), _ptr(ws_act), _ptr(ws_u), _ptr(ws_c4r), _ptr(ws_sr),
-              _ptr(status), _stream())
+              _ptr(ws_path), _ptr(ws_r4c), _ptr(ws_sc), _ptr(ws_act), _ptr(ws_cols[0]), _ptr(ws_cols[1]),
+              _ptr(ws_cols[2]), _ptr(ws_u), _ptr(ws_c4r), _ptr(ws_sr), _ptr(status), _stream())
     return [gt_inds[col_off[i]:col_off[i + 1]] for i in range(nb)], status
 
 

@@ -71,6 +71,34 @@ def test_hungarian_v2_vs_oracle_seeds(seed):
     assert nbad == 0, '%d of %d indices differ from scipy' % (nbad, got.numel())
 
 
+@pytest.mark.parametrize('case', range(5))
+def test_device_lsa_reproduces_scipy_on_identical_costs(golden_dir, case):
+    """Same fp32 cost matrix in -> bit-identical indices out, INCLUDING exactly tied optima (the L1 distance cost
+    makes them common): the kernel follows scipy's scan order and tie rules."""
+    from pointtinybenchmark_amd import ops
+    g = np.load(os.path.join(golden_dir, 'assigners.npz'))
+    n_side, G, C, k = [int(v) for v in g['ha%d_cfg' % case]]
+    pred, logits, gt, labels, shp = assigner_inputs(200 + case, n_side, 4, G, C)
+    inds, lab, cost = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=k)
+    (got,), status = ops.lsa_topk([cost.t().contiguous().cuda()], k)
+    assert int(status[0]) == 0
+    assert np.array_equal(got.cpu().numpy(), g['ha%d_gt_inds' % case])
+    assert torch.equal(got.cpu(), inds)
+
+
+def test_device_lsa_batched_problems():
+    from pointtinybenchmark_amd import ops
+    costs, refs = [], []
+    for seed, (n_side, G, k) in enumerate([(20, 9, 3), (33, 40, 3), (16, 5, 3)]):
+        pred, logits, gt, labels, shp = assigner_inputs(700 + seed, n_side, 4, G, 1)
+        inds, _, cost = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=3)
+        costs.append(cost.t().contiguous().cuda())
+        refs.append(inds)
+    outs, status = ops.lsa_topk(costs, 3)
+    for o, r in zip(outs, refs):
+        assert torch.equal(o.cpu(), r)
+
+
 def test_hungarian_edge_cases():
     ha = _ha(5)
     pred, logits, gt, labels, shp = assigner_inputs(1, 8, 4, 3, 1)

@@ -1,0 +1,45 @@
+"""Runs one conv shape repeatedly (for rocprofv3 --pmc passes).  Default: the CPR head's 3x3 256->256 conv on a
+(B,160,160,256) map with the fused GN-apply input and GN-stats epilogue, exactly as the forward launches it."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointtinybenchmark_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=8)
+ap.add_argument('--hw', type=int, default=160)
+ap.add_argument('--cin', type=int, default=256)
+ap.add_argument('--cout', type=int, default=256)
+ap.add_argument('--k', type=int, default=3)
+ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--plain', action='store_true')
+args = ap.parse_args()
+g = torch.Generator().manual_seed(0)
+x = torch.randn((args.batch, args.hw, args.hw, args.cin), generator=g).cuda()
+w = (torch.randn((args.cout, args.cin, args.k, args.k), generator=g) * 0.02).cuda()
+pc = ops.PackedConv(w, 1, args.k // 2)
+a = (torch.rand((args.batch, args.cin), generator=g) + 0.5).cuda()
+b = torch.randn((args.batch, args.cin), generator=g).cuda()
+for _ in range(args.iters):
+    if args.plain:
+        ops.conv2d(x, pc)
+    else:
+        ops.conv2d(x, pc, in_ab=(a, b), in_relu=True, gn_part=True)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(args.iters):
+    if args.plain:
+        ops.conv2d(x, pc)
+    else:
+        ops.conv2d(x, pc, in_ab=(a, b), in_relu=True, gn_part=True)
+e.record()
+torch.cuda.synchronize()
+ms = s.elapsed_time(e) / args.iters
+fl = 2.0 * args.batch * args.hw * args.hw * args.cout * args.cin * args.k * args.k
+print('conv %dx%d %d->%d k%d B=%d: %.3f ms  %.1f TFLOP/s' % (args.hw, args.hw, args.cin, args.cout, args.k, args.batch,
+                                                              ms, fl / ms / 1e9))
