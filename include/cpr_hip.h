@@ -38,6 +38,8 @@ int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* s
 
 /* test / benchmark hook: force the conv output tile (bm, bn in {0 = heuristic, 64, 128}) */
 int cpr_conv_force_tile(int bm, int bn);
+/* K-loop schedule: 1 = interleaved (default), 0 = phase-separated (kept for A/B measurements) */
+int cpr_conv_set_pipeline(int mode);
 
 /* network input (N,C<=4,H,W) NCHW -> (N,H,W,4) NHWC, missing channels zero */
 int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, void* stream);

@@ -44,7 +44,7 @@ constexpr int LDSW = 36;  // padded row (floats)
 
 // BM x BN output tile (BM, BN in {64, 128}); MODE 0: Cin % 32 == 0, MODE 1: Cin == 4 (stem, one tap per float4);
 // XF: fused per-(image, channel) affine (+ReLU) on the input = GroupNorm-apply of the producing layer.
-template <int BM, int BN, int MODE, bool XF>
+template <int BM, int BN, int MODE, bool XF, int PIPE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     constexpr int WM = BM / 2;
     constexpr int WN = BN / 2;
@@ -98,64 +98,80 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     unsigned okmask = 0;         // bit j: row j of the tile in flight is a real (not padded) pixel
     int kh = 0, kw = 0, c0 = 0;  // MODE 0 running tap state
     constexpr bool xform = XF;   // host guarantees OH*OW % BM == 0 then: one image per M-tile
+    const float relu_floor = p.in_relu ? 0.f : -INFINITY;
     const int nblk = (m0 < p.M ? m0 : 0) / ohw;
 
     // Loads are issued raw (from clamped, always-valid addresses) and stay in flight during the MFMA phase;
     // zero padding and the fused GN-apply+ReLU are applied when the registers are written to LDS.
-    auto load_tile = [&](int kt) {
-        okmask = 0;
+    // Everything is split into per-row "pieces" so the pipelined K loop can drop one piece behind each MFMA.
+    auto load_a = [&](int kt, int j) {
+        if (j == 0) okmask = 0;
+        int iy, ix;
+        bool tok = true;
         if (MODE == 0) {
-#pragma unroll
-            for (int j = 0; j < AL; ++j) {
-                const int iy = iy0[j] + kh, ix = ix0[j] + kw;
-                const bool ok = mok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                okmask |= (ok ? 1u : 0u) << j;
-                const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-                const float* src = p.in + ((size_t)(nimg[j] * p.H + iyc) * p.W + ixc) * p.Cin + c0 + c4 * 4;
-                ra[j] = *reinterpret_cast<const f32x4*>(src);
-            }
+            iy = iy0[j] + kh;
+            ix = ix0[j] + kw;
+        } else {
+            const int tap = kt * 8 + c4;
+            const int th = tap / p.KW, tw = tap - th * p.KW;
+            tok = tap < p.KH * p.KW;
+            iy = iy0[j] + th;
+            ix = ix0[j] + tw;
+        }
+        const bool ok = tok && mok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        okmask |= (ok ? 1u : 0u) << j;
+        const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+        const size_t pix = (size_t)(nimg[j] * p.H + iyc) * p.W + ixc;
+        const float* src = (MODE == 0) ? p.in + pix * p.Cin + c0 + c4 * 4 : p.in + pix * 4;
+        ra[j] = *reinterpret_cast<const f32x4*>(src);
+    };
+    auto load_x_advance = [&]() {  // after the last A row of a tile: GN affine of this K-chunk, then next tap
+        if (MODE == 0) {
             if (xform) {
                 const int ci = nblk * p.Cin + c0 + c4 * 4;
                 xa = *reinterpret_cast<const f32x4*>(p.in_a + ci);
                 xb = *reinterpret_cast<const f32x4*>(p.in_b + ci);
             }
+            // branch-free running tap state (keeps the K loop body one basic block)
             c0 += BK;
-            if (c0 == p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
-        } else {
-            const int tap = kt * 8 + c4;
-            const int th = tap / p.KW, tw = tap - th * p.KW;
-            const bool tok = tap < p.KH * p.KW;
-#pragma unroll
-            for (int j = 0; j < AL; ++j) {
-                const int iy = iy0[j] + th, ix = ix0[j] + tw;
-                const bool ok = tok && mok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                okmask |= (ok ? 1u : 0u) << j;
-                const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-                ra[j] = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(nimg[j] * p.H + iyc) * p.W + ixc) * 4);
-            }
+            const int wrap_c = (c0 == p.Cin) ? 1 : 0;
+            c0 = wrap_c ? 0 : c0;
+            kw += wrap_c;
+            const int wrap_w = (kw == p.KW) ? 1 : 0;
+            kw = wrap_w ? 0 : kw;
+            kh += wrap_w;
         }
+    };
+    const int kt_last = p.Kpad / BK - 1;
+    auto load_b = [&](int kt, int j) {  // tile indices past the end are clamped (the pipeline prefetches 2 ahead)
+        rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + min(kt, kt_last) * BK);
+    };
+    auto store_a = [&](int buf, int j) {
+        f32x4 v = ra[j];
+        if (MODE == 0 && xform) {
+            v = v * xa + xb;
+            v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
+            v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+        }
+        if (!((okmask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(As + buf * BM * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) = v;
+    };
+    auto store_b = [&](int buf, int j) {
+        *reinterpret_cast<f32x4*>(Bs + buf * BN * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) =
+            wok[j] ? rb[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto load_tile = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < BL; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + kt * BK);
+        for (int j = 0; j < AL; ++j) load_a(kt, j);
+        load_x_advance();
+#pragma unroll
+        for (int j = 0; j < BL; ++j) load_b(kt, j);
     };
     auto store_tile = [&](int buf) {
-        float* a = As + buf * BM * LDSW;
-        float* b = Bs + buf * BN * LDSW;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < AL; ++j) {
-            f32x4 v = ra[j];
-            if (MODE == 0 && xform) {
-                v = v * xa + xb;
-                if (p.in_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-            }
-            if (!((okmask >> j) & 1u)) v = zero;
-            *reinterpret_cast<f32x4*>(a + (r0 + 32 * j) * LDSW + c4 * 4) = v;
-        }
+        for (int j = 0; j < AL; ++j) store_a(buf, j);
 #pragma unroll
-        for (int j = 0; j < BL; ++j)
-            *reinterpret_cast<f32x4*>(b + (r0 + 32 * j) * LDSW + c4 * 4) = wok[j] ? rb[j] : zero;
+        for (int j = 0; j < BL; ++j) store_b(buf, j);
     };
 
     f32x16 acc[MI][NI];
@@ -172,31 +188,123 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     const int koff = 4 * (lane >> 5);
 
     const int KT = p.Kpad / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
-        const float* a = As + buf * BM * LDSW + arow * LDSW + koff;
-        const float* b = Bs + buf * BN * LDSW + brow * LDSW + koff;
+    const float* a_lds = As + arow * LDSW + koff;
+    const float* b_lds = Bs + brow * LDSW + koff;
+    auto read_frags = [&](int buf, int kk, f32x4 (&fa)[MI], f32x4 (&fb)[NI]) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 fa[MI], fb[NI];
+        for (int i = 0; i < MI; ++i)
+            fa[i] = *reinterpret_cast<const f32x4*>(a_lds + buf * BM * LDSW + i * 32 * LDSW + kk * 8);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDSW + kk * 8);
+        for (int j = 0; j < NI; ++j)
+            fb[j] = *reinterpret_cast<const f32x4*>(b_lds + buf * BN * LDSW + j * 32 * LDSW + kk * 8);
+    };
+    auto mfma_group = [&](const f32x4 (&fa)[MI], const f32x4 (&fb)[NI]) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDSW + kk * 8);
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < KT) store_tile(buf ^ 1);
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    };
+
+    if (PIPE == 0) {
+        // phase-separated schedule: [issue loads t+1] [MFMAs of t] [write t+1] barrier
+        load_tile(0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < KT) load_tile(kt + 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                f32x4 fa[MI], fb[NI];
+                read_frags(buf, kk, fa, fb);
+                mfma_group(fa, fb);
+            }
+            if (kt + 1 < KT) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // interleaved schedule: the two workgroups sharing a CU start together and run in lockstep, so a phase without
+        // MFMAs idles the matrix pipe for BOTH (PMC: MFMA busy 70 % with the phase-separated loop).  Here every
+        // non-MFMA instruction of an iteration sits in the shadow of that wave's own MFMAs:
+        //   kk0: MFMAs | prefetch frags kk1
+        //   kk1: MFMAs | prefetch frags kk2 | write tile t+1 (loaded during iteration t-1) to the other LDS buffer
+        //   kk2: MFMAs | prefetch frags kk3 | issue global loads of tile t+2
+        //   barrier (all reads of this buffer are complete, all writes of the other are visible)
+        //   kk3: MFMAs | prefetch frags kk0 of tile t+1
+        f32x4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+        load_tile(0);
+        store_tile(0);
+        load_tile(1);
+        __syncthreads();
+        read_frags(0, 0, fa0, fb0);
+        constexpr int NM = 4 * MI * NI;  // MFMAs (= slots) per k-group
+        constexpr int NF = MI + NI;      // fragment reads per k-group
+        // one MFMA of a k-group: slot q -> (t, i, j)
+#define MFMA_SLOT(FA, FB, q)                                                                                  \
+    acc[((q) / NI) % MI][(q) % NI] = __builtin_amdgcn_mfma_f32_32x32x2f32(                                  \
+        FA[((q) / NI) % MI][(q) / (MI * NI)], FB[(q) % NI][(q) / (MI * NI)], acc[((q) / NI) % MI][(q) % NI], 0, 0, 0)
+        // fragment-read piece z (0..NF-1) of k-step kk from LDS buffer `buf` into (FA, FB)
+#define FRAG_PIECE(FA, FB, buf, kk, z)                                                                        \
+    do {                                                                                                      \
+        if ((z) < MI)                                                                                         \
+            FA[(z) < MI ? (z) : 0] = *reinterpret_cast<const f32x4*>(a_lds + (buf) * BM * LDSW +              \
+                                                                     ((z) < MI ? (z) : 0) * 32 * LDSW + (kk) * 8); \
+        else                                                                                                  \
+            FB[(z) >= MI ? (z) - MI : 0] = *reinterpret_cast<const f32x4*>(                                   \
+                b_lds + (buf) * BN * LDSW + ((z) >= MI ? (z) - MI : 0) * 32 * LDSW + (kk) * 8);                \
+    } while (0)
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            // ---- k-step 0: MFMAs on (fa0, fb0) | prefetch k-step 1 fragments
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                MFMA_SLOT(fa0, fb0, q);
+#pragma unroll
+                for (int z = q; z < NF; z += NM) FRAG_PIECE(fa1, fb1, buf, 1, z);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- k-step 1: MFMAs on (fa1, fb1) | prefetch k-step 2 | write tile kt+1 into the other LDS buffer
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                MFMA_SLOT(fa1, fb1, q);
+#pragma unroll
+                for (int z = q; z < NF + AL + BL; z += NM) {
+                    if (z < NF) FRAG_PIECE(fa0, fb0, buf, 2, z);
+                    else if (z < NF + AL) store_a(buf ^ 1, z - NF < AL ? z - NF : 0);
+                    else store_b(buf ^ 1, z - NF - AL);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- k-step 2: MFMAs on (fa0, fb0) | prefetch k-step 3 | issue the global loads of tile kt+2
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                MFMA_SLOT(fa0, fb0, q);
+#pragma unroll
+                for (int z = q; z < NF + AL + 1 + BL; z += NM) {
+                    if (z < NF) FRAG_PIECE(fa1, fb1, buf, 3, z);
+                    else if (z < NF + AL) load_a(kt + 2, z - NF < AL ? z - NF : 0);
+                    else if (z == NF + AL) load_x_advance();
+                    else load_b(kt + 2, z - NF - AL - 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS reads/writes are done; loads stay in flight
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- k-step 3: MFMAs on (fa1, fb1) | prefetch k-step 0 of tile kt+1 (other buffer, now complete)
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                MFMA_SLOT(fa1, fb1, q);
+#pragma unroll
+                for (int z = q; z < NF; z += NM) FRAG_PIECE(fa0, fb0, buf ^ 1, 0, z);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef MFMA_SLOT
+#undef FRAG_PIECE
     }
 
     // ---- epilogue.  D layout: col j = lane&31 (cout), row i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).
@@ -264,6 +372,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 
 // C-ABI ------------------------------------------------------------------------------------------
 static int force_tile_bm = 0, force_tile_bn = 0;  // test/bench hook (cpr_conv_force_tile), 0 = heuristic
+static int conv_pipeline = 1;                      // 1 = interleaved K loop (default), 0 = phase-separated (A/B reference)
+extern "C" int cpr_conv_set_pipeline(int mode) {
+    CPR_CHECK_ARG(mode == 0 || mode == 1);
+    conv_pipeline = mode;
+    return CPR_OK;
+}
 extern "C" int cpr_conv_force_tile(int bm, int bn) {
     CPR_CHECK_ARG((bm == 0 || bm == 64 || bm == 128) && (bn == 0 || bn == 64 || bn == 128));
     force_tile_bm = bm;
@@ -311,8 +425,13 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     p.tilesN = (Cout + bn - 1) / bn;
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
-#define LAUNCH(BM_, BN_, MODE_, XF_) \
-    hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_>), dim3(grid), dim3(256), 0, stream, p)
+#define LAUNCH(BM_, BN_, MODE_, XF_)                                                                               \
+    do {                                                                                                           \
+        if (conv_pipeline == 0)                                                                                    \
+            hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 0>), dim3(grid), dim3(256), 0, stream, p); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 1>), dim3(grid), dim3(256), 0, stream, p); \
+    } while (0)
     if (mode1) {
         if (bn == 64) LAUNCH(128, 64, 1, false); else LAUNCH(128, 128, 1, false);
     } else if (in_a) {

@@ -19,7 +19,12 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--pipeline', type=int, default=1)
+    ap.add_argument('--tile', default='0,0')
     args = ap.parse_args()
+    from pointtinybenchmark_amd import _lib
+    _lib.call('cpr_conv_set_pipeline', args.pipeline)
+    _lib.call('cpr_conv_force_tile', *[int(v) for v in args.tile.split(',')])
     model = P.build_detector(bench.model_cfg()).cuda()
     model.load_state_dict(synthetic.locator_state_dict(50, 1, 0, 'cpr', 0), strict=True)
     batch = synthetic.synthetic_batch(args.batch, 640, 640, 32, 1, 0)

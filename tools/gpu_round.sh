@@ -16,6 +16,10 @@ echo "bench exit: $?"; cat gpurun_out/${TAG}_bench.json; tail -5 gpurun_out/${TA
 if [ "${CONVBENCH:-1}" = "1" ]; then
   timeout 300 python tools/conv_bench.py --batch ${BATCH:-16} --out gpurun_out/${TAG}_convbench.json > gpurun_out/${TAG}_convbench.txt 2>&1
   tail -45 gpurun_out/${TAG}_convbench.txt
+  if [ "${AB:-0}" = "1" ]; then
+    timeout 300 python tools/conv_bench.py --batch ${BATCH:-16} --pipeline 0 > gpurun_out/${TAG}_convbench_pipe0.txt 2>&1
+    tail -3 gpurun_out/${TAG}_convbench_pipe0.txt
+  fi
 fi
 if [ "${PMC:-0}" = "1" ]; then bash tools/gpu_pmc.sh ${TAG}; fi
 if [ "${PROFILE:-1}" = "1" ]; then
