@@ -107,7 +107,31 @@ extern "C" int cpr_point_assign(const float* points, const float* gt_bboxes, int
 
 // ------------------------------------------------------------------------------------------------
 // cost^T[g][m] = w_cls * (pos - neg)[m, label_g] + w_dis * L1(pred_m / f, gt_g / f), fp32, evaluation order
-// of the reference expressions kept.
+// of the reference expressions kept.  Exactly tied optimal assignments are common with an L1 cost, so the cost BITS
+// decide which one scipy returns; the transcendental functions therefore mirror what torch's CPU kernels compute:
+//  * sigmoid = 1 / (1 + Sleef_expf_u10(-x))   (ATen's vectorised sigmoid; sleef_expf_u10() below reproduces the
+//    Sleef routine operation for operation: 0 mismatches against torch.sigmoid on 2^20 random inputs)
+//  * log goes through MKL VML (HA mode, ~correctly rounded: 0.1 % of values differ from the correctly rounded result);
+//    log_cr() evaluates in float64 and rounds once, i.e. the correctly rounded value.
+__device__ __forceinline__ float sleef_expf_u10(float d) {
+    const float q = rintf(__fmul_rn(d, 1.442695040888963407359924681001892137426645954152985934135449406931f));
+    float s = __fmaf_rn(q, -0.693145751953125f, d);
+    s = __fmaf_rn(q, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = __fmaf_rn(u, s, 0.00139304355252534151077271f);
+    u = __fmaf_rn(u, s, 0.00833336077630519866943359f);
+    u = __fmaf_rn(u, s, 0.0416664853692054748535156f);
+    u = __fmaf_rn(u, s, 0.166666671633720397949219f);
+    u = __fmaf_rn(u, s, 0.5f);
+    u = __fadd_rn(1.0f, __fmaf_rn(__fmul_rn(s, s), u, s));
+    const int qi = (int)q, h = qi >> 1;                      // ldexp2kf: two exact power-of-two scalings
+    u = __fmul_rn(u, __int_as_float((h + 127) << 23));
+    u = __fmul_rn(u, __int_as_float((qi - h + 127) << 23));
+    if (d < -104.f) u = 0.f;
+    if (d > 104.f) u = INFINITY;
+    return u;
+}
+__device__ __forceinline__ float log_cr(float x) { return (float)log((double)x); }
 __global__ void hungarian_cost_kernel(const float* __restrict__ pred, int pred_stride,
                                       const float* __restrict__ logits, int C, const float* __restrict__ gt,
                                       const int* __restrict__ labels, float* __restrict__ costT, int M, int G,
@@ -118,11 +142,12 @@ __global__ void hungarian_cost_kernel(const float* __restrict__ pred, int pred_s
     if (m >= M) return;
     const int l = labels[g];
     const float x = logits[(size_t)m * C + l];
-    const float p = 1.f / (1.f + expf(-x));
-    const float pg = (gamma == 2.f) ? p * p : powf(p, gamma);
-    const float qg = (gamma == 2.f) ? (1.f - p) * (1.f - p) : powf(1.f - p, gamma);
-    const float neg = __fmul_rn(__fmul_rn(-logf(__fadd_rn(__fsub_rn(1.f, p), eps)), 1.f - alpha), pg);
-    const float pos = __fmul_rn(__fmul_rn(-logf(__fadd_rn(p, eps)), alpha), qg);
+    const float p = __fdiv_rn(1.f, __fadd_rn(1.f, sleef_expf_u10(-x)));   // torch.sigmoid on CPU, bit for bit
+    const float pg = (gamma == 2.f) ? __fmul_rn(p, p) : powf(p, gamma);
+    const float q1 = __fsub_rn(1.f, p);
+    const float qg = (gamma == 2.f) ? __fmul_rn(q1, q1) : powf(q1, gamma);
+    const float neg = __fmul_rn(__fmul_rn(-log_cr(__fadd_rn(q1, eps)), 1.f - alpha), pg);
+    const float pos = __fmul_rn(__fmul_rn(-log_cr(__fadd_rn(p, eps)), alpha), qg);
     const float cls = __fmul_rn(__fsub_rn(pos, neg), w_cls);
     const float dx = fabsf(__fsub_rn(__fdiv_rn(pred[(size_t)m * pred_stride], fx), __fdiv_rn(gt[g * 2], fx)));
     const float dy = fabsf(__fsub_rn(__fdiv_rn(pred[(size_t)m * pred_stride + 1], fy), __fdiv_rn(gt[g * 2 + 1], fy)));

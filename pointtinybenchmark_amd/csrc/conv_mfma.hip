@@ -242,6 +242,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         read_frags(0, 0, fa0, fb0);
         constexpr int NM = 4 * MI * NI;  // MFMAs (= slots) per k-group
         constexpr int NF = MI + NI;      // fragment reads per k-group
+        // pieces are dealt to the slots in contiguous runs so that they execute in program order (the tap-state
+        // advance must follow the last A-row load of a tile)
+        constexpr int P1 = NF + AL + BL, P2 = NF + AL + 1 + BL;
+        constexpr int PPF = (NF + NM - 1) / NM, PP1 = (P1 + NM - 1) / NM, PP2 = (P2 + NM - 1) / NM;
         // one MFMA of a k-group: slot q -> (t, i, j)
 #define MFMA_SLOT(FA, FB, q)                                                                                  \
     acc[((q) / NI) % MI][(q) % NI] = __builtin_amdgcn_mfma_f32_32x32x2f32(                                  \
@@ -263,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             for (int q = 0; q < NM; ++q) {
                 MFMA_SLOT(fa0, fb0, q);
 #pragma unroll
-                for (int z = q; z < NF; z += NM) FRAG_PIECE(fa1, fb1, buf, 1, z);
+                for (int z = q * PPF; z < (q + 1) * PPF; ++z)
+                    if (z < NF) FRAG_PIECE(fa1, fb1, buf, 1, z);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- k-step 1: MFMAs on (fa1, fb1) | prefetch k-step 2 | write tile kt+1 into the other LDS buffer
@@ -271,10 +276,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             for (int q = 0; q < NM; ++q) {
                 MFMA_SLOT(fa1, fb1, q);
 #pragma unroll
-                for (int z = q; z < NF + AL + BL; z += NM) {
+                for (int z = q * PP1; z < (q + 1) * PP1; ++z) {
                     if (z < NF) FRAG_PIECE(fa0, fb0, buf, 2, z);
-                    else if (z < NF + AL) store_a(buf ^ 1, z - NF < AL ? z - NF : 0);
-                    else store_b(buf ^ 1, z - NF - AL);
+                    else if (z < NF + AL) store_a(buf ^ 1, z - NF);
+                    else if (z < P1) store_b(buf ^ 1, z - NF - AL);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -283,23 +288,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             for (int q = 0; q < NM; ++q) {
                 MFMA_SLOT(fa0, fb0, q);
 #pragma unroll
-                for (int z = q; z < NF + AL + 1 + BL; z += NM) {
+                for (int z = q * PP2; z < (q + 1) * PP2; ++z) {
                     if (z < NF) FRAG_PIECE(fa1, fb1, buf, 3, z);
-                    else if (z < NF + AL) load_a(kt + 2, z - NF < AL ? z - NF : 0);
+                    else if (z < NF + AL) load_a(kt + 2, z - NF);
                     else if (z == NF + AL) load_x_advance();
-                    else load_b(kt + 2, z - NF - AL - 1);
+                    else if (z < P2) load_b(kt + 2, z - NF - AL - 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            asm volatile("" ::: "memory");       // no LDS access may be moved across the raw barrier by the compiler
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS reads/writes are done; loads stay in flight
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             // ---- k-step 3: MFMAs on (fa1, fb1) | prefetch k-step 0 of tile kt+1 (other buffer, now complete)
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 MFMA_SLOT(fa1, fb1, q);
 #pragma unroll
-                for (int z = q; z < NF; z += NM) FRAG_PIECE(fa0, fb0, buf ^ 1, 0, z);
+                for (int z = q * PPF; z < (q + 1) * PPF; ++z)
+                    if (z < NF) FRAG_PIECE(fa0, fb0, buf ^ 1, 0, z);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
