@@ -2,12 +2,14 @@
 SingleStageDetector/BaseDetector: T/mmdet/models/detectors/single_stage.py:35-104, base.py:114-247).
 The drop-in boundary: ``forward_train(img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes)
 -> dict of losses`` and ``simple_test(img, img_metas, rescale, **gt_kwargs)``."""
+import os
 from collections import OrderedDict
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from ..ops import from_nchw as ops_from_nchw
 from ..registry import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -36,10 +38,49 @@ class BasicLocator(nn.Module):
             x = self.neck(x)
         return x
 
+    # Independent images can be pushed through backbone -> neck -> head towers as ``num_streams`` sub-batches on
+    # separate HIP streams: the deep layers launch fewer workgroups than the chip has slots (tile quantisation), and
+    # blocks of another sub-batch's kernel fill those idle CUs.  The loss runs once on the re-joined batch (its
+    # normalisers are batch-level).  Set with ``model.num_streams = k`` or CPR_STREAMS=k; 1 = single stream.
+    num_streams = 1
+
+    def _towers_multistream(self, img, k):
+        head = self.bbox_head
+        n = img.shape[0]
+        k = max(1, min(k, n))
+        bounds = [round(i * n / k) for i in range(k + 1)]
+        main = torch.cuda.current_stream()
+        if not hasattr(self, '_streams') or len(self._streams) < k:
+            self._streams = [torch.cuda.Stream() for _ in range(k)]
+        parts = []
+        for i in range(k):
+            s = self._streams[i]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                feats = self.extract_feat(img[bounds[i]:bounds[i + 1]])
+                cls_feat, _ = head(feats)
+                parts.append(cls_feat)
+        for i in range(k):
+            main.wait_stream(self._streams[i])
+        nlvl = len(parts[0])
+        out = []
+        for lvl in range(nlvl):
+            t = torch.cat([ops_from_nchw(p[lvl]) for p in parts], dim=0)
+            for p in parts:
+                p[lvl].record_stream(main)
+            out.append(t.permute(0, 3, 1, 2))
+        return out, out
+
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
         batch_input_shape = tuple(img[0].size()[-2:])
         for m in img_metas:
             m['batch_input_shape'] = batch_input_shape
+        k = int(os.environ.get('CPR_STREAMS', self.num_streams))
+        if k > 1 and img.is_cuda and hasattr(self.bbox_head, 'loss'):
+            outs = self._towers_multistream(img, k)
+            return self.bbox_head.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
+                                       **({'gt_true_bboxes': gt_true_bboxes} if 'CPR' in type(self.bbox_head).__name__
+                                          else {}))
         x = self.extract_feat(img)
         return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes)
 
