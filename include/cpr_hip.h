@@ -40,6 +40,9 @@ int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* s
 int cpr_conv_force_tile(int bm, int bn);
 /* K-loop schedule: 1 = interleaved (default), 0 = phase-separated (kept for A/B measurements) */
 int cpr_conv_set_pipeline(int mode);
+/* benchmark-only ablation of the K loop (bit0 no loads/LDS writes, bit1 no fragment reads, bit2 no barrier); results are
+ * wrong when non-zero; 0 = product behaviour */
+int cpr_conv_set_ablation(int mode);
 
 /* network input (N,C<=4,H,W) NCHW -> (N,H,W,4) NHWC, missing channels zero */
 int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, void* stream);

@@ -44,7 +44,9 @@ constexpr int LDSW = 36;  // padded row (floats)
 
 // BM x BN output tile (BM, BN in {64, 128}); MODE 0: Cin % 32 == 0, MODE 1: Cin == 4 (stem, one tap per float4);
 // XF: fused per-(image, channel) affine (+ReLU) on the input = GroupNorm-apply of the producing layer.
-template <int BM, int BN, int MODE, bool XF, int PIPE>
+// ABL (benchmark-only ablations of the pipelined loop, results are then WRONG): bit0 = no global loads / LDS writes,
+// bit1 = no fragment reads, bit2 = no barrier.  ABL = 0 in every product launch.
+template <int BM, int BN, int MODE, bool XF, int PIPE, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     constexpr int WM = BM / 2;
     constexpr int WN = BN / 2;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     const int c4 = tid & 7, r0 = tid >> 3;
 
     // ---- per-thread A row descriptors (AL rows: r0 + 32 j)
-    int iy0[AL], ix0[AL], nimg[AL];
+    int iy0[AL], ix0[AL], nimg[AL], rowoff[AL];
     bool mok[AL];
     const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -83,19 +85,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         nimg[j] = n;
         iy0[j] = oy * p.stride - p.pad;
         ix0[j] = ox * p.stride - p.pad;
+        // 32-bit element offset of (n, iy0, ix0, c4*4); may be "negative" for padded rows/cols -- only used when in range
+        rowoff[j] = ((n * p.H + iy0[j]) * p.W + ix0[j]) * p.Cin + c4 * 4;
     }
+    // Buffer descriptors: out-of-range offsets return 0, which IS the conv zero padding (no clamps, no selects)
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wgt), 0, (int)((size_t)p.Cout * p.Kpad * 4), 0x00020000);
     // ---- B row pointers
     const float* wrow[BL];
+    int woff[BL];  // byte offset of this thread's float4 in weight row j (-1 = row beyond Cout -> reads 0)
     bool wok[BL];
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
         int c = n0 + r0 + 32 * j;
         wok[j] = c < p.Cout;
         wrow[j] = p.wgt + (size_t)(wok[j] ? c : 0) * p.Kpad + c4 * 4;
+        woff[j] = wok[j] ? (c * p.Kpad + c4 * 4) * 4 : -1;
     }
 
     f32x4 ra[AL], rb[BL], xa, xb;
     unsigned okmask = 0;         // bit j: row j of the tile in flight is a real (not padded) pixel
+    int tapoff = 0;              // element offset of the current tap / channel chunk (wave-uniform)
     int kh = 0, kw = 0, c0 = 0;  // MODE 0 running tap state
     constexpr bool xform = XF;   // host guarantees OH*OW % BM == 0 then: one image per M-tile
     const float relu_floor = p.in_relu ? 0.f : -INFINITY;
@@ -106,24 +118,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     // Everything is split into per-row "pieces" so the pipelined K loop can drop one piece behind each MFMA.
     auto load_a = [&](int kt, int j) {
         if (j == 0) okmask = 0;
-        int iy, ix;
-        bool tok = true;
         if (MODE == 0) {
-            iy = iy0[j] + kh;
-            ix = ix0[j] + kw;
+            const int iy = iy0[j] + kh, ix = ix0[j] + kw;
+            // bitwise (not short-circuit) so the slot stays branch-free
+            const bool ok = mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            okmask |= (ok ? 1u : 0u) << j;
+            if (j == 0) tapoff = (kh * p.W + kw) * p.Cin + c0;  // wave-uniform (SALU), once per tile
+            const int voff = ok ? (rowoff[j] + tapoff) * 4 : -1;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0));
         } else {
             const int tap = kt * 8 + c4;
             const int th = tap / p.KW, tw = tap - th * p.KW;
-            tok = tap < p.KH * p.KW;
-            iy = iy0[j] + th;
-            ix = ix0[j] + tw;
+            const int iy = iy0[j] + th, ix = ix0[j] + tw;
+            const bool ok = (tap < p.KH * p.KW) & mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            okmask |= (ok ? 1u : 0u) << j;
+            const int voff = ok ? ((nimg[j] * p.H + iy) * p.W + ix) * 16 : -1;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0));
         }
-        const bool ok = tok && mok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        okmask |= (ok ? 1u : 0u) << j;
-        const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-        const size_t pix = (size_t)(nimg[j] * p.H + iyc) * p.W + ixc;
-        const float* src = (MODE == 0) ? p.in + pix * p.Cin + c0 + c4 * 4 : p.in + pix * 4;
-        ra[j] = *reinterpret_cast<const f32x4*>(src);
     };
     auto load_x_advance = [&]() {  // after the last A row of a tile: GN affine of this K-chunk, then next tap
         if (MODE == 0) {
@@ -144,7 +155,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     };
     const int kt_last = p.Kpad / BK - 1;
     auto load_b = [&](int kt, int j) {  // tile indices past the end are clamped (the pipeline prefetches 2 ahead)
-        rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + min(kt, kt_last) * BK);
+        const int voff = woff[j] < 0 ? -1 : woff[j] + min(kt, kt_last) * (BK * 4);
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, 0, 0));
     };
     auto store_a = [&](int buf, int j) {
         f32x4 v = ra[j];
@@ -153,12 +165,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
             v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
         }
-        if (!((okmask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0 && xform) {  // padded pixels must stay exactly 0 AFTER the affine (+ReLU)
+            if (!((okmask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         *reinterpret_cast<f32x4*>(As + buf * BM * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) = v;
     };
     auto store_b = [&](int buf, int j) {
-        *reinterpret_cast<f32x4*>(Bs + buf * BN * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) =
-            wok[j] ? rb[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Bs + buf * BN * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) = rb[j];
     };
     auto load_tile = [&](int kt) {
 #pragma unroll
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 MFMA_SLOT(fa0, fb0, q);
 #pragma unroll
                 for (int z = q * PPF; z < (q + 1) * PPF; ++z)
-                    if (z < NF) FRAG_PIECE(fa1, fb1, buf, 1, z);
+                    if (z < NF && !(ABL & 2)) FRAG_PIECE(fa1, fb1, buf, 1, z);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- k-step 1: MFMAs on (fa1, fb1) | prefetch k-step 2 | write tile kt+1 into the other LDS buffer
@@ -277,7 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 MFMA_SLOT(fa1, fb1, q);
 #pragma unroll
                 for (int z = q * PP1; z < (q + 1) * PP1; ++z) {
-                    if (z < NF) FRAG_PIECE(fa0, fb0, buf, 2, z);
+                    if (z < NF) { if (!(ABL & 2)) FRAG_PIECE(fa0, fb0, buf, 2, z); }
+                    else if (ABL & 1) {}
                     else if (z < NF + AL) store_a(buf ^ 1, z - NF);
                     else if (z < P1) store_b(buf ^ 1, z - NF - AL);
                 }
@@ -289,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 MFMA_SLOT(fa0, fb0, q);
 #pragma unroll
                 for (int z = q * PP2; z < (q + 1) * PP2; ++z) {
-                    if (z < NF) FRAG_PIECE(fa1, fb1, buf, 3, z);
+                    if (z < NF) { if (!(ABL & 2)) FRAG_PIECE(fa1, fb1, buf, 3, z); }
+                    else if (ABL & 1) {}
                     else if (z < NF + AL) load_a(kt + 2, z - NF);
                     else if (z == NF + AL) load_x_advance();
                     else if (z < P2) load_b(kt + 2, z - NF - AL - 1);
@@ -298,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             }
             asm volatile("" ::: "memory");       // no LDS access may be moved across the raw barrier by the compiler
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS reads/writes are done; loads stay in flight
-            __builtin_amdgcn_s_barrier();
+            if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             // ---- k-step 3: MFMAs on (fa1, fb1) | prefetch k-step 0 of tile kt+1 (other buffer, now complete)
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 MFMA_SLOT(fa1, fb1, q);
 #pragma unroll
                 for (int z = q * PPF; z < (q + 1) * PPF; ++z)
-                    if (z < NF) FRAG_PIECE(fa0, fb0, buf ^ 1, 0, z);
+                    if (z < NF && !(ABL & 2)) FRAG_PIECE(fa0, fb0, buf ^ 1, 0, z);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -381,6 +396,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 // C-ABI ------------------------------------------------------------------------------------------
 static int force_tile_bm = 0, force_tile_bn = 0;  // test/bench hook (cpr_conv_force_tile), 0 = heuristic
 static int conv_pipeline = 1;                      // 1 = interleaved K loop (default), 0 = phase-separated (A/B reference)
+static int conv_ablate = 0;                        // benchmark-only (cpr_conv_set_ablation); 0 in production
+extern "C" int cpr_conv_set_ablation(int mode) {
+    CPR_CHECK_ARG(mode >= 0 && mode <= 7);
+    conv_ablate = mode;
+    return CPR_OK;
+}
 extern "C" int cpr_conv_set_pipeline(int mode) {
     CPR_CHECK_ARG(mode == 0 || mode == 1);
     conv_pipeline = mode;
@@ -409,7 +430,9 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     p.OW = (W + 2 * pad - KW) / stride + 1;
     CPR_CHECK_ARG(p.OH > 0 && p.OW > 0);
     long long M = (long long)N * p.OH * p.OW;
-    CPR_CHECK_ARG(M < (1ll << 31) && (long long)N * H * W * Cin < (1ll << 40));
+    // 32-bit byte offsets inside the buffer descriptors: < 2 GiB per tensor (B=64 at 160x160x256 is 1.7 GB)
+    if ((long long)N * H * W * Cin * 4 >= (1ll << 31) || (long long)Cout * Kpad * 4 >= (1ll << 31) || M >= (1ll << 31))
+        return CPR_ERR_UNSUPPORTED;
     p.M = (int)M;
     const bool mode1 = (Cin == 4);
     if (!mode1) {
@@ -440,7 +463,15 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
         else                                                                                                       \
             hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 1>), dim3(grid), dim3(256), 0, stream, p); \
     } while (0)
-    if (mode1) {
+    if (conv_ablate && !mode1 && !in_a && bm == 128 && bn == 128) {
+        switch (conv_ablate) {
+            case 1: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 1>), dim3(grid), dim3(256), 0, stream, p); break;
+            case 2: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 2>), dim3(grid), dim3(256), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 3>), dim3(grid), dim3(256), 0, stream, p); break;
+            case 4: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 4>), dim3(grid), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 7>), dim3(grid), dim3(256), 0, stream, p); break;
+        }
+    } else if (mode1) {
         if (bn == 64) LAUNCH(128, 64, 1, false); else LAUNCH(128, 128, 1, false);
     } else if (in_a) {
         if (bn == 64) LAUNCH(128, 64, 0, true); else LAUNCH(128, 128, 0, true);

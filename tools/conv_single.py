@@ -17,7 +17,12 @@ ap.add_argument('--cout', type=int, default=256)
 ap.add_argument('--k', type=int, default=3)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--plain', action='store_true')
+ap.add_argument('--ablate', type=int, default=0)
+ap.add_argument('--pipeline', type=int, default=1)
 args = ap.parse_args()
+from pointtinybenchmark_amd import _lib  # noqa: E402
+_lib.call('cpr_conv_set_ablation', args.ablate)
+_lib.call('cpr_conv_set_pipeline', args.pipeline)
 g = torch.Generator().manual_seed(0)
 x = torch.randn((args.batch, args.hw, args.hw, args.cin), generator=g).cuda()
 w = (torch.randn((args.cout, args.cin, args.k, args.k), generator=g) * 0.02).cuda()
