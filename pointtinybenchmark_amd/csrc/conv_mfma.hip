@@ -116,17 +116,31 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     // Loads are issued raw (from clamped, always-valid addresses) and stay in flight during the MFMA phase;
     // zero padding and the fused GN-apply+ReLU are applied when the registers are written to LDS.
     // Everything is split into per-row "pieces" so the pipelined K loop can drop one piece behind each MFMA.
-    auto load_a = [&](int kt, int j) {
-        if (j == 0) okmask = 0;
-        if (MODE == 0) {
+    // MODE 0: per-row byte offsets (or -1 = zero padding) are invariant while the tap (kh, kw) stays the same, i.e. for
+    // Cin/32 consecutive K-chunks; they are refreshed only when the tap changes.  Inside a tap the chunk offset is the
+    // buffer instruction's SCALAR offset, so a load slot is a bare buffer_load (no per-lane address arithmetic).
+    int voffA[AL];
+    unsigned okcur = 0;
+    auto refresh_rows = [&]() {
+        okcur = 0;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
             const int iy = iy0[j] + kh, ix = ix0[j] + kw;
-            // bitwise (not short-circuit) so the slot stays branch-free
             const bool ok = mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-            okmask |= (ok ? 1u : 0u) << j;
-            if (j == 0) tapoff = (kh * p.W + kw) * p.Cin + c0;  // wave-uniform (SALU), once per tile
-            const int voff = ok ? (rowoff[j] + tapoff) * 4 : -1;
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0));
+            okcur |= (ok ? 1u : 0u) << j;
+            voffA[j] = ok ? rowoff[j] * 4 : -1;
+        }
+    };
+    if (MODE == 0) refresh_rows();
+    auto load_a = [&](int kt, int j) {
+        if (MODE == 0) {
+            if (j == 0) {
+                okmask = okcur;
+                tapoff = ((kh * p.W + kw) * p.Cin + c0) * 4;  // wave-uniform byte offset (SALU)
+            }
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voffA[j], tapoff, 0));
         } else {
+            if (j == 0) okmask = 0;
             const int tap = kt * 8 + c4;
             const int th = tap / p.KW, tw = tap - th * p.KW;
             const int iy = iy0[j] + th, ix = ix0[j] + tw;
@@ -143,20 +157,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 xa = *reinterpret_cast<const f32x4*>(p.in_a + ci);
                 xb = *reinterpret_cast<const f32x4*>(p.in_b + ci);
             }
-            // branch-free running tap state (keeps the K loop body one basic block)
             c0 += BK;
-            const int wrap_c = (c0 == p.Cin) ? 1 : 0;
-            c0 = wrap_c ? 0 : c0;
-            kw += wrap_c;
-            const int wrap_w = (kw == p.KW) ? 1 : 0;
-            kw = wrap_w ? 0 : kw;
-            kh += wrap_w;
+            if (c0 == p.Cin) {  // wave-uniform, once per Cin/32 chunks: next tap -> refresh the row offsets
+                c0 = 0;
+                if (++kw == p.KW) { kw = 0; ++kh; }
+                refresh_rows();
+            }
         }
     };
     const int kt_last = p.Kpad / BK - 1;
     auto load_b = [&](int kt, int j) {  // tile indices past the end are clamped (the pipeline prefetches 2 ahead)
-        const int voff = woff[j] < 0 ? -1 : woff[j] + min(kt, kt_last) * (BK * 4);
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, 0, 0));
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[j], min(kt, kt_last) * (BK * 4), 0));
     };
     auto store_a = [&](int buf, int j) {
         f32x4 v = ra[j];
@@ -292,6 +303,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 for (int z = q * PP1; z < (q + 1) * PP1; ++z) {
                     if (z < NF) { if (!(ABL & 2)) FRAG_PIECE(fa0, fb0, buf, 2, z); }
                     else if (ABL & 1) {}
+                    else if (ABL & 8) {  // keep the loaded registers alive, skip the LDS write
+                        if (z < NF + AL) asm volatile("" ::"v"(ra[z - NF < AL ? z - NF : 0]));
+                        else if (z < P1) asm volatile("" ::"v"(rb[z - NF - AL < BL ? z - NF - AL : 0]));
+                    }
                     else if (z < NF + AL) store_a(buf ^ 1, z - NF);
                     else if (z < P1) store_b(buf ^ 1, z - NF - AL);
                 }
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
                 for (int z = q * PP2; z < (q + 1) * PP2; ++z) {
                     if (z < NF) { if (!(ABL & 2)) FRAG_PIECE(fa1, fb1, buf, 3, z); }
-                    else if (ABL & 1) {}
+                    else if (ABL & (1 | 16)) {}
                     else if (z < NF + AL) load_a(kt + 2, z - NF);
                     else if (z == NF + AL) load_x_advance();
                     else if (z < P2) load_b(kt + 2, z - NF - AL - 1);
@@ -398,7 +413,7 @@ static int force_tile_bm = 0, force_tile_bn = 0;  // test/bench hook (cpr_conv_f
 static int conv_pipeline = 1;                      // 1 = interleaved K loop (default), 0 = phase-separated (A/B reference)
 static int conv_ablate = 0;                        // benchmark-only (cpr_conv_set_ablation); 0 in production
 extern "C" int cpr_conv_set_ablation(int mode) {
-    CPR_CHECK_ARG(mode >= 0 && mode <= 7);
+    CPR_CHECK_ARG(mode >= 0 && mode <= 16);
     conv_ablate = mode;
     return CPR_OK;
 }
@@ -469,6 +484,8 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
             case 2: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 2>), dim3(grid), dim3(256), 0, stream, p); break;
             case 3: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 3>), dim3(grid), dim3(256), 0, stream, p); break;
             case 4: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 4>), dim3(grid), dim3(256), 0, stream, p); break;
+            case 8: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 8>), dim3(grid), dim3(256), 0, stream, p); break;
+            case 16: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 16>), dim3(grid), dim3(256), 0, stream, p); break;
             default: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 7>), dim3(grid), dim3(256), 0, stream, p); break;
         }
     } else if (mode1) {
