@@ -123,12 +123,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     unsigned okcur = 0;
     auto refresh_rows = [&]() {
         okcur = 0;
+        // the tap's pixel shift goes into the VECTOR offset (it must be a valid non-negative offset by itself: the
+        // hardware range check looks at the vector offset only); the channel chunk is the scalar offset
+        const int tapshift = (kh * p.W + kw) * p.Cin;
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             const int iy = iy0[j] + kh, ix = ix0[j] + kw;
             const bool ok = mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             okcur |= (ok ? 1u : 0u) << j;
-            voffA[j] = ok ? rowoff[j] * 4 : -1;
+            voffA[j] = ok ? (rowoff[j] + tapshift) * 4 : -1;
         }
     };
     if (MODE == 0) refresh_rows();
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         if (MODE == 0) {
             if (j == 0) {
                 okmask = okcur;
-                tapoff = ((kh * p.W + kw) * p.Cin + c0) * 4;  // wave-uniform byte offset (SALU)
+                tapoff = c0 * 4;  // channel-chunk byte offset, wave-uniform (SALU)
             }
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voffA[j], tapoff, 0));
         } else {
