@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_TRAFFIC_NOTE = None         # PMC FETCH/WRITE_SIZE are collected by tools/gpu_pmc.sh (profiles/), not inside the bench
 GN = dict(type='GN', num_groups=32, requires_grad=True)
 
 
@@ -60,8 +61,9 @@ class ConvProbe:
         self.records = []
 
     def install(self):
-        from pointtinybenchmark_amd import ops
+        from pointtinybenchmark_amd import _lib, ops
         self._orig = ops.conv2d
+        self._lib = _lib
         probe = self
 
         def conv2d(x, pc, *a, **k):
@@ -71,7 +73,9 @@ class ConvProbe:
             e.record()
             N, H, W, _ = x.shape
             OH, OW = pc.out_hw(H, W)
-            variant = '%d,%d' % (64 if pc.Cout <= 64 else 128, 1 if pc.Cin == 4 else 0)
+            v = probe._lib.load().cpr_conv_last_variant()
+            variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
+                                                                  'true' if v // 10 % 10 else 'false', v % 10)
             kreal = pc.KH * pc.KW * (3 if pc.Cin == 4 else pc.Cin)
             probe.records.append((variant, 2.0 * N * OH * OW * pc.Cout * kreal, s, e))
             return out
@@ -205,15 +209,18 @@ def main():
         }
         if probe:
             summ = probe.summary()
-            dom = summ.get('128,0')
-            if dom:
-                ach = dom['tflops']
-                out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                   'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
-                                   'kernel': 'conv_mfma_kernel<128,0>', 'launches': dom['launches'],
-                                   'avg_launch_ms': dom['seconds'] / dom['launches'] * 1e3,
-                                   'all_conv_variants': {k: round(v['tflops'], 2) for k, v in summ.items()}}
+            name = max(summ, key=lambda k: summ[k]['seconds'])      # dominant template instance by total time
+            dom = summ[name]
+            ach = dom['tflops']
             conv_s = sum(v['seconds'] for v in summ.values())
+            conv_f = sum(v['flops'] for v in summ.values())
+            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': HBM_TRAFFIC_NOTE, 'kernel': name,
+                               'launches': dom['launches'], 'flops_per_launch': dom['flops'] / dom['launches'],
+                               'avg_launch_ms': dom['seconds'] / dom['launches'] * 1e3,
+                               'share_of_step_time': dom['seconds'] / elapsed,
+                               'all_conv_instances_tflops': conv_f / conv_s / 1e12,
+                               'per_instance_tflops': {k: round(v['tflops'], 2) for k, v in summ.items()}}
             out['conv_time_frac'] = conv_s / elapsed
             out['end_to_end_tflops'] = 224.0e9 * total_imgs / world / elapsed / 1e12
         if world == 1 and not args.no_cpu_baseline:

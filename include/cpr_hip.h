@@ -43,6 +43,8 @@ int cpr_conv_set_pipeline(int mode);
 /* benchmark-only ablation of the K loop (bit0 no loads/LDS writes, bit1 no fragment reads, bit2 no barrier); results are
  * wrong when non-zero; 0 = product behaviour */
 int cpr_conv_set_ablation(int mode);
+/* template instance of the last cpr_conv2d_fwd launch: bm*1e6 + bn*1e3 + mode*100 + xf*10 + pipe (for profilers) */
+int cpr_conv_last_variant(void);
 
 /* network input (N,C<=4,H,W) NCHW -> (N,H,W,4) NHWC, missing channels zero */
 int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, void* stream);

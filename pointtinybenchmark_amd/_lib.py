@@ -20,6 +20,7 @@ SIGNATURES = {
     'cpr_conv_force_tile': [_i, _i],
     'cpr_conv_set_pipeline': [_i],
     'cpr_conv_set_ablation': [_i],
+    'cpr_conv_last_variant': [],
     'cpr_nchw_to_nhwc4': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_nhwc_to_nchw': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_maxpool3x3s2': [_p, _p, _i, _i, _i, _i, _p],

@@ -415,6 +415,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 static int force_tile_bm = 0, force_tile_bn = 0;  // test/bench hook (cpr_conv_force_tile), 0 = heuristic
 static int conv_pipeline = 1;                      // 1 = interleaved K loop (default), 0 = phase-separated (A/B reference)
 static int conv_ablate = 0;                        // benchmark-only (cpr_conv_set_ablation); 0 in production
+static int last_variant = 0;                       // bm*1e6 + bn*1e3 + mode*100 + xf*10 + pipe of the last launch
+extern "C" int cpr_conv_last_variant(void) { return last_variant; }
 extern "C" int cpr_conv_set_ablation(int mode) {
     CPR_CHECK_ARG(mode >= 0 && mode <= 16);
     conv_ablate = mode;
@@ -460,16 +462,19 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     }
     if (gn_part || in_a) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
     if (in_a) CPR_CHECK_ARG(in_b && p.OH == H && p.OW == W);
-    // tile selection: 128x128 when it fills the chip (>= one round of 2 blocks/CU); smaller tiles for the small-M
-    // deep layers so that 256 CUs all get work; GN-fused launches keep 128-pixel tiles (one stats slot per tile).
+    // tile selection (measured per layer on MI355X, profiles/round1_tile_sweep.txt): 64x64 tiles run 4 workgroups per CU
+    // (36.9 KB LDS, 74 VGPRs) and win on everything except very large, long-K problems -- finer granularity against
+    // tile quantisation and 4 waves/SIMD to hide the prologue/epilogue latency of short-K 1x1 convs.  128x128 is kept for
+    // the long, wide launches; GN-fused launches keep 128-pixel tiles (one statistics slot per tile).
     int bm = 128, bn = (Cout <= 64) ? 64 : 128;
-    auto ntiles = [&](int a, int b) { return (long long)((p.M + a - 1) / a) * ((Cout + b - 1) / b); };
     if (!gn_part && !in_a && !mode1) {
-        if (ntiles(bm, bn) < 512) bm = 64;
-        if (ntiles(bm, bn) < 384 && bn == 128) bn = 64;
+        const long long t128 = (long long)((p.M + 127) / 128) * ((Cout + 127) / 128);
+        const int kt = Kpad / BK;
+        if (!(kt >= 16 && t128 >= 4096 && Cout > 64)) { bm = 64; bn = 64; }
     }
     if (force_tile_bm > 0 && !gn_part && !in_a && !mode1) { bm = force_tile_bm; }
     if (force_tile_bn > 0 && Cout > 64 && !mode1) { bn = force_tile_bn; }
+    last_variant = bm * 1000000 + bn * 1000 + (mode1 ? 100 : 0) + (in_a ? 10 : 0) + conv_pipeline;
     p.tilesM = (p.M + bm - 1) / bm;
     p.tilesN = (Cout + bn - 1) / bn;
     const int T = p.tilesM * p.tilesN;
