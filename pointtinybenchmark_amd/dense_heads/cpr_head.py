@@ -151,16 +151,15 @@ class CPRHead(nn.Module):
             ins.append(f[1])
         return cls, ins
 
-    def forward_single(self, x):
-        x = ops.from_nchw(x)
-        ab, n = None, len(self.cls_convs)
+    def _tower(self, x, ab=None, in_relu=True):
+        """4 x [conv3x3 -> GN -> ReLU]; returns the LAST layer un-normalised: (raw, (a, b))."""
         for i, m in enumerate(self.cls_convs):
-            last = i == n - 1
-            if last:
-                x = conv_gn(self._cache, m, x, in_ab=ab, in_relu=True, materialize=True)
-            else:
-                x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=True, materialize=False)
-        out = ops.as_nchw(x)
+            x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=(in_relu if i == 0 else True), materialize=False)
+        return x, ab
+
+    def forward_single(self, x):
+        raw, ab = self._tower(ops.from_nchw(x))
+        out = ops.as_nchw(ops.gn_apply(raw, ab[0], ab[1], relu=True, out=raw))
         return out, out
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, gt_true_bboxes=None,
@@ -172,9 +171,21 @@ class CPRHead(nn.Module):
             return losses
         return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
 
+    def forward_train_lazy(self, lazy_feats, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
+                           gt_true_bboxes=None):
+        """Fused training path used by BasicLocator: the neck hands over (raw, (a, b)) and neither the neck output nor
+        the last tower layer is ever materialised in normalised form -- the consumer convs (tower layer 0, the logit
+        projection) apply the GroupNorm affine (+ReLU) on load.  Same arithmetic as forward() + loss()."""
+        assert len(lazy_feats) == 1
+        raw, ab = lazy_feats[0]
+        raw, ab = self._tower(raw, ab, in_relu=False)
+        return self.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
+                         gt_true_bboxes=gt_true_bboxes)
+
     # ------------------------------------------------------------------ shared extraction
-    def _logit_map(self, feat_nhwc):
-        """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C)] (or C when the classifier is shared)."""
+    def _logit_map(self, feat_nhwc, in_ab=None):
+        """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C)] (or C when the classifier is shared).
+        in_ab: the input is the raw last-layer conv output and (a, b) its GroupNorm affine (+ReLU), applied on load."""
         def make():
             w = [self.cls_out.weight] + ([] if self.ins_share_head_classifier else [self.ins_out.weight])
             b = [self.cls_out.bias] + ([] if self.ins_share_head_classifier else [self.ins_out.bias])
@@ -182,7 +193,9 @@ class CPRHead(nn.Module):
             return ops.PackedConv(wt, 1, 0), torch.cat(b, 0).detach().float().contiguous()
         srcs = [self.cls_out.weight, self.cls_out.bias, self.ins_out.weight, self.ins_out.bias]
         pc, bias = self._cache.get('proj', srcs, make)
-        return ops.conv2d(feat_nhwc, pc, bias=bias)
+        if in_ab is not None and (feat_nhwc.shape[1] * feat_nhwc.shape[2]) % 128 != 0:
+            feat_nhwc, in_ab = ops.gn_apply(feat_nhwc, in_ab[0], in_ab[1], relu=True), None
+        return ops.conv2d(feat_nhwc, pc, bias=bias, in_ab=in_ab, in_relu=True)
 
     def _gt_tensors(self, gt_bboxes, gt_labels, img_metas, device, shape_key):
         counts = [int(len(l)) for l in gt_labels]
@@ -213,9 +226,12 @@ class CPRHead(nn.Module):
         assert len(gt_labels) > 0
         assert len(cls_feat) == 1, 'single FPN level (the reference asserts the same: cpr_head.py:1152)'
         ex, C, stride = self.train_pts_extractor, self.num_classes, self.strides[0]
-        feat = ops.from_nchw(cls_feat[0])
+        if isinstance(cls_feat[0], tuple):          # (raw, (a, b)) from forward_train_lazy
+            feat, ab = cls_feat[0]
+        else:
+            feat, ab = ops.from_nchw(cls_feat[0]), None
         dev = feat.device
-        lmap = self._logit_map(feat)
+        lmap = self._logit_map(feat, ab)
         centers, labels, gt_start, gt_img, pad_hw, _ = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev,
                                                                         'pad_shape')
         _, valid, bag_logits = ops.bag_sample(lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)

@@ -81,6 +81,11 @@ class BasicLocator(nn.Module):
             return self.bbox_head.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
                                        **({'gt_true_bboxes': gt_true_bboxes} if 'CPR' in type(self.bbox_head).__name__
                                           else {}))
+        if self.with_neck and hasattr(self.neck, 'forward_lazy') and hasattr(self.bbox_head, 'forward_train_lazy') \
+                and os.environ.get('CPR_LAZY_GN', '1') == '1':
+            lazy = self.neck.forward_lazy(self.backbone(img))
+            return self.bbox_head.forward_train_lazy(lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore,
+                                                     gt_true_bboxes)
         x = self.extract_feat(img)
         return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes)
 

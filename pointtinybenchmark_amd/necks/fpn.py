@@ -37,7 +37,7 @@ class FPN(nn.Module):
     def init_weights(self):
         pass
 
-    def forward(self, inputs):
+    def _run(self, inputs, lazy):
         assert len(inputs) == len(self.in_channels)
         c = self._cache
         xs = [ops.from_nchw(inputs[i + self.start_level]) for i in range(len(self.lateral_convs))]
@@ -47,4 +47,12 @@ class FPN(nn.Module):
             up = lat[i + 1] if i + 1 < len(xs) else None
             lat[i] = conv_gn(c, self.lateral_convs[i], xs[i], up=up)
         used = min(len(lat), self.num_outs)
-        return tuple(ops.as_nchw(conv_gn(c, self.fpn_convs[i], lat[i])) for i in range(used))
+        return [conv_gn(c, self.fpn_convs[i], lat[i], materialize=not lazy) for i in range(used)]
+
+    def forward(self, inputs):
+        return tuple(ops.as_nchw(t) for t in self._run(inputs, lazy=False))
+
+    def forward_lazy(self, inputs):
+        """Internal fast path: per level (raw conv output NHWC, (a, b)) -- the consumer conv applies the GroupNorm
+        affine while loading (no activation after the FPN convs: act_cfg=None)."""
+        return self._run(inputs, lazy=True)

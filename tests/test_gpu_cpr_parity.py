@@ -143,3 +143,23 @@ def test_cpr_path_vs_oracle_more_seeds(seed, hw, G, C):
     dets = torch.cat([d for d, _ in r['dets']])
     rd = torch.cat([x['dets'] for x in ref])
     np.testing.assert_allclose(dets.numpy(), rd.numpy(), rtol=1e-4, atol=2e-3)
+
+
+def test_fused_forward_train_matches_module_by_module_path():
+    """BasicLocator.forward_train (lazy GroupNorm hand-off neck -> head -> projection, optional sub-batch streams) gives
+    the same losses as running backbone / neck / head / loss module by module."""
+    cfg = dict(depth=18, num_classes=2, start_level=0, stride=4, radius=5, head_std=0.3, seed=31, batch=4, height=128,
+               width=128, num_gts=5, ragged=True)
+    m, sd = build_hip_locator(cfg)
+    batch = synthetic.synthetic_batch(4, 128, 128, 5, 2, 31, True)
+    cb = to_cuda(batch)
+    with torch.no_grad():
+        feats = m.neck(m.backbone(cb['img']))
+        ref = m.bbox_head.loss(*m.bbox_head(feats), cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'])
+        fused = m.forward_train(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+        m.num_streams = 2
+        streamed = m.forward_train(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+        torch.cuda.synchronize()
+    for k in ref:
+        assert _relerr(float(fused[k]), float(ref[k])) <= 1e-5, (k, float(fused[k]), float(ref[k]))
+        assert _relerr(float(streamed[k]), float(ref[k])) <= 1e-5, (k, float(streamed[k]), float(ref[k]))
