@@ -24,7 +24,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-HBM_TRAFFIC_NOTE = None         # PMC FETCH/WRITE_SIZE are collected by tools/gpu_pmc.sh (profiles/), not inside the bench
+
+
+def pmc_traffic(kernel_name, batch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_dominant_kernel.json,
+    produced by tools/gpu_pmc.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950
+    note of MI355X_MICROARCH.md).  Counters cannot be read from inside the timed run, so this is the profile's figure,
+    scaled linearly if the batch differs; null when no profile of this kernel is committed."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    if d.get('kernel', '').replace(' ', '') != kernel_name.replace(' ', ''):
+        return None
+    return d['hbm_bytes_per_launch'] * batch / d['batch']
 GN = dict(type='GN', num_groups=32, requires_grad=True)
 
 
@@ -215,7 +228,7 @@ def main():
             conv_s = sum(v['seconds'] for v in summ.values())
             conv_f = sum(v['flops'] for v in summ.values())
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': HBM_TRAFFIC_NOTE, 'kernel': name,
+                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(name, args.batch), 'kernel': name,
                                'launches': dom['launches'], 'flops_per_launch': dom['flops'] / dom['launches'],
                                'avg_launch_ms': dom['seconds'] / dom['launches'] * 1e3,
                                'share_of_step_time': dom['seconds'] / elapsed,
