@@ -54,9 +54,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     constexpr int NI = WN / 32;
     constexpr int AL = BM * 8 / 256;  // float4 A loads per thread
     constexpr int BL = BN * 8 / 256;  // float4 B loads per thread
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDSW];
+    constexpr int XFMAX = 512;  // fused-GN launches keep the image's (a, b) table in LDS (Cin <= 512)
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDSW + (XF ? 2 * XFMAX : 0)];
     float* As = smem;
     float* Bs = smem + 2 * BM * LDSW;
+    float* ABs = smem + 2 * (BM + BN) * LDSW;  // [a(Cin) | b(Cin)] of this tile's image (XF only)
 
     // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles (cout tiles
     // fastest) so the activations' 3x3 halo rows and the two cout tiles of one pixel tile share one L2.
@@ -107,11 +109,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 
     f32x4 ra[AL], rb[BL], xa, xb;
     unsigned okmask = 0;         // bit j: row j of the tile in flight is a real (not padded) pixel
+    bool any_pad = true;         // wave-uniform: some lane of this wave has a padded row in the tile being stored
     int tapoff = 0;              // element offset of the current tap / channel chunk (wave-uniform)
     int kh = 0, kw = 0, c0 = 0;  // MODE 0 running tap state
     constexpr bool xform = XF;   // host guarantees OH*OW % BM == 0 then: one image per M-tile
     const float relu_floor = p.in_relu ? 0.f : -INFINITY;
     const int nblk = (m0 < p.M ? m0 : 0) / ohw;
+    if (XF) {  // this tile's image: per-channel GroupNorm affine -> LDS once
+        for (int i = tid; i < p.Cin; i += 256) {
+            ABs[i] = p.in_a[nblk * p.Cin + i];
+            ABs[XFMAX + i] = p.in_b[nblk * p.Cin + i];
+        }
+        __syncthreads();
+    }
 
     // Loads are issued raw (from clamped, always-valid addresses) and stay in flight during the MFMA phase;
     // zero padding and the fused GN-apply+ReLU are applied when the registers are written to LDS.
@@ -156,9 +166,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     auto load_x_advance = [&]() {  // after the last A row of a tile: GN affine of this K-chunk, then next tap
         if (MODE == 0) {
             if (xform) {
-                const int ci = nblk * p.Cin + c0 + c4 * 4;
-                xa = *reinterpret_cast<const f32x4*>(p.in_a + ci);
-                xb = *reinterpret_cast<const f32x4*>(p.in_b + ci);
+                xa = *reinterpret_cast<const f32x4*>(ABs + c0 + c4 * 4);
+                xb = *reinterpret_cast<const f32x4*>(ABs + XFMAX + c0 + c4 * 4);
             }
             c0 += BK;
             if (c0 == p.Cin) {  // wave-uniform, once per Cin/32 chunks: next tap -> refresh the row offsets
@@ -180,7 +189,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
         }
         if (MODE == 0 && xform) {  // padded pixels must stay exactly 0 AFTER the affine (+ReLU)
-            if (!((okmask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j == 0) any_pad = __builtin_amdgcn_ballot_w64(okmask != ((1u << AL) - 1u)) != 0;  // wave-uniform
+            if (any_pad) {  // interior tiles (the vast majority) skip the selects with one scalar branch
+                if (!((okmask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         *reinterpret_cast<f32x4*>(As + buf * BM * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) = v;
     };
@@ -461,7 +473,7 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
         CPR_CHECK_ARG(Kpad >= KH * KW * 4 && in_a == nullptr);
     }
     if (gn_part || in_a) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
-    if (in_a) CPR_CHECK_ARG(in_b && p.OH == H && p.OW == W);
+    if (in_a) CPR_CHECK_ARG(in_b && p.OH == H && p.OW == W && Cin <= 512);
     // tile selection (measured per layer on MI355X, profiles/round1_tile_sweep.txt): 64x64 tiles run 4 workgroups per CU
     // (36.9 KB LDS, 74 VGPRs) and win on everything except very large, long-K problems -- finer granularity against
     // tile quantisation and 4 waves/SIMD to hide the prologue/epilogue latency of short-K 1x1 convs.  128x128 is kept for
