@@ -111,3 +111,35 @@ def test_full_size_conv_linearity():
     rhs = 1.5 * ops.conv2d(x, pc) + ops.conv2d(y, pc)
     err = float((lhs - rhs).abs().max())
     assert err <= 2e-5 * float(rhs.abs().max()) + 1e-5, err
+
+
+@pytest.mark.parametrize('name,cfg', [
+    # BASELINE.json configs[2]: COCO-style 1333x800 padded to /32 -> 800x1344, 80 classes, stride 8, radius 8
+    # (T/configs2/COCO/coarsepointv2/coarse_point_refine_r50_fpn_1x_coco400.py:20,51,75-96).  100x168 map: NOT 128-pixel
+    # aligned, so this also covers the unfused GroupNorm-statistics path at full size.
+    ('coco_style_800x1344', dict(depth=50, num_classes=80, start_level=1, stride=8, radius=8, head_std=0.3, seed=41,
+                                 batch=1, height=800, width=1344, num_gts=24)),
+    # configs[4] backbone: ResNet-101 (fp32; the bf16 variant of that config is not built yet)
+    ('r101_384', dict(depth=101, num_classes=1, start_level=0, stride=4, radius=5, head_std=0.3, seed=43, batch=1,
+                      height=384, width=384, num_gts=12)),
+])
+def test_other_baseline_configs_parity_with_oracle(name, cfg):
+    m, sd = build_hip_locator(cfg)
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'])
+    cb = to_cuda(batch)
+    cls_feat, losses, dets = _run(m, cb)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref_losses, ref_feat, per = O.locator_forward_train(sd, batch, cfg['depth'], cfg['start_level'], cfg['stride'],
+                                                            cfg['radius'], cfg['num_classes'])
+        ref = O.cpr_refine(sd, ref_feat, batch['gt_bboxes'], batch['gt_labels'], batch['gt_anns_id'],
+                           batch['img_metas'], cfg['stride'], cfg['radius'], cfg['num_classes'])
+    scale = max(1.0, float(ref_feat.abs().max()))
+    err = float((cls_feat.cpu() - ref_feat).abs().max())
+    assert err <= 3e-4 * scale, '%s: cls_feat max abs err %.3e (scale %.2e)' % (name, err, scale)
+    for k in ('gt_loss', 'pos_loss', 'neg_loss', 'bag_acc'):
+        a, b = float(losses[k]), float(ref_losses[k])
+        assert abs(a - b) <= 5e-4 * max(abs(b), 1e-6), (name, k, a, b)
+    np.testing.assert_allclose(torch.cat([d for d, _ in dets]).cpu().numpy(),
+                               torch.cat([r['dets'] for r in ref]).numpy(), rtol=1e-4, atol=5e-3)
