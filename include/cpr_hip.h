@@ -46,6 +46,19 @@ int cpr_conv_set_ablation(int mode);
 /* template instance of the last cpr_conv2d_fwd launch: bm*1e6 + bn*1e3 + mode*100 + xf*10 + pipe (for profilers) */
 int cpr_conv_last_variant(void);
 
+/* bf16 compute mode (BASELINE.json configs[4]): bf16 activations / weights / residual, fp32 accumulate
+ * (v_mfma_f32_32x32x16_bf16), K chunks of 64 (Cin % 64 == 0, Kpad == KH*KW*Cin), output bf16 or fp32 (out_fp32).
+ * No fused producer-GroupNorm input; GroupNorm statistics come from the fp32 accumulators.  In cpr_conv2d_fwd the
+ * `relu` argument's bit 1 requests a bf16 output (the 3-channel stem runs on the fp32 kernel and hands over bf16). */
+int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+                        const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                        int stride, int pad, int Kpad, int relu, int out_fp32, void* stream);
+int cpr_conv_bf16_last_variant(void); /* bm*1000 + bn of the last cpr_conv2d_fwd_bf16 launch */
+int cpr_maxpool3x3s2_bf16(const void* in, void* out, int N, int H, int W, int C, void* stream);
+int cpr_gn_stats_bf16(const void* x, float* part, int N, int HW, int C, int P, void* stream);
+int cpr_gn_apply_bf16(const void* x, const float* a, const float* b, const void* up, void* y, int N, int H, int W,
+                      int C, int UH, int UW, int relu, void* stream);
+
 /* network input (N,C<=4,H,W) NCHW -> (N,H,W,4) NHWC, missing channels zero */
 int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, void* stream);
 /* (N,H,W,C) -> dense (N,C,H,W) (export in the reference's layout) */

@@ -21,6 +21,11 @@ SIGNATURES = {
     'cpr_conv_set_pipeline': [_i],
     'cpr_conv_set_ablation': [_i],
     'cpr_conv_last_variant': [],
+    'cpr_conv2d_fwd_bf16': [_p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p],
+    'cpr_conv_bf16_last_variant': [],
+    'cpr_maxpool3x3s2_bf16': [_p, _p, _i, _i, _i, _i, _p],
+    'cpr_gn_stats_bf16': [_p, _p, _i, _i, _i, _i, _p],
+    'cpr_gn_apply_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_nchw_to_nhwc4': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_nhwc_to_nchw': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_maxpool3x3s2': [_p, _p, _i, _i, _i, _i, _p],

@@ -5,6 +5,7 @@ Interface of T/mmdet/models/backbones/resnet.py:305-657 (ctor kwargs, ``forward(
 BatchNorm is always evaluated with running statistics on this path (norm_eval=True in every CPR/P2P config)
 and is folded into the conv epilogue; the bottleneck shortcut add + ReLU are fused into conv3's epilogue.
 Forward only: backward is SURVEY.md §8(f) rank 1 ("next")."""
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -34,15 +35,16 @@ class _Block(nn.Module):
         identity = x
         if self.downsample is not None:
             s, b = folded_bn(cache, self.downsample[1])
-            identity = ops.conv2d(x, packed_conv(cache, self.downsample[0]), scale=s, bias=b)
+            identity = ops.conv2d(x, packed_conv(cache, self.downsample[0], x.dtype), scale=s, bias=b)
+        dt = x.dtype
         s1, b1 = folded_bn(cache, self.bn1)
-        o = ops.conv2d(x, packed_conv(cache, self.conv1), scale=s1, bias=b1, relu=True)
+        o = ops.conv2d(x, packed_conv(cache, self.conv1, dt), scale=s1, bias=b1, relu=True)
         s2, b2 = folded_bn(cache, self.bn2)
         if self.kind == 'bottleneck':
-            o = ops.conv2d(o, packed_conv(cache, self.conv2), scale=s2, bias=b2, relu=True)
+            o = ops.conv2d(o, packed_conv(cache, self.conv2, dt), scale=s2, bias=b2, relu=True)
             s3, b3 = folded_bn(cache, self.bn3)
-            return ops.conv2d(o, packed_conv(cache, self.conv3), scale=s3, bias=b3, residual=identity, relu=True)
-        return ops.conv2d(o, packed_conv(cache, self.conv2), scale=s2, bias=b2, residual=identity, relu=True)
+            return ops.conv2d(o, packed_conv(cache, self.conv3, dt), scale=s3, bias=b3, residual=identity, relu=True)
+        return ops.conv2d(o, packed_conv(cache, self.conv2, dt), scale=s2, bias=b2, residual=identity, relu=True)
 
 
 @BACKBONES.register_module()
@@ -86,6 +88,7 @@ class ResNet(nn.Module):
             self.add_module(name, nn.Sequential(*layer))
             self.res_layers.append(name)
         self.feat_dim = inplanes
+        self.compute_dtype = torch.float32   # torch.bfloat16 = bf16 activations/weights from the stem output on
         self._cache = _PackCache()
         self._freeze_stages()
 
@@ -111,7 +114,8 @@ class ResNet(nn.Module):
         c = self._cache
         x = ops.nchw_to_nhwc(x) if x.shape[1] <= 4 else ops.from_nchw(x)
         s, b = folded_bn(c, self.bn1)
-        x = ops.conv2d(x, packed_conv(c, self.conv1), scale=s, bias=b, relu=True)
+        # bf16 compute mode: the 3-channel stem stays on the fp32 kernel and emits a bf16 map
+        x = ops.conv2d(x, packed_conv(c, self.conv1), scale=s, bias=b, relu=True, out_dtype=self.compute_dtype)
         x = ops.maxpool3x3s2(x)
         outs = []
         for i, name in enumerate(self.res_layers):

@@ -35,7 +35,7 @@ struct ConvParams {
     const float* in_a;      // [N][Cin] or null: input transform x*a+b then ReLU (fused GN apply of the producer)
     const float* in_b;
     float* gn_part;         // [tilesM][Cout][2] per-M-tile per-channel (sum, sumsq) of the output, or null
-    int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, in_relu;
+    int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, in_relu, out_bf16;
     int tilesM, tilesN;
 };
 
@@ -391,7 +391,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 float v = acc[i][j][r] * sc + bi + res[r];
                 if (p.relu) v = fmaxf(v, 0.f);
                 const bool ok = cok && m < p.M;
-                if (ok) p.out[(size_t)m * p.Cout + c] = v;
+                if (ok) {
+                    if (p.out_bf16) {  // bf16 compute mode: the fp32 stem hands a bf16 map to the bf16 layers
+                        const __bf16 hv = (__bf16)v;
+                        reinterpret_cast<unsigned short*>(p.out)[(size_t)m * p.Cout + c] = __builtin_bit_cast(unsigned short, hv);
+                    } else {
+                        p.out[(size_t)m * p.Cout + c] = v;
+                    }
+                }
                 v = ok ? v : 0.f;
                 gsum += v;
                 gsq += v * v;
@@ -457,7 +464,7 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     p.in = in; p.wgt = wgt; p.out = out; p.scale = scale; p.bias = bias; p.residual = residual;
     p.in_a = in_a; p.in_b = in_b; p.gn_part = gn_part;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
-    p.Kpad = Kpad; p.relu = relu; p.in_relu = in_relu;
+    p.Kpad = Kpad; p.relu = relu & 1; p.in_relu = in_relu; p.out_bf16 = (relu >> 1) & 1;  // relu bit1 = bf16 output
     p.OH = (H + 2 * pad - KH) / stride + 1;
     p.OW = (W + 2 * pad - KW) / stride + 1;
     CPR_CHECK_ARG(p.OH > 0 && p.OW > 0);

@@ -1,0 +1,336 @@
+// bf16 implicit-GEMM convolution (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the bf16 compute mode of
+// BASELINE.json configs[4] (ResNet-101 + FPN + CPRHead in bf16).  Same design as conv_mfma.hip (NHWC, K-contiguous
+// weights, double-buffered LDS with 144-byte rows, interleaved K loop with bare buffer_load slots, XCD-aware tile order,
+// fused scale/bias/residual/ReLU epilogue and GroupNorm partial statistics taken from the fp32 accumulators), with
+//   * activations / weights / residual in bf16, K chunk = 64 elements (the same 128 bytes per row as the fp32 kernel),
+//   * one MFMA per (i, j) per 16-wide k-step: a lane's ds_read_b128 = 8 bf16 = A[i][k0 + 8*(lane>>5) .. +7],
+//   * output bf16 (round-to-nearest-even via v_cvt_pk_bf16_f32) or fp32 (the head's logit projection stays fp32 so the
+//     loss kernels are shared with the fp32 path).
+// The GroupNorm-apply of the producer is NOT fused into the load here (8 unpack + 8 fma + 8 max + 4 pack per 16 bytes
+// would make the loop VALU-bound at bf16 MFMA rates); bf16 mode materialises GN+ReLU with the streaming gn_apply kernel.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+struct ConvParamsBf16 {
+    const unsigned short* in;
+    const unsigned short* wgt;
+    void* out;
+    const float* scale;
+    const float* bias;
+    const unsigned short* residual;
+    float* gn_part;
+    int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, out_fp32;
+    int tilesM, tilesN;
+};
+
+constexpr int BKH = 64;    // K elements per chunk
+constexpr int LDSWH = 72;  // padded LDS row, in bf16 elements (144 bytes)
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p) {
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+    constexpr int AL = BM * 8 / 256, BL = BN * 8 / 256;  // 16-byte loads per thread
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BM + BN) * LDSWH];
+    unsigned short* As = smem;
+    unsigned short* Bs = smem + 2 * BM * LDSWH;
+
+    const int T = p.tilesM * p.tilesN;
+    const int per = (T + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= T) return;
+    const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c8 = tid & 7, r0 = tid >> 3;
+
+    int iy0[AL], ix0[AL], rowoff[AL];
+    bool mok[AL];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        int m = m0 + r0 + 32 * j;
+        mok[j] = m < p.M;
+        int mm = mok[j] ? m : 0;
+        int n = mm / ohw;
+        int rem = mm - n * ohw;
+        int oy = rem / p.OW, ox = rem - oy * p.OW;
+        iy0[j] = oy * p.stride - p.pad;
+        ix0[j] = ox * p.stride - p.pad;
+        rowoff[j] = ((n * p.H + iy0[j]) * p.W + ix0[j]) * p.Cin + c8 * 8;  // element offset
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.wgt), 0, (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000);
+    int woff[BL];
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+        int c = n0 + r0 + 32 * j;
+        woff[j] = c < p.Cout ? (c * p.Kpad + c8 * 8) * 2 : -1;
+    }
+
+    f32x4 ra[AL], rb[BL];  // raw 16-byte pieces (8 bf16 each)
+    int kh = 0, kw = 0, c0 = 0, tapoff = 0;
+    int voffA[AL];
+    auto refresh_rows = [&]() {
+        const int tapshift = (kh * p.W + kw) * p.Cin;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            const int iy = iy0[j] + kh, ix = ix0[j] + kw;
+            const bool ok = mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            voffA[j] = ok ? (rowoff[j] + tapshift) * 2 : -1;
+        }
+    };
+    refresh_rows();
+    auto load_a = [&](int j) {
+        if (j == 0) tapoff = c0 * 2;
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voffA[j], tapoff, 0));
+    };
+    auto advance = [&]() {
+        c0 += BKH;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            if (++kw == p.KW) { kw = 0; ++kh; }
+            refresh_rows();
+        }
+    };
+    const int kt_last = p.Kpad / BKH - 1;
+    auto load_b = [&](int kt, int j) {
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[j], min(kt, kt_last) * (BKH * 2), 0));
+    };
+    auto store_a = [&](int buf, int j) {
+        *reinterpret_cast<f32x4*>(As + buf * BM * LDSWH + (r0 + 32 * j) * LDSWH + c8 * 8) = ra[j];
+    };
+    auto store_b = [&](int buf, int j) {
+        *reinterpret_cast<f32x4*>(Bs + buf * BN * LDSWH + (r0 + 32 * j) * LDSWH + c8 * 8) = rb[j];
+    };
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < AL; ++j) load_a(j);
+        advance();
+#pragma unroll
+        for (int j = 0; j < BL; ++j) load_b(kt, j);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AL; ++j) store_a(buf, j);
+#pragma unroll
+        for (int j = 0; j < BL; ++j) store_b(buf, j);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = wave & 1, wn = wave >> 1;
+    const int half = lane >> 5;
+    const unsigned short* a_lds = As + (wm * WM + (lane & 31)) * LDSWH + 8 * half;
+    const unsigned short* b_lds = Bs + (wn * WN + (lane & 31)) * LDSWH + 8 * half;
+    const int KT = p.Kpad / BKH;
+
+    constexpr int NM = MI * NI;  // MFMAs (= slots) per 16-wide k-step
+    constexpr int NF = MI + NI;
+    constexpr int P1 = NF + AL + BL, P2 = NF + AL + 1 + BL;
+    constexpr int PPF = (NF + NM - 1) / NM, PP1 = (P1 + NM - 1) / NM, PP2 = (P2 + NM - 1) / NM;
+    f32x4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+#define MFMA_SLOT(FA, FB, q)                                                                      \
+    acc[(q) / NI][(q) % NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                            \
+        __builtin_bit_cast(bf16x8, FA[(q) / NI]), __builtin_bit_cast(bf16x8, FB[(q) % NI]), acc[(q) / NI][(q) % NI], 0, 0, 0)
+#define FRAG_PIECE(FA, FB, buf, kk, z)                                                                                \
+    do {                                                                                                              \
+        if ((z) < MI)                                                                                                 \
+            FA[(z) < MI ? (z) : 0] = *reinterpret_cast<const f32x4*>(a_lds + (buf) * BM * LDSWH +                     \
+                                                                     ((z) < MI ? (z) : 0) * 32 * LDSWH + (kk) * 16);  \
+        else                                                                                                          \
+            FB[(z) >= MI ? (z) - MI : 0] = *reinterpret_cast<const f32x4*>(                                           \
+                b_lds + (buf) * BN * LDSWH + ((z) >= MI ? (z) - MI : 0) * 32 * LDSWH + (kk) * 16);                     \
+    } while (0)
+
+    load_tile(0);
+    store_tile(0);
+    load_tile(1);
+    __syncthreads();
+#pragma unroll
+    for (int z = 0; z < NF; ++z) FRAG_PIECE(fa0, fb0, 0, 0, z);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {  // k-step 0 | prefetch k-step 1
+            MFMA_SLOT(fa0, fb0, q);
+#pragma unroll
+            for (int z = q * PPF; z < (q + 1) * PPF; ++z)
+                if (z < NF) FRAG_PIECE(fa1, fb1, buf, 1, z);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {  // k-step 1 | prefetch 2 | LDS writes of tile kt+1
+            MFMA_SLOT(fa1, fb1, q);
+#pragma unroll
+            for (int z = q * PP1; z < (q + 1) * PP1; ++z) {
+                if (z < NF) FRAG_PIECE(fa0, fb0, buf, 2, z);
+                else if (z < NF + AL) store_a(buf ^ 1, z - NF);
+                else if (z < P1) store_b(buf ^ 1, z - NF - AL);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {  // k-step 2 | prefetch 3 | global loads of tile kt+2
+            MFMA_SLOT(fa0, fb0, q);
+#pragma unroll
+            for (int z = q * PP2; z < (q + 1) * PP2; ++z) {
+                if (z < NF) FRAG_PIECE(fa1, fb1, buf, 3, z);
+                else if (z < NF + AL) load_a(z - NF);
+                else if (z == NF + AL) advance();
+                else if (z < P2) load_b(kt + 2, z - NF - AL - 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {  // k-step 3 | prefetch k-step 0 of tile kt+1
+            MFMA_SLOT(fa1, fb1, q);
+#pragma unroll
+            for (int z = q * PPF; z < (q + 1) * PPF; ++z)
+                if (z < NF) FRAG_PIECE(fa0, fb0, buf ^ 1, 0, z);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef MFMA_SLOT
+#undef FRAG_PIECE
+
+    // ---- epilogue: col j = lane&31 (cout), row i = (r&3) + 8*(r>>2) + 4*half (pixel)
+    float* smf = reinterpret_cast<float*>(smem);
+    unsigned short* out16 = reinterpret_cast<unsigned short*>(p.out);
+    float* out32 = reinterpret_cast<float*>(p.out);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int c = n0 + wn * WN + j * 32 + (lane & 31);
+        const bool cok = c < p.Cout;
+        const int cc = cok ? c : p.Cout - 1;
+        const float sc = p.scale ? p.scale[cc] : 1.f;
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        float gsum = 0.f, gsq = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rbase = m0 + wm * WM + i * 32 + 4 * half;
+            float res[16];
+            if (p.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    res[r] = bf16_to_f32(p.residual[(size_t)m * p.Cout + cc]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + (r & 3) + 8 * (r >> 2);
+                float x = acc[i][j][r] * sc + bi + res[r];
+                if (p.relu) x = fmaxf(x, 0.f);
+                const bool ok = cok && m < p.M;
+                x = ok ? x : 0.f;
+                v[r] = x;
+                gsum += x;
+                gsq += x * x;
+            }
+            if (p.out_fp32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && m < p.M) out32[(size_t)m * p.Cout + c] = v[r];
+                }
+            } else if ((p.Cout & 1) == 0) {
+                // pack cout pairs: even lanes write the even rows of the register set, odd lanes the odd ones, each as one
+                // dword = (cout even, cout odd) -> 8 dword stores per lane instead of 16 two-byte stores
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float nb = __shfl_xor(v[r], 1, 64);
+                    const bool mine = ((r & 1) == (lane & 1));
+                    const int m = rbase + (r & 3) + 8 * (r >> 2);
+                    if (mine && m < p.M && (c & ~1) < p.Cout) {
+                        const bf16x2 pk = (lane & 1) ? bf16x2{(__bf16)nb, (__bf16)v[r]} : bf16x2{(__bf16)v[r], (__bf16)nb};
+                        *reinterpret_cast<unsigned*>(out16 + (size_t)m * p.Cout + (c & ~1)) = __builtin_bit_cast(unsigned, pk);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && m < p.M) {
+                        const __bf16 h = (__bf16)v[r];
+                        out16[(size_t)m * p.Cout + c] = __builtin_bit_cast(unsigned short, h);
+                    }
+                }
+            }
+        }
+        if (p.gn_part) {
+            gsum += __shfl_xor(gsum, 32, 64);
+            gsq += __shfl_xor(gsq, 32, 64);
+            const int cl = wn * WN + j * 32 + (lane & 31);
+            if (half == 0) {
+                smf[(wm * BN + cl) * 2 + 0] = gsum;
+                smf[(wm * BN + cl) * 2 + 1] = gsq;
+            }
+        }
+    }
+    if (p.gn_part) {
+        __syncthreads();
+        if (tid < BN) {
+            const int c = n0 + tid;
+            if (c < p.Cout) {
+                p.gn_part[((size_t)tm * p.Cout + c) * 2 + 0] = smf[tid * 2] + smf[(BN + tid) * 2];
+                p.gn_part[((size_t)tm * p.Cout + c) * 2 + 1] = smf[tid * 2 + 1] + smf[(BN + tid) * 2 + 1];
+            }
+        }
+    }
+}
+
+static int last_variant_bf16 = 0;  // bm*1000 + bn of the last launch (for profilers)
+extern "C" int cpr_conv_bf16_last_variant(void) { return last_variant_bf16; }
+
+extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+                                   const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
+                                   int KW, int stride, int pad, int Kpad, int relu, int out_fp32, hipStream_t stream) {
+    CPR_CHECK_ARG(in && wgt && out);
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    CPR_CHECK_ARG(Cin % BKH == 0 && Kpad == KH * KW * Cin);
+    ConvParamsBf16 p;
+    p.in = (const unsigned short*)in; p.wgt = (const unsigned short*)wgt; p.out = out; p.scale = scale; p.bias = bias;
+    p.residual = (const unsigned short*)residual; p.gn_part = gn_part;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Kpad = Kpad; p.relu = relu; p.out_fp32 = out_fp32;
+    p.OH = (H + 2 * pad - KH) / stride + 1;
+    p.OW = (W + 2 * pad - KW) / stride + 1;
+    CPR_CHECK_ARG(p.OH > 0 && p.OW > 0);
+    const long long M = (long long)N * p.OH * p.OW;
+    if ((long long)N * H * W * Cin * 2 >= (1ll << 31) || (long long)Cout * Kpad * 2 >= (1ll << 31) || M >= (1ll << 31))
+        return CPR_ERR_UNSUPPORTED;
+    p.M = (int)M;
+    if (gn_part) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
+    const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+    const bool big = gn_part || (Kpad / BKH >= 8 && t128 >= 4096 && Cout > 64);
+    const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+    p.tilesM = (int)((M + bm - 1) / bm);
+    p.tilesN = (Cout + bn - 1) / bn;
+    last_variant_bf16 = bm * 1000 + bn;
+    const int T = p.tilesM * p.tilesN;
+    const int grid = ((T + 7) / 8) * 8;
+    if (big) hipLaunchKernelGGL((conv_mfma_bf16_kernel<128, 128>), dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_mfma_bf16_kernel<64, 64>), dim3(grid), dim3(256), 0, stream, p);
+    CPR_LAUNCH_STATUS();
+}

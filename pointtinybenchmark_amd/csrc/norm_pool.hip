@@ -227,3 +227,135 @@ extern "C" int cpr_gn_apply(const float* x, const float* a, const float* b, cons
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, stream, x, a, b, up, y, N, H, W, C / 4, UH, UW, relu);
     CPR_LAUNCH_STATUS();
 }
+
+// ================================================================================================
+// bf16 variants (bf16 compute mode, BASELINE.json configs[4]): same kernels with 4 bf16 (8 bytes) per lane, fp32 math.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ f32x4 ld_bf16x4(const unsigned short* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    f32x4 v;
+    v.x = __uint_as_float(u.x << 16); v.y = __uint_as_float(u.x & 0xffff0000u);
+    v.z = __uint_as_float(u.y << 16); v.w = __uint_as_float(u.y & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ void st_bf16x4(unsigned short* p, f32x4 v) {
+    const bf16x2_t lo = {(__bf16)v.x, (__bf16)v.y}, hi = {(__bf16)v.z, (__bf16)v.w};
+    uint2 u;
+    u.x = __builtin_bit_cast(unsigned, lo);
+    u.y = __builtin_bit_cast(unsigned, hi);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+__global__ void maxpool3x3s2_bf16_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, int N,
+                                         int H, int W, int C4, int OH, int OW) {
+    const long long total = (long long)N * OH * OW * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int n = (int)(r / OH);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = ld_bf16x4(in + (((size_t)n * H + iy) * W + ix) * C4 * 4 + c * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        st_bf16x4(out + i * 4, m);
+    }
+}
+extern "C" int cpr_maxpool3x3s2_bf16(const void* in, void* out, int N, int H, int W, int C, hipStream_t stream) {
+    CPR_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * OH * OW * (C / 4);
+    const int grid = (int)(cdivll(total, 256) < 16384 ? cdivll(total, 256) : 16384);
+    hipLaunchKernelGGL(maxpool3x3s2_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned short*)in,
+                       (unsigned short*)out, N, H, W, C / 4, OH, OW);
+    CPR_LAUNCH_STATUS();
+}
+
+__global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, float* __restrict__ part, int HW, int C,
+                                     int P) {
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, slot = blockIdx.x;
+    const int Q = C >> 2;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q, PP = 256 / Q;
+    const int per = (HW + P - 1) / P;
+    const int p0 = slot * per, p1 = min(HW, p0 + per);
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (int p = p0 + pl; p < p1; p += PP) {
+        const f32x4 v = ld_bf16x4(x + ((size_t)n * HW + p) * C + q * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[threadIdx.x * 8 + k] = s[k];
+        red[threadIdx.x * 8 + 4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < PP; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += red[(r * Q + q) * 8 + k];
+        float* dst = part + (((size_t)n * P + slot) * C + q * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[k * 2] = a[k];
+            dst[k * 2 + 1] = a[4 + k];
+        }
+    }
+}
+extern "C" int cpr_gn_stats_bf16(const void* x, float* part, int N, int HW, int C, int P, hipStream_t stream) {
+    CPR_CHECK_ARG(x && part && N > 0 && HW > 0 && P > 0);
+    CPR_CHECK_ARG(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
+    hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(P, N), dim3(256), 0, stream, (const unsigned short*)x, part, HW, C, P);
+    CPR_LAUNCH_STATUS();
+}
+
+__global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ a,
+                                     const float* __restrict__ b, const unsigned short* __restrict__ up,
+                                     unsigned short* __restrict__ y, int N, int H, int W, int C4, int UH, int UW,
+                                     int relu) {
+    const long long total = (long long)N * H * W * C4;
+    const float sy = (float)UH / (float)H, sx = (float)UW / (float)W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int px = (int)(r % W);
+        r /= W;
+        const int py = (int)(r % H);
+        const int n = (int)(r / H);
+        f32x4 v = ld_bf16x4(x + i * 4);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + ((size_t)n * C4 + c) * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + ((size_t)n * C4 + c) * 4);
+        v = v * av + bv;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (up) {
+            const int uy = min((int)floorf(py * sy), UH - 1), ux = min((int)floorf(px * sx), UW - 1);
+            v = v + ld_bf16x4(up + ((((size_t)n * UH + uy) * UW + ux) * C4 + c) * 4);
+        }
+        st_bf16x4(y + i * 4, v);
+    }
+}
+extern "C" int cpr_gn_apply_bf16(const void* x, const float* a, const float* b, const void* up, void* y, int N, int H,
+                                 int W, int C, int UH, int UW, int relu, hipStream_t stream) {
+    CPR_CHECK_ARG(x && a && b && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    if (up) CPR_CHECK_ARG(UH > 0 && UW > 0);
+    const long long total = (long long)N * H * W * (C / 4);
+    const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
+    hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, a, b,
+                       (const unsigned short*)up, (unsigned short*)y, N, H, W, C / 4, UH, UW, relu);
+    CPR_LAUNCH_STATUS();
+}

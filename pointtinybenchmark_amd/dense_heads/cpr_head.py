@@ -186,16 +186,19 @@ class CPRHead(nn.Module):
     def _logit_map(self, feat_nhwc, in_ab=None):
         """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C)] (or C when the classifier is shared).
         in_ab: the input is the raw last-layer conv output and (a, b) its GroupNorm affine (+ReLU), applied on load."""
+        dt = feat_nhwc.dtype
+
         def make():
             w = [self.cls_out.weight] + ([] if self.ins_share_head_classifier else [self.ins_out.weight])
             b = [self.cls_out.bias] + ([] if self.ins_share_head_classifier else [self.ins_out.bias])
             wt = torch.cat(w, 0).detach()[:, :, None, None]
-            return ops.PackedConv(wt, 1, 0), torch.cat(b, 0).detach().float().contiguous()
+            return ops.PackedConv(wt, 1, 0, dt), torch.cat(b, 0).detach().float().contiguous()
         srcs = [self.cls_out.weight, self.cls_out.bias, self.ins_out.weight, self.ins_out.bias]
-        pc, bias = self._cache.get('proj', srcs, make)
-        if in_ab is not None and (feat_nhwc.shape[1] * feat_nhwc.shape[2]) % 128 != 0:
+        pc, bias = self._cache.get(('proj', dt), srcs, make)
+        if in_ab is not None and ((feat_nhwc.shape[1] * feat_nhwc.shape[2]) % 128 != 0 or dt != torch.float32):
             feat_nhwc, in_ab = ops.gn_apply(feat_nhwc, in_ab[0], in_ab[1], relu=True), None
-        return ops.conv2d(feat_nhwc, pc, bias=bias, in_ab=in_ab, in_relu=True)
+        # the logit map is always fp32 (the loss / sampling kernels are shared by both compute modes)
+        return ops.conv2d(feat_nhwc, pc, bias=bias, in_ab=in_ab, in_relu=True, out_dtype=torch.float32)
 
     def _gt_tensors(self, gt_bboxes, gt_labels, img_metas, device, shape_key):
         counts = [int(len(l)) for l in gt_labels]

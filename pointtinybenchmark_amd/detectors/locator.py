@@ -28,6 +28,14 @@ class BasicLocator(nn.Module):
         self.bbox_head = build_head(bbox_head)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
 
+    def set_compute_dtype(self, dtype):
+        """'fp32' (default: exact fp32 MFMA, the parity mode) or 'bf16' (BASELINE.json configs[4]: bf16 activations and
+        weights from the stem output on, fp32 accumulate / statistics / losses).  Parameters stay fp32 masters."""
+        dt = {'fp32': torch.float32, 'bf16': torch.bfloat16, torch.float32: torch.float32,
+              torch.bfloat16: torch.bfloat16}[dtype]
+        self.backbone.compute_dtype = dt
+        return self
+
     @property
     def with_neck(self):
         return self.neck is not None

@@ -25,9 +25,9 @@ class _PackCache:
         return val
 
 
-def packed_conv(cache, conv):
-    return cache.get(('pc', id(conv)), [conv.weight],
-                     lambda: ops.PackedConv(conv.weight, conv.stride[0], conv.padding[0]))
+def packed_conv(cache, conv, dtype=torch.float32):
+    return cache.get(('pc', id(conv), dtype), [conv.weight],
+                     lambda: ops.PackedConv(conv.weight, conv.stride[0], conv.padding[0], dtype))
 
 
 def folded_bn(cache, bn):
@@ -84,12 +84,13 @@ def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None):
     with ``materialize=False`` the raw conv output and the per-(image, channel) affine (a, b) are returned so
     the CONSUMER conv applies normalisation + ReLU while loading its input tile (no apply pass either).
     """
-    pc = packed_conv(cache, m.conv)
+    pc = packed_conv(cache, m.conv, x.dtype)
     gn = m.norm
     N, H, W, _ = x.shape
     OH, OW = pc.out_hw(H, W)
     fused_stats = (OH * OW) % 128 == 0
-    fuse_in = in_ab is not None and (H * W) % 128 == 0 and pc.stride == 1 and (OH, OW) == (H, W)
+    fuse_in = in_ab is not None and (H * W) % 128 == 0 and pc.stride == 1 and (OH, OW) == (H, W) \
+        and x.dtype == torch.float32   # the bf16 kernel does not fuse the producer GN (see conv_mfma_bf16.hip)
     if in_ab is not None and not fuse_in:
         x = ops.gn_apply(x, in_ab[0], in_ab[1], relu=in_relu)
         in_ab = None

@@ -21,10 +21,15 @@ def _stream():
 
 
 def _check(t, dtype=torch.float32):
+    """dtype may be a tuple of accepted dtypes (fp32 / bf16 activations)."""
     if not t.is_cuda:
         raise _lib.CprHipError('HIP op called with a CPU tensor: the product path has no CPU fallback')
-    assert t.dtype == dtype and t.is_contiguous(), (t.dtype, t.stride())
+    ok = t.dtype in dtype if isinstance(dtype, tuple) else t.dtype == dtype
+    assert ok and t.is_contiguous(), (t.dtype, t.stride())
     return t
+
+
+ACT = (torch.float32, torch.bfloat16)   # activation dtypes: fp32 (default, parity mode) or bf16 (configs[4] mode)
 
 
 def as_nchw(x_nhwc):
@@ -61,9 +66,17 @@ class PackedConv:
     """Conv weight repacked for the implicit-GEMM kernel: [Cout][KH][KW][Cin'] fp32, rows padded to a
     multiple of 32 floats.  Cin' = 4 for the 3-channel stem (zero 4th channel)."""
 
-    def __init__(self, weight, stride=1, padding=0):
+    def __init__(self, weight, stride=1, padding=0, dtype=torch.float32):
         Cout, Cin, KH, KW = weight.shape
         w = weight.detach().to(torch.float32).permute(0, 2, 3, 1)  # OHWI
+        self.dtype = dtype
+        if dtype == torch.bfloat16:
+            # bf16 kernel: K chunks of 64 elements, no stem mode (the 3-channel stem stays on the fp32 kernel)
+            assert Cin % 64 == 0, 'bf16 conv needs Cin % 64 == 0'
+            self.w = w.reshape(Cout, KH * KW * Cin).to(torch.bfloat16).contiguous()
+            self.Cout, self.Cin, self.KH, self.KW, self.Kpad = Cout, Cin, KH, KW, KH * KW * Cin
+            self.stride, self.padding = stride, padding
+            return
         if Cin <= 4:
             wp = torch.zeros((Cout, KH, KW, 4), device=weight.device, dtype=torch.float32)
             wp[..., :Cin] = w
@@ -85,44 +98,59 @@ class PackedConv:
 
 
 def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, in_relu=False, gn_part=False,
-           out=None):
+           out=None, out_dtype=None):
     """x (N,H,W,Cin) -> (N,OH,OW,Cout).  Epilogue: *scale[c] + bias[c] (+residual) (ReLU).
-    in_ab=(a,b) applies x*a[n,c]+b[n,c] (+ReLU) to the input on load (fused GroupNorm of the producer).
-    gn_part=True also returns per-128-pixel-tile per-channel (sum, sumsq) partials of the output."""
-    _check(x)
+    in_ab=(a,b) applies x*a[n,c]+b[n,c] (+ReLU) to the input on load (fused GroupNorm of the producer; fp32 only).
+    gn_part=True also returns per-128-pixel-tile per-channel (sum, sumsq) partials of the output.
+    bf16 inputs run the bf16 MFMA kernel (fp32 accumulate); out_dtype overrides the output type (the fp32 stem can
+    emit bf16, the bf16 logit projection emits fp32)."""
+    _check(x, ACT)
     N, H, W, Cin = x.shape
     assert Cin == pc.Cin, (Cin, pc.Cin)
+    assert x.dtype == pc.dtype, 'weights were packed for %s, input is %s' % (pc.dtype, x.dtype)
     OH, OW = pc.out_hw(H, W)
+    odt = out_dtype or x.dtype
     if out is None:
-        out = torch.empty((N, OH, OW, pc.Cout), device=x.device, dtype=torch.float32)
+        out = torch.empty((N, OH, OW, pc.Cout), device=x.device, dtype=odt)
     part = None
     if gn_part:
         assert (OH * OW) % 128 == 0
         part = torch.empty((N * OH * OW // 128, pc.Cout, 2), device=x.device, dtype=torch.float32)
+    if x.dtype == torch.bfloat16:
+        assert in_ab is None, 'the bf16 kernel does not fuse the producer GroupNorm (materialise with gn_apply)'
+        _lib.call('cpr_conv2d_fwd_bf16', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
+                  _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding, pc.Kpad, int(relu),
+                  int(odt == torch.float32), _stream())
+        return (out, part) if gn_part else out
     a = b = None
     if in_ab is not None:
         a, b = in_ab
+    flags = int(relu) | (2 if odt == torch.bfloat16 else 0)
     _lib.call('cpr_conv2d_fwd', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias),
               _ptr(residual), _ptr(a), _ptr(b), _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride,
-              pc.padding, pc.Kpad, int(relu), int(in_relu), _stream())
+              pc.padding, pc.Kpad, flags, int(in_relu), _stream())
     return (out, part) if gn_part else out
 
 
+def _sfx(x):
+    return '_bf16' if x.dtype == torch.bfloat16 else ''
+
+
 def maxpool3x3s2(x):
-    N, H, W, C = _check(x).shape
-    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), device=x.device, dtype=torch.float32)
-    _lib.call('cpr_maxpool3x3s2', _ptr(x), _ptr(out), N, H, W, C, _stream())
+    N, H, W, C = _check(x, ACT).shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), device=x.device, dtype=x.dtype)
+    _lib.call('cpr_maxpool3x3s2' + _sfx(x), _ptr(x), _ptr(out), N, H, W, C, _stream())
     return out
 
 
 def gn_stats(x, slots=None):
     """Per (image, slot, channel) (sum, sumsq) partials of an NHWC tensor."""
-    N, H, W, C = _check(x).shape
+    N, H, W, C = _check(x, ACT).shape
     HW = H * W
     if slots is None:
         slots = max(1, min(256, HW // 256))
     part = torch.empty((N * slots, C, 2), device=x.device, dtype=torch.float32)
-    _lib.call('cpr_gn_stats', _ptr(x), _ptr(part), N, HW, C, slots, _stream())
+    _lib.call('cpr_gn_stats' + _sfx(x), _ptr(x), _ptr(part), N, HW, C, slots, _stream())
     return part
 
 
@@ -143,13 +171,14 @@ def gn_finalize(part, gamma, beta, N, HW, groups=32, eps=1e-5, want_stats=False)
 
 def gn_apply(x, a, b, relu=False, up=None, out=None):
     """y = x*a[n,c] + b[n,c] (ReLU) (+ nearest-upsampled ``up``).  In place when out is x."""
-    N, H, W, C = _check(x).shape
+    N, H, W, C = _check(x, ACT).shape
     if out is None:
         out = torch.empty_like(x)
     UH = UW = 0
     if up is not None:
+        assert up.dtype == x.dtype
         UH, UW = up.shape[1], up.shape[2]
-    _lib.call('cpr_gn_apply', _ptr(x), _ptr(a), _ptr(b), _ptr(up), _ptr(out), N, H, W, C, UH, UW, int(relu),
+    _lib.call('cpr_gn_apply' + _sfx(x), _ptr(x), _ptr(a), _ptr(b), _ptr(up), _ptr(out), N, H, W, C, UH, UW, int(relu),
               _stream())
     return out
 

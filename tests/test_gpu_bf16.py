@@ -1,0 +1,120 @@
+"""-m gpu: the bf16 compute mode (BASELINE.json configs[4]: bf16 MFMA conv path, fp32 accumulate).  The reference has no
+bf16 path, so the tolerance is stated here: conv outputs within bf16 rounding of an fp32 conv on the same bf16-rounded
+operands (2^-8 relative + accumulation noise), end-to-end feature maps within 5e-2 of the fp32 oracle after GroupNorm,
+losses within 3 %, integer outputs (bag validity, negative mask) still bit-exact (they do not depend on the features)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpr_oracle as O
+from pointtinybenchmark_amd import synthetic
+from tests.test_gpu_cpr_parity import build_hip_locator, to_cuda
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (2, 64, 40, 40, 64, 3, 1, 1, ''), (2, 256, 24, 20, 64, 1, 1, 0, 'bn relu'), (1, 128, 33, 29, 128, 3, 2, 1, 'bn relu'),
+    (2, 256, 20, 20, 512, 1, 2, 0, 'bn'), (2, 64, 25, 21, 256, 1, 1, 0, 'bn res relu'), (1, 256, 32, 32, 256, 3, 1, 1, 'bias gn'),
+    (3, 512, 7, 9, 2048, 1, 1, 0, 'bn res relu'), (2, 256, 16, 16, 2, 1, 1, 0, 'bias f32out'), (1, 2048, 5, 5, 256, 1, 1, 0, ''),
+    (2, 256, 64, 64, 256, 3, 1, 1, 'gn'), (1, 64, 16, 16, 3, 1, 1, 0, 'bias'),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'n%d_c%d_%dx%d_o%d_k%d_s%d_%s' % (c[:7] + (c[8].replace(' ', '-'),)))
+def test_conv2d_bf16_vs_torch(case):
+    from pointtinybenchmark_amd import ops
+    N, Cin, H, W, Cout, k, stride, pad, flags = case
+    g = torch.Generator().manual_seed(abs(hash(case[:8])) % 1000)
+    x = torch.randn((N, Cin, H, W), generator=g).bfloat16()
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    ref = F.conv2d(x.float(), w.float(), None, stride, pad)
+    scale = bias = res = None
+    if 'bn' in flags:
+        scale = torch.rand(Cout, generator=g) + 0.5
+        bias = torch.randn(Cout, generator=g)
+        ref = ref * scale[None, :, None, None] + bias[None, :, None, None]
+    elif 'bias' in flags:
+        bias = torch.randn(Cout, generator=g)
+        ref = ref + bias[None, :, None, None]
+    if 'res' in flags:
+        res = torch.randn(ref.shape, generator=g).bfloat16()
+        ref = ref + res.float()
+    if 'relu' in flags:
+        ref = F.relu(ref)
+    pc = ops.PackedConv(w.float().cuda(), stride, pad, torch.bfloat16)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    f32out = 'f32out' in flags
+    out = ops.conv2d(xin, pc, scale=None if scale is None else scale.cuda(), bias=None if bias is None else bias.cuda(),
+                     residual=None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda(), relu='relu' in flags,
+                     gn_part='gn' in flags, out_dtype=torch.float32 if f32out else None)
+    part = None
+    if 'gn' in flags:
+        out, part = out
+    torch.cuda.synchronize()
+    assert out.dtype == (torch.float32 if f32out else torch.bfloat16)
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    tol = (1e-4 if f32out else 2.0 ** -7) * ref.abs() + 2e-3
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), 'max abs err %.3e, %d/%d over tol' % (float((got - ref).abs().max()), int(bad.sum()), bad.numel())
+    if part is not None:       # statistics come from the fp32 accumulators, not the rounded outputs
+        s = part.reshape(N, -1, Cout, 2).sum(1).cpu()
+        np.testing.assert_allclose(s[..., 0].numpy(), ref.sum(dim=(2, 3)).numpy(), rtol=1e-3, atol=2e-2)
+        np.testing.assert_allclose(s[..., 1].numpy(), (ref * ref).sum(dim=(2, 3)).numpy(), rtol=1e-3, atol=2e-2)
+
+
+def test_bf16_aux_kernels():
+    from pointtinybenchmark_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((2, 256, 20, 28), generator=g).bfloat16()
+    u = torch.randn((2, 256, 10, 14), generator=g).bfloat16()
+    gam, bet = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    ref = F.relu(F.group_norm(x.float(), 32, gam, bet, 1e-5)) + F.interpolate(u.float(), size=(20, 28), mode='nearest')
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    part = ops.gn_stats(xn)
+    a, b = ops.gn_finalize(part, gam.cuda(), bet.cuda(), 2, 20 * 28, 32, 1e-5)
+    out = ops.gn_apply(xn, a, b, relu=True, up=u.permute(0, 2, 3, 1).contiguous().cuda())
+    assert out.dtype == torch.bfloat16
+    err = (out.float().permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert float(err.max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-3
+    p = torch.randn((2, 64, 33, 31), generator=g).bfloat16()
+    mp = ops.maxpool3x3s2(p.permute(0, 2, 3, 1).contiguous().cuda())
+    assert torch.equal(mp.float().permute(0, 3, 1, 2).cpu(), F.max_pool2d(p.float(), 3, 2, 1))
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(depth=50, num_classes=1, start_level=0, stride=4, radius=5, head_std=0.3, seed=51, batch=2, height=256, width=256,
+         num_gts=8),
+    dict(depth=101, num_classes=3, start_level=0, stride=4, radius=5, head_std=0.3, seed=53, batch=1, height=384,
+         width=320, num_gts=10),
+], ids=['r50_256', 'r101_384x320'])
+def test_bf16_path_vs_fp32_oracle(cfg):
+    from pointtinybenchmark_amd import ops
+    m, sd = build_hip_locator(cfg)
+    m.set_compute_dtype('bf16')
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'])
+    cb = to_cuda(batch)
+    with torch.no_grad():
+        feats = m.neck(m.backbone(cb['img']))
+        assert feats[0].dtype == torch.bfloat16
+        cls_feat, ins_feat = m.bbox_head(feats)
+        losses = m.bbox_head.loss(cls_feat, ins_feat, cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'])
+        fused = m.forward_train(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+        dets = m.bbox_head.get_bboxes(cls_feat, ins_feat, cb['img_metas'], gt_bboxes=cb['gt_bboxes'],
+                                      gt_labels=cb['gt_labels'], gt_anns_id=cb['gt_anns_id'])
+        torch.cuda.synchronize()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref_losses, ref_feat, per = O.locator_forward_train(sd, batch, cfg['depth'], 0, 4, 5, cfg['num_classes'])
+    scale = max(1.0, float(ref_feat.abs().max()))
+    err = (cls_feat[0].float().cpu() - ref_feat).abs()
+    assert float(err.max()) <= 8e-2 * scale and float(err.mean()) <= 1e-2 * scale, \\
+        'bf16 cls_feat: max %.3e mean %.3e (scale %.2e)' % (float(err.max()), float(err.mean()), scale)
+    for k in ('gt_loss', 'pos_loss', 'neg_loss'):
+        a, b = float(losses[k]), float(ref_losses[k])
+        assert abs(a - b) <= 3e-2 * max(abs(b), 1e-3), (k, a, b)
+        assert abs(float(fused[k]) - a) <= 1e-5 * max(abs(a), 1e-6)
+    assert all(bool(torch.isfinite(d).all()) for d, _ in dets)
