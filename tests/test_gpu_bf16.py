@@ -111,7 +111,7 @@ def test_bf16_path_vs_fp32_oracle(cfg):
         ref_losses, ref_feat, per = O.locator_forward_train(sd, batch, cfg['depth'], 0, 4, 5, cfg['num_classes'])
     scale = max(1.0, float(ref_feat.abs().max()))
     err = (cls_feat[0].float().cpu() - ref_feat).abs()
-    assert float(err.max()) <= 8e-2 * scale and float(err.mean()) <= 1e-2 * scale, \\
+    assert float(err.max()) <= 8e-2 * scale and float(err.mean()) <= 1e-2 * scale, \
         'bf16 cls_feat: max %.3e mean %.3e (scale %.2e)' % (float(err.max()), float(err.mean()), scale)
     for k in ('gt_loss', 'pos_loss', 'neg_loss'):
         a, b = float(losses[k]), float(ref_losses[k])
