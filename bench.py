@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); only used with --dtype bf16
 
 
 def pmc_traffic(kernel_name, batch):
@@ -86,9 +87,13 @@ class ConvProbe:
             e.record()
             N, H, W, _ = x.shape
             OH, OW = pc.out_hw(H, W)
-            v = probe._lib.load().cpr_conv_last_variant()
-            variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
-                                                                  'true' if v // 10 % 10 else 'false', v % 10)
+            if x.dtype == torch.bfloat16:
+                v = probe._lib.load().cpr_conv_bf16_last_variant()
+                variant = 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
+            else:
+                v = probe._lib.load().cpr_conv_last_variant()
+                variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
+                                                                      'true' if v // 10 % 10 else 'false', v % 10)
             kreal = pc.KH * pc.KW * (3 if pc.Cin == 4 else pc.Cin)
             probe.records.append((variant, 2.0 * N * OH * OW * pc.Cout * kreal, s, e))
             return out
@@ -154,6 +159,10 @@ def main():
     ap.add_argument('--num-gts', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help="fp32 = the headline metric (exact fp32 MFMA); bf16 = the bf16 compute mode of configs[4]")
+    ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--size', type=int, default=640)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -168,10 +177,11 @@ def main():
 
     import pointtinybenchmark_amd as P
     from pointtinybenchmark_amd import synthetic
-    model = P.build_detector(model_cfg()).cuda()
-    model.load_state_dict(synthetic.locator_state_dict(50, 1, 0, 'cpr', 0), strict=True)
+    model = P.build_detector(model_cfg(args.depth)).cuda()
+    model.load_state_dict(synthetic.locator_state_dict(args.depth, 1, 0, 'cpr', 0), strict=True)
     model.train()
-    batch = synthetic.synthetic_batch(args.batch, 640, 640, args.num_gts, 1, seed=rank)   # each rank its own shard
+    model.set_compute_dtype(args.dtype)
+    batch = synthetic.synthetic_batch(args.batch, args.size, args.size, args.num_gts, 1, seed=rank)   # per-rank shard
     img = batch['img'].cuda()
     gtb = [b.cuda() for b in batch['gt_bboxes']]
     gtl = [l.cuda() for l in batch['gt_labels']]
@@ -213,9 +223,10 @@ def main():
             'metric': 'img/s (640x640) CPR R50-FPN fwd+loss',
             'value': total_imgs / elapsed, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
-            'config': {'workload': 'CPR ResNet-50 + FPN(num_outs=1, stride 4) + CPRHead, 640x640, forward + loss '
-                                   '(configs[1])', 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'CPR ResNet-%d + FPN(num_outs=1, stride 4) + CPRHead, %dx%d, forward + loss%s' % (
+                args.depth, args.size, args.size, ' (configs[1])' if (args.depth, args.size, args.dtype) == (50, 640, 'fp32')
+                else ' (NOT the headline config)'), 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'gts_per_image': args.num_gts, 'parallelism': 'dp%d' % world,
                        'weights': 'random init (synthetic.locator_state_dict seed 0)'},
             'losses': loss_vals,
@@ -227,15 +238,16 @@ def main():
             ach = dom['tflops']
             conv_s = sum(v['seconds'] for v in summ.values())
             conv_f = sum(v['flops'] for v in summ.values())
-            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(name, args.batch), 'kernel': name,
+            peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in name else PEAK_FP32_MFMA_TFLOPS
+            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                               'frac': ach / peak, 'traffic': pmc_traffic(name, args.batch), 'kernel': name,
                                'launches': dom['launches'], 'flops_per_launch': dom['flops'] / dom['launches'],
                                'avg_launch_ms': dom['seconds'] / dom['launches'] * 1e3,
                                'share_of_step_time': dom['seconds'] / elapsed,
                                'all_conv_instances_tflops': conv_f / conv_s / 1e12,
                                'per_instance_tflops': {k: round(v['tflops'], 2) for k, v in summ.items()}}
             out['conv_time_frac'] = conv_s / elapsed
-            out['end_to_end_tflops'] = 224.0e9 * total_imgs / world / elapsed / 1e12
+            out['end_to_end_tflops'] = conv_f / args.steps / (elapsed / args.steps) / 1e12   # conv FLOPs of a step / step time
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(2, args.num_gts)
         print(json.dumps(out), flush=True)
