@@ -159,6 +159,56 @@ int cpr_p2p_loss(const float* logits, const float* pred, const long long* gt_ind
                  float alpha, float gamma, float beta, float pos_w, float neg_w, float reg_norm, float w_cls,
                  float w_reg, void* stream);
 
+/* ---- training step: backward + optimizer ------------------------------------------------
+ * The reference gets these from torch autograd over mmcv ConvModule / nn.GroupNorm / F.grid_sample and
+ * torch.optim.SGD driven by mmcv's OptimizerHook (T/configs2/COCO/CPRNet/CPR_R50_FPN_1x_coco_coarse.py optimizer /
+ * optimizer_config); tests/test_gpu_backward.py checks every function against torch autograd on the oracle.
+ *
+ * weight gradient of conv2d_fwd: dy (N,OH,OW,Cout) x (N,H,W,Cin) NHWC fp32 -> grad_w [Cout][Cin][KH][KW] (the
+ * parameter's own layout).  Optional fused input transform x' = max(x*in_a[n,c]+in_b[n,c], in_relu?0:-inf) (the
+ * GroupNorm(+ReLU) the forward applied on load).  ws: cpr_conv2d_wgrad_workspace(...) floats.  Cin%4==0, Cout%4==0. */
+int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
+int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w, float* ws,
+                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int in_relu,
+                     int accumulate, void* stream);
+/* nn.GroupNorm (+ReLU) backward from the raw conv output x, the forward affine a,b (N,C), mean/rstd (N,G):
+ * dx (N,HW,C), dgamma/dbeta (C).  ws_part N*P*C*2 floats, ws_k 2*N*G + 2*N*C floats. */
+int cpr_gn_bwd(const float* x, const float* dz, const float* a, const float* b, const float* mean, const float* rstd,
+               const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws_part, float* ws_k, int N, int HW,
+               int C, int G, int P, int relu, int accumulate, void* stream);
+/* FPN top-down path backward (fpn.py:176-185): dcoarse (N,UH,UW,C) (+)= sum over the nearest-upsample children of dfine */
+int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W, int UH, int UW, int C, int accumulate,
+                         void* stream);
+/* backward of the fused conv epilogue y = relu?(conv*scale + shift (+ identity)) of an eval-mode BatchNorm
+ * (resnet.py Bottleneck.forward): g = dy*(y>0) (y NULL: g = dy) is the shortcut gradient and the un-scaled conv-output
+ * gradient; colsum (C) (+)= per-channel sums of g (= dshift; also the Linear/conv bias gradient).  (M,C) row-major,
+ * C%4==0.  g_out may be NULL (sums only).  ws_part ceil(M/512)*C floats. */
+int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out, float* colsum, float* ws_part, long long M, int C,
+                        int accumulate, void* stream);
+/* parameter side of the folded BN: Gw = cpr_conv2d_wgrad(g, x) [Cout][K] -> in place dW = scale[c]*Gw[c];
+ * dgamma = inv_sigma*(<W[c],Gw[c]> - mean*colsum_g), dbeta = colsum_g (either may be NULL). */
+int cpr_bn_fold_bwd(float* Gw, const float* weight, const float* scale, const float* mean, const float* inv_sigma,
+                    const float* colsum_g, float* dgamma, float* dbeta, int Cout, int K, void* stream);
+/* y = alpha*x + beta*y on flat fp32 buffers */
+int cpr_axpby(float* y, const float* x, float alpha, float beta, long long n, void* stream);
+/* out (N,H,W,C) = dy (N,OH,OW,C) with s-1 zeros inserted between pixels (data gradient of a stride-s conv as a
+ * stride-1 conv over the dilated gradient) */
+int cpr_zero_insert(const float* dy, float* out, int N, int OH, int OW, int C, int H, int W, int s, void* stream);
+/* d(gt_loss + pos_loss + neg_loss)/d(logit map) of CPRHead.loss (cpr_head.py:1101-1229): negative-grid term, MIL bag
+ * and gt-centre terms scattered back through the bilinear taps (float atomics).  Inputs are the forward's own buffers
+ * (neg mask, out5, bag logits, valid, bag_ws).  dbag_ws (G,K,J) workspace; dmap (N,H,W,Jd), Jd >= J, fully written. */
+int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* out5, const float* bag_logits,
+                 const unsigned char* valid, const int* labels, const float* gt_weight, const float* bag_ws,
+                 const float* centers, const int* gt_img, const float* offsets, float* dbag_ws, float* dmap, int N,
+                 int H, int W, int J, int Jd, int ins_off, int G, int K, int C, float stride, float eps, float w_mil,
+                 float w_gt, float w_neg, void* stream);
+/* sum of squares of a flat gradient buffer into out[0] (double; accumulate across buffers); ws_partial 1024 doubles */
+int cpr_grad_sumsq(const float* g, long long n, double* ws_partial, double* out, int accumulate, void* stream);
+/* torch.optim.SGD step (momentum, weight decay) with clip_grad_norm_'s coefficient taken from norm2 on the device:
+ * g = min(1, max_norm/(sqrt(norm2)*grad_scale+1e-6)) * grad_scale * grad + wd*p; buf = first ? g : mu*buf+g; p -= lr*buf */
+int cpr_sgd_step(float* p, const float* grad, float* buf, const double* norm2, long long n, float lr, float mu, float wd,
+                 float max_norm, float grad_scale, int first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libcprhip.so')
 _p = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
+_l = ctypes.c_longlong
 
 # name -> argtypes (restype is always int: 0 ok, <0 error).  Mirrors include/cpr_hip.h one to one.
 SIGNATURES = {
@@ -45,6 +46,18 @@ SIGNATURES = {
     'cpr_p2p_decode': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'cpr_rowmax_sigmoid': [_p, _p, ctypes.c_longlong, _i, _p],
     'cpr_p2p_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p],
+    # training step: backward + optimizer
+    'cpr_conv2d_wgrad_workspace': [_i] * 7,
+    'cpr_conv2d_wgrad': [_p] * 6 + [_i] * 11 + [_p],
+    'cpr_gn_bwd': [_p] * 12 + [_i] * 7 + [_p],
+    'cpr_upsample_add_bwd': [_p, _p] + [_i] * 7 + [_p],
+    'cpr_relu_bwd_colsum': [_p] * 5 + [_l, _i, _i, _p],
+    'cpr_bn_fold_bwd': [_p] * 8 + [_i, _i, _p],
+    'cpr_axpby': [_p, _p, _f, _f, _l, _p],
+    'cpr_zero_insert': [_p, _p] + [_i] * 7 + [_p],
+    'cpr_loss_bwd': [_p] * 13 + [_i] * 9 + [_f] * 5 + [_p],
+    'cpr_grad_sumsq': [_p, _l, _p, _p, _i, _p],
+    'cpr_sgd_step': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p],
 }
 
 _lib = None
@@ -74,10 +87,13 @@ def load():
     return lib
 
 
-def call(name, *args):
+def call(name, *args, positive=False):
     """Invoke a C-ABI entry point; non-zero status -> RuntimeError (the reference raises Python
-    exceptions / asserts on bad inputs; this is the same contract across the boundary)."""
+    exceptions / asserts on bad inputs; this is the same contract across the boundary).
+    positive=True: a non-negative return is a value (size queries), only negatives are errors."""
     rc = getattr(load(), name)(*args)
+    if positive and rc >= 0:
+        return rc
     if rc != 0:
         if rc == -1001:
             raise CprHipError('%s: invalid argument' % name)

@@ -1,0 +1,564 @@
+// Backward kernels of the CPR training step, everything except the conv data/weight gradients:
+//   GroupNorm(+ReLU) backward as two streaming passes, eval-BatchNorm(+residual)+ReLU backward, FPN top-down add backward,
+//   the CPR loss gradients (negative grid, MIL bags, gt centre) and the bilinear scatter back onto the logit map,
+//   SGD-momentum with global-norm gradient clipping.
+// References for the math: torch autograd on oracle/cpr_oracle.py (tests/test_gpu_backward.py compares against it).
+#include "common.h"
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------ GroupNorm backward
+// forward: y = x*a[n,c] + b[n,c] (a = rstd*gamma, b = beta - mean*a), z = relu?(y).  Given dz:
+//   dy = dz * (y > 0 | !relu);  xhat = (x - mean) * rstd
+//   dgamma[c] = sum dy*xhat, dbeta[c] = sum dy
+//   dx = dy*a + x*k2[n,g] + k3[n,g],  k2 = -rstd^2 * m2, k3 = -rstd*m1 + mean*rstd^2*m2,
+//        m1 = mean_g(dy*gamma), m2 = mean_g(dy*gamma*xhat)
+// pass 1: per (image, slot, channel) partial (sum dy, sum dy*xhat)   -- same [N][P][C][2] layout as the forward stats
+__global__ void gn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                    const float* __restrict__ a, const float* __restrict__ b,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    float* __restrict__ part, int HW, int C, int G, int P, int relu) {
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, slot = blockIdx.x;
+    const int Q = C >> 2;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q, PP = 256 / Q;
+    const int per = (HW + P - 1) / P;
+    const int p0 = slot * per, p1 = min(HW, p0 + per);
+    const int cpg = C / G;
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a + (size_t)n * C + q * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + (size_t)n * C + q * 4);
+    float mu[4], rs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int g = (q * 4 + k) / cpg;
+        mu[k] = mean[n * G + g];
+        rs[k] = rstd[n * G + g];
+    }
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int p = p0 + pl; p < p1; p += PP) {
+        const size_t o = ((size_t)n * HW + p) * C + q * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dz + o);
+        const f32x4 y = xv * av + bv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dy = (relu && !(y[k] > 0.f)) ? 0.f : dv[k];
+            s1[k] += dy;
+            s2[k] += dy * (xv[k] - mu[k]) * rs[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[threadIdx.x * 8 + k] = s1[k];
+        red[threadIdx.x * 8 + 4 + k] = s2[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < PP; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += red[(r * Q + q) * 8 + k];
+        float* dst = part + (((size_t)n * P + slot) * C + q * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[k * 2] = acc[k];
+            dst[k * 2 + 1] = acc[4 + k];
+        }
+    }
+}
+
+// pass 1b: one block per image: per-channel sums over slots (double), group means, k2/k3; per-image dgamma/dbeta
+// contributions go to dgb_part [N][C][2] and are summed over images by the caller's second launch (gn_bwd_params).
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       float* __restrict__ k2, float* __restrict__ k3, float* __restrict__ dgb_part,
+                                       int P, int C, int G, double count) {
+    extern __shared__ double sh[];  // [C][2]
+    const int n = blockIdx.x;
+    const int cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s1 = 0, s2 = 0;
+        for (int t = 0; t < P; ++t) {
+            const float* src = part + (((size_t)n * P + t) * C + c) * 2;
+            s1 += (double)src[0];
+            s2 += (double)src[1];
+        }
+        sh[c * 2] = s1;
+        sh[c * 2 + 1] = s2;
+        dgb_part[((size_t)n * C + c) * 2] = (float)s1;       // dbeta contribution
+        dgb_part[((size_t)n * C + c) * 2 + 1] = (float)s2;   // dgamma contribution
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double A = 0, B = 0;
+        for (int k = 0; k < cpg; ++k) {
+            const double gm = (double)gamma[g * cpg + k];
+            A += gm * sh[(g * cpg + k) * 2];
+            B += gm * sh[(g * cpg + k) * 2 + 1];
+        }
+        const double m1 = A / count, m2 = B / count;
+        const double r = (double)rstd[n * G + g], mu = (double)mean[n * G + g];
+        k2[n * G + g] = (float)(-r * r * m2);
+        k3[n * G + g] = (float)(-r * m1 + mu * r * r * m2);
+    }
+}
+__global__ void gn_bwd_params_kernel(const float* __restrict__ dgb_part, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int N, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sb = 0, sg = 0;
+    for (int n = 0; n < N; ++n) {
+        sb += (double)dgb_part[((size_t)n * C + c) * 2];
+        sg += (double)dgb_part[((size_t)n * C + c) * 2 + 1];
+    }
+    dbeta[c] = accumulate ? dbeta[c] + (float)sb : (float)sb;
+    dgamma[c] = accumulate ? dgamma[c] + (float)sg : (float)sg;
+}
+
+// pass 2: dx = dy*a + x*k2 + k3
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                    const float* __restrict__ a, const float* __restrict__ b,
+                                    const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
+                                    int N, int HW, int C4, int G, int relu) {
+    const long long total = (long long)N * HW * C4;
+    const int cpg4 = (C4 * 4) / G;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const int n = (int)(i / ((long long)HW * C4));
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dz + i * 4);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + ((size_t)n * C4 + c) * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + ((size_t)n * C4 + c) * 4);
+        const f32x4 y = xv * av + bv;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = (c * 4 + k) / cpg4;
+            const float dy = (relu && !(y[k] > 0.f)) ? 0.f : dv[k];
+            o[k] = dy * av[k] + xv[k] * k2[n * G + g] + k3[n * G + g];
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+    }
+}
+
+extern "C" int cpr_gn_bwd(const float* x, const float* dz, const float* a, const float* b, const float* mean,
+                          const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws_part,
+                          float* ws_k, int N, int HW, int C, int G, int P, int relu, int accumulate, hipStream_t stream) {
+    // ws_part: N*P*C*2 floats; ws_k: 2*N*G + 2*N*C floats (k2 | k3 | per-image dgamma/dbeta contributions)
+    CPR_CHECK_ARG(x && dz && a && b && mean && rstd && gamma && dx && dgamma && dbeta && ws_part && ws_k);
+    CPR_CHECK_ARG(N > 0 && HW > 0 && G > 0 && P > 0 && C % G == 0 && (C / G) % 4 == 0 || (C / G) >= 1);
+    CPR_CHECK_ARG(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
+    float* k2 = ws_k;
+    float* k3 = ws_k + (size_t)N * G;
+    float* dgb = ws_k + (size_t)2 * N * G;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(P, N), dim3(256), 0, stream, x, dz, a, b, mean, rstd, ws_part, HW, C, G,
+                       P, relu);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), (size_t)2 * C * sizeof(double), stream, ws_part, gamma,
+                       mean, rstd, k2, k3, dgb, P, C, G, (double)HW * (C / G));
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, dgb, dgamma, dbeta, N, C,
+                       accumulate);
+    const long long total = (long long)N * HW * (C / 4);
+    const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, x, dz, a, b, k2, k3, dx, N, HW, C / 4, G,
+                       relu);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------ FPN top-down add
+// forward: fine = gn(fine_raw) + up_nearest(coarse).  backward wrt coarse: dcoarse[u] (+)= sum of dfine over its children
+__global__ void upsample_add_bwd_kernel(const float* __restrict__ dfine, float* __restrict__ dcoarse, int N, int H, int W,
+                                        int UH, int UW, int C4, int accumulate) {
+    const long long total = (long long)N * UH * UW * C4;
+    const float sy = (float)UH / (float)H, sx = (float)UW / (float)W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ux = (int)(r % UW);
+        r /= UW;
+        const int uy = (int)(r % UH);
+        const int n = (int)(r / UH);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        const int y0 = max(0, (int)(uy / sy) - 1), y1 = min(H - 1, (int)((uy + 1) / sy) + 1);
+        const int x0 = max(0, (int)(ux / sx) - 1), x1 = min(W - 1, (int)((ux + 1) / sx) + 1);
+        for (int y = y0; y <= y1; ++y) {
+            if (min((int)floorf(y * sy), UH - 1) != uy) continue;
+            for (int x = x0; x <= x1; ++x) {
+                if (min((int)floorf(x * sx), UW - 1) != ux) continue;
+                s = s + *reinterpret_cast<const f32x4*>(dfine + ((((size_t)n * H + y) * W + x) * C4 + c) * 4);
+            }
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(dcoarse + i * 4);
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+extern "C" int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W, int UH, int UW, int C,
+                                    int accumulate, hipStream_t stream) {
+    CPR_CHECK_ARG(dfine && dcoarse && N > 0 && H > 0 && W > 0 && UH > 0 && UW > 0 && C % 4 == 0);
+    const long long total = (long long)N * UH * UW * (C / 4);
+    const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid), dim3(256), 0, stream, dfine, dcoarse, N, H, W, UH, UW, C / 4,
+                       accumulate);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------ BN(eval)+add+ReLU
+// forward (conv epilogue): y = relu?(conv*s[c] + t[c] (+ identity)).  Given dy:  g = dy * (y > 0 | !relu) is at once the
+// gradient of the shortcut and (times s, folded into the data-gradient weights / applied to the weight gradient by
+// bn_fold_bwd) of the conv output.  This kernel writes g and the per-channel column sums of g (= dshift).
+// (M, C) row-major, C % 4 == 0.  y == nullptr: no mask (g = dy; g_out may be null -> column sums only).
+__global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ g_out,
+                                       float* __restrict__ part, long long M, int C, int rows_per_block) {
+    __shared__ float red[256 * 4];
+    const int Q = C >> 2;
+    const int PP = 256 / Q;                         // rows handled per pass; threads >= PP*Q idle
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s1[4] = {0, 0, 0, 0};
+    if (pl < PP) {
+        for (long long r = r0 + pl; r < r1; r += PP) {
+            const size_t o = (size_t)r * C + q * 4;
+            f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+            if (y) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = (yv[k] > 0.f) ? g[k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s1[k] += g[k];
+            if (g_out) *reinterpret_cast<f32x4*>(g_out + o) = g;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] = s1[k];
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        float acc[4] = {0, 0, 0, 0};
+        for (int r = 0; r < PP; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += red[(r * Q + q) * 4 + k];
+        float* dst = part + (size_t)blockIdx.x * C + q * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = acc[k];
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int blocks, int C,
+                                    int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int k = 0; k < blocks; ++k) s += (double)part[(size_t)k * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+extern "C" int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out, float* colsum, float* ws_part,
+                                   long long M, int C, int accumulate, hipStream_t stream) {
+    // ws_part: ceil(M/512)*C floats
+    CPR_CHECK_ARG(dy && colsum && ws_part && M > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256);
+    const int rows_per_block = 512;
+    const int blocks = (int)cdivll(M, rows_per_block);
+    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, stream, dy, y, g_out, ws_part, M, C,
+                       rows_per_block);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, ws_part, colsum, blocks, C,
+                       accumulate);
+    CPR_LAUNCH_STATUS();
+}
+// parameter side of the folded BatchNorm: Gw = wgrad(g, x) [Cout][K] (unscaled), W [Cout][K], scale = gamma*inv_sigma:
+//   dscale[c] = <W[c], Gw[c]> (= sum_p g*conv),  dshift[c] = colsum_g[c]
+//   dgamma = inv_sigma*(dscale - mean*dshift),  dbeta = dshift,  dW[c] = scale[c]*Gw[c]  (in place)
+// One block per output channel.
+__global__ void bn_fold_bwd_kernel(float* __restrict__ Gw, const float* __restrict__ Wt, const float* __restrict__ scale,
+                                   const float* __restrict__ mean, const float* __restrict__ inv_sigma,
+                                   const float* __restrict__ colsum_g, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta, int K) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const float sc = scale[c];
+    double dot = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float gv = Gw[(size_t)c * K + k];
+        dot += (double)gv * (double)Wt[(size_t)c * K + k];
+        Gw[(size_t)c * K + k] = gv * sc;
+    }
+    dot = wave_sum_d(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double dscale = red[0] + red[1] + red[2] + red[3];
+        const double dshift = (double)colsum_g[c];
+        if (dgamma) dgamma[c] = (float)((double)inv_sigma[c] * (dscale - (double)mean[c] * dshift));
+        if (dbeta) dbeta[c] = (float)dshift;
+    }
+}
+extern "C" int cpr_bn_fold_bwd(float* Gw, const float* weight, const float* scale, const float* mean,
+                               const float* inv_sigma, const float* colsum_g, float* dgamma, float* dbeta, int Cout, int K,
+                               hipStream_t stream) {
+    CPR_CHECK_ARG(Gw && weight && scale && mean && inv_sigma && colsum_g && Cout > 0 && K > 0);
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(Cout), dim3(256), 0, stream, Gw, weight, scale, mean, inv_sigma, colsum_g,
+                       dgamma, dbeta, K);
+    CPR_LAUNCH_STATUS();
+}
+
+// elementwise helpers on flat fp32 buffers
+__global__ void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, float beta, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = alpha * x[i] + beta * y[i];
+}
+extern "C" int cpr_axpby(float* y, const float* x, float alpha, float beta, long long n, hipStream_t stream) {
+    CPR_CHECK_ARG(n >= 0);
+    if (n == 0) return CPR_OK;
+    CPR_CHECK_ARG(x && y);
+    const int grid = (int)(cdivll(n, 256) < 32768 ? cdivll(n, 256) : 32768);
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, stream, y, x, alpha, beta, n);
+    CPR_LAUNCH_STATUS();
+}
+// stride-2 data gradient helper: out (N,2H',2W',C)-like zero-inserted copy of dy: out[n, y*s, x*s, :] = dy[n,y,x,:]
+__global__ void zero_insert_kernel(const float* __restrict__ dy, float* __restrict__ out, int N, int OH, int OW, int C4,
+                                   int H, int W, int s) {
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const int n = (int)(r / H);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y % s == 0 && x % s == 0 && y / s < OH && x / s < OW)
+            v = *reinterpret_cast<const f32x4*>(dy + ((((size_t)n * OH + y / s) * OW + x / s) * C4 + c) * 4);
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+extern "C" int cpr_zero_insert(const float* dy, float* out, int N, int OH, int OW, int C, int H, int W, int s,
+                               hipStream_t stream) {
+    CPR_CHECK_ARG(dy && out && N > 0 && OH > 0 && OW > 0 && C % 4 == 0 && H > 0 && W > 0 && s >= 1);
+    const long long total = (long long)N * H * W * (C / 4);
+    const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
+    hipLaunchKernelGGL(zero_insert_kernel, dim3(grid), dim3(256), 0, stream, dy, out, N, OH, OW, C / 4, H, W, s);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------ CPR loss backward
+// d(total loss)/d(logit map) for the negative term (cpr_head.py:1216-1228): f = -p^2 log(1-p+eps) on valid (pixel,class)
+// entries, scaled by w_neg/num_sample (num_sample = out5[4] of the forward).  Also zero-fills the remaining channels so the
+// bag scatter can accumulate on top.  dmap (N,HW,Jd), Jd >= J (padded so the conv data/weight-gradient kernels can eat it).
+__global__ void neg_loss_bwd_kernel(const float* __restrict__ logit, const unsigned char* __restrict__ mask,
+                                    const float* __restrict__ out5, float* __restrict__ dmap, long long NP, int J, int Jd,
+                                    int C, float eps, float w_neg) {
+    const float scale = w_neg / out5[4];
+    const long long total = NP * Jd;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Jd);
+        const long long p = i / Jd;
+        float g = 0.f;
+        if (j < C && mask[p * C + j]) {
+            const float s = sigm(logit[p * J + j]);
+            const float om = 1.f - s + eps;
+            g = (-2.f * s * logf(om) + s * s / om) * s * (1.f - s) * scale;
+        }
+        dmap[i] = g;
+    }
+}
+
+// gfocal derivative wrt the probability:  L = -(p-q)^2 [q log(p+eps) + (1-q) log(1-p+eps)]
+__device__ __forceinline__ float gfocal_dp(float p, float q, float eps) {
+    const float l2 = q * logf(p + eps) + (1.f - q) * logf(1.f - p + eps);
+    return -(2.f * (p - q) * l2 + (p - q) * (p - q) * (q / (p + eps) - (1.f - q) / (1.f - p + eps)));
+}
+
+// one wave per bag: gradient of (pos_loss + gt_loss) wrt the sampled bag logits dbag (G,K,J)
+//   P = sum_k s_k w_k, w_k = softmax_k(ins)*valid / sum;  dP/dcls_k = w_k s_k (1-s_k);  dP/dins_k = w_k (s_k - P)
+__global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int ins_off,
+                                    const unsigned char* __restrict__ valid, const int* __restrict__ labels,
+                                    const float* __restrict__ gt_weight, const float* __restrict__ bag,
+                                    float* __restrict__ dbag, int G, int K, int C, float eps, float w_mil, float w_gt) {
+    __shared__ double red[2][4];
+    // num_sample / num_pos_gt: deterministic block-local recount of the forward's per-bag flags
+    double ns = 0, ng = 0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        ns += (double)bag[(size_t)g * 5 + 2];
+        ng += (double)bag[(size_t)g * 5 + 3];
+    }
+    ns = wave_sum_d(ns);
+    ng = wave_sum_d(ng);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = ns;
+        red[1][threadIdx.x >> 6] = ng;
+    }
+    __syncthreads();
+    const double num_sample = fmax(red[0][0] + red[0][1] + red[0][2] + red[0][3], 1.0);
+    const double num_pos_gt = fmax(red[1][0] + red[1][1] + red[1][2] + red[1][3], 1.0);
+    const float k_mil = (float)((double)w_mil / num_sample), k_gt = (float)((double)w_gt / num_pos_gt);
+
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= G) return;
+    const float* L = logits + (size_t)g * K * J;
+    float* D = dbag + (size_t)g * K * J;
+    const unsigned char* V = valid + (size_t)g * K;
+    const int label = labels[g];
+    const float wg = gt_weight ? gt_weight[g] : 1.f;
+    for (int i = lane; i < K * J; i += 64) D[i] = 0.f;
+    float nvalid = 0.f;
+    for (int k = lane; k < K; k += 64) nvalid += V[k] ? 1.f : 0.f;
+    nvalid = wave_sum(nvalid);
+    const float lw = (nvalid * wg > 0.f) ? 1.f : 0.f;
+    const float gtv = V[K - 1] ? wg : 0.f;
+    __builtin_amdgcn_s_waitcnt(0);   // the zero fill above is ordered before the accumulating stores (same lanes/addresses differ)
+    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < C; ++c) {
+        float m = -INFINITY;
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, L[(size_t)k * J + ins_off + c]);
+        m = wave_max(m);
+        float se = 0.f;
+        for (int k = lane; k < K; k += 64) se += expf(L[(size_t)k * J + ins_off + c] - m);
+        se = wave_sum(se);
+        float sv = 0.f, sp = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float pi = expf(L[(size_t)k * J + ins_off + c] - m) / se * (V[k] ? wg : 0.f);
+            sv += pi;
+            sp += sigm(L[(size_t)k * J + c]) * pi;
+        }
+        sv = wave_sum(sv);
+        sp = wave_sum(sp);
+        const float den = fmaxf(sv, 1e-12f);
+        const float P = sp / den;
+        const float q = (c == label) ? 1.f : 0.f;
+        const float dP = gfocal_dp(P, q, eps) * lw * k_mil;
+        const bool norm_live = sv > 1e-12f;   // F.normalize: below eps the denominator is the constant eps
+        for (int k = lane; k < K; k += 64) {
+            const float sig = expf(L[(size_t)k * J + ins_off + c] - m) / se;
+            const float pi = sig * (V[k] ? wg : 0.f);
+            const float w = pi / den;
+            const float s = sigm(L[(size_t)k * J + c]);
+            float dcls = dP * w * s * (1.f - s);
+            // d/dins_k of sum_j s_j pi_j / den:  norm live: w_k (s_k - P);  clamped: (pi_k s_k - sig_k * sp) / den
+            const float dins = norm_live ? dP * w * (s - P) : dP * (pi * s - sig * sp) / den;
+            if (k == K - 1) {
+                const float gp = s;
+                dcls += gfocal_dp(gp, q, eps) * gtv * k_gt * gp * (1.f - gp);
+            }
+            D[(size_t)k * J + c] = dcls;
+            D[(size_t)k * J + ins_off + c] = dins;
+        }
+    }
+}
+
+// scatter dbag (G,K,J) through the bilinear taps of bag_sample onto dmap (N,H,W,J) with float atomics
+__global__ void bag_scatter_bwd_kernel(const float* __restrict__ dbag, int J, const float* __restrict__ ctr,
+                                       const int* __restrict__ gt_img, const float* __restrict__ offs,
+                                       float* __restrict__ dmap, int Jd, int G, int K, int H, int W, float stride) {
+    const long long total = (long long)G * K * J;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % J);
+    const long long gk = i / J;
+    const int k = (int)(gk % K), g = (int)(gk / K);
+    const float d = dbag[i];
+    if (d == 0.f) return;
+    const int n = gt_img[g];
+    const float cx = ctr[g * 2], cy = ctr[g * 2 + 1];
+    const float px = (k < K - 1) ? __fadd_rn(offs[k * 2], cx) : cx;
+    const float py = (k < K - 1) ? __fadd_rn(offs[k * 2 + 1], cy) : cy;
+    const float fw = (float)W, fh = (float)H;
+    float gx = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(px, stride), 1.f), fw), 1.f);
+    float gy = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(py, stride), 1.f), fh), 1.f);
+    float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), fw), 1.f) * 0.5f;
+    float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), fh), 1.f) * 0.5f;
+    ix = fminf(fw - 1.f, fmaxf(ix, 0.f));
+    iy = fminf(fh - 1.f, fmaxf(iy, 0.f));
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float ww = ix - x0f, we = 1.f - ww, wn_ = iy - y0f, ws = 1.f - wn_;
+    const bool x1ok = x1 < W, y1ok = y1 < H;
+    float* base = dmap + (size_t)n * H * W * Jd + j;
+    atomicAdd(base + ((size_t)y0 * W + x0) * Jd, d * ws * we);
+    if (x1ok) atomicAdd(base + ((size_t)y0 * W + x1) * Jd, d * ws * ww);
+    if (y1ok) atomicAdd(base + ((size_t)y1 * W + x0) * Jd, d * wn_ * we);
+    if (x1ok && y1ok) atomicAdd(base + ((size_t)y1 * W + x1) * Jd, d * wn_ * ww);
+}
+
+extern "C" int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* out5, const float* bag_logits,
+                            const unsigned char* valid, const int* labels, const float* gt_weight, const float* bag_ws,
+                            const float* centers, const int* gt_img, const float* offsets, float* dbag_ws, float* dmap,
+                            int N, int H, int W, int J, int Jd, int ins_off, int G, int K, int C, float stride, float eps,
+                            float w_mil, float w_gt, float w_neg, hipStream_t stream) {
+    CPR_CHECK_ARG(lmap && neg_mask && out5 && bag_logits && valid && labels && bag_ws && centers && gt_img && dbag_ws && dmap);
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && G > 0 && K > 0 && C > 0 && J >= ins_off + C && Jd >= J && (K == 1 || offsets));
+    const long long NP = (long long)N * H * W;
+    const int grid = (int)(cdivll(NP * Jd, 256) < 32768 ? cdivll(NP * Jd, 256) : 32768);
+    hipLaunchKernelGGL(neg_loss_bwd_kernel, dim3(grid), dim3(256), 0, stream, lmap, neg_mask, out5, dmap, NP, J, Jd, C,
+                       eps, w_neg);
+    hipLaunchKernelGGL(bag_loss_bwd_kernel, dim3(cdiv(G, 4)), dim3(256), 0, stream, bag_logits, J, ins_off, valid, labels,
+                       gt_weight, bag_ws, dbag_ws, G, K, C, eps, w_mil, w_gt);
+    const long long total = (long long)G * K * J;
+    hipLaunchKernelGGL(bag_scatter_bwd_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, dbag_ws, J,
+                       centers, gt_img, offsets, dmap, Jd, G, K, H, W, stride);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+// global gradient norm (mmcv Fp32/OptimizerHook grad_clip -> torch clip_grad_norm_): sum of squares in double, per-buffer
+// partials reduced by a second launch into norm2[0]; deterministic.
+__global__ void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double s = 0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        s += (double)g[i] * (double)g[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const double* __restrict__ partial, int n, double* __restrict__ out, int accumulate) {
+    __shared__ double red[4];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + red[0] + red[1] + red[2] + red[3];
+}
+extern "C" int cpr_grad_sumsq(const float* g, long long n, double* ws_partial, double* out, int accumulate,
+                              hipStream_t stream) {
+    // ws_partial: 1024 doubles
+    CPR_CHECK_ARG(g && ws_partial && out && n > 0);
+    const int grid = (int)(cdivll(n, 1024) < 1024 ? cdivll(n, 1024) : 1024);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, g, n, ws_partial);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, ws_partial, grid, out, accumulate);
+    CPR_LAUNCH_STATUS();
+}
+// torch.optim.SGD step on one flat fp32 buffer (momentum, dampening 0, no nesterov), with the clip coefficient read from
+// the device: coef = min(1, max_norm / (sqrt(norm2) + 1e-6)) when max_norm > 0 (clip_grad_norm_), else 1.
+//   g = coef*grad*grad_scale + wd*p;  buf = first ? g : mu*buf + g;  p -= lr*buf
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ buf,
+                           const double* __restrict__ norm2, long long n, float lr, float mu, float wd, float max_norm,
+                           float grad_scale, int first) {
+    float coef = grad_scale;
+    if (max_norm > 0.f) {
+        const float tn = (float)sqrt(norm2[0]) * grad_scale;
+        const float c = max_norm / (tn + 1e-6f);
+        coef *= fminf(c, 1.f);
+    }
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float g = grad[i] * coef;
+        const float pv = p[i];
+        if (wd != 0.f) g = g + wd * pv;
+        float b = g;
+        if (mu != 0.f) {
+            b = first ? g : mu * buf[i] + g;
+            buf[i] = b;
+        }
+        p[i] = pv - lr * b;
+    }
+}
+extern "C" int cpr_sgd_step(float* p, const float* grad, float* buf, const double* norm2, long long n, float lr, float mu,
+                            float wd, float max_norm, float grad_scale, int first, hipStream_t stream) {
+    CPR_CHECK_ARG(p && grad && n > 0 && (mu == 0.f || buf) && (max_norm <= 0.f || norm2));
+    const int grid = (int)(cdivll(n, 256) < 8192 ? cdivll(n, 256) : 8192);
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, stream, p, grad, buf, norm2, n, lr, mu, wd, max_norm,
+                       grad_scale, first);
+    CPR_LAUNCH_STATUS();
+}

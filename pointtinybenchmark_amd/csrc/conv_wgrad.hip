@@ -1,0 +1,206 @@
+// Weight gradient of the implicit-GEMM convolution, exact fp32 on the matrix cores (backward).
+//   dW[co][kh][kw][ci] = sum_m dY[m][co] * X[(n, oy*s + kh - pad, ox*s + kw - pad)][ci],   m = (n, oy, ox)
+// GEMM view: rows = cout, cols = (tap, cin), reduction over the M output pixels.  One workgroup owns a
+// 128(cout) x 128(cin of ONE tap) tile and a slab of the pixel range (split-K); slabs are summed by wgrad_reduce, which
+// also converts to the parameter layout [Cout][Cin][KH][KW] (deterministic: no float atomics).
+// Both operands are pixel-major (NHWC), i.e. the reduction index is the slow one: tiles are staged in LDS k-major
+// ([32 pixels][128 channels]) and MFMA fragments are read with ds_read_b32 (32 consecutive channels per half-wave:
+// conflict-free).  The X operand takes the conv zero padding from the buffer-load range check and, optionally, the fused
+// GroupNorm-apply + ReLU of the producing layer (the forward never materialised that tensor).
+#include "common.h"
+
+struct WgradParams {
+    const float* dy;   // (N, OH, OW, Cout)
+    const float* x;    // (N, H, W, Cin)
+    const float* in_a; // (N, Cin) or null
+    const float* in_b;
+    float* part;       // [S][Cout][KH*KW][Cin]
+    int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, M, in_relu;
+    int tilesCo, tilesCi, S, chunks_per_slab;
+};
+
+constexpr int WG_BK = 32;     // pixels per chunk
+constexpr int WG_T = 128;     // tile edge (cout and cin)
+constexpr int WG_LD = 132;    // LDS row stride in floats (132 = 128 + 4 keeps float4 writes 16-byte aligned)
+
+template <bool XF>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * WG_BK * WG_LD];
+    float* As = smem;                         // [2][32][132]  dY tile (k = pixel, i = cout)
+    float* Bs = smem + 2 * WG_BK * WG_LD;     // [2][32][132]  X tile  (k = pixel, j = cin)
+    const int KK = p.KH * p.KW;
+    int b = blockIdx.x;
+    const int slab = b % p.S; b /= p.S;
+    const int tci = b % p.tilesCi; b /= p.tilesCi;
+    const int tap = b % KK; b /= KK;
+    const int tco = b;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int co0 = tco * WG_T, ci0 = tci * WG_T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 31, kr = tid >> 5;   // 32 threads (x float4) cover a 128-channel row; 8 rows per pass
+
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+    const bool co_ok = co0 + c4 * 4 < p.Cout;   // Cout % 4 == 0 is checked by the launcher
+    const bool ci_ok = ci0 + c4 * 4 < p.Cin;
+
+    const int m_begin = slab * p.chunks_per_slab * WG_BK;
+    const int nchunks = min(p.chunks_per_slab, (p.M - m_begin + WG_BK - 1) / WG_BK);
+    const int ohw = p.OH * p.OW;
+
+    f32x4 ra[4], rb[4], xa[4], xb[4];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m_begin + c * WG_BK + kr + 8 * j;
+            const bool mok = m < p.M;
+            const int mm = mok ? m : 0;
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            const int iy = oy * p.stride + kh - p.pad, ix = ox * p.stride + kw - p.pad;
+            const bool xok = mok & ci_ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const int va = (mok & co_ok) ? (mm * p.Cout + co0 + c4 * 4) * 4 : -1;
+            const int vb = xok ? (((n * p.H + iy) * p.W + ix) * p.Cin + ci0 + c4 * 4) * 4 : -1;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, va, 0, 0));
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vb, 0, 0));
+            if (XF) {
+                const int ai = xok ? n * p.Cin + ci0 + c4 * 4 : 0;
+                xa[j] = xok ? *reinterpret_cast<const f32x4*>(p.in_a + ai) : f32x4{0.f, 0.f, 0.f, 0.f};
+                xb[j] = xok ? *reinterpret_cast<const f32x4*>(p.in_b + ai) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    const float relu_floor = p.in_relu ? 0.f : -INFINITY;
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = rb[j];
+            if (XF) {  // padded / out-of-range entries have a = b = 0 -> max(0, floor) = 0 for either floor
+                v = v * xa[j] + xb[j];
+                v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
+                v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+            }
+            *reinterpret_cast<f32x4*>(As + (buf * WG_BK + kr + 8 * j) * WG_LD + c4 * 4) = ra[j];
+            *reinterpret_cast<f32x4*>(Bs + (buf * WG_BK + kr + 8 * j) * WG_LD + c4 * 4) = v;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int half = lane >> 5;
+    const float* a_lds = As + half * WG_LD + wm * 64 + (lane & 31);
+    const float* b_lds = Bs + half * WG_LD + wn * 64 + (lane & 31);
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+            for (int k2 = 0; k2 < WG_BK / 2; ++k2) {   // MFMA k = 2: lanes < 32 take pixel 2*k2, lanes >= 32 pixel 2*k2+1
+                float fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = a_lds[(buf * WG_BK + 2 * k2) * WG_LD + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = b_lds[(buf * WG_BK + 2 * k2) * WG_LD + j * 32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial[slab][co][tap][ci]: col j = lane&31 (cin), row i = (r&3) + 8*(r>>2) + 4*half (cout)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < p.Cout && ci < p.Cin)
+                    p.part[(((size_t)slab * p.Cout + co) * KK + tap) * p.Cin + ci] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// sum the slabs; write (or accumulate into) the parameter-layout gradient [Cout][Cin][KH][KW]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int S, int Cout, int KK,
+                                    int Cin, int accumulate) {
+    const long long total = (long long)Cout * KK * Cin;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * total + i];
+    const int ci = (int)(i % Cin);
+    const long long r = i / Cin;
+    const int tap = (int)(r % KK), co = (int)(r / KK);
+    float* dst = grad + ((size_t)co * Cin + ci) * KK + tap;
+    *dst = accumulate ? *dst + s : s;
+}
+
+// workspace floats needed by cpr_conv2d_wgrad for these shapes (the split factor is chosen here, once)
+static int wgrad_split(long long M, int Cout, int Cin, int KK) {
+    const long long tiles = (long long)((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T) * KK;
+    const long long chunks = (M + WG_BK - 1) / WG_BK;
+    long long S = (1536 + tiles - 1) / tiles;          // aim at >= ~1500 workgroups (3 rounds of 2/CU)
+    if (S > chunks) S = chunks;
+    if (S < 1) S = 1;
+    if (S > 256) S = 256;
+    return (int)S;
+}
+extern "C" int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {
+    CPR_CHECK_ARG(N > 0 && OH > 0 && OW > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0);
+    const int S = wgrad_split((long long)N * OH * OW, Cout, Cin, KH * KW);
+    const long long n = (long long)S * Cout * KH * KW * Cin;
+    return n < (1ll << 31) ? (int)n : CPR_ERR_UNSUPPORTED;
+}
+
+extern "C" int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
+                                float* ws, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                int in_relu, int accumulate, hipStream_t stream) {
+    CPR_CHECK_ARG(dy && x && grad_w && ws);
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    CPR_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0);
+    if (in_a) CPR_CHECK_ARG(in_b != nullptr);
+    WgradParams p;
+    p.dy = dy; p.x = x; p.in_a = in_a; p.in_b = in_b; p.part = ws;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.in_relu = in_relu;
+    p.OH = (H + 2 * pad - KH) / stride + 1;
+    p.OW = (W + 2 * pad - KW) / stride + 1;
+    CPR_CHECK_ARG(p.OH > 0 && p.OW > 0);
+    const long long M = (long long)N * p.OH * p.OW;
+    if (M * Cout * 4 >= (1ll << 31) || (long long)N * H * W * Cin * 4 >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
+    p.M = (int)M;
+    const int KK = KH * KW;
+    p.tilesCo = (Cout + WG_T - 1) / WG_T;
+    p.tilesCi = (Cin + WG_T - 1) / WG_T;
+    p.S = wgrad_split(M, Cout, Cin, KK);
+    const int chunks = (int)((M + WG_BK - 1) / WG_BK);
+    p.chunks_per_slab = (chunks + p.S - 1) / p.S;
+    const long long grid = (long long)p.tilesCo * KK * p.tilesCi * p.S;
+    CPR_CHECK_ARG(grid < (1ll << 31));
+    if (in_a) hipLaunchKernelGGL((conv_wgrad_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    const long long total = (long long)Cout * KK * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, ws, grad_w, p.S, Cout,
+                       KK, Cin, accumulate);
+    CPR_LAUNCH_STATUS();
+}

@@ -369,3 +369,133 @@ def p2p_loss(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, b
               float(alpha), float(gamma), float(beta), float(pos_w), float(neg_w), float(reg_norm), float(w_cls),
               float(w_reg), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ backward / optimizer
+def dgrad_pack(weight, stride, padding):
+    """PackedConv that computes the data gradient of ``conv2d(x, weight, stride, padding)`` as a stride-1 forward conv
+    over dy (zero-inserted first when stride > 1): channels swapped, taps flipped, padding K-1-p."""
+    Cout, Cin, KH, KW = weight.shape
+    assert KH == KW
+    wt = weight.detach().float().flip(2, 3).permute(1, 0, 2, 3).contiguous()      # (Cin, Cout, KH, KW)
+    return PackedConv(wt, 1, KH - 1 - padding)
+
+
+def conv2d_dgrad(dy, pc_t, in_hw, stride=1):
+    """dx (N,H,W,Cin) of a conv whose transposed/flipped weights are ``pc_t`` (dgrad_pack)."""
+    N, OH, OW, Cout = _check(dy).shape
+    H, W = in_hw
+    if stride > 1:
+        # dilated gradient of extent (H + 2p - K + 1): rows/cols past (O-1)*s are the zeros the forward never read
+        He, We = H + 2 * (pc_t.KH - 1 - pc_t.padding) - pc_t.KH + 1, W + 2 * (pc_t.KW - 1 - pc_t.padding) - pc_t.KW + 1
+        z = torch.empty((N, He, We, Cout), device=dy.device, dtype=torch.float32)
+        _lib.call('cpr_zero_insert', _ptr(dy), _ptr(z), N, OH, OW, Cout, He, We, stride, _stream())
+        dy = z
+    out = conv2d(dy, pc_t)
+    assert out.shape[1] == H and out.shape[2] == W, (out.shape, in_hw)
+    return out
+
+
+def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False, grad=None):
+    """grad_w [Cout][Cin][KH][KW] (+= when ``grad`` is given).  in_ab: fused GroupNorm affine (+ReLU) of the input."""
+    N, H, W, Cin = _check(x).shape
+    _, OH, OW, Cout = _check(dy).shape
+    KH, KW = weight_shape[2], weight_shape[3]
+    assert weight_shape[0] == Cout and weight_shape[1] == Cin, (weight_shape, Cout, Cin)
+    n = _lib.call('cpr_conv2d_wgrad_workspace', N, OH, OW, Cin, Cout, KH, KW, positive=True)
+    ws = torch.empty((n,), device=x.device, dtype=torch.float32)
+    acc = grad is not None
+    if grad is None:
+        grad = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
+    a = b = None
+    if in_ab is not None:
+        a, b = in_ab
+    _lib.call('cpr_conv2d_wgrad', _ptr(dy), _ptr(x), _ptr(a), _ptr(b), _ptr(grad), _ptr(ws), N, H, W, Cin, Cout, KH, KW,
+              stride, padding, int(in_relu), int(acc), _stream())
+    return grad
+
+
+def gn_bwd(x, dz, a, b, mean, rstd, gamma, relu, dgamma=None, dbeta=None, slots=None):
+    """GroupNorm(+ReLU) backward -> (dx, dgamma, dbeta); accumulates into dgamma/dbeta when given."""
+    N, H, W, C = _check(x).shape
+    HW, G = H * W, mean.shape[1]
+    if slots is None:
+        slots = max(1, min(256, HW // 256))
+    acc = dgamma is not None
+    if not acc:
+        dgamma = torch.empty((C,), device=x.device, dtype=torch.float32)
+        dbeta = torch.empty((C,), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    ws_part = torch.empty((N * slots * C * 2,), device=x.device, dtype=torch.float32)
+    ws_k = torch.empty((2 * N * G + 2 * N * C,), device=x.device, dtype=torch.float32)
+    _lib.call('cpr_gn_bwd', _ptr(x), _ptr(_check(dz)), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(_check(gamma)),
+              _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws_part), _ptr(ws_k), N, HW, C, G, slots, int(relu), int(acc),
+              _stream())
+    return dx, dgamma, dbeta
+
+
+def upsample_add_bwd(dfine, dcoarse_or_shape, accumulate=True):
+    N, H, W, C = _check(dfine).shape
+    if isinstance(dcoarse_or_shape, torch.Tensor):
+        dc = dcoarse_or_shape
+    else:
+        dc, accumulate = torch.empty(dcoarse_or_shape, device=dfine.device, dtype=torch.float32), False
+    _lib.call('cpr_upsample_add_bwd', _ptr(dfine), _ptr(dc), N, H, W, dc.shape[1], dc.shape[2], C, int(accumulate),
+              _stream())
+    return dc
+
+
+def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None):
+    """g = dy*(y>0) (y None: g = dy) and per-channel column sums of g -> (g|None, colsum (C))."""
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    acc = colsum is not None
+    if not acc:
+        colsum = torch.empty((C,), device=dy.device, dtype=torch.float32)
+    g = torch.empty_like(dy) if want_g else None
+    ws = torch.empty(((M + 511) // 512 * C,), device=dy.device, dtype=torch.float32)
+    _lib.call('cpr_relu_bwd_colsum', _ptr(_check(dy)), _ptr(y), _ptr(g), _ptr(colsum), _ptr(ws), M, C, int(acc),
+              _stream())
+    return g, colsum
+
+
+def bn_fold_bwd(Gw, weight, scale, mean, inv_sigma, colsum_g, want_affine=True):
+    """In place dW = scale*Gw; returns (dgamma, dbeta) of the folded eval BatchNorm (or (None, None))."""
+    Cout = Gw.shape[0]
+    K = Gw.numel() // Cout
+    dg = db = None
+    if want_affine:
+        dg = torch.empty((Cout,), device=Gw.device, dtype=torch.float32)
+        db = torch.empty((Cout,), device=Gw.device, dtype=torch.float32)
+    _lib.call('cpr_bn_fold_bwd', _ptr(Gw), _ptr(_check(weight)), _ptr(scale), _ptr(mean), _ptr(inv_sigma),
+              _ptr(colsum_g), _ptr(dg), _ptr(db), Cout, K, _stream())
+    return dg, db
+
+
+def axpby(y, x, alpha=1.0, beta=1.0):
+    assert y.numel() == x.numel()
+    _lib.call('cpr_axpby', _ptr(_check(y)), _ptr(_check(x)), float(alpha), float(beta), y.numel(), _stream())
+    return y
+
+
+def cpr_loss_bwd(lmap, neg_mask, out5, bag_logits, valid, labels, bag_ws, centers, gt_img, offsets, ins_off, num_classes,
+                 stride, w_mil, w_gt, w_neg, Jd, gt_weight=None, eps=1e-6):
+    """-> dmap (N,H,W,Jd): gradient of gt_loss + pos_loss + neg_loss wrt the logit map (channels >= J are zero)."""
+    N, H, W, J = _check(lmap).shape
+    G, K, _ = bag_logits.shape
+    dmap = torch.empty((N, H, W, Jd), device=lmap.device, dtype=torch.float32)
+    dbag = torch.empty((G, K, J), device=lmap.device, dtype=torch.float32)
+    _lib.call('cpr_loss_bwd', _ptr(lmap), _ptr(neg_mask), _ptr(out5), _ptr(bag_logits), _ptr(valid), _ptr(labels),
+              _ptr(gt_weight), _ptr(bag_ws), _ptr(centers), _ptr(gt_img), _ptr(offsets), _ptr(dbag), _ptr(dmap), N, H, W,
+              J, Jd, ins_off, G, K, num_classes, float(stride), float(eps), float(w_mil), float(w_gt), float(w_neg),
+              _stream())
+    return dmap, dbag
+
+
+def grad_sumsq(g, out, ws, accumulate):
+    _lib.call('cpr_grad_sumsq', _ptr(_check(g)), g.numel(), _ptr(ws), _ptr(out), int(accumulate), _stream())
+
+
+def sgd_step(p, grad, buf, norm2, lr, momentum, weight_decay, max_norm, grad_scale, first):
+    _lib.call('cpr_sgd_step', _ptr(p), _ptr(grad), _ptr(buf), _ptr(norm2), p.numel(), float(lr), float(momentum),
+              float(weight_decay), float(max_norm), float(grad_scale), int(first), _stream())
