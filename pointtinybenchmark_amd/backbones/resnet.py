@@ -4,7 +4,7 @@ Interface of T/mmdet/models/backbones/resnet.py:305-657 (ctor kwargs, ``forward(
 ``out_indices`` stage outputs, ``frozen_stages`` / ``norm_eval`` train() semantics, state-dict keys).
 BatchNorm is always evaluated with running statistics on this path (norm_eval=True in every CPR/P2P config)
 and is folded into the conv epilogue; the bottleneck shortcut add + ReLU are fused into conv3's epilogue.
-Forward only: backward is SURVEY.md §8(f) rank 1 ("next")."""
+The backward of the trainable stages is driven by training.CprTrainer from the per-block records of ``forward(tape=)``."""
 import torch
 import torch.nn as nn
 
@@ -31,20 +31,26 @@ class _Block(nn.Module):
             self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
-    def run(self, cache, x):
+    def run(self, cache, x, save=None):
+        """save (dict): training mode -- keeps the block's activations for the backward pass."""
         identity = x
         if self.downsample is not None:
             s, b = folded_bn(cache, self.downsample[1])
             identity = ops.conv2d(x, packed_conv(cache, self.downsample[0], x.dtype), scale=s, bias=b)
         dt = x.dtype
         s1, b1 = folded_bn(cache, self.bn1)
-        o = ops.conv2d(x, packed_conv(cache, self.conv1, dt), scale=s1, bias=b1, relu=True)
+        o1 = ops.conv2d(x, packed_conv(cache, self.conv1, dt), scale=s1, bias=b1, relu=True)
         s2, b2 = folded_bn(cache, self.bn2)
         if self.kind == 'bottleneck':
-            o = ops.conv2d(o, packed_conv(cache, self.conv2, dt), scale=s2, bias=b2, relu=True)
+            o2 = ops.conv2d(o1, packed_conv(cache, self.conv2, dt), scale=s2, bias=b2, relu=True)
             s3, b3 = folded_bn(cache, self.bn3)
-            return ops.conv2d(o, packed_conv(cache, self.conv3, dt), scale=s3, bias=b3, residual=identity, relu=True)
-        return ops.conv2d(o, packed_conv(cache, self.conv2, dt), scale=s2, bias=b2, residual=identity, relu=True)
+            out = ops.conv2d(o2, packed_conv(cache, self.conv3, dt), scale=s3, bias=b3, residual=identity, relu=True)
+        else:
+            o2 = None
+            out = ops.conv2d(o1, packed_conv(cache, self.conv2, dt), scale=s2, bias=b2, residual=identity, relu=True)
+        if save is not None:
+            save.update(block=self, x=x, o1=o1, o2=o2, identity=identity, out=out)
+        return out
 
 
 @BACKBONES.register_module()
@@ -109,8 +115,9 @@ class ResNet(nn.Module):
     def init_weights(self):
         pass
 
-    def forward(self, x):
-        """x: (N,3,H,W) -> tuple of NCHW-shaped (channels_last) stage outputs."""
+    def forward(self, x, tape=None):
+        """x: (N,3,H,W) -> tuple of NCHW-shaped (channels_last) stage outputs.
+        tape (list): training mode -- one record per block with trainable parameters, in forward order."""
         c = self._cache
         x = ops.nchw_to_nhwc(x) if x.shape[1] <= 4 else ops.from_nchw(x)
         s, b = folded_bn(c, self.bn1)
@@ -120,7 +127,11 @@ class ResNet(nn.Module):
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):
-                x = blk.run(c, x)
+                rec = None
+                if tape is not None and blk.conv1.weight.requires_grad:
+                    rec = dict(stage=i)
+                    tape.append(rec)
+                x = blk.run(c, x, rec)
             if i in self.out_indices:
                 outs.append(ops.as_nchw(x))
         return tuple(outs)

@@ -151,10 +151,15 @@ class CPRHead(nn.Module):
             ins.append(f[1])
         return cls, ins
 
-    def _tower(self, x, ab=None, in_relu=True):
+    def _tower(self, x, ab=None, in_relu=True, tape=None):
         """4 x [conv3x3 -> GN -> ReLU]; returns the LAST layer un-normalised: (raw, (a, b))."""
         for i, m in enumerate(self.cls_convs):
-            x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=(in_relu if i == 0 else True), materialize=False)
+            rec = None
+            if tape is not None:
+                rec = dict(kind='tower', level=i)
+                tape.append(rec)
+            x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=(in_relu if i == 0 else True), materialize=False,
+                            save=rec)
         return x, ab
 
     def forward_single(self, x):
@@ -172,15 +177,15 @@ class CPRHead(nn.Module):
         return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
 
     def forward_train_lazy(self, lazy_feats, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
-                           gt_true_bboxes=None):
+                           gt_true_bboxes=None, tape=None, save=None):
         """Fused training path used by BasicLocator: the neck hands over (raw, (a, b)) and neither the neck output nor
         the last tower layer is ever materialised in normalised form -- the consumer convs (tower layer 0, the logit
         projection) apply the GroupNorm affine (+ReLU) on load.  Same arithmetic as forward() + loss()."""
         assert len(lazy_feats) == 1
         raw, ab = lazy_feats[0]
-        raw, ab = self._tower(raw, ab, in_relu=False)
+        raw, ab = self._tower(raw, ab, in_relu=False, tape=tape)
         return self.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
-                         gt_true_bboxes=gt_true_bboxes)
+                         gt_true_bboxes=gt_true_bboxes, save=save)
 
     # ------------------------------------------------------------------ shared extraction
     def _logit_map(self, feat_nhwc, in_ab=None):
@@ -225,7 +230,7 @@ class CPRHead(nn.Module):
 
     # ------------------------------------------------------------------ loss (cpr_head.py:1101-1229)
     def loss(self, cls_feat, ins_feat, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None, gt_true_bboxes=None,
-             gt_weights=None):
+             gt_weights=None, save=None):
         assert len(gt_labels) > 0
         assert len(cls_feat) == 1, 'single FPN level (the reference asserts the same: cpr_head.py:1152)'
         ex, C, stride = self.train_pts_extractor, self.num_classes, self.strides[0]
@@ -239,16 +244,22 @@ class CPRHead(nn.Module):
                                                                         'pad_shape')
         _, valid, bag_logits = ops.bag_sample(lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
         cfg = self.loss_cfg
-        partial = None
+        partial = neg_mask = None
         if cfg.get('with_neg', True):
             assert not ex.neg_is_anchor
-            _, partial = ops.neg_mask_loss(lmap, centers, labels, gt_start, pad_hw, C, stride,
+            neg_mask, partial = ops.neg_mask_loss(lmap, centers, labels, gt_start, pad_hw, C, stride,
                                            self._d2_threshold(stride, ex.neg_radius), self.loss_mil.eps,
                                            ex.neg_class_wise)
         w = None if gt_weights is None else torch.cat(list(gt_weights)).float().to(dev).contiguous()
         ins_off = 0 if self.ins_share_head_classifier else C
         out = self.loss_mil.forward_logits(bag_logits, ins_off, valid, labels, C, w, partial,
-                                           cfg.get('gt_loss_weight', 1.0), cfg.get('neg_loss_weight', 1.0))
+                                           cfg.get('gt_loss_weight', 1.0), cfg.get('neg_loss_weight', 1.0),
+                                           want_bag_ws=save is not None)
+        if save is not None:
+            out, bag_ws = out
+            save.update(feat=feat, ab=ab, lmap=lmap, neg_mask=neg_mask, out5=out, bag_logits=bag_logits, valid=valid,
+                        labels=labels, gt_weight=w, bag_ws=bag_ws, centers=centers, gt_img=gt_img,
+                        offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride)
         losses = {}
         if cfg.get('with_gt_loss', False):
             losses['gt_loss'] = out[0]

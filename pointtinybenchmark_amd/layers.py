@@ -9,6 +9,15 @@ import torch.nn as nn
 from . import ops
 
 
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Called by the native optimizer: its kernels update parameters through raw pointers, which torch's version counter
+    does not see."""
+    _WEIGHT_EPOCH[0] += 1
+
+
 class _PackCache:
     """Repacked weights / folded norms, rebuilt when the source parameter is modified in place."""
 
@@ -17,6 +26,8 @@ class _PackCache:
 
     def get(self, key, tensors, make):
         ver = tuple((t.data_ptr(), t._version) for t in tensors)
+        if any(t.requires_grad for t in tensors):
+            ver = ver + (_WEIGHT_EPOCH[0],)
         hit = self._d.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -77,12 +88,14 @@ class ConvModule(nn.Module):
         return getattr(self, self.norm_name) if self.norm_name else None
 
 
-def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None):
+def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None, save=None):
     """Run a ConvModule(conv, GN[, ReLU]) on an NHWC tensor.
 
     The GroupNorm statistics come out of the conv epilogue when the map is tile-aligned (no extra pass);
     with ``materialize=False`` the raw conv output and the per-(image, channel) affine (a, b) are returned so
     the CONSUMER conv applies normalisation + ReLU while loading its input tile (no apply pass either).
+    ``save`` (dict): training mode -- records what the backward needs (conv input and its pending affine, raw output,
+    GroupNorm affine and statistics) and keeps the raw output intact (the apply pass goes out of place).
     """
     pc = packed_conv(cache, m.conv, x.dtype)
     gn = m.norm
@@ -100,7 +113,11 @@ def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None):
     else:
         raw = ops.conv2d(x, pc, bias=bias, in_ab=in_ab, in_relu=in_relu)
         part = ops.gn_stats(raw)
-    a, b = ops.gn_finalize(part, gn.weight, gn.bias, N, OH * OW, gn.num_groups, gn.eps)
+    if save is not None:
+        a, b, mean, rstd = ops.gn_finalize(part, gn.weight, gn.bias, N, OH * OW, gn.num_groups, gn.eps, want_stats=True)
+        save.update(module=m, x=x, in_ab=in_ab, in_relu=in_relu, raw=raw, a=a, b=b, mean=mean, rstd=rstd)
+    else:
+        a, b = ops.gn_finalize(part, gn.weight, gn.bias, N, OH * OW, gn.num_groups, gn.eps)
     if not materialize:
         return raw, (a, b)
-    return ops.gn_apply(raw, a, b, relu=m.with_activation, up=up, out=raw)
+    return ops.gn_apply(raw, a, b, relu=m.with_activation, up=up, out=None if save is not None else raw)

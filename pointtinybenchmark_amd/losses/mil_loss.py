@@ -17,12 +17,12 @@ class MILLoss(nn.Module):
         self.binary_ins, self.loss_weight, self.eps, self.loss_type = binary_ins, loss_weight, eps, loss_type
 
     def forward_logits(self, bag_logits, ins_off, valid_u8, labels_i32, num_classes, weight=None, neg_partial=None,
-                       w_gt=0.0, w_neg=0.0):
+                       w_gt=0.0, w_neg=0.0, want_bag_ws=False):
         """Fused entry used by CPRHead: bag_logits (B,N,J) raw cls logits in [0,C) and ins logits in
         [ins_off, ins_off+C).  Returns the 5-vector {gt_loss, pos_loss, bag_acc, neg_loss, num_sample}."""
-        out, _ = ops.mil_loss(bag_logits, ins_off, valid_u8, labels_i32, num_classes, neg_partial, self.loss_weight,
-                              w_gt, w_neg, gt_weight=weight, eps=self.eps)
-        return out
+        out, bag_ws = ops.mil_loss(bag_logits, ins_off, valid_u8, labels_i32, num_classes, neg_partial,
+                                   self.loss_weight, w_gt, w_neg, gt_weight=weight, eps=self.eps)
+        return (out, bag_ws) if want_bag_ws else out   # bag_ws (B,5): per-bag terms the backward kernel re-reads
 
     def forward(self, bag_cls_prob, bag_ins_outs, labels, valid, weight=None):
         """Reference signature: (B,N,C) probabilities, (B,N,C) instance logits, (B,) labels, (B,N,1) validity

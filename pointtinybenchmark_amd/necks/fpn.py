@@ -37,7 +37,7 @@ class FPN(nn.Module):
     def init_weights(self):
         pass
 
-    def _run(self, inputs, lazy):
+    def _run(self, inputs, lazy, tape=None):
         assert len(inputs) == len(self.in_channels)
         c = self._cache
         xs = [ops.from_nchw(inputs[i + self.start_level]) for i in range(len(self.lateral_convs))]
@@ -45,14 +45,25 @@ class FPN(nn.Module):
         lat = [None] * len(xs)
         for i in range(len(xs) - 1, -1, -1):
             up = lat[i + 1] if i + 1 < len(xs) else None
-            lat[i] = conv_gn(c, self.lateral_convs[i], xs[i], up=up)
+            rec = None
+            if tape is not None:
+                rec = dict(kind='lateral', level=i)
+                tape.append(rec)
+            lat[i] = conv_gn(c, self.lateral_convs[i], xs[i], up=up, save=rec)
         used = min(len(lat), self.num_outs)
-        return [conv_gn(c, self.fpn_convs[i], lat[i], materialize=not lazy) for i in range(used)]
+        outs = []
+        for i in range(used):
+            rec = None
+            if tape is not None:
+                rec = dict(kind='out', level=i)
+                tape.append(rec)
+            outs.append(conv_gn(c, self.fpn_convs[i], lat[i], materialize=not lazy, save=rec))
+        return outs
 
     def forward(self, inputs):
         return tuple(ops.as_nchw(t) for t in self._run(inputs, lazy=False))
 
-    def forward_lazy(self, inputs):
+    def forward_lazy(self, inputs, tape=None):
         """Internal fast path: per level (raw conv output NHWC, (a, b)) -- the consumer conv applies the GroupNorm
-        affine while loading (no activation after the FPN convs: act_cfg=None)."""
-        return self._run(inputs, lazy=True)
+        affine while loading (no activation after the FPN convs: act_cfg=None).  tape: training records."""
+        return self._run(inputs, lazy=True, tape=tape)

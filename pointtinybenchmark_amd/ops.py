@@ -396,8 +396,9 @@ def conv2d_dgrad(dy, pc_t, in_hw, stride=1):
     return out
 
 
-def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False, grad=None):
-    """grad_w [Cout][Cin][KH][KW] (+= when ``grad`` is given).  in_ab: fused GroupNorm affine (+ReLU) of the input."""
+def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False, grad=None, out=None):
+    """grad_w [Cout][Cin][KH][KW]: accumulated into ``grad`` when given, written into ``out`` when given, else a new
+    tensor.  in_ab: fused GroupNorm affine (+ReLU) of the input."""
     N, H, W, Cin = _check(x).shape
     _, OH, OW, Cout = _check(dy).shape
     KH, KW = weight_shape[2], weight_shape[3]
@@ -406,7 +407,8 @@ def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False
     ws = torch.empty((n,), device=x.device, dtype=torch.float32)
     acc = grad is not None
     if grad is None:
-        grad = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
+        grad = out if out is not None else torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
+    assert tuple(grad.shape) == tuple(weight_shape) and grad.is_contiguous()
     a = b = None
     if in_ab is not None:
         a, b = in_ab
@@ -415,16 +417,17 @@ def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False
     return grad
 
 
-def gn_bwd(x, dz, a, b, mean, rstd, gamma, relu, dgamma=None, dbeta=None, slots=None):
-    """GroupNorm(+ReLU) backward -> (dx, dgamma, dbeta); accumulates into dgamma/dbeta when given."""
+def gn_bwd(x, dz, a, b, mean, rstd, gamma, relu, dgamma=None, dbeta=None, slots=None, out_dgamma=None, out_dbeta=None):
+    """GroupNorm(+ReLU) backward -> (dx, dgamma, dbeta); accumulates into dgamma/dbeta when given, writes into
+    out_dgamma/out_dbeta when given."""
     N, H, W, C = _check(x).shape
     HW, G = H * W, mean.shape[1]
     if slots is None:
         slots = max(1, min(256, HW // 256))
     acc = dgamma is not None
     if not acc:
-        dgamma = torch.empty((C,), device=x.device, dtype=torch.float32)
-        dbeta = torch.empty((C,), device=x.device, dtype=torch.float32)
+        dgamma = out_dgamma if out_dgamma is not None else torch.empty((C,), device=x.device, dtype=torch.float32)
+        dbeta = out_dbeta if out_dbeta is not None else torch.empty((C,), device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x)
     ws_part = torch.empty((N * slots * C * 2,), device=x.device, dtype=torch.float32)
     ws_k = torch.empty((2 * N * G + 2 * N * C,), device=x.device, dtype=torch.float32)
@@ -459,12 +462,12 @@ def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None):
     return g, colsum
 
 
-def bn_fold_bwd(Gw, weight, scale, mean, inv_sigma, colsum_g, want_affine=True):
+def bn_fold_bwd(Gw, weight, scale, mean, inv_sigma, colsum_g, want_affine=True, out_dgamma=None, out_dbeta=None):
     """In place dW = scale*Gw; returns (dgamma, dbeta) of the folded eval BatchNorm (or (None, None))."""
     Cout = Gw.shape[0]
     K = Gw.numel() // Cout
-    dg = db = None
-    if want_affine:
+    dg, db = out_dgamma, out_dbeta
+    if want_affine and dg is None:
         dg = torch.empty((Cout,), device=Gw.device, dtype=torch.float32)
         db = torch.empty((Cout,), device=Gw.device, dtype=torch.float32)
     _lib.call('cpr_bn_fold_bwd', _ptr(Gw), _ptr(_check(weight)), _ptr(scale), _ptr(mean), _ptr(inv_sigma),

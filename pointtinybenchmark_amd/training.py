@@ -1,0 +1,286 @@
+"""The CPR training step beyond forward+loss: explicit backward over the recorded forward, a
+DDP-style bucketed gradient all-reduce and the SGD update -- all on HIP kernels, no torch autograd.
+
+What it replaces in the reference: ``loss.backward()`` (torch autograd over mmcv ConvModule / nn.GroupNorm /
+F.grid_sample / the frozen-statistics BatchNorm of ResNet), MMDistributedDataParallel's gradient reducer
+(T/mmdet/apis/train.py:75-86) and mmcv's OptimizerHook (clip_grad_norm_ max_norm=35 + torch.optim.SGD momentum 0.9,
+weight decay 1e-4: T/configs/_base_/schedules/schedule_1x.py:2, configs2/_base_/.../base_TinyPersonV2_640.py:99-100).
+
+Layout: all trainable parameters live in ONE flat fp32 buffer (``nn.Parameter.data`` are views into it), ordered by the
+moment their gradient becomes final during the backward (head first, backbone stage 2 last); gradients and momentum are
+flat buffers of the same layout.  Buckets are contiguous ranges of the gradient buffer: each is all-reduced (RCCL) as
+soon as its last gradient has been enqueued, overlapping with the rest of the backward; the optimizer is one kernel over
+the flat buffers (the clip coefficient is read from the device, no host sync)."""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .layers import bump_weight_epoch, folded_bn
+
+
+class GradBuckets:
+    """Contiguous buckets over a flat gradient buffer.  ``ready(end)`` says gradients [0, end) are final; every bucket
+    fully below ``end`` is all-reduced asynchronously (on the process group's own stream).  Works on CPU tensors with
+    gloo (tests) and on device tensors with nccl (= RCCL)."""
+
+    def __init__(self, flat, bucket_elems, group=None):
+        self.flat, self.group = flat, group
+        n = flat.numel()
+        self.bounds = list(range(0, n, bucket_elems)) + [n]
+        if len(self.bounds) > 2 and self.bounds[-1] - self.bounds[-2] < bucket_elems // 4:
+            del self.bounds[-2]            # fold a small tail into the previous bucket
+        self.reset()
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def reset(self):
+        self.next, self.pending = 0, []
+
+    def ready(self, end):
+        if self.world_size == 1:
+            return
+        while self.next + 1 < len(self.bounds) and self.bounds[self.next + 1] <= end:
+            lo, hi = self.bounds[self.next], self.bounds[self.next + 1]
+            self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True))
+            self.next += 1
+
+    def finish(self):
+        """All buckets reduced and visible to the current stream.  The sum is NOT divided here: the optimizer kernel
+        applies 1/world_size (``grad_scale``) while it reads the gradient."""
+        self.ready(self.flat.numel())
+        for w in self.pending:
+            w.wait()
+        self.reset()
+        return 1.0 / self.world_size
+
+
+class CprTrainer:
+    def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_mb=25.0, group=None):
+        self.model = model
+        self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
+        order = self._backward_order()
+        seen = {id(p) for p in order}
+        missing = [n for n, p in model.named_parameters() if p.requires_grad and id(p) not in seen]
+        assert not missing, 'trainable parameters without a backward rule: %s' % missing[:8]
+        self.params = order
+        dev = order[0].device
+        n = sum(p.numel() for p in order)
+        self.flat_p = torch.empty((n,), device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros((n,), device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros((n,), device=dev, dtype=torch.float32)
+        self.offset, off = {}, 0
+        for p in order:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + k].view(p.shape)
+            p.grad = self.flat_g[off:off + k].view(p.shape)
+            self.offset[id(p)] = (off, off + k)
+            off += k
+        self.buckets = GradBuckets(self.flat_g, max(1, int(bucket_mb * (1 << 20) / 4)), group)
+        self.norm2 = torch.zeros((1,), device=dev, dtype=torch.float64)
+        self._ws = torch.empty((1024,), device=dev, dtype=torch.float64)
+        self.steps = 0
+        bump_weight_epoch()
+
+    # ------------------------------------------------------------------ parameter order = gradient completion order
+    def _backward_order(self):
+        m = self.model
+        head, neck, bb = m.bbox_head, m.neck, m.backbone
+        out = []
+
+        def add(*ps):
+            for p in ps:
+                if p is not None and p.requires_grad and all(p is not q for q in out):
+                    out.append(p)
+        add(head.cls_out.weight, head.cls_out.bias, head.ins_out.weight, head.ins_out.bias)
+        for cm in reversed(list(head.cls_convs)):
+            add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
+        for cm in neck.fpn_convs:
+            add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
+        for cm in neck.lateral_convs:
+            add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
+        for name in reversed(bb.res_layers):
+            for blk in reversed(list(getattr(bb, name))):
+                if blk.kind == 'bottleneck':
+                    add(blk.conv3.weight, blk.bn3.weight, blk.bn3.bias)
+                add(blk.conv2.weight, blk.bn2.weight, blk.bn2.bias, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias)
+                if blk.downsample is not None:
+                    add(blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias)
+        return out      # a trainable stem (frozen_stages < 0) has no backward rule and trips the constructor's check
+
+    def _done(self, p):
+        """The gradient of ``p`` (and of everything before it in the flat order) is final."""
+        self.buckets.ready(self.offset[id(p)][1])
+
+    # ------------------------------------------------------------------ forward (recorded) + backward
+    def forward_backward(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
+        """-> dict of losses (device scalars, identical to BasicLocator.forward_train); parameter .grad filled (summed
+        over ranks once ``step`` has waited for the buckets)."""
+        m = self.model
+        head, neck, bb = m.bbox_head, m.neck, m.backbone
+        assert bb.compute_dtype == torch.float32, 'the backward pass is fp32 (bf16 training: SURVEY.md §8f, later round)'
+        batch_input_shape = tuple(img[0].size()[-2:])
+        for meta in img_metas:
+            meta['batch_input_shape'] = batch_input_shape
+        bb_tape, neck_tape, head_tape, lsave = [], [], [], {}
+        feats = bb(img, tape=bb_tape)
+        lazy = neck.forward_lazy(feats, tape=neck_tape)
+        losses = head.forward_train_lazy(lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes,
+                                         tape=head_tape, save=lsave)
+        self.buckets.reset()
+        d_stage = self._backward_head_neck(head, neck, lsave, head_tape, neck_tape, feats)
+        self._backward_backbone(bb, bb_tape, d_stage)
+        return losses
+
+    @staticmethod
+    def _gn_conv_backward(rec, dz, relu, need_dx):
+        """Backward of conv -> GN (-> ReLU) given dz wrt the module output.  Writes the three parameter gradients;
+        returns the gradient wrt the conv INPUT as the consumer saw it (after the producer's pending affine, if any)."""
+        cm = rec['module']
+        w, gn = cm.conv.weight, cm.gn
+        assert cm.conv.bias is None
+        draw, _, _ = ops.gn_bwd(rec['raw'], dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
+                                out_dgamma=gn.weight.grad, out_dbeta=gn.bias.grad)
+        ops.conv2d_wgrad(draw, rec['x'], w.shape, cm.conv.stride[0], cm.conv.padding[0], in_ab=rec['in_ab'],
+                         in_relu=rec['in_relu'], out=w.grad)
+        if not need_dx:
+            return None
+        pt = ops.dgrad_pack(w, cm.conv.stride[0], cm.conv.padding[0])
+        return ops.conv2d_dgrad(draw, pt, (rec['x'].shape[1], rec['x'].shape[2]), cm.conv.stride[0])
+
+    def _backward_head_neck(self, head, neck, s, head_tape, neck_tape, feats):
+        C = head.num_classes
+        cfg = head.loss_cfg
+        J = s['lmap'].shape[-1]
+        Jd = 4 if J <= 4 else (J + 31) // 32 * 32
+        w_mil = head.loss_mil.loss_weight if cfg.get('with_mil_loss', True) else 0.0
+        w_gt = cfg.get('gt_loss_weight', 1.0) if cfg.get('with_gt_loss', False) else 0.0
+        w_neg = cfg.get('neg_loss_weight', 1.0) if cfg.get('with_neg', True) else 0.0
+        assert s['neg_mask'] is not None, 'with_neg=False is not on the training path'
+        dmap, _ = ops.cpr_loss_bwd(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
+                                   s['bag_ws'], s['centers'], s['gt_img'], s['offsets'], s['ins_off'], C, s['stride'],
+                                   w_mil, w_gt, w_neg, Jd, gt_weight=s['gt_weight'], eps=head.loss_mil.eps)
+        # ---- logit projection (cls_out ++ ins_out as one 1x1 conv over the un-normalised last tower layer)
+        shared = head.ins_share_head_classifier
+        wcat = head.cls_out.weight if shared else torch.cat([head.cls_out.weight, head.ins_out.weight], 0)
+        wpad = torch.zeros((Jd, wcat.shape[1], 1, 1), device=wcat.device, dtype=torch.float32)
+        wpad[:J, :, 0, 0] = wcat.detach()
+        gw = ops.conv2d_wgrad(dmap, s['feat'], wpad.shape, 1, 0, in_ab=s['ab'], in_relu=True)
+        _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
+        head.cls_out.weight.grad.copy_(gw[:C, :, 0, 0])
+        head.cls_out.bias.grad.copy_(gb[:C])
+        if not shared:
+            head.ins_out.weight.grad.copy_(gw[C:2 * C, :, 0, 0])
+            head.ins_out.bias.grad.copy_(gb[C:2 * C])
+        self._done(head.ins_out.bias if not shared else head.cls_out.bias)
+        dz = ops.conv2d_dgrad(dmap, ops.dgrad_pack(wpad, 1, 0), (dmap.shape[1], dmap.shape[2]))
+        # ---- tower, last layer first; layer 0 consumes the (un-activated) FPN output
+        for rec in reversed(head_tape):
+            dz = self._gn_conv_backward(rec, dz, relu=True, need_dx=True)
+            self._done(rec['module'].conv.weight)
+        # ---- FPN: output conv(s), then the top-down chain from the finest lateral to the coarsest
+        lat_recs = {r['level']: r for r in neck_tape if r['kind'] == 'lateral'}
+        out_recs = {r['level']: r for r in neck_tape if r['kind'] == 'out'}
+        assert list(out_recs) == [0], 'num_outs == 1 (every shipped CPR config)'
+        dlat = self._gn_conv_backward(out_recs[0], dz, relu=False, need_dx=True)
+        self._done(out_recs[0]['module'].conv.weight)
+        d_stage = {}
+        L = len(lat_recs)
+        for i in range(L):
+            rec = lat_recs[i]
+            stage = i + neck.start_level
+            need_dx = bool(self._stage_trainable(stage))
+            d_stage[stage] = self._gn_conv_backward(rec, dlat, relu=False, need_dx=need_dx)
+            self._done(rec['module'].conv.weight)
+            if i + 1 < L:
+                nxt = lat_recs[i + 1]['raw'].shape
+                dlat = ops.upsample_add_bwd(dlat, tuple(nxt))
+        return d_stage
+
+    def _stage_trainable(self, stage):
+        bb = self.model.backbone
+        return any(p.requires_grad for p in getattr(bb, bb.res_layers[stage]).parameters())
+
+    def _backward_backbone(self, bb, tape, d_stage):
+        c = bb._cache
+        dx = None            # gradient flowing down from the block above
+        cur_stage = None
+        for idx in range(len(tape) - 1, -1, -1):
+            rec = tape[idx]
+            blk, stage = rec['block'], rec['stage']
+            if stage != cur_stage:       # entering a stage from above: its output also feeds an FPN lateral
+                cur_stage = stage
+                lat = d_stage.get(stage)
+                if lat is not None:
+                    dx = lat if dx is None else ops.axpby(dx, lat, 1.0, 1.0)
+            assert dx is not None, 'no gradient reaches backbone stage %d' % stage
+            need_dx = idx > 0
+            dx = self._block_backward(c, blk, rec, dx, need_dx)
+
+    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx):
+        """conv -> folded eval-BN given g = d(pre-activation output) (un-scaled) and its column sums."""
+        scale, _ = folded_bn(cache, bn)
+        inv_sigma = cache.get(('bn_is', id(bn)), [bn.running_var],
+                              lambda: (1.0 / torch.sqrt(bn.running_var + bn.eps)).float().contiguous())
+        w = conv.weight
+        if w.requires_grad:
+            ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=w.grad)
+            aff = bn.weight.requires_grad
+            ops.bn_fold_bwd(w.grad, w, scale, bn.running_mean, inv_sigma, colsum,
+                            out_dgamma=bn.weight.grad if aff else None, out_dbeta=bn.bias.grad if aff else None)
+        if not need_dx:
+            return None
+        pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
+                       lambda: ops.dgrad_pack(w.detach() * scale[:, None, None, None], conv.stride[0], conv.padding[0]))
+        return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0])
+
+    def _block_backward(self, cache, blk, rec, dout, need_dx):
+        x = rec['x']
+        g3, cs3 = ops.relu_bwd_colsum(dout, rec['out'])            # also the shortcut gradient
+        if blk.kind == 'bottleneck':
+            d2 = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, rec['o2'], True)
+            g2, cs2 = ops.relu_bwd_colsum(d2, rec['o2'])
+            d1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, rec['o1'], True)
+            last = blk.bn3
+        else:
+            d1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, rec['o1'], True)
+            last = blk.bn2
+        self._done(last.bias if last.bias.requires_grad else blk.conv2.weight)
+        g1, cs1 = ops.relu_bwd_colsum(d1, rec['o1'])
+        dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx)
+        if blk.downsample is not None:     # the shortcut conv sees the same g3 (no activation on that branch)
+            dxd = self._conv_bn_backward(cache, blk.downsample[0], blk.downsample[1], g3, cs3, x, need_dx)
+            if need_dx:
+                dx = ops.axpby(dx, dxd, 1.0, 1.0)
+            tail = blk.downsample[1].bias if blk.downsample[1].bias.requires_grad else blk.downsample[0].weight
+        else:
+            if need_dx:
+                dx = ops.axpby(dx, g3, 1.0, 1.0)
+            tail = blk.bn1.bias if blk.bn1.bias.requires_grad else blk.conv1.weight
+        self._done(tail)
+        return dx
+
+    # ------------------------------------------------------------------ optimizer
+    def step(self, lr=None):
+        """Wait for the gradient buckets, clip by the global norm, SGD-momentum update of every trainable parameter."""
+        grad_scale = self.buckets.finish()
+        if self.max_norm and self.max_norm > 0:
+            ops.grad_sumsq(self.flat_g, self.norm2, self._ws, accumulate=False)
+        ops.sgd_step(self.flat_p, self.flat_g, self.flat_m, self.norm2, self.lr if lr is None else lr, self.momentum,
+                     self.weight_decay, self.max_norm or 0.0, grad_scale, first=self.steps == 0)
+        self.steps += 1
+        bump_weight_epoch()
+
+    def grad_norm(self):
+        """Global L2 norm of the (rank-averaged) gradient the last ``step`` clipped with (host sync: logging only)."""
+        return float(self.norm2.sqrt()) / self.buckets.world_size
+
+    def train_step(self, data, lr=None):
+        """One optimisation step; returns BasicLocator.train_step's dict (base.py:214-247)."""
+        losses = self.forward_backward(**data)
+        self.step(lr)
+        loss, log_vars = self.model._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))

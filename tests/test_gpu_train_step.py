@@ -1,0 +1,103 @@
+"""-m gpu: the full CPR training step (recorded forward, HIP backward, clip + SGD) against torch autograd / torch.optim
+running over the CPU oracle on the same seeded weights and batch.  Gradients are floating point: the bar is a relative
+L2 error of 2e-3 per parameter tensor (fp32 accumulation orders differ across ~50 layers), 1e-4 on the losses."""
+import os
+
+import pytest
+import torch
+
+from oracle import cpr_oracle as O
+from oracle.gen_golden import CPR_CASES
+from pointtinybenchmark_amd import synthetic
+from tests.test_gpu_cpr_parity import build_hip_locator, to_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_grads(cfg, sd, batch, trainable):
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    losses, _, _ = O.locator_forward_train(sd, batch, cfg['depth'], cfg['start_level'], cfg['stride'], cfg['radius'],
+                                           cfg['num_classes'])
+    total = sum(v for k, v in losses.items() if 'loss' in k)
+    total.backward()
+    return sd, {k: float(v) for k, v in losses.items()}, {k: sd[k].grad for k in trainable}
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().cpu().double().flatten(), b.detach().cpu().double().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread', 'cpr_r50_c80_s8_r8'])
+def test_backward_matches_autograd(name):
+    from pointtinybenchmark_amd.training import CprTrainer
+    cfg = CPR_CASES[name]
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    m, sd = build_hip_locator(cfg)
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'], cfg.get('ragged', False))
+    cb = to_cuda(batch)
+    with torch.no_grad():
+        ref_fwd = m.forward_train(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+        ref_fwd = {k: float(v) for k, v in ref_fwd.items()}
+    tr = CprTrainer(m)
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert any(k.startswith('backbone.layer2') for k in trainable) and not any(
+        k.startswith('backbone.layer1') for k in trainable)
+    losses = tr.forward_backward(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+    torch.cuda.synchronize()
+    got = {k: float(v) for k, v in losses.items()}
+    assert got == ref_fwd, 'the recorded forward must be the forward_train arithmetic: %s vs %s' % (got, ref_fwd)
+    _, oloss, ograd = _oracle_grads(cfg, sd, batch, trainable)
+    for k, v in oloss.items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    params = dict(m.named_parameters())
+    worst = []
+    for k in trainable:
+        g, r = params[k].grad, ograd[k]
+        assert r is not None, k
+        assert torch.isfinite(g).all(), k
+        worst.append((_rel_l2(g, r), k, float(r.abs().max())))
+    worst.sort(reverse=True)
+    # tensors whose true gradient is numerically nil are compared in absolute terms against the global scale
+    gmax = max(w[2] for w in worst)
+    bad = [(e, k, mx) for e, k, mx in worst if e > 2e-3 and mx > 1e-6 * gmax]
+    assert not bad, 'gradient mismatch (rel L2, key, ref max): %s' % bad[:6]
+
+
+def test_train_steps_match_torch_sgd():
+    """Three optimisation steps: HIP trainer vs torch autograd + clip_grad_norm_(35) + SGD(0.9, 1e-4) on the oracle."""
+    from pointtinybenchmark_amd.training import CprTrainer
+    cfg = CPR_CASES['cpr_r18_c3_128']
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    m, sd0 = build_hip_locator(cfg)
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    lr = 0.05
+    tr = CprTrainer(m, lr=lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    opt = torch.optim.SGD([sd[k] for k in trainable], lr=lr, momentum=0.9, weight_decay=1e-4)
+    for step in range(3):
+        batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                          cfg['seed'] + step, True)
+        out = tr.train_step(dict(img=batch['img'].cuda(), img_metas=batch['img_metas'],
+                                 gt_bboxes=[b.cuda() for b in batch['gt_bboxes']],
+                                 gt_labels=[l.cuda() for l in batch['gt_labels']]))
+        opt.zero_grad()
+        losses, _, _ = O.locator_forward_train(sd, batch, cfg['depth'], 0, 4, 5, cfg['num_classes'])
+        total = sum(v for k, v in losses.items() if 'loss' in k)
+        total.backward()
+        tn = torch.nn.utils.clip_grad_norm_([sd[k] for k in trainable], 35.0)
+        opt.step()
+        assert abs(out['log_vars']['loss'] - float(total)) <= 2e-4 * max(1.0, abs(float(total))), (step, out, total)
+        assert abs(tr.grad_norm() - float(tn)) <= 2e-3 * float(tn), (step, tr.grad_norm(), float(tn))
+    params = dict(m.named_parameters())
+    for k in trainable:
+        upd = (sd[k].detach() - sd0[k]).norm()
+        err = (params[k].detach().cpu() - sd[k].detach()).norm()
+        assert float(err) <= 5e-3 * max(float(upd), 1e-12) + 1e-7, (k, float(err), float(upd))
+    # state dict keys/values still load strictly (parameters are views into the flat buffer)
+    m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
