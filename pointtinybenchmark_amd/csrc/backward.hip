@@ -211,14 +211,15 @@ extern "C" int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, i
 __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ g_out,
                                        float* __restrict__ part, long long M, int C, int rows_per_block) {
     __shared__ float red[256 * 4];
-    const int Q = C >> 2;
+    const int c0 = blockIdx.y * 1024;               // blockIdx.y: 1024-channel column group
+    const int Q = min(1024, C - c0) >> 2;
     const int PP = 256 / Q;                         // rows handled per pass; threads >= PP*Q idle
     const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
     const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float s1[4] = {0, 0, 0, 0};
     if (pl < PP) {
         for (long long r = r0 + pl; r < r1; r += PP) {
-            const size_t o = (size_t)r * C + q * 4;
+            const size_t o = (size_t)r * C + c0 + q * 4;
             f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
             if (y) {
                 const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
@@ -238,7 +239,7 @@ __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float
         for (int r = 0; r < PP; ++r)
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] += red[(r * Q + q) * 4 + k];
-        float* dst = part + (size_t)blockIdx.x * C + q * 4;
+        float* dst = part + (size_t)blockIdx.x * C + c0 + q * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) dst[k] = acc[k];
     }
@@ -254,11 +255,11 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 extern "C" int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out, float* colsum, float* ws_part,
                                    long long M, int C, int accumulate, hipStream_t stream) {
     // ws_part: ceil(M/512)*C floats
-    CPR_CHECK_ARG(dy && colsum && ws_part && M > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256);
+    CPR_CHECK_ARG(dy && colsum && ws_part && M > 0 && C > 0 && C % 4 == 0);
     const int rows_per_block = 512;
     const int blocks = (int)cdivll(M, rows_per_block);
-    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3(blocks), dim3(256), 0, stream, dy, y, g_out, ws_part, M, C,
-                       rows_per_block);
+    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, y, g_out, ws_part,
+                       M, C, rows_per_block);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, ws_part, colsum, blocks, C,
                        accumulate);
     CPR_LAUNCH_STATUS();

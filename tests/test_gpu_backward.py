@@ -150,9 +150,12 @@ def test_bn_fold_relu_backward():
     _cmp('dgamma', dg, gamma.grad, atol=2e-4 * float(gamma.grad.abs().max()))
     _cmp('dbeta', db, beta.grad, atol=2e-4 * float(beta.grad.abs().max()))
     # colsum without a mask / without writing g, odd channel count for the thread layout (C/4 = 40)
-    t = torch.randn((3, 7, 5, 160), generator=g)
-    _, cs = ops.relu_bwd_colsum(t.cuda(), None, want_g=False)
-    _cmp('colsum', cs, t.sum((0, 1, 2)), atol=1e-4)
+    for C in (160, 2048, 1028):
+        t = torch.randn((3, 7, 5, C), generator=g)
+        _, cs = ops.relu_bwd_colsum(t.cuda(), None, want_g=False)
+        _cmp('colsum C=%d' % C, cs, t.sum((0, 1, 2)), atol=1e-4)
+        gt, cs = ops.relu_bwd_colsum(t.cuda(), (t * 0 + torch.randn(t.shape, generator=g)).cuda())
+        assert float((gt != 0).float().mean()) > 0.3
 
 
 def test_sgd_clip_vs_torch():

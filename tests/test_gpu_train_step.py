@@ -22,7 +22,7 @@ def _oracle_grads(cfg, sd, batch, trainable):
                                            cfg['num_classes'])
     total = sum(v for k, v in losses.items() if 'loss' in k)
     total.backward()
-    return sd, {k: float(v) for k, v in losses.items()}, {k: sd[k].grad for k in trainable}
+    return sd, {k: float(v.detach()) for k, v in losses.items()}, {k: sd[k].grad for k in trainable}
 
 
 def _rel_l2(a, b):

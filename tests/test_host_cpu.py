@@ -114,3 +114,45 @@ def test_two_rank_gloo_log_var_reduction(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+_BUCKET_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(sys.argv[1]); os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[2]
+dist.init_process_group('gloo', rank=rank, world_size=2)
+from pointtinybenchmark_amd.training import GradBuckets
+n = 950
+flat = torch.arange(n, dtype=torch.float32) * (rank + 1)          # rank-dependent "gradients"
+b = GradBuckets(flat, bucket_elems=300)                            # 300,300,350 (a tail under a quarter bucket is folded)
+assert b.bounds == [0, 300, 600, 950], b.bounds
+b.ready(250); assert b.next == 0 and not b.pending                 # bucket 0 not complete yet
+b.ready(650); assert b.next == 2 and len(b.pending) == 2           # buckets 0 and 1 in flight, 2 still open
+scale = b.finish()                                                 # launches the tail, waits for all
+assert scale == 0.5 and b.next == 0 and not b.pending
+ref = torch.arange(n, dtype=torch.float32) * 3.0                   # SUM over ranks; the optimizer applies 1/world
+assert torch.equal(flat, ref), (flat[:4], ref[:4])
+# a second step re-uses the object
+flat.fill_(float(rank)); b.ready(n); b.finish(); assert torch.equal(flat, torch.ones(n))
+dist.barrier(); dist.destroy_process_group(); print('rank', rank, 'ok')
+'''
+
+
+def test_two_rank_gloo_gradient_buckets(tmp_path):
+    """The bucketed reducer of the training step (training.GradBuckets) under gloo, world_size 2."""
+    script = tmp_path / 'bworker.py'
+    script.write_text(_BUCKET_WORKER % ROOT)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+def test_gradient_buckets_single_process_is_a_no_op():
+    from pointtinybenchmark_amd.training import GradBuckets
+    flat = torch.ones(10)
+    b = GradBuckets(flat, 4)
+    b.ready(10)
+    assert b.finish() == 1.0 and torch.equal(flat, torch.ones(10))
