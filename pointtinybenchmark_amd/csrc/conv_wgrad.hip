@@ -29,8 +29,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     float* As = smem;                         // [2][32][132]  dY tile (k = pixel, i = cout)
     float* Bs = smem + 2 * WG_BK * WG_LD;     // [2][32][132]  X tile  (k = pixel, j = cin)
     const int KK = p.KH * p.KW;
-    int b = blockIdx.x;
-    const int slab = b % p.S; b /= p.S;
+    // XCD-aware order: workgroup b runs on XCD b % 8.  All tiles of one pixel slab (they stream the same dY / X rows) are
+    // consecutive workgroups of ONE XCD, so the slab is fetched from HBM once and re-read from that XCD's L2 as a sliding
+    // window by the other tiles; slabs are dealt round-robin to the XCDs (S % 8 == 0).
+    const int xcd = blockIdx.x & 7;
+    const int local = blockIdx.x >> 3;
+    const int tiles = p.tilesCo * KK * p.tilesCi;
+    const int slab = (local / tiles) * 8 + xcd;
+    int b = local % tiles;
     const int tci = b % p.tilesCi; b /= p.tilesCi;
     const int tap = b % KK; b /= KK;
     const int tco = b;
@@ -43,47 +49,78 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         const_cast<float*>(p.dy), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+    const int tab_bytes = XF ? p.N * p.Cin * 4 : 0;
+    const __amdgpu_buffer_rsrc_t rs_ta = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_a), 0, tab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_tb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_b), 0, tab_bytes, 0x00020000);
     const bool co_ok = co0 + c4 * 4 < p.Cout;   // Cout % 4 == 0 is checked by the launcher
     const bool ci_ok = ci0 + c4 * 4 < p.Cin;
 
     const int m_begin = slab * p.chunks_per_slab * WG_BK;
     const int nchunks = min(p.chunks_per_slab, (p.M - m_begin + WG_BK - 1) / WG_BK);
     const int ohw = p.OH * p.OW;
+    // per-thread pixel rows kr + 8j of the current chunk, decoded once and then advanced by 32 pixels per chunk
+    const int q32 = WG_BK / p.OW, r32 = WG_BK - q32 * p.OW;
+    int rn[4], roy[4], rox[4], rm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m_begin + kr + 8 * j;
+        rm[j] = m;
+        const int n = m / ohw;
+        const int rem = m - n * ohw;
+        rn[j] = n;
+        roy[j] = rem / p.OW;
+        rox[j] = rem - roy[j] * p.OW;
+    }
+    const bool big_map = ohw >= WG_BK;
+    const int cho = (co0 + c4 * 4) * 4, chi = (ci0 + c4 * 4) * 4;   // byte offsets of this thread's channel group
 
     f32x4 ra[4], rb[4], xa[4], xb[4];
-    auto load_chunk = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m_begin + c * WG_BK + kr + 8 * j;
-            const bool mok = m < p.M;
-            const int mm = mok ? m : 0;
-            const int n = mm / ohw;
-            const int rem = mm - n * ohw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const int iy = oy * p.stride + kh - p.pad, ix = ox * p.stride + kw - p.pad;
-            const bool xok = mok & ci_ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-            const int va = (mok & co_ok) ? (mm * p.Cout + co0 + c4 * 4) * 4 : -1;
-            const int vb = xok ? (((n * p.H + iy) * p.W + ix) * p.Cin + ci0 + c4 * 4) * 4 : -1;
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, va, 0, 0));
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vb, 0, 0));
-            if (XF) {
-                const int ai = xok ? n * p.Cin + ci0 + c4 * 4 : 0;
-                xa[j] = xok ? *reinterpret_cast<const f32x4*>(p.in_a + ai) : f32x4{0.f, 0.f, 0.f, 0.f};
-                xb[j] = xok ? *reinterpret_cast<const f32x4*>(p.in_b + ai) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+    // row piece j: loads the row (rm, rn, roy, rox)[j] currently points at, then advances it by one chunk
+    auto load_row = [&](int j) {
+        const bool mok = rm[j] < p.M;
+        const int iy = roy[j] * p.stride + kh - p.pad, ix = rox[j] * p.stride + kw - p.pad;
+        const bool xok = mok & ci_ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        // out-of-range rows get voffset -1 (= beyond num_records: the load returns 0); OR with an all-ones mask instead
+        // of a select so the compiler cannot turn the address arithmetic into divergent control flow
+        const int xmask = -(int)(!xok);
+        const int va = (rm[j] * p.Cout * 4 + cho) | -(int)(!(mok & co_ok));
+        const int vb = (((rn[j] * p.H + iy) * p.W + ix) * p.Cin * 4 + chi) | xmask;
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, va, 0, 0));
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vb, 0, 0));
+        if (XF) {   // rows that must read as zero get a = b = 0 from the range check as well (branch-free)
+            const int vt = (rn[j] * p.Cin * 4 + chi) | xmask;
+            xa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ta, vt, 0, 0));
+            xb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_tb, vt, 0, 0));
+        }
+        rm[j] += WG_BK;
+        if (big_map) {               // 32 pixels cross at most one image boundary: select-only update
+            const int ox = rox[j] + r32;
+            const int cx = ox >= p.OW ? 1 : 0;
+            const int oy = roy[j] + q32 + cx;
+            const int cy = oy >= p.OH ? 1 : 0;
+            rox[j] = ox - cx * p.OW;
+            roy[j] = oy - cy * p.OH;
+            rn[j] += cy;
+        } else {                     // tiny maps (unit-test sizes): decode from scratch
+            const int n = rm[j] / ohw, rem = rm[j] - n * ohw;
+            rn[j] = n;
+            roy[j] = rem / p.OW;
+            rox[j] = rem - roy[j] * p.OW;
         }
     };
     const float relu_floor = p.in_relu ? 0.f : -INFINITY;
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+    // store piece z: z < 4 -> dY row z, else X row z-4 (with the fused GroupNorm affine + ReLU)
+    auto store_piece = [&](int buf, int z) {
+        if (z < 4) {
+            *reinterpret_cast<f32x4*>(As + (buf * WG_BK + kr + 8 * z) * WG_LD + c4 * 4) = ra[z];
+        } else {
+            const int j = z - 4;
             f32x4 v = rb[j];
             if (XF) {  // padded / out-of-range entries have a = b = 0 -> max(0, floor) = 0 for either floor
                 v = v * xa[j] + xb[j];
                 v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
                 v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
             }
-            *reinterpret_cast<f32x4*>(As + (buf * WG_BK + kr + 8 * j) * WG_LD + c4 * 4) = ra[j];
             *reinterpret_cast<f32x4*>(Bs + (buf * WG_BK + kr + 8 * j) * WG_LD + c4 * 4) = v;
         }
     };
@@ -100,30 +137,72 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const float* a_lds = As + half * WG_LD + wm * 64 + (lane & 31);
     const float* b_lds = Bs + half * WG_LD + wn * 64 + (lane & 31);
 
+    // A "k-group" is 4 MFMA k-steps (8 pixels: lanes < 32 take the even pixel of a step, lanes >= 32 the odd one) =
+    // 16 MFMAs.  Fragment sets: F[step][0..1] = A values of the two 32-row sub-tiles, F[step][2..3] = B values.
+    // Same interleaved schedule as the forward kernel (conv_mfma.hip): every non-MFMA instruction of a chunk sits
+    // behind one of that wave's own MFMAs, because the two workgroups sharing a CU run in lockstep:
+    //   g0: MFMAs(set0) | read set1 <- group 1
+    //   g1: MFMAs(set1) | read set0 <- group 2 | write chunk c+1 (registers loaded during chunk c-1) to the other buffer
+    //   g2: MFMAs(set0) | read set1 <- group 3 | issue the global loads of chunk c+2
+    //   barrier
+    //   g3: MFMAs(set1) | read set0 <- group 0 of chunk c+1 (other buffer, now complete)
+    float f0[4][4], f1[4][4];
+#define WG_FRAG(F, buf, g, z)                                                                         \
+    do {                                                                                              \
+        const float* src_ = ((z) & 1 ? b_lds : a_lds) + ((buf) * WG_BK + (g) * 8 + ((z) >> 1) * 2) * WG_LD; \
+        F[(z) >> 1][((z) & 1) * 2] = src_[0];                                                         \
+        F[(z) >> 1][((z) & 1) * 2 + 1] = src_[32];                                                    \
+    } while (0)
+#define WG_MFMA(F, q)                                                                                 \
+    acc[((q) >> 1) & 1][(q) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(                              \
+        F[(q) >> 2][((q) >> 1) & 1], F[(q) >> 2][2 + ((q) & 1)], acc[((q) >> 1) & 1][(q) & 1], 0, 0, 0)
     if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_row(j);
+#pragma unroll
+        for (int z = 0; z < 8; ++z) store_piece(0, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_row(j);
         __syncthreads();
+#pragma unroll
+        for (int z = 0; z < 8; ++z) WG_FRAG(f0, 0, 0, z);
         for (int c = 0; c < nchunks; ++c) {
             const int buf = c & 1;
-            if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll
-            for (int k2 = 0; k2 < WG_BK / 2; ++k2) {   // MFMA k = 2: lanes < 32 take pixel 2*k2, lanes >= 32 pixel 2*k2+1
-                float fa[2], fb[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = a_lds[(buf * WG_BK + 2 * k2) * WG_LD + i * 32];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = b_lds[(buf * WG_BK + 2 * k2) * WG_LD + j * 32];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int q = 0; q < 16; ++q) {
+                WG_MFMA(f0, q);
+                if (q < 8) WG_FRAG(f1, buf, 1, q);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (c + 1 < nchunks) store_chunk(buf ^ 1);
-            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                WG_MFMA(f1, q);
+                if (q < 8) WG_FRAG(f0, buf, 2, q);
+                else store_piece(buf ^ 1, q - 8);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                WG_MFMA(f0, q);
+                if (q < 8) WG_FRAG(f1, buf, 3, q);
+                else if (q < 12) load_row(q - 8);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("" ::: "memory");       // no LDS access may be moved across the raw barrier by the compiler
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS traffic is done; global loads stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                WG_MFMA(f1, q);
+                if (q < 8) WG_FRAG(f0, buf ^ 1, 0, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
+#undef WG_FRAG
+#undef WG_MFMA
     // partial[slab][co][tap][ci]: col j = lane&31 (cin), row i = (r&3) + 8*(r>>2) + 4*half (cout)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -159,10 +238,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 static int wgrad_split(long long M, int Cout, int Cin, int KK) {
     const long long tiles = (long long)((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T) * KK;
     const long long chunks = (M + WG_BK - 1) / WG_BK;
-    long long S = (1536 + tiles - 1) / tiles;          // aim at >= ~1500 workgroups (3 rounds of 2/CU)
-    if (S > chunks) S = chunks;
-    if (S < 1) S = 1;
-    if (S > 256) S = 256;
+    // S % 8 == 0 (slabs are dealt to the 8 XCDs).  The chip holds 512 workgroups at a time (2 per CU): pick the slab count
+    // whose grid fills whole rounds of 512 best (a 3.4-round grid runs at 3.4/4 of peak), between ~2 and ~8 rounds.
+    long long smax = (4096 + tiles - 1) / tiles;
+    smax = (smax + 7) / 8 * 8;
+    if (smax > 256) smax = 256;
+    while (smax > 8 && smax > chunks) smax -= 8;       // no more slabs than chunks (empty slabs still write zeros)
+    long long smin = (1024 + tiles - 1) / tiles;
+    smin = (smin + 7) / 8 * 8;
+    if (smin > smax) smin = smax;
+    long long S = smin;
+    double best = 0.0;
+    for (long long c = smin; c <= smax; c += 8) {
+        const double rounds = (double)(c * tiles) / 512.0;
+        const double eff = rounds / (double)((c * tiles + 511) / 512);
+        if (eff > best + 0.02) { best = eff; S = c; }  // prefer fewer slabs unless clearly better
+    }
     return (int)S;
 }
 extern "C" int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {

@@ -1,0 +1,107 @@
+"""Per-call timing of every op of one CPR training step (HIP events around each ops.* call of the backward).
+Groups by (op, shape) and prints time, TFLOP/s for the MFMA ops, and each group's share of the step."""
+import argparse
+import os
+import sys
+from collections import OrderedDict
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import pointtinybenchmark_amd as P  # noqa: E402
+from pointtinybenchmark_amd import ops, synthetic  # noqa: E402
+from pointtinybenchmark_amd.training import CprTrainer  # noqa: E402
+
+TIMED = ['conv2d', 'conv2d_wgrad', 'conv2d_dgrad', 'gn_bwd', 'relu_bwd_colsum', 'bn_fold_bwd', 'upsample_add_bwd',
+         'axpby', 'cpr_loss_bwd', 'dgrad_pack', 'gn_apply', 'gn_stats', 'gn_finalize', 'maxpool3x3s2', 'bag_sample',
+         'neg_mask_loss', 'mil_loss', 'grad_sumsq', 'sgd_step']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--top', type=int, default=45)
+    args = ap.parse_args()
+    model = P.build_detector(bench.model_cfg()).cuda()
+    model.load_state_dict(synthetic.locator_state_dict(50, 1, 0, 'cpr', 0), strict=True)
+    model.train()
+    batch = synthetic.synthetic_batch(args.batch, 640, 640, 32, 1, 0)
+    img = batch['img'].cuda()
+    gtb = [b.cuda() for b in batch['gt_bboxes']]
+    gtl = [l.cuda() for l in batch['gt_labels']]
+    tr = CprTrainer(model, lr=1e-3)
+    for _ in range(2):
+        tr.forward_backward(img, batch['img_metas'], gtb, gtl)
+        tr.step()
+    torch.cuda.synchronize()
+    events = []
+    depth = [0]
+    originals = {}
+
+    def wrap(name, fn):
+        def inner(*a, **k):
+            if depth[0] > 0:                 # nested call (conv2d inside conv2d_dgrad): timed by the outer op
+                return fn(*a, **k)
+            depth[0] += 1
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*a, **k)
+            e.record()
+            depth[0] -= 1
+            shp, flops = '', 0.0
+            if name == 'conv2d':
+                x, pc = a[0], a[1]
+                OH, OW = pc.out_hw(x.shape[1], x.shape[2])
+                shp = '%s->%d k%d s%d' % (tuple(x.shape), pc.Cout, pc.KH, pc.stride)
+                flops = 2.0 * x.shape[0] * OH * OW * pc.Cout * pc.KH * pc.KW * x.shape[3]
+            elif name == 'conv2d_wgrad':
+                dy, x, ws = a[0], a[1], a[2]
+                shp = 'dy%s x%s k%d s%d xf%d' % (tuple(dy.shape), tuple(x.shape), ws[2], a[3], int(k.get('in_ab') is not None))
+                flops = 2.0 * dy.numel() * ws[1] * ws[2] * ws[3]
+            elif name == 'conv2d_dgrad':
+                dy, pt = a[0], a[1]
+                st = a[3] if len(a) > 3 else k.get('stride', 1)
+                shp = 'dy%s ->%d k%d s%d' % (tuple(dy.shape), pt.Cout, pt.KH, st)
+                flops = 2.0 * dy.shape[0] * a[2][0] * a[2][1] * pt.Cout * pt.KH * pt.KW * dy.shape[3] / (st * st)
+            elif a and isinstance(a[0], torch.Tensor):
+                shp = str(tuple(a[0].shape))
+            events.append((name, shp, flops, s, e))
+            return out
+        return inner
+    for n in TIMED:
+        originals[n] = getattr(ops, n)
+        setattr(ops, n, wrap(n, originals[n]))
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    tr.forward_backward(img, batch['img_metas'], gtb, gtl)
+    tr.step()
+    t1.record()
+    torch.cuda.synchronize()
+    for n, f in originals.items():
+        setattr(ops, n, f)
+    step_ms = t0.elapsed_time(t1)
+    groups = OrderedDict()
+    for name, shp, flops, s, e in events:
+        g = groups.setdefault((name, shp), [0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += s.elapsed_time(e)
+        g[2] += flops
+    rows = sorted(groups.items(), key=lambda kv: -kv[1][1])
+    print('step (instrumented) %.2f ms, B=%d' % (step_ms, args.batch))
+    by_op = OrderedDict()
+    for (name, shp), (cnt, ms, fl) in rows:
+        o = by_op.setdefault(name, [0, 0.0, 0.0])
+        o[0] += cnt; o[1] += ms; o[2] += fl
+    print('%-18s %5s %9s %8s' % ('op', 'calls', 'ms', 'TF/s'))
+    for name, (cnt, ms, fl) in sorted(by_op.items(), key=lambda kv: -kv[1][1]):
+        print('%-18s %5d %9.3f %8.1f' % (name, cnt, ms, fl / ms / 1e9 if ms > 0 else 0))
+    print()
+    print('%-16s %-58s %3s %8s %7s' % ('op', 'shape', 'cnt', 'ms', 'TF/s'))
+    for (name, shp), (cnt, ms, fl) in rows[:args.top]:
+        print('%-16s %-58s %3d %8.3f %7.1f' % (name, shp, cnt, ms, fl / ms / 1e9 if ms > 0 else 0))
+
+
+if __name__ == '__main__':
+    main()

@@ -9,7 +9,7 @@ cd /tmp; export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -E "^\s*(gpu-agent|Name|SQ_|TCC_|GRBM_|FETCH|WRITE|Mfma|VALU|LDS)" | head -400 > $OUT/${TAG}_counters.txt 2>&1
 run() { # name, counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/${TAG}_$name -o $name -- python $REPO/tools/conv_single.py ${CONV_ARGS:-} > /tmp/${TAG}_$name.log 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/${TAG}_$name -o $name -- python $REPO/tools/${PMC_SCRIPT:-conv_single.py} ${CONV_ARGS:-} > /tmp/${TAG}_$name.log 2>&1
   echo "pmc $name exit $?"; tail -2 /tmp/${TAG}_$name.log
   for f in $(find /tmp/${TAG}_$name -name "*counter_collection.csv"); do cp $f $OUT/${TAG}_${name}_counters.csv; done
 }
