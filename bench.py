@@ -197,7 +197,8 @@ def main():
 
     def make_trainer():
         from pointtinybenchmark_amd.training import CprTrainer
-        return CprTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
+        return CprTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4, max_norm=35.0,
+                          two_streams=os.environ.get('CPR_TRAIN_STREAMS', '2') != '1')
 
     def train_step():
         losses = trainer.forward_backward(img, metas, gtb, gtl)

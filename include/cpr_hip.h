@@ -185,6 +185,8 @@ int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W
  * C%4==0.  g_out may be NULL (sums only).  ws_part ceil(M/512)*C floats. */
 int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out, float* colsum, float* ws_part, long long M, int C,
                         int accumulate, void* stream);
+/* column sums (C) of a conv output from the epilogue partials cpr_conv2d_fwd wrote into gn_part [tiles][C][2] */
+int cpr_part_colsum(const float* part, float* out, int tiles, int C, void* stream);
 /* parameter side of the folded BN: Gw = cpr_conv2d_wgrad(g, x) [Cout][K] -> in place dW = scale[c]*Gw[c];
  * dgamma = inv_sigma*(<W[c],Gw[c]> - mean*colsum_g), dbeta = colsum_g (either may be NULL). */
 int cpr_bn_fold_bwd(float* Gw, const float* weight, const float* scale, const float* mean, const float* inv_sigma,

@@ -264,6 +264,28 @@ extern "C" int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out
                        accumulate);
     CPR_LAUNCH_STATUS();
 }
+// column sums from the conv epilogue's per-tile partials [tiles][C][2] (element 0 = sum): 32 channels x 8 tile lanes
+// per block, fixed summation order (deterministic)
+__global__ void part_colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int tiles, int C) {
+    __shared__ double red[8][33];
+    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0;
+    if (c < C)
+        for (int t = r; t < tiles; t += 8) s += (double)part[((size_t)t * C + c) * 2];
+    red[r][cl] = s;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        double a = 0;
+        for (int k = 0; k < 8; ++k) a += red[k][cl];
+        out[c] = (float)a;
+    }
+}
+extern "C" int cpr_part_colsum(const float* part, float* out, int tiles, int C, hipStream_t stream) {
+    CPR_CHECK_ARG(part && out && tiles > 0 && C > 0);
+    hipLaunchKernelGGL(part_colsum_kernel, dim3(cdiv(C, 32)), dim3(256), 0, stream, part, out, tiles, C);
+    CPR_LAUNCH_STATUS();
+}
 // parameter side of the folded BatchNorm: Gw = wgrad(g, x) [Cout][K] (unscaled), W [Cout][K], scale = gamma*inv_sigma:
 //   dscale[c] = <W[c], Gw[c]> (= sum_p g*conv),  dshift[c] = colsum_g[c]
 //   dgamma = inv_sigma*(dscale - mean*dshift),  dbeta = dshift,  dW[c] = scale[c]*Gw[c]  (in place)

@@ -36,6 +36,7 @@ struct ConvParams {
     const float* in_b;
     float* gn_part;         // [tilesM][Cout][2] per-M-tile per-channel (sum, sumsq) of the output, or null
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, in_relu, out_bf16;
+    int res_mask;           // residual is a ReLU mask source: out = residual > 0 ? v : 0 (backward of a fused ReLU)
     int tilesM, tilesN;
 };
 
@@ -388,7 +389,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = rbase + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] * sc + bi + res[r];
+                float v = acc[i][j][r] * sc + bi;
+                if (p.res_mask) v = res[r] > 0.f ? v : 0.f;
+                else v += res[r];
                 if (p.relu) v = fmaxf(v, 0.f);
                 const bool ok = cok && m < p.M;
                 if (ok) {
@@ -465,6 +468,9 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     p.in_a = in_a; p.in_b = in_b; p.gn_part = gn_part;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.Kpad = Kpad; p.relu = relu & 1; p.in_relu = in_relu; p.out_bf16 = (relu >> 1) & 1;  // relu bit1 = bf16 output
+    p.res_mask = (relu >> 2) & 1;          // bit2: residual is a ReLU mask source
+    const bool colsum_mode = (relu >> 3) & 1;   // bit3: gn_part partials are only summed over the whole tensor (any tile)
+    if (p.res_mask) CPR_CHECK_ARG(residual != nullptr);
     p.OH = (H + 2 * pad - KH) / stride + 1;
     p.OW = (W + 2 * pad - KW) / stride + 1;
     CPR_CHECK_ARG(p.OH > 0 && p.OW > 0);
@@ -479,19 +485,19 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     } else {
         CPR_CHECK_ARG(Kpad >= KH * KW * 4 && in_a == nullptr);
     }
-    if (gn_part || in_a) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
+    if ((gn_part && !colsum_mode) || in_a) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
     if (in_a) CPR_CHECK_ARG(in_b && p.OH == H && p.OW == W && Cin <= 512);
     // tile selection (measured per layer on MI355X, profiles/round1_tile_sweep.txt): 64x64 tiles run 4 workgroups per CU
     // (36.9 KB LDS, 74 VGPRs) and win on everything except very large, long-K problems -- finer granularity against
     // tile quantisation and 4 waves/SIMD to hide the prologue/epilogue latency of short-K 1x1 convs.  128x128 is kept for
     // the long, wide launches; GN-fused launches keep 128-pixel tiles (one statistics slot per tile).
     int bm = 128, bn = (Cout <= 64) ? 64 : 128;
-    if (!gn_part && !in_a && !mode1) {
+    if ((!gn_part || colsum_mode) && !in_a && !mode1) {
         const long long t128 = (long long)((p.M + 127) / 128) * ((Cout + 127) / 128);
         const int kt = Kpad / BK;
         if (!(kt >= 16 && t128 >= 4096 && Cout > 64)) { bm = 64; bn = 64; }
     }
-    if (force_tile_bm > 0 && !gn_part && !in_a && !mode1) { bm = force_tile_bm; }
+    if (force_tile_bm > 0 && (!gn_part || colsum_mode) && !in_a && !mode1) { bm = force_tile_bm; }
     if (force_tile_bn > 0 && Cout > 64 && !mode1) { bn = force_tile_bn; }
     last_variant = bm * 1000000 + bn * 1000 + (mode1 ? 100 : 0) + (in_a ? 10 : 0) + conv_pipeline;
     p.tilesM = (p.M + bm - 1) / bm;

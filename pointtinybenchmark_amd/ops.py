@@ -98,12 +98,14 @@ class PackedConv:
 
 
 def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, in_relu=False, gn_part=False,
-           out=None, out_dtype=None):
+           out=None, out_dtype=None, res_mask=False, colsum=False):
     """x (N,H,W,Cin) -> (N,OH,OW,Cout).  Epilogue: *scale[c] + bias[c] (+residual) (ReLU).
     in_ab=(a,b) applies x*a[n,c]+b[n,c] (+ReLU) to the input on load (fused GroupNorm of the producer; fp32 only).
     gn_part=True also returns per-128-pixel-tile per-channel (sum, sumsq) partials of the output.
     bf16 inputs run the bf16 MFMA kernel (fp32 accumulate); out_dtype overrides the output type (the fp32 stem can
-    emit bf16, the bf16 logit projection emits fp32)."""
+    emit bf16, the bf16 logit projection emits fp32).
+    Backward helpers (fp32): res_mask=True turns ``residual`` into a ReLU mask source (out = residual > 0 ? v : 0);
+    colsum=True also returns the per-channel sums of the output (C,), taken from the epilogue partials."""
     _check(x, ACT)
     N, H, W, Cin = x.shape
     assert Cin == pc.Cin, (Cin, pc.Cin)
@@ -114,8 +116,12 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
         out = torch.empty((N, OH, OW, pc.Cout), device=x.device, dtype=odt)
     part = None
     if gn_part:
-        assert (OH * OW) % 128 == 0
+        assert (OH * OW) % 128 == 0 and not colsum
         part = torch.empty((N * OH * OW // 128, pc.Cout, 2), device=x.device, dtype=torch.float32)
+    if colsum:
+        part = torch.empty(((N * OH * OW + 63) // 64, pc.Cout, 2), device=x.device, dtype=torch.float32)
+    if x.dtype == torch.bfloat16:
+        assert not (res_mask or colsum), 'backward helpers are fp32'
     if x.dtype == torch.bfloat16:
         assert in_ab is None, 'the bf16 kernel does not fuse the producer GroupNorm (materialise with gn_apply)'
         _lib.call('cpr_conv2d_fwd_bf16', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
@@ -125,11 +131,30 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     a = b = None
     if in_ab is not None:
         a, b = in_ab
-    flags = int(relu) | (2 if odt == torch.bfloat16 else 0)
+    flags = int(relu) | (2 if odt == torch.bfloat16 else 0) | (4 if res_mask else 0) | (8 if colsum else 0)
     _lib.call('cpr_conv2d_fwd', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias),
               _ptr(residual), _ptr(a), _ptr(b), _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride,
               pc.padding, pc.Kpad, flags, int(in_relu), _stream())
+    if colsum:
+        bm = _lib.call('cpr_conv_last_variant', positive=True) // 1000000     # tile edge the launcher picked
+        return out, TilePartials(part, (N * OH * OW + bm - 1) // bm, pc.Cout)
     return (out, part) if gn_part else out
+
+
+class TilePartials:
+    """Per-tile per-channel sums left by a conv epilogue; ``reduce()`` -> (C,) column sums on the CURRENT stream (the
+    training step does it on its side stream, next to the only consumer, so the main chain never waits for it)."""
+
+    def __init__(self, part, tiles, C):
+        self.part, self.tiles, self.C = part, tiles, C
+
+    def record_stream(self, stream):
+        self.part.record_stream(stream)
+
+    def reduce(self):
+        cs = torch.empty((self.C,), device=self.part.device, dtype=torch.float32)
+        _lib.call('cpr_part_colsum', _ptr(self.part), _ptr(cs), self.tiles, self.C, _stream())
+        return cs
 
 
 def _sfx(x):
@@ -381,8 +406,12 @@ def dgrad_pack(weight, stride, padding):
     return PackedConv(wt, 1, KH - 1 - padding)
 
 
-def conv2d_dgrad(dy, pc_t, in_hw, stride=1):
-    """dx (N,H,W,Cin) of a conv whose transposed/flipped weights are ``pc_t`` (dgrad_pack)."""
+def conv2d_dgrad(dy, pc_t, in_hw, stride=1, mask=None, add=None, colsum=False):
+    """dx (N,H,W,Cin) of a conv whose transposed/flipped weights are ``pc_t`` (dgrad_pack).
+    mask: the forward's post-ReLU input -- the result is the gradient BEFORE that ReLU (dx * (mask > 0)), fused into
+    the epilogue; add: another gradient of the same tensor summed in the epilogue; colsum: also return the
+    per-channel sums of the result as TilePartials (-> (dx, partials); ``partials.reduce()`` gives the (C,) vector)."""
+    assert mask is None or add is None
     N, OH, OW, Cout = _check(dy).shape
     H, W = in_hw
     if stride > 1:
@@ -391,8 +420,10 @@ def conv2d_dgrad(dy, pc_t, in_hw, stride=1):
         z = torch.empty((N, He, We, Cout), device=dy.device, dtype=torch.float32)
         _lib.call('cpr_zero_insert', _ptr(dy), _ptr(z), N, OH, OW, Cout, He, We, stride, _stream())
         dy = z
-    out = conv2d(dy, pc_t)
-    assert out.shape[1] == H and out.shape[2] == W, (out.shape, in_hw)
+    res = mask if mask is not None else add
+    out = conv2d(dy, pc_t, residual=res, res_mask=mask is not None, colsum=colsum)
+    o = out[0] if colsum else out
+    assert o.shape[1] == H and o.shape[2] == W, (o.shape, in_hw)
     return out
 
 

@@ -38,6 +38,9 @@ class GradBuckets:
     def reset(self):
         self.next, self.pending = 0, []
 
+    def would_launch(self, end):
+        return self.world_size > 1 and self.next + 1 < len(self.bounds) and self.bounds[self.next + 1] <= end
+
     def ready(self, end):
         if self.world_size == 1:
             return
@@ -58,7 +61,8 @@ class GradBuckets:
 
 
 class CprTrainer:
-    def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_mb=25.0, group=None):
+    def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_mb=25.0, group=None,
+                 two_streams=True):
         self.model = model
         self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
         order = self._backward_order()
@@ -83,6 +87,9 @@ class CprTrainer:
         self.norm2 = torch.zeros((1,), device=dev, dtype=torch.float64)
         self._ws = torch.empty((1024,), device=dev, dtype=torch.float64)
         self.steps = 0
+        # weight gradients run on a second stream: they are off the critical path (nothing downstream of the backward
+        # chain reads them) and the deep layers' launches are too small to fill 256 CUs on their own
+        self.side = torch.cuda.Stream(device=dev) if two_streams and dev.type == 'cuda' else None
         bump_weight_epoch()
 
     # ------------------------------------------------------------------ parameter order = gradient completion order
@@ -112,8 +119,23 @@ class CprTrainer:
         return out      # a trainable stem (frozen_stages < 0) has no backward rule and trips the constructor's check
 
     def _done(self, p):
-        """The gradient of ``p`` (and of everything before it in the flat order) is final."""
-        self.buckets.ready(self.offset[id(p)][1])
+        """The gradient of ``p`` (and of everything before it in the flat order) has been enqueued."""
+        end = self.offset[id(p)][1]
+        if self.side is not None and self.buckets.would_launch(end):
+            torch.cuda.current_stream().wait_stream(self.side)      # the collective must see the side stream's grads
+        self.buckets.ready(end)
+
+    def _param_side(self, fn, *tensors):
+        """Run the parameter-gradient work ``fn`` on the side stream, ordered after everything enqueued so far on the
+        main stream.  ``tensors``: its inputs that may be released by the main stream before the side stream ran."""
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            fn()
 
     # ------------------------------------------------------------------ forward (recorded) + backward
     def forward_backward(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
@@ -133,10 +155,11 @@ class CprTrainer:
         self.buckets.reset()
         d_stage = self._backward_head_neck(head, neck, lsave, head_tape, neck_tape, feats)
         self._backward_backbone(bb, bb_tape, d_stage)
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
         return losses
 
-    @staticmethod
-    def _gn_conv_backward(rec, dz, relu, need_dx):
+    def _gn_conv_backward(self, rec, dz, relu, need_dx):
         """Backward of conv -> GN (-> ReLU) given dz wrt the module output.  Writes the three parameter gradients;
         returns the gradient wrt the conv INPUT as the consumer saw it (after the producer's pending affine, if any)."""
         cm = rec['module']
@@ -144,8 +167,8 @@ class CprTrainer:
         assert cm.conv.bias is None
         draw, _, _ = ops.gn_bwd(rec['raw'], dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
                                 out_dgamma=gn.weight.grad, out_dbeta=gn.bias.grad)
-        ops.conv2d_wgrad(draw, rec['x'], w.shape, cm.conv.stride[0], cm.conv.padding[0], in_ab=rec['in_ab'],
-                         in_relu=rec['in_relu'], out=w.grad)
+        self._param_side(lambda: ops.conv2d_wgrad(draw, rec['x'], w.shape, cm.conv.stride[0], cm.conv.padding[0],
+                                                  in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=w.grad), draw)
         if not need_dx:
             return None
         pt = ops.dgrad_pack(w, cm.conv.stride[0], cm.conv.padding[0])
@@ -220,45 +243,50 @@ class CprTrainer:
             need_dx = idx > 0
             dx = self._block_backward(c, blk, rec, dx, need_dx)
 
-    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx):
-        """conv -> folded eval-BN given g = d(pre-activation output) (un-scaled) and its column sums."""
+    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx, mask=None, add=None, want_colsum=False):
+        """conv -> folded eval-BN given g = d(pre-activation output) (un-scaled) and its column sums.  Parameter
+        gradients go to the side stream; returns the data gradient wrt x -- with ``mask`` (x itself, when x is the
+        output of a fused ReLU) already taken through that ReLU, with ``add`` summed in, with ``want_colsum`` as
+        (gradient, column sums): all three ride in the conv epilogue."""
         scale, _ = folded_bn(cache, bn)
         inv_sigma = cache.get(('bn_is', id(bn)), [bn.running_var],
                               lambda: (1.0 / torch.sqrt(bn.running_var + bn.eps)).float().contiguous())
         w = conv.weight
         if w.requires_grad:
-            ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=w.grad)
             aff = bn.weight.requires_grad
-            ops.bn_fold_bwd(w.grad, w, scale, bn.running_mean, inv_sigma, colsum,
-                            out_dgamma=bn.weight.grad if aff else None, out_dbeta=bn.bias.grad if aff else None)
+
+            def param_grads():
+                cs = colsum.reduce() if isinstance(colsum, ops.TilePartials) else colsum
+                ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=w.grad)
+                ops.bn_fold_bwd(w.grad, w, scale, bn.running_mean, inv_sigma, cs,
+                                out_dgamma=bn.weight.grad if aff else None, out_dbeta=bn.bias.grad if aff else None)
+            self._param_side(param_grads, g, colsum)
         if not need_dx:
             return None
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
                        lambda: ops.dgrad_pack(w.detach() * scale[:, None, None, None], conv.stride[0], conv.padding[0]))
-        return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0])
+        return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
 
     def _block_backward(self, cache, blk, rec, dout, need_dx):
         x = rec['x']
         g3, cs3 = ops.relu_bwd_colsum(dout, rec['out'])            # also the shortcut gradient
         if blk.kind == 'bottleneck':
-            d2 = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, rec['o2'], True)
-            g2, cs2 = ops.relu_bwd_colsum(d2, rec['o2'])
-            d1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, rec['o1'], True)
+            g2, cs2 = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, rec['o2'], True, mask=rec['o2'],
+                                             want_colsum=True)
+            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, rec['o1'], True, mask=rec['o1'],
+                                             want_colsum=True)
             last = blk.bn3
         else:
-            d1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, rec['o1'], True)
+            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, rec['o1'], True, mask=rec['o1'],
+                                             want_colsum=True)
             last = blk.bn2
         self._done(last.bias if last.bias.requires_grad else blk.conv2.weight)
-        g1, cs1 = ops.relu_bwd_colsum(d1, rec['o1'])
-        dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx)
         if blk.downsample is not None:     # the shortcut conv sees the same g3 (no activation on that branch)
-            dxd = self._conv_bn_backward(cache, blk.downsample[0], blk.downsample[1], g3, cs3, x, need_dx)
-            if need_dx:
-                dx = ops.axpby(dx, dxd, 1.0, 1.0)
+            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx)
+            dx = self._conv_bn_backward(cache, blk.downsample[0], blk.downsample[1], g3, cs3, x, need_dx, add=dx)
             tail = blk.downsample[1].bias if blk.downsample[1].bias.requires_grad else blk.downsample[0].weight
         else:
-            if need_dx:
-                dx = ops.axpby(dx, g3, 1.0, 1.0)
+            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx, add=g3)
             tail = blk.bn1.bias if blk.bn1.bias.requires_grad else blk.conv1.weight
         self._done(tail)
         return dx

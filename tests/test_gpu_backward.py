@@ -182,3 +182,28 @@ def test_sgd_clip_vs_torch():
             ops.sgd_step(p, gr, b, norm2, 0.01, 0.9, 1e-4, 35.0, 1.0, first=(step == 0))
         for p, r in zip(dev, ref):
             _cmp('sgd step %d' % step, p, r, atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('case', [(2, 128, 17, 15, 64, 3, 1, 1), (2, 256, 14, 14, 512, 1, 2, 0), (2, 128, 16, 16, 128, 3, 2, 1),
+                                  (4, 64, 40, 40, 256, 1, 1, 0)], ids=lambda c: 'n%d_c%d_%dx%d_o%d_k%d_s%d_p%d' % c)
+def test_dgrad_fused_relu_mask_add_colsum(case):
+    """The data-gradient conv with the consumer-side ReLU backward, a second gradient and the column sums in its epilogue."""
+    ops = _ops()
+    N, Cin, H, W, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    pre = torch.randn((N, Cin, H, W), generator=g, requires_grad=True)
+    x = pre.relu()
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5)
+    y = F.conv2d(x, w, None, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    pt = ops.dgrad_pack(w.cuda(), stride, pad)
+    dpre, cs = ops.conv2d_dgrad(_nhwc(dy), pt, (H, W), stride, mask=_nhwc(x), colsum=True)
+    sc = float(pre.grad.abs().max())
+    _cmp('masked dgrad', _nchw(dpre), pre.grad, atol=2e-4 * sc)
+    _cmp('colsum', cs.reduce(), pre.grad.sum((0, 2, 3)), atol=2e-4 * sc * (N * H * W) ** 0.5)
+    other = torch.randn((N, Cin, H, W), generator=g)
+    x2 = x.detach().clone().requires_grad_(True)
+    F.conv2d(x2, w, None, stride, pad).backward(dy)
+    dsum = ops.conv2d_dgrad(_nhwc(dy), pt, (H, W), stride, add=_nhwc(other))
+    _cmp('dgrad + add', _nchw(dsum), x2.grad + other, atol=2e-4 * sc)

@@ -31,7 +31,7 @@ def main():
     img = batch['img'].cuda()
     gtb = [b.cuda() for b in batch['gt_bboxes']]
     gtl = [l.cuda() for l in batch['gt_labels']]
-    tr = CprTrainer(model, lr=1e-3)
+    tr = CprTrainer(model, lr=1e-3, two_streams=os.environ.get('CPR_TRAIN_STREAMS', '2') != '1')
     for _ in range(2):
         tr.forward_backward(img, batch['img_metas'], gtb, gtl)
         tr.step()
