@@ -211,6 +211,18 @@ int cpr_grad_sumsq(const float* g, long long n, double* ws_partial, double* out,
 int cpr_sgd_step(float* p, const float* grad, float* buf, const double* norm2, long long n, float lr, float mu, float wd,
                  float max_norm, float grad_scale, int first, void* stream);
 
+/* ---- data side feeding the path ----------------------------------------------------------
+ * RandomFlip(horizontal) -> Normalize -> Pad(0 after normalisation) -> channels-last float of the mmdet pipeline
+ * (T/mmdet/datasets/pipelines/transforms.py:431-480,560-680, formating.py:180-214) in one pass: img (N,H,W,3) uint8
+ * decoded images on the device -> out (N,Hp,Wp,4) fp32, the stem's input layout (4th channel and padding zero).
+ * mean3 / stdinv3: HOST pointers to 3 floats (stdinv = float32(1/float64(std)) as mmcv.imnormalize_); flip (N) int32
+ * device flags or NULL. */
+int cpr_preprocess_u8(const unsigned char* img, const int* flip, const float* mean3, const float* stdinv3, int to_rgb,
+                      float* out, int N, int H, int W, int Hp, int Wp, void* stream);
+/* RandomFlip.bbox_flip, horizontal (transforms.py:397-415), in place: boxes (n,4) xyxy, img_of (n) image index,
+ * flip / widths per image (width = img_shape[1]) */
+int cpr_flip_boxes(float* boxes, const int* img_of, const int* flip, const int* widths, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

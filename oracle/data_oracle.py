@@ -1,0 +1,138 @@
+"""TEST INFRASTRUCTURE ONLY.  Oracle for the data side feeding the path.
+
+* Annotation parsing: the REFERENCE's own method bodies (`CocoFmtDataset._parse_ann_info`, `._filter_imgs`,
+  `CocoDataset._filter_imgs`, `RandomFlip.bbox_flip`) are cut out of the source files under /root/reference and executed
+  on a synthetic COCO-format dataset (the modules themselves import mmcv / huicv / terminaltables, none installed).
+  `python -m oracle.data_oracle` writes tests/golden/data_side.json.
+* Image tail (flip -> normalise -> pad -> channels-last): numpy restatement of mmcv.imflip / mmcv.imnormalize_ /
+  mmcv.impad / DefaultFormatBundle.  mmcv and cv2 are third-party, un-vendored and not installed: PARITY UNPINNED for the
+  float rounding of OpenCV's subtract/multiply (assumed: fp32 arithmetic with the scalars converted to float, which is
+  what OpenCV documents for CV_32F sources)."""
+import json
+import os
+import re
+import textwrap
+
+import numpy as np
+
+T = '/root/reference/TOV_mmdetection/mmdet/'
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'data_side.json')
+
+
+def _method(path, cls_marker, name):
+    src = open(path).read()
+    start = src.index(cls_marker)
+    m = re.search(r'\n    def %s\(.*?(?=\n    def |\n    @|\nclass |\Z)' % name, src[start:], flags=re.S)
+    return textwrap.dedent(m.group(0))
+
+
+def synthetic_dataset(seed=0):
+    rng = np.random.RandomState(seed)
+    images, anns, aid = [], [], 1
+    for i in range(7):
+        w, h = (640, 640) if i != 5 else (24, 640)        # image 5 is below min_size 32
+        images.append(dict(id=100 + i, width=w, height=h, file_name='t%d.jpg' % i))
+        n = 0 if i == 3 else int(rng.randint(1, 6))       # image 3 has no annotation
+        for _ in range(n):
+            cx, cy = rng.uniform(-10, 650, 2)              # some boxes fall outside the image
+            bw = bh = 16.0 if i != 6 else 1.5               # image 6: only boxes under min_gt_size
+            a = dict(id=aid, image_id=100 + i, category_id=int(rng.choice([1, 2, 7])), iscrowd=int(rng.rand() < 0.15),
+                     ignore=int(rng.rand() < 0.2), bbox=[float(cx - bw / 2), float(cy - bh / 2), bw, bh],
+                     area=float(bw * bh) if rng.rand() > 0.1 else 0.0, segmentation=[[1.0, 2.0]])
+            if i % 2 == 0:
+                a['true_bbox'] = [float(cx - 9), float(cy - 20), 18.0, 40.0]
+            anns.append(a)
+            aid += 1
+    return dict(images=images, annotations=anns,
+                categories=[dict(id=1, name='person'), dict(id=2, name='rider'), dict(id=7, name='other')])
+
+
+class _Coco:
+    def __init__(self, ds):
+        self.dataset = ds
+        self.anns = {a['id']: a for a in ds['annotations']}
+        self.imgToAnns, self.cat_img_map = {}, {}
+        for im in ds['images']:
+            self.imgToAnns[im['id']] = []
+        for a in ds['annotations']:
+            self.imgToAnns[a['image_id']].append(a)
+            self.cat_img_map.setdefault(a['category_id'], []).append(a['image_id'])
+        for c in ds['categories']:
+            self.cat_img_map.setdefault(c['id'], [])
+
+
+def reference_parse(ds, classes, min_gt_size, train_ignore_as_bg=True):
+    """Runs the reference method bodies; returns (valid image ids after filtering, per-image ann_info)."""
+    ns = {'np': np, 'print': lambda *a, **k: None}
+    base = 'class Base:\n' + textwrap.indent(_method(T + 'datasets/coco.py', 'class CocoDataset', '_filter_imgs'), '    ')
+    sub = 'class Sub(Base):\n' + textwrap.indent(
+        _method(T + 'datasets/cocofmt.py', 'class CocoFmtDataset', '_filter_imgs').replace(
+            'super(CocoFmtDataset, self)', 'super(Sub, self)'), '    ') + '\n' + textwrap.indent(
+        _method(T + 'datasets/cocofmt.py', 'class CocoFmtDataset', '_parse_ann_info'), '    ')
+    exec(base + '\n' + sub, ns)
+    d = ns['Sub']()
+    d.coco = _Coco(ds)
+    by_name = {c['name']: c['id'] for c in ds['categories']}
+    d.cat_ids = [by_name[n] for n in classes]
+    d.cat2label = {c: i for i, c in enumerate(d.cat_ids)}
+    d.img_ids = [im['id'] for im in ds['images']]
+    d.data_infos = [dict(im, filename=im['file_name']) for im in ds['images']]
+    d.filter_empty_gt, d.min_gt_size, d.train_ignore_as_bg = True, min_gt_size, train_ignore_as_bg
+    valid = d._filter_imgs()
+    infos = [d.data_infos[i] for i in valid]
+    parsed = [d._parse_ann_info(info, d.coco.imgToAnns[info['id']]) for info in infos]
+    return d.img_ids, parsed
+
+
+def reference_bbox_flip(boxes, img_shape):
+    ns = {'np': np}
+    exec('class F:\n' + textwrap.indent(_method(T + 'datasets/pipelines/transforms.py', 'class RandomFlip', 'bbox_flip'),
+                                        '    '), ns)
+    return ns['F']().bbox_flip(boxes, img_shape, 'horizontal')
+
+
+def image_tail(img_u8_bgr, flip, mean, std, to_rgb=True, size_divisor=32):
+    """mmcv.imflip -> mmcv.imnormalize -> mmcv.impad(pad_val=0) -> HWC float32 (restated; see the header)."""
+    img = img_u8_bgr[:, ::-1] if flip else img_u8_bgr
+    img = img.astype(np.float32)
+    mean = np.float64(np.asarray(mean, np.float32).reshape(1, -1))
+    stdinv = 1 / np.float64(np.asarray(std, np.float32).reshape(1, -1))
+    if to_rgb:
+        img = img[:, :, ::-1]
+    img = (img - mean.astype(np.float32)).astype(np.float32)
+    img = (img * stdinv.astype(np.float32)).astype(np.float32)
+    h, w = img.shape[:2]
+    ph, pw = (h + size_divisor - 1) // size_divisor * size_divisor, (w + size_divisor - 1) // size_divisor * size_divisor
+    out = np.zeros((ph, pw, 3), np.float32)
+    out[:h, :w] = img
+    return out
+
+
+def _jsonable(o):
+    if isinstance(o, dict):
+        return {k: _jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_jsonable(v) for v in o]
+    if isinstance(o, np.ndarray):
+        return dict(dtype=str(o.dtype), shape=list(o.shape), data=o.tolist())
+    if isinstance(o, np.generic):
+        return o.item()
+    return o
+
+
+def main():
+    out = {}
+    for name, classes, mgs, seed in (('all3_min2', ['person', 'rider', 'other'], 2, 0), ('person_only', ['person'], 2, 1),
+                                     ('no_min', ['person', 'rider'], None, 2)):
+        ds = synthetic_dataset(seed)
+        ids, parsed = reference_parse(ds, classes, mgs)
+        out[name] = dict(seed=seed, classes=classes, min_gt_size=mgs, img_ids=ids, parsed=_jsonable(parsed))
+    rng = np.random.RandomState(0)
+    b = rng.uniform(0, 600, (9, 4)).astype(np.float32)
+    out['bbox_flip'] = dict(boxes=b.tolist(), width=633, flipped=reference_bbox_flip(b, (480, 633)).tolist())
+    json.dump(out, open(GOLDEN, 'w'))
+    print('wrote', GOLDEN, {k: len(v.get('img_ids', [])) for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    main()

@@ -119,7 +119,8 @@ class ResNet(nn.Module):
         """x: (N,3,H,W) -> tuple of NCHW-shaped (channels_last) stage outputs.
         tape (list): training mode -- one record per block with trainable parameters, in forward order."""
         c = self._cache
-        x = ops.nchw_to_nhwc(x) if x.shape[1] <= 4 else ops.from_nchw(x)
+        # (N,3,H,W) float image -> NHWC4; a 4-channel channels-last view (datasets.GpuImagePipeline output) is taken as is
+        x = ops.from_nchw(x) if (x.shape[1] > 4 or (x.shape[1] == 4 and x.stride(1) == 1)) else ops.nchw_to_nhwc(x)
         s, b = folded_bn(c, self.bn1)
         # bf16 compute mode: the 3-channel stem stays on the fp32 kernel and emits a bf16 map
         x = ops.conv2d(x, packed_conv(c, self.conv1), scale=s, bias=b, relu=True, out_dtype=self.compute_dtype)

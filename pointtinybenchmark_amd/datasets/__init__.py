@@ -1,0 +1,4 @@
+"""Data side feeding the hot path: annotation parsing of CocoFmtDataset and the device tail of the
+image pipeline (flip, normalise, pad, batch, channels-last)."""
+from .cocofmt import CocoFmtDataset  # noqa: F401
+from .pipeline import GpuImagePipeline  # noqa: F401

@@ -1,0 +1,166 @@
+"""CocoFmtDataset annotation side (T/mmdet/datasets/cocofmt.py:63-225 on top of CocoDataset, coco.py:40-118): COCO-format
+json -> per-image ``ann_info`` with the fork's extra fields (``true_bboxes``, ``anns_id``) that become the pipeline keys
+``gt_true_bboxes`` / ``gt_anns_id`` (pipelines/loading.py:246-278, formating.py:210).  Host-side, pure Python + numpy; the
+pycocotools index (third party, not vendored) is replaced by three dict look-ups.
+
+Not built (they live in the un-vendored ``huicv`` package and only rewrite annotation FILES before training):
+``corner_kwargs`` (640x640 tile generation with overlap) and ``noise_kwargs`` (pseudo-box synthesis) -- the shipped CPR
+configs point ``ann_file`` at the already generated files and pass neither."""
+import json
+import os
+
+import numpy as np
+
+from ..registry import Registry
+
+DATASETS = Registry('dataset')
+
+
+@DATASETS.register_module()
+class CocoFmtDataset:
+    CLASSES = None
+
+    def __init__(self, ann_file, pipeline=None, classes=None, data_root=None, img_prefix='', test_mode=False,
+                 filter_empty_gt=True, corner_kwargs=None, train_ignore_as_bg=True, noise_kwargs=None,
+                 merge_after_infer_kwargs=None, min_gt_size=None, image_loader=None):
+        assert corner_kwargs is None and noise_kwargs is None, \
+            'corner / noise file generation lives in huicv (not vendored); point ann_file at the generated json'
+        if data_root is not None and not os.path.isabs(ann_file):
+            ann_file = os.path.join(data_root, ann_file)
+        if data_root is not None and img_prefix and not os.path.isabs(img_prefix):
+            img_prefix = os.path.join(data_root, img_prefix)
+        self.ann_file, self.img_prefix, self.test_mode = ann_file, img_prefix, test_mode
+        self.filter_empty_gt, self.train_ignore_as_bg, self.min_gt_size = filter_empty_gt, train_ignore_as_bg, min_gt_size
+        self.merge_after_infer_kwargs = merge_after_infer_kwargs
+        self.pipeline, self.image_loader = pipeline, image_loader
+        if classes is not None:
+            self.CLASSES = list(classes)
+        self.data_infos = self.load_annotations(ann_file)
+        if not test_mode:
+            valid = self._filter_imgs()
+            self.data_infos = [self.data_infos[i] for i in valid]
+
+    # ------------------------------------------------------------------ cocofmt.py:104-133
+    def load_annotations(self, ann_file):
+        ds = json.load(open(ann_file)) if isinstance(ann_file, str) else ann_file
+        self.dataset = ds
+        self.anns = {a['id']: a for a in ds.get('annotations', [])}
+        assert len(self.anns) == len(ds.get('annotations', [])), "Annotation ids in '%s' are not unique!" % (ann_file,)
+        self.img_to_anns = {}
+        for a in ds.get('annotations', []):
+            self.img_to_anns.setdefault(a['image_id'], []).append(a)
+        if self.CLASSES is None:
+            self.CLASSES = [c['name'] for c in ds['categories']]
+        by_name = {c['name']: c['id'] for c in ds['categories']}
+        self.cat_ids = [by_name[n] for n in self.CLASSES if n in by_name]
+        self.cat2label = {cid: i for i, cid in enumerate(self.cat_ids)}
+        self.img_ids = [im['id'] for im in ds['images']]
+        infos = []
+        for im in ds['images']:
+            info = dict(im)
+            info['filename'] = info['file_name']
+            infos.append(info)
+        return infos
+
+    # ------------------------------------------------------------------ coco.py:96-118 + cocofmt.py:135-155
+    def _filter_imgs(self, min_size=32):
+        ids_with_ann = {a['image_id'] for a in self.anns.values()}
+        ids_in_cat = {a['image_id'] for a in self.anns.values() if a.get('category_id') in self.cat_ids}
+        ids_in_cat &= ids_with_ann
+        valid_inds, valid_img_ids = [], []
+        for i, info in enumerate(self.data_infos):
+            img_id = self.img_ids[i]
+            if self.filter_empty_gt and img_id not in ids_in_cat:
+                continue
+            if min(info['width'], info['height']) >= min_size:
+                valid_inds.append(i)
+                valid_img_ids.append(img_id)
+        self.img_ids = valid_img_ids
+        if self.min_gt_size:
+            new_inds, new_ids = [], []
+            for i, img_id in enumerate(self.img_ids):
+                ok = False
+                for ann in self.img_to_anns.get(img_id, []):
+                    if 'ignore' in ann and ann['ignore']:
+                        continue
+                    if ann['bbox'][-1] > self.min_gt_size and ann['bbox'][-2] > self.min_gt_size:
+                        ok = True
+                if ok:
+                    new_inds.append(valid_inds[i])
+                    new_ids.append(img_id)
+            self.img_ids, valid_inds = new_ids, new_inds
+        return valid_inds
+
+    def __len__(self):
+        return len(self.data_infos)
+
+    def get_ann_info(self, idx):
+        info = self.data_infos[idx]
+        return self._parse_ann_info(info, self.img_to_anns.get(info['id'], []))
+
+    # ------------------------------------------------------------------ cocofmt.py:157-225
+    def _parse_ann_info(self, img_info, ann_info):
+        gt_bboxes, gt_labels, gt_bboxes_ignore, gt_masks_ann = [], [], [], []
+        true_bboxes, anns_id = [], []
+        for ann in ann_info:
+            if self.train_ignore_as_bg and ann.get('ignore', False):
+                continue
+            x1, y1, w, h = ann['bbox']
+            inter_w = max(0, min(x1 + w, img_info['width']) - max(x1, 0))
+            inter_h = max(0, min(y1 + h, img_info['height']) - max(y1, 0))
+            if inter_w * inter_h == 0:
+                continue
+            if ann['area'] <= 0 or w < 1 or h < 1:
+                continue
+            if ann['category_id'] not in self.cat_ids:
+                continue
+            bbox = [x1, y1, x1 + w, y1 + h]
+            if ann.get('iscrowd', False):
+                gt_bboxes_ignore.append(bbox)
+            else:
+                gt_bboxes.append(bbox)
+                gt_labels.append(self.cat2label[ann['category_id']])
+                gt_masks_ann.append(ann.get('segmentation', None))
+                if 'true_bbox' in ann:
+                    tx, ty, tw, th = ann['true_bbox']
+                    true_bboxes.append([tx, ty, tx + tw, ty + th])
+                anns_id.append(ann['id'])
+        if len(true_bboxes) > 0:
+            true_bboxes = np.array(true_bboxes, dtype=np.float32)
+            anns_id = np.array(anns_id, dtype=np.int64)
+        if gt_bboxes:
+            gt_bboxes = np.array(gt_bboxes, dtype=np.float32)
+            gt_labels = np.array(gt_labels, dtype=np.int64)
+        else:
+            gt_bboxes = np.zeros((0, 4), dtype=np.float32)
+            gt_labels = np.array([], dtype=np.int64)
+        if gt_bboxes_ignore:
+            gt_bboxes_ignore = np.array(gt_bboxes_ignore, dtype=np.float32)
+        else:
+            gt_bboxes_ignore = np.zeros((0, 4), dtype=np.float32)
+        ann = dict(bboxes=gt_bboxes, labels=gt_labels, anns_id=anns_id, bboxes_ignore=gt_bboxes_ignore,
+                   masks=gt_masks_ann, seg_map=img_info['filename'].replace('jpg', 'png'))
+        if len(true_bboxes) > 0:
+            ann['true_bboxes'] = true_bboxes
+        return ann
+
+    # ------------------------------------------------------------------ sample assembly (custom.py:185-215 + LoadAnnotations)
+    def load_sample(self, idx):
+        """One un-augmented sample: decoded uint8 BGR image (H,W,3) + the LoadAnnotations fields
+        (pipelines/loading.py:246-278).  ``image_loader(path) -> uint8 HxWx3 BGR`` is supplied by the caller (the
+        reference decodes with cv2 through mmcv; neither is a dependency here)."""
+        info = self.data_infos[idx]
+        ann = self.get_ann_info(idx)
+        path = os.path.join(self.img_prefix, info['filename']) if self.img_prefix else info['filename']
+        assert self.image_loader is not None, 'pass image_loader= (e.g. datasets.pipeline.pil_bgr_loader)'
+        img = self.image_loader(path)
+        s = dict(img=img, filename=path, ori_filename=info['filename'], ori_shape=tuple(img.shape),
+                 gt_bboxes=ann['bboxes'].copy(), gt_labels=ann['labels'].copy(),
+                 gt_bboxes_ignore=ann['bboxes_ignore'].copy(),
+                 gt_true_bboxes=(ann['true_bboxes'] if 'true_bboxes' in ann else ann['bboxes']).copy())
+        s['gt_anns_id'] = np.asarray(ann['anns_id'], dtype=np.int64).copy()      # loading.py:274-275
+        return s
+
+    def load_batch(self, indices, rng=None):
+        samples = [self.load_sample(i) for i in indices]
+        return self.pipeline(samples, rng) if self.pipeline is not None else samples
