@@ -91,6 +91,16 @@ def reference_bbox_flip(boxes, img_shape):
     return ns['F']().bbox_flip(boxes, img_shape, 'horizontal')
 
 
+def bbox_flip(boxes, img_shape):
+    """RandomFlip.bbox_flip horizontal, restated (pinned against the reference body by tests/golden/data_side.json);
+    usable where /root/reference does not exist (the GPU box)."""
+    f = boxes.copy()
+    w = img_shape[1]
+    f[..., 0::4] = w - boxes[..., 2::4]
+    f[..., 2::4] = w - boxes[..., 0::4]
+    return f
+
+
 def image_tail(img_u8_bgr, flip, mean, std, to_rgb=True, size_divisor=32):
     """mmcv.imflip -> mmcv.imnormalize -> mmcv.impad(pad_val=0) -> HWC float32 (restated; see the header)."""
     img = img_u8_bgr[:, ::-1] if flip else img_u8_bgr
