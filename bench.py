@@ -114,6 +114,54 @@ class ConvProbe:
                 for v, d in agg.items()}
 
 
+def hbm_probe(batch, size):
+    """The HBM-bound kernels of the step, each timed alone with HIP events on its real shape: algorithmic bytes (one read
+    of every input, one write of every output) / time vs the 8 TB/s roof (reported separately from the
+    MFMA-bound convs)."""
+    from pointtinybenchmark_amd import ops
+    dev = 'cuda'
+    h = size // 4
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((batch, h, h, 256), device=dev, generator=g)
+    a = torch.rand((batch, 256), device=dev, generator=g) + 0.5
+    b = torch.randn((batch, 256), device=dev, generator=g)
+    img = torch.randn((batch, 3, size, size), device=dev, generator=g)
+    stem = torch.randn((batch, size // 2, size // 2, 64), device=dev, generator=g)
+    dz = torch.randn_like(x)
+    part = ops.gn_stats(x)
+    gam, bet = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    _, _, mean, rstd = ops.gn_finalize(part, gam, bet, batch, h * h, 32, 1e-5, want_stats=True)
+    u8 = torch.randint(0, 256, (batch, size, size, 3), device=dev, dtype=torch.uint8, generator=g)
+    pre_out = torch.empty((batch, size, size, 4), device=dev)
+    from pointtinybenchmark_amd.datasets import GpuImagePipeline
+    pipe = GpuImagePipeline(device=dev)
+    nb = x.numel() * 4
+    cases = [
+        ('gn_apply_kernel (GroupNorm apply + ReLU, head map)', lambda: ops.gn_apply(x, a, b, relu=True), 2 * nb),
+        ('gn_stats_kernel (statistics pass)', lambda: ops.gn_stats(x), nb),
+        ('maxpool3x3s2_kernel (stem)', lambda: ops.maxpool3x3s2(stem), stem.numel() * 4 * 1.25),
+        ('nchw_to_nhwc4_kernel (network input)', lambda: ops.nchw_to_nhwc(img), img.numel() * 4 * (1 + 4 / 3)),
+        ('preprocess_u8_kernel (uint8 HWC -> normalised NHWC4)',
+         lambda: pipe._launch(u8, None, pre_out, batch, size, size, size, size), u8.numel() + pre_out.numel() * 4),
+        ('gn_bwd (stats + apply passes of the GroupNorm backward)',
+         lambda: ops.gn_bwd(x, dz, a, b, mean, rstd, gam, True), 5 * nb),
+        ('relu_bwd_colsum_kernel (ReLU backward + column sums)', lambda: ops.relu_bwd_colsum(dz, x), 3 * nb),
+    ]
+    out = []
+    for name, fn, byts in cases:
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        t = s.elapsed_time(e) / 10 * 1e-3
+        out.append({'kernel': name, 'bytes': byts, 'ms': t * 1e3, 'GB/s': byts / t / 1e9, 'frac_of_8TBs': byts / t / 8e12})
+    return out
+
+
 def cpu_baseline(batch_size, num_gts, seconds_budget=30.0):
     """The CPU oracle on this box's host cores: same synthetic workload, bounded sample.  The box reports 256 logical
     CPUs but torch/oneDNN throughput is far from monotone in the thread count there (cgroup quota, SMT, NUMA), so the
@@ -299,6 +347,11 @@ def main():
                                'per_instance_tflops': {k: round(v['tflops'], 2) for k, v in summ.items()}}
             out['conv_time_frac'] = conv_s / elapsed
             out['end_to_end_tflops'] = conv_f / args.steps / (elapsed / args.steps) / 1e12   # conv FLOPs of a step / step time
+        if world == 1 and not args.no_probe:
+            try:
+                out['hbm_kernels'] = hbm_probe(args.batch, args.size)
+            except Exception as e:   # noqa: BLE001
+                out['hbm_kernels'] = {'error': repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(2, args.num_gts)
         print(json.dumps(out), flush=True)
