@@ -182,11 +182,12 @@ int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W
 /* backward of the fused conv epilogue y = relu?(conv*scale + shift (+ identity)) of an eval-mode BatchNorm
  * (resnet.py Bottleneck.forward): g = dy*(y>0) (y NULL: g = dy) is the shortcut gradient and the un-scaled conv-output
  * gradient; colsum (C) (+)= per-channel sums of g (= dshift; also the Linear/conv bias gradient).  (M,C) row-major,
- * C%4==0.  g_out may be NULL (sums only).  ws_part ceil(M/512)*C floats. */
+ * C%4==0.  g_out may be NULL (sums only).  ws_part (ceil(M/128)+64)*C floats. */
 int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out, float* colsum, float* ws_part, long long M, int C,
                         int accumulate, void* stream);
-/* column sums (C) of a conv output from the epilogue partials cpr_conv2d_fwd wrote into gn_part [tiles][C][2] */
-int cpr_part_colsum(const float* part, float* out, int tiles, int C, void* stream);
+/* column sums (C) of a conv output from the epilogue partials cpr_conv2d_fwd wrote into gn_part [tiles][C][2];
+ * ws: 64*C floats */
+int cpr_part_colsum(const float* part, float* out, float* ws, int tiles, int C, void* stream);
 /* parameter side of the folded BN: Gw = cpr_conv2d_wgrad(g, x) [Cout][K] -> in place dW = scale[c]*Gw[c];
  * dgamma = inv_sigma*(<W[c],Gw[c]> - mean*colsum_g), dbeta = colsum_g (either may be NULL). */
 int cpr_bn_fold_bwd(float* Gw, const float* weight, const float* scale, const float* mean, const float* inv_sigma,
@@ -204,6 +205,15 @@ int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* 
                  const float* centers, const int* gt_img, const float* offsets, float* dbag_ws, float* dmap, int N,
                  int H, int W, int J, int Jd, int ins_off, int G, int K, int C, float stride, float eps, float w_mil,
                  float w_gt, float w_neg, void* stream);
+/* OIHW fp32 master weights -> the conv kernels' layout [rows][KH][KW][cols'] (row stride Kpad, zero padded).
+ * transpose 0: forward pack (rows = O).  transpose 1: data-gradient pack (rows = I, taps flipped, optional per-O scale =
+ * the folded BatchNorm scale of the forward conv).  colsp = padded column count (4 for <= 4 channels). */
+int cpr_pack_weights(const float* w, const float* scale, float* out, int O, int I, int KH, int KW, int colsp, int Kpad,
+                     int transpose, void* stream);
+/* eval-mode BatchNorm (resnet.py norm_eval) -> conv-epilogue affine: scale = gamma/sqrt(var+eps), shift = beta - mean*scale,
+ * inv_sigma (optional) = 1/sqrt(var+eps) */
+int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                float* shift, float* inv_sigma, int C, void* stream);
 /* sum of squares of a flat gradient buffer into out[0] (double; accumulate across buffers); ws_partial 1024 doubles */
 int cpr_grad_sumsq(const float* g, long long n, double* ws_partial, double* out, int accumulate, void* stream);
 /* torch.optim.SGD step (momentum, weight decay) with clip_grad_norm_'s coefficient taken from norm2 on the device:

@@ -10,7 +10,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcprhip.so')
 SOURCES = ['conv_mfma.hip', 'conv_mfma_bf16.hip', 'conv_wgrad.hip', 'norm_pool.hip', 'cpr_points.hip', 'assign.hip',
-           'postproc.hip', 'backward.hip', 'preprocess.hip']
+           'postproc.hip', 'backward.hip', 'preprocess.hip', 'pack.hip']
 
 
 def _hipcc():

@@ -203,6 +203,54 @@ extern "C" int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, i
     CPR_LAUNCH_STATUS();
 }
 
+// ------------------------------------------------------------------------------------------------ column sums
+// out[c] (+)= sum_t src[t*row_stride + c*col_stride], t < rows.  32 channels x 8 row lanes per workgroup, 4 loads in
+// flight per thread, blockIdx.y splits the rows; a second pass of the same kernel folds the splits.  Fixed summation
+// order (deterministic).
+__global__ void strided_colsum_kernel(const float* __restrict__ src, float* __restrict__ out, int rows, int C,
+                                      long long row_stride, int col_stride, int rows_per_split, int accumulate) {
+    __shared__ double red[8][33];
+    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int t0 = blockIdx.y * rows_per_split, t1 = min(rows, t0 + rows_per_split);
+    double s = 0;
+    if (c < C) {
+        const float* p = src + (size_t)c * col_stride;
+        int t = t0 + r;
+        for (; t + 24 < t1; t += 32) {
+            const float a0 = p[(size_t)t * row_stride], a1 = p[(size_t)(t + 8) * row_stride];
+            const float a2 = p[(size_t)(t + 16) * row_stride], a3 = p[(size_t)(t + 24) * row_stride];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        }
+        for (; t < t1; t += 8) s += (double)p[(size_t)t * row_stride];
+    }
+    red[r][cl] = s;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        double a = 0;
+        for (int k = 0; k < 8; ++k) a += red[k][cl];
+        float* dst = out + (size_t)blockIdx.y * C + c;
+        *dst = accumulate ? *dst + (float)a : (float)a;
+    }
+}
+// tmp: 64*C floats (only touched when rows > 256)
+static void launch_colsum(const float* src, float* out, float* tmp, int rows, int C, long long row_stride, int col_stride,
+                          int accumulate, hipStream_t stream) {
+    int nsplit = (rows + 255) / 256;
+    if (nsplit > 64) nsplit = 64;
+    if (nsplit <= 1) {
+        hipLaunchKernelGGL(strided_colsum_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, stream, src, out, rows, C, row_stride,
+                           col_stride, rows, accumulate);
+        return;
+    }
+    const int per = (rows + nsplit - 1) / nsplit;
+    nsplit = (rows + per - 1) / per;
+    hipLaunchKernelGGL(strided_colsum_kernel, dim3(cdiv(C, 32), nsplit), dim3(256), 0, stream, src, tmp, rows, C, row_stride,
+                       col_stride, per, 0);
+    hipLaunchKernelGGL(strided_colsum_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, stream, tmp, out, nsplit, C, (long long)C,
+                       1, nsplit, accumulate);
+}
+
 // ------------------------------------------------------------------------------------------------ BN(eval)+add+ReLU
 // forward (conv epilogue): y = relu?(conv*s[c] + t[c] (+ identity)).  Given dy:  g = dy * (y > 0 | !relu) is at once the
 // gradient of the shortcut and (times s, folded into the data-gradient weights / applied to the weight gradient by
@@ -218,17 +266,32 @@ __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float
     const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float s1[4] = {0, 0, 0, 0};
     if (pl < PP) {
-        for (long long r = r0 + pl; r < r1; r += PP) {
-            const size_t o = (size_t)r * C + c0 + q * 4;
-            f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
-            if (y) {
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+        // 4 rows in flight per thread: the kernel is pure streaming, so memory-level parallelism is what sets its speed
+        for (long long r = r0 + pl; r < r1; r += 4 * PP) {
+            f32x4 g[4], yv[4];
+            bool ok[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) g[k] = (yv[k] > 0.f) ? g[k] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const long long ru = r + (long long)u * PP;
+                ok[u] = ru < r1;
+                const size_t o = (size_t)(ok[u] ? ru : r) * C + c0 + q * 4;
+                g[u] = *reinterpret_cast<const f32x4*>(dy + o);
+                if (y) yv[u] = *reinterpret_cast<const f32x4*>(y + o);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s1[k] += g[k];
-            if (g_out) *reinterpret_cast<f32x4*>(g_out + o) = g;
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                if (y) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[u][k] = (yv[u][k] > 0.f) ? g[u][k] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s1[k] += g[u][k];
+                if (g_out) {
+                    const size_t o = (size_t)(r + (long long)u * PP) * C + c0 + q * 4;
+                    *reinterpret_cast<f32x4*>(g_out + o) = g[u];
+                }
+            }
         }
     }
 #pragma unroll
@@ -244,46 +307,21 @@ __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float
         for (int k = 0; k < 4; ++k) dst[k] = acc[k];
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int blocks, int C,
-                                    int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0;
-    for (int k = 0; k < blocks; ++k) s += (double)part[(size_t)k * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
-}
 extern "C" int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out, float* colsum, float* ws_part,
                                    long long M, int C, int accumulate, hipStream_t stream) {
-    // ws_part: ceil(M/512)*C floats
+    // ws_part: (ceil(M/128) + 64)*C floats
     CPR_CHECK_ARG(dy && colsum && ws_part && M > 0 && C > 0 && C % 4 == 0);
-    const int rows_per_block = 512;
+    const int rows_per_block = 128;
     const int blocks = (int)cdivll(M, rows_per_block);
     hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, y, g_out, ws_part,
                        M, C, rows_per_block);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, ws_part, colsum, blocks, C,
-                       accumulate);
+    launch_colsum(ws_part, colsum, ws_part + (size_t)blocks * C, blocks, C, (long long)C, 1, accumulate, stream);
     CPR_LAUNCH_STATUS();
 }
-// column sums from the conv epilogue's per-tile partials [tiles][C][2] (element 0 = sum): 32 channels x 8 tile lanes
-// per block, fixed summation order (deterministic)
-__global__ void part_colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int tiles, int C) {
-    __shared__ double red[8][33];
-    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s = 0;
-    if (c < C)
-        for (int t = r; t < tiles; t += 8) s += (double)part[((size_t)t * C + c) * 2];
-    red[r][cl] = s;
-    __syncthreads();
-    if (r == 0 && c < C) {
-        double a = 0;
-        for (int k = 0; k < 8; ++k) a += red[k][cl];
-        out[c] = (float)a;
-    }
-}
-extern "C" int cpr_part_colsum(const float* part, float* out, int tiles, int C, hipStream_t stream) {
-    CPR_CHECK_ARG(part && out && tiles > 0 && C > 0);
-    hipLaunchKernelGGL(part_colsum_kernel, dim3(cdiv(C, 32)), dim3(256), 0, stream, part, out, tiles, C);
+// column sums from the conv epilogue's per-tile partials [tiles][C][2] (element 0 = sum); ws: 64*C floats
+extern "C" int cpr_part_colsum(const float* part, float* out, float* ws, int tiles, int C, hipStream_t stream) {
+    CPR_CHECK_ARG(part && out && ws && tiles > 0 && C > 0);
+    launch_colsum(part, out, ws, tiles, C, (long long)2 * C, 2, 0, stream);
     CPR_LAUNCH_STATUS();
 }
 // parameter side of the folded BatchNorm: Gw = wgrad(g, x) [Cout][K] (unscaled), W [Cout][K], scale = gamma*inv_sigma:

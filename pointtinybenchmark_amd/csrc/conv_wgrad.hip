@@ -226,7 +226,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= total) return;
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[(size_t)k * total + i];
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {   // 8 loads in flight (the kernel is latency-bound otherwise); fixed order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * total + i];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; k < S; ++k) s += part[(size_t)k * total + i];
     const int ci = (int)(i % Cin);
     const long long r = i / Cin;
     const int tap = (int)(r % KK), co = (int)(r / KK);

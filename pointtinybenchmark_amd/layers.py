@@ -45,6 +45,8 @@ def folded_bn(cache, bn):
     """Eval-mode BatchNorm as a per-channel affine for the conv epilogue:
     scale = gamma / sqrt(var + eps), shift = beta - mean * scale."""
     def make():
+        if bn.weight.is_cuda:
+            return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)[:2]
         with torch.no_grad():
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
             shift = (bn.bias - bn.running_mean * scale).float().contiguous()

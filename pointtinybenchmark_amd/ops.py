@@ -78,19 +78,47 @@ class PackedConv:
             self.stride, self.padding = stride, padding
             return
         if Cin <= 4:
-            wp = torch.zeros((Cout, KH, KW, 4), device=weight.device, dtype=torch.float32)
-            wp[..., :Cin] = w
-            w, cin_p = wp, 4
+            cin_p = 4
         else:
             assert Cin % 32 == 0, 'input channels must be a multiple of 32 (or <= 4 for the stem)'
             cin_p = Cin
         K = KH * KW * cin_p
         Kpad = (K + 31) // 32 * 32
-        packed = torch.zeros((Cout, Kpad), device=weight.device, dtype=torch.float32)
-        packed[:, :K] = w.reshape(Cout, K)
-        self.w = packed.contiguous()
         self.Cout, self.Cin, self.KH, self.KW, self.Kpad = Cout, cin_p, KH, KW, Kpad
         self.stride, self.padding = stride, padding
+        if weight.is_cuda:       # one HIP launch (the training step re-packs every conv after each optimizer update)
+            src = weight.detach()
+            if src.dtype != torch.float32 or not src.is_contiguous():
+                src = src.float().contiguous()
+            self.w = torch.empty((Cout, Kpad), device=weight.device, dtype=torch.float32)
+            _lib.call('cpr_pack_weights', _ptr(src), None, _ptr(self.w), Cout, Cin, KH, KW, cin_p, Kpad, 0, _stream())
+            return
+        wp = torch.zeros((Cout, KH, KW, cin_p), device=weight.device, dtype=torch.float32)
+        wp[..., :Cin] = w
+        packed = torch.zeros((Cout, Kpad), device=weight.device, dtype=torch.float32)
+        packed[:, :K] = wp.reshape(Cout, K)
+        self.w = packed.contiguous()
+
+    @classmethod
+    def for_dgrad(cls, weight, padding, scale=None):
+        """Weights of the stride-1 conv over dy that yields the data gradient: in/out channels swapped, taps flipped,
+        optional per-output-channel scale of the FORWARD conv (folded BatchNorm) multiplied in, padding K-1-p."""
+        Cout, Cin, KH, KW = weight.shape
+        assert KH == KW and weight.is_cuda
+        assert Cout % 32 == 0 or Cout <= 4, 'gradient channels must be a multiple of 32 (or <= 4)'
+        self = cls.__new__(cls)
+        self.dtype = torch.float32
+        cols_p = 4 if Cout <= 4 else Cout
+        K = KH * KW * cols_p
+        Kpad = (K + 31) // 32 * 32
+        self.Cout, self.Cin, self.KH, self.KW, self.Kpad = Cin, cols_p, KH, KW, Kpad
+        self.stride, self.padding = 1, KH - 1 - padding
+        src = weight.detach()
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        self.w = torch.empty((Cin, Kpad), device=weight.device, dtype=torch.float32)
+        _lib.call('cpr_pack_weights', _ptr(src), _ptr(scale), _ptr(self.w), Cout, Cin, KH, KW, cols_p, Kpad, 1, _stream())
+        return self
 
     def out_hw(self, H, W):
         return ((H + 2 * self.padding - self.KH) // self.stride + 1,
@@ -153,12 +181,25 @@ class TilePartials:
 
     def reduce(self):
         cs = torch.empty((self.C,), device=self.part.device, dtype=torch.float32)
-        _lib.call('cpr_part_colsum', _ptr(self.part), _ptr(cs), self.tiles, self.C, _stream())
+        ws = torch.empty((64 * self.C,), device=self.part.device, dtype=torch.float32)
+        _lib.call('cpr_part_colsum', _ptr(self.part), _ptr(cs), _ptr(ws), self.tiles, self.C, _stream())
         return cs
 
 
 def _sfx(x):
     return '_bf16' if x.dtype == torch.bfloat16 else ''
+
+
+def bn_fold(gamma, beta, mean, var, eps, want_inv_sigma=False):
+    """Eval-mode BatchNorm as a per-channel affine: (scale, shift[, inv_sigma])."""
+    C = gamma.numel()
+    dev = gamma.device
+    scale = torch.empty((C,), device=dev, dtype=torch.float32)
+    shift = torch.empty((C,), device=dev, dtype=torch.float32)
+    inv = torch.empty((C,), device=dev, dtype=torch.float32) if want_inv_sigma else None
+    _lib.call('cpr_bn_fold', _ptr(_check(gamma.detach())), _ptr(_check(beta.detach())), _ptr(_check(mean)), _ptr(_check(var)),
+              float(eps), _ptr(scale), _ptr(shift), _ptr(inv), C, _stream())
+    return scale, shift, inv
 
 
 def maxpool3x3s2(x):
@@ -397,13 +438,11 @@ def p2p_loss(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, b
 
 
 # ------------------------------------------------------------------------------------------------ backward / optimizer
-def dgrad_pack(weight, stride, padding):
+def dgrad_pack(weight, stride, padding, scale=None):
     """PackedConv that computes the data gradient of ``conv2d(x, weight, stride, padding)`` as a stride-1 forward conv
-    over dy (zero-inserted first when stride > 1): channels swapped, taps flipped, padding K-1-p."""
-    Cout, Cin, KH, KW = weight.shape
-    assert KH == KW
-    wt = weight.detach().float().flip(2, 3).permute(1, 0, 2, 3).contiguous()      # (Cin, Cout, KH, KW)
-    return PackedConv(wt, 1, KH - 1 - padding)
+    over dy (zero-inserted first when stride > 1): channels swapped, taps flipped, padding K-1-p; ``scale`` (Cout,) is
+    the forward conv's folded-BatchNorm scale, multiplied into the weights."""
+    return PackedConv.for_dgrad(weight, padding, scale)
 
 
 def conv2d_dgrad(dy, pc_t, in_hw, stride=1, mask=None, add=None, colsum=False):
@@ -487,7 +526,7 @@ def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None):
     if not acc:
         colsum = torch.empty((C,), device=dy.device, dtype=torch.float32)
     g = torch.empty_like(dy) if want_g else None
-    ws = torch.empty(((M + 511) // 512 * C,), device=dy.device, dtype=torch.float32)
+    ws = torch.empty((((M + 127) // 128 + 64) * C,), device=dy.device, dtype=torch.float32)
     _lib.call('cpr_relu_bwd_colsum', _ptr(_check(dy)), _ptr(y), _ptr(g), _ptr(colsum), _ptr(ws), M, C, int(acc),
               _stream())
     return g, colsum

@@ -250,7 +250,7 @@ class CprTrainer:
         (gradient, column sums): all three ride in the conv epilogue."""
         scale, _ = folded_bn(cache, bn)
         inv_sigma = cache.get(('bn_is', id(bn)), [bn.running_var],
-                              lambda: (1.0 / torch.sqrt(bn.running_var + bn.eps)).float().contiguous())
+                              lambda: ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, True)[2])
         w = conv.weight
         if w.requires_grad:
             aff = bn.weight.requires_grad
@@ -264,7 +264,7 @@ class CprTrainer:
         if not need_dx:
             return None
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
-                       lambda: ops.dgrad_pack(w.detach() * scale[:, None, None, None], conv.stride[0], conv.padding[0]))
+                       lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
         return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
 
     def _block_backward(self, cache, blk, rec, dout, need_dx):
