@@ -194,6 +194,10 @@ int cpr_bn_fold_bwd(float* Gw, const float* weight, const float* scale, const fl
                     const float* colsum_g, float* dgamma, float* dbeta, int Cout, int K, void* stream);
 /* y = alpha*x + beta*y on flat fp32 buffers */
 int cpr_axpby(float* y, const float* x, float alpha, float beta, long long n, void* stream);
+/* phase decomposition of a stride-s data gradient: dst[n, s*i+py, s*j+px, :] += src[n, i+sh, j+sw, :] for all targets
+ * inside (H, W); src (N,Hs,Ws,C) = the stride-1 sub-convolution over dy that serves output parity (py, px) */
+int cpr_phase_scatter_add(const float* src, float* dst, int N, int Hs, int Ws, int C, int H, int W, int py, int px,
+                          int sh, int sw, int s, void* stream);
 /* out (N,H,W,C) = dy (N,OH,OW,C) with s-1 zeros inserted between pixels (data gradient of a stride-s conv as a
  * stride-1 conv over the dilated gradient) */
 int cpr_zero_insert(const float* dy, float* out, int N, int OH, int OW, int C, int H, int W, int s, void* stream);

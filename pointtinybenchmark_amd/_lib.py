@@ -55,6 +55,7 @@ SIGNATURES = {
     'cpr_bn_fold_bwd': [_p] * 8 + [_i, _i, _p],
     'cpr_part_colsum': [_p, _p, _p, _i, _i, _p],
     'cpr_axpby': [_p, _p, _f, _f, _l, _p],
+    'cpr_phase_scatter_add': [_p, _p] + [_i] * 11 + [_p],
     'cpr_zero_insert': [_p, _p] + [_i] * 7 + [_p],
     'cpr_loss_bwd': [_p] * 13 + [_i] * 9 + [_f] * 5 + [_p],
     # data side

@@ -373,6 +373,38 @@ extern "C" int cpr_axpby(float* y, const float* x, float alpha, float beta, long
     hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, stream, y, x, alpha, beta, n);
     CPR_LAUNCH_STATUS();
 }
+// phase decomposition of a strided data gradient: dst[n, s*i+py, s*j+px, :] += src[n, i+sh, j+sw, :] for every (i, j) whose
+// target lies inside (H, W).  src (N,Hs,Ws,C) is the stride-1 sub-convolution of one output-parity class.
+__global__ void phase_scatter_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int Hs, int Ws,
+                                         int C4, int H, int W, int py, int px, int sh, int sw, int s) {
+    const int nh = (H - py + s - 1) / s, nw = (W - px + s - 1) / s;
+    const long long total = (long long)N * nh * nw * C4;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        long long r = idx / C4;
+        const int j = (int)(r % nw);
+        r /= nw;
+        const int i = (int)(r % nh);
+        const int n = (int)(r / nh);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((((size_t)n * Hs + i + sh) * Ws + j + sw) * C4 + c) * 4);
+        f32x4* d = reinterpret_cast<f32x4*>(dst + ((((size_t)n * H + s * i + py) * W + s * j + px) * C4 + c) * 4);
+        *d = *d + v;
+    }
+}
+extern "C" int cpr_phase_scatter_add(const float* src, float* dst, int N, int Hs, int Ws, int C, int H, int W, int py,
+                                     int px, int sh, int sw, int s, hipStream_t stream) {
+    CPR_CHECK_ARG(src && dst && N > 0 && Hs > 0 && Ws > 0 && C % 4 == 0 && H > 0 && W > 0 && s >= 1);
+    CPR_CHECK_ARG(py >= 0 && py < s && px >= 0 && px < s && sh >= 0 && sw >= 0);
+    const int nh = (H - py + s - 1) / s, nw = (W - px + s - 1) / s;
+    CPR_CHECK_ARG(nh + sh <= Hs && nw + sw <= Ws);
+    const long long total = (long long)N * nh * nw * (C / 4);
+    if (total <= 0) return CPR_OK;
+    const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
+    hipLaunchKernelGGL(phase_scatter_add_kernel, dim3(grid), dim3(256), 0, stream, src, dst, N, Hs, Ws, C / 4, H, W, py, px,
+                       sh, sw, s);
+    CPR_LAUNCH_STATUS();
+}
 // stride-2 data gradient helper: out (N,2H',2W',C)-like zero-inserted copy of dy: out[n, y*s, x*s, :] = dy[n,y,x,:]
 __global__ void zero_insert_kernel(const float* __restrict__ dy, float* __restrict__ out, int N, int OH, int OW, int C4,
                                    int H, int W, int s) {

@@ -100,11 +100,12 @@ class PackedConv:
         self.w = packed.contiguous()
 
     @classmethod
-    def for_dgrad(cls, weight, padding, scale=None):
+    def for_dgrad(cls, weight, padding, scale=None, pad_override=None):
         """Weights of the stride-1 conv over dy that yields the data gradient: in/out channels swapped, taps flipped,
-        optional per-output-channel scale of the FORWARD conv (folded BatchNorm) multiplied in, padding K-1-p."""
+        optional per-output-channel scale of the FORWARD conv (folded BatchNorm) multiplied in, padding K-1-p
+        (``pad_override``: explicit padding, used by the per-parity sub-kernels of a strided conv)."""
         Cout, Cin, KH, KW = weight.shape
-        assert KH == KW and weight.is_cuda
+        assert (KH == KW or pad_override is not None) and weight.is_cuda
         assert Cout % 32 == 0 or Cout <= 4, 'gradient channels must be a multiple of 32 (or <= 4)'
         self = cls.__new__(cls)
         self.dtype = torch.float32
@@ -112,7 +113,7 @@ class PackedConv:
         K = KH * KW * cols_p
         Kpad = (K + 31) // 32 * 32
         self.Cout, self.Cin, self.KH, self.KW, self.Kpad = Cin, cols_p, KH, KW, Kpad
-        self.stride, self.padding = 1, KH - 1 - padding
+        self.stride, self.padding = 1, (KH - 1 - padding if pad_override is None else pad_override)
         src = weight.detach()
         if src.dtype != torch.float32 or not src.is_contiguous():
             src = src.float().contiguous()
@@ -441,8 +442,50 @@ def p2p_loss(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, b
 def dgrad_pack(weight, stride, padding, scale=None):
     """PackedConv that computes the data gradient of ``conv2d(x, weight, stride, padding)`` as a stride-1 forward conv
     over dy (zero-inserted first when stride > 1): channels swapped, taps flipped, padding K-1-p; ``scale`` (Cout,) is
-    the forward conv's folded-BatchNorm scale, multiplied into the weights."""
+    the forward conv's folded-BatchNorm scale, multiplied into the weights.  Stride-2 convs with k in {1, 3} and
+    padding k//2 (every strided conv of the ResNet body) get the phase-decomposed form (PhasedDgrad)."""
+    if stride == 2 and weight.shape[2] == weight.shape[3] and weight.shape[2] in (1, 3) and padding == weight.shape[2] // 2 \
+            and _PHASED[0]:
+        return PhasedDgrad(weight, stride, padding, scale)
     return PackedConv.for_dgrad(weight, padding, scale)
+
+
+_PHASED = [True]     # test hook: False forces the zero-insertion form for strided convs
+
+
+class PhasedDgrad:
+    """Data gradient of a stride-2 conv (k in {1, 3}, padding k//2) without zero insertion: one stride-1 sub-convolution
+    over dy per output-parity class (py, px) using only the taps that can reach that class (1+2+2+4 = 9 of the 9 taps
+    instead of 4 x 9 over a dilated gradient), scattered to the strided positions."""
+
+    def __init__(self, weight, stride, padding, scale=None):
+        Cout, Cin, KH, KW = weight.shape
+        assert stride == 2 and KH == KW and KH in (1, 3) and padding == KH // 2 and weight.is_cuda
+        self.Cin, self.stride, self.classes = Cin, stride, []
+        for py in range(2):
+            khs = [kh for kh in range(KH) if (py + padding - kh) % 2 == 0]
+            for px in range(2):
+                kws = [kw for kw in range(KW) if (px + padding - kw) % 2 == 0]
+                if not khs or not kws:
+                    continue                       # no tap reaches this class (1x1: only (0, 0))
+                # dy offsets (py+p-kh)/2 form a contiguous range [dmin, dmax]; a symmetric-pad conv has offsets t-P
+                dh = [(py + padding - kh) // 2 for kh in khs]
+                dw = [(px + padding - kw) // 2 for kw in kws]
+                P = max(0, max(dh), max(dw), -min(dh), -min(dw))
+                sub = weight.detach()[:, :, khs][:, :, :, kws].contiguous()    # ascending kh/kw; for_dgrad flips the taps
+                pc = PackedConv.for_dgrad(sub, 0, scale, pad_override=P)
+                # flipped tap t <-> descending kh <-> offset dmin + t, conv offset t - P  =>  out row i' = i + dmin + P
+                self.classes.append((py, px, pc, min(dh) + P, min(dw) + P))
+
+    def __call__(self, dy, in_hw, add=None):
+        N = dy.shape[0]
+        H, W = in_hw
+        dx = add.clone() if add is not None else torch.zeros((N, H, W, self.Cin), device=dy.device, dtype=torch.float32)
+        for py, px, pc, sh, sw in self.classes:
+            o = conv2d(dy, pc)
+            _lib.call('cpr_phase_scatter_add', _ptr(o), _ptr(dx), N, o.shape[1], o.shape[2], self.Cin, H, W, py, px, sh, sw,
+                      self.stride, _stream())
+        return dx
 
 
 def conv2d_dgrad(dy, pc_t, in_hw, stride=1, mask=None, add=None, colsum=False):
@@ -453,6 +496,13 @@ def conv2d_dgrad(dy, pc_t, in_hw, stride=1, mask=None, add=None, colsum=False):
     assert mask is None or add is None
     N, OH, OW, Cout = _check(dy).shape
     H, W = in_hw
+    if isinstance(pc_t, PhasedDgrad):
+        dx = pc_t(dy, in_hw, add=add)
+        if mask is not None or colsum:
+            g, cs = relu_bwd_colsum(dx, mask, want_g=mask is not None)
+            dx = g if mask is not None else dx
+            return (dx, cs) if colsum else dx
+        return dx
     if stride > 1:
         # dilated gradient of extent (H + 2p - K + 1): rows/cols past (O-1)*s are the zeros the forward never read
         He, We = H + 2 * (pc_t.KH - 1 - pc_t.padding) - pc_t.KH + 1, W + 2 * (pc_t.KW - 1 - pc_t.padding) - pc_t.KW + 1

@@ -201,9 +201,37 @@ def test_dgrad_fused_relu_mask_add_colsum(case):
     dpre, cs = ops.conv2d_dgrad(_nhwc(dy), pt, (H, W), stride, mask=_nhwc(x), colsum=True)
     sc = float(pre.grad.abs().max())
     _cmp('masked dgrad', _nchw(dpre), pre.grad, atol=2e-4 * sc)
-    _cmp('colsum', cs.reduce(), pre.grad.sum((0, 2, 3)), atol=2e-4 * sc * (N * H * W) ** 0.5)
+    cs = cs.reduce() if hasattr(cs, 'reduce') else cs        # strided layers return the reduced vector directly
+    _cmp('colsum', cs, pre.grad.sum((0, 2, 3)), atol=2e-4 * sc * (N * H * W) ** 0.5)
     other = torch.randn((N, Cin, H, W), generator=g)
     x2 = x.detach().clone().requires_grad_(True)
     F.conv2d(x2, w, None, stride, pad).backward(dy)
     dsum = ops.conv2d_dgrad(_nhwc(dy), pt, (H, W), stride, add=_nhwc(other))
     _cmp('dgrad + add', _nchw(dsum), x2.grad + other, atol=2e-4 * sc)
+
+
+@pytest.mark.parametrize('case', [(2, 128, 17, 15, 64, 3, 2, 1), (2, 256, 14, 14, 512, 1, 2, 0), (1, 64, 9, 12, 32, 3, 2, 1)],
+                         ids=lambda c: 'n%d_c%d_%dx%d_o%d_k%d_s%d_p%d' % c)
+def test_strided_dgrad_phased_equals_zero_insertion(case):
+    """The two forms of the stride-2 data gradient (per-parity sub-convolutions vs conv over the dilated gradient)."""
+    ops = _ops()
+    N, Cin, H, W, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, Cin, H, W), generator=g, requires_grad=True)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    y = F.conv2d(x, w * scale[:, None, None, None], None, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    outs = []
+    for phased in (True, False):
+        ops._PHASED[0] = phased
+        try:
+            pt = ops.dgrad_pack(w.cuda(), stride, pad, scale=scale.cuda())
+            assert isinstance(pt, ops.PhasedDgrad) == phased
+            outs.append(ops.conv2d_dgrad(_nhwc(dy), pt, (H, W), stride))
+        finally:
+            ops._PHASED[0] = True
+    sc = float(x.grad.abs().max())
+    _cmp('phased', _nchw(outs[0]), x.grad, atol=2e-4 * sc)
+    _cmp('zero-insert', _nchw(outs[1]), x.grad, atol=2e-4 * sc)
