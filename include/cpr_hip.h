@@ -167,6 +167,9 @@ int cpr_p2p_loss(const float* logits, const float* pred, const long long* gt_ind
  * weight gradient of conv2d_fwd: dy (N,OH,OW,Cout) x (N,H,W,Cin) NHWC fp32 -> grad_w [Cout][Cin][KH][KW] (the
  * parameter's own layout).  Optional fused input transform x' = max(x*in_a[n,c]+in_b[n,c], in_relu?0:-inf) (the
  * GroupNorm(+ReLU) the forward applied on load).  ws: cpr_conv2d_wgrad_workspace(...) floats.  Cin%4==0, Cout%4==0. */
+/* benchmark hook: main-loop ablations of the plain weight-gradient kernel (1 no loads, 2 no LDS stores, 4 no barrier,
+ * 8 no fragment reads, 3 = 1|2, 15 = all); results are wrong by construction, 0 restores the product kernel */
+int cpr_wgrad_set_ablation(int mode);
 int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
 int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w, float* ws,
                      int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int in_relu,

@@ -48,6 +48,7 @@ SIGNATURES = {
     'cpr_p2p_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p],
     # training step: backward + optimizer
     'cpr_conv2d_wgrad_workspace': [_i] * 7,
+    'cpr_wgrad_set_ablation': [_i],
     'cpr_conv2d_wgrad': [_p] * 6 + [_i] * 11 + [_p],
     'cpr_gn_bwd': [_p] * 12 + [_i] * 7 + [_p],
     'cpr_upsample_add_bwd': [_p, _p] + [_i] * 7 + [_p],

@@ -23,7 +23,18 @@ constexpr int WG_BK = 32;     // pixels per chunk
 constexpr int WG_T = 128;     // tile edge (cout and cin)
 constexpr int WG_LD = 132;    // LDS row stride in floats (132 = 128 + 4 keeps float4 writes 16-byte aligned)
 
-template <bool XF>
+// ABL: benchmark-only ablations of the main loop (cpr_wgrad_set_ablation; results are wrong by construction):
+//   1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads, 16 loads without address advance,
+//   32 address advance without loads
+// GEO: geometry class of the launch, fixed at compile time so the per-row state update carries no branch and as few VALU
+// instructions as the geometry allows (measured: every VALU instruction between two MFMAs costs ~12 cycles of matrix-pipe
+// time -- the two workgroups of a CU run in lockstep, so nothing else fills the pipe):
+//   2  1x1, stride 1, no padding: both operands advance linearly, no validity besides m < M
+//   1  'same' convolutions (stride 1, OH == H, OW == W): the input row of (pixel m, tap) is m + const, only the border
+//      masks need the pixel's (ox, oy)
+//   0  general (strided): full input-coordinate tracking
+//  -1  images with fewer than 32 output pixels (unit-test sizes): decode from scratch every chunk
+template <bool XF, int ABL = 0, int GEO = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * WG_BK * WG_LD];
     float* As = smem;                         // [2][32][132]  dY tile (k = pixel, i = cout)
@@ -58,64 +69,135 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const int m_begin = slab * p.chunks_per_slab * WG_BK;
     const int nchunks = min(p.chunks_per_slab, (p.M - m_begin + WG_BK - 1) / WG_BK);
     const int ohw = p.OH * p.OW;
-    // per-thread pixel rows kr + 8j of the current chunk, decoded once and then advanced by 32 pixels per chunk
+    // per-thread pixel rows kr + 8j of the current chunk: decoded once, then advanced by 32 pixels per chunk with adds and
+    // selects of wave-uniform constants only (integer multiplies are quarter rate and sit in the MFMA shadow otherwise)
     const int q32 = WG_BK / p.OW, r32 = WG_BK - q32 * p.OW;
-    int rn[4], roy[4], rox[4], rm[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m_begin + kr + 8 * j;
-        rm[j] = m;
+    constexpr bool big_map = GEO >= 0;      // 32 pixels cross at most one image boundary
+    const int cho = (co0 + c4 * 4) * 4, chi = (ci0 + c4 * 4) * 4;   // byte offsets of this thread's channel group
+    const int pxb = p.Cin * 4, rowb = p.W * pxb;                    // bytes per input pixel / input row
+    const int dX0 = r32 * p.stride, dX1 = (r32 - p.OW) * p.stride;  // input-x step without / with a row wrap
+    const int dY0 = q32 * p.stride, dY1 = (q32 + 1) * p.stride, dYw = p.OH * p.stride;
+    const int bX0 = dX0 * pxb, bX1 = dX1 * pxb, bY0 = dY0 * rowb, bY1 = dY1 * rowb;
+    const int bN = (p.H - dYw) * rowb;                              // image wrap: +H rows, -OH*stride rows
+    const int va_step = WG_BK * p.Cout * 4, vb_step = WG_BK * pxb;
+    const int dkh = kh - p.pad, dkw = kw - p.pad;
+    int rm[4], rox[4], roy[4], rix[4], riy[4], va[4], vb[4], vt[4];
+    auto decode_row = [&](int j) {
+        const int m = rm[j];
         const int n = m / ohw;
         const int rem = m - n * ohw;
-        rn[j] = n;
         roy[j] = rem / p.OW;
         rox[j] = rem - roy[j] * p.OW;
+        riy[j] = roy[j] * p.stride + kh - p.pad;
+        rix[j] = rox[j] * p.stride + kw - p.pad;
+        va[j] = m * p.Cout * 4 + cho;
+        vb[j] = ((n * p.H + riy[j]) * p.W + rix[j]) * pxb + chi;
+        vt[j] = n * pxb + chi;
+        if (GEO == 2) rox[j] = rem;           // pixel index inside the image (see advance_row)
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rm[j] = m_begin + kr + 8 * j;
+        decode_row(j);
     }
-    const bool big_map = ohw >= WG_BK;
-    const int cho = (co0 + c4 * 4) * 4, chi = (ci0 + c4 * 4) * 4;   // byte offsets of this thread's channel group
 
-    f32x4 ra[4], rb[4], xa[4], xb[4];
-    // row piece j: loads the row (rm, rn, roy, rox)[j] currently points at, then advances it by one chunk
-    auto load_row = [&](int j) {
+    // Global-load register sets.  The plain variant keeps TWO chunks in flight (loads are issued 2.5 chunks = ~7000 cycles
+    // before their LDS store: first-touch HBM latency under load exceeds the ~2800 cycles of a single-chunk distance and
+    // every stalled wave holds its workgroup at the barrier); the XF variant has no registers left for a second set.
+    constexpr int NSET = XF ? 1 : 2;
+    f32x4 ra[NSET][4], rb[NSET][4], xa[4], xb[4];
+    // Row pieces.  issue_row(j): the loads of row j at its current state.  advance_rows(stage): the state update of ALL
+    // four rows, cut into three short stages that go behind three different MFMAs -- measured (cpr_wgrad_set_ablation 32):
+    // one row's update as a single dependent VALU chain behind one MFMA costs 16 % of the kernel (the chain's
+    // issue-to-use latencies add up to several MFMA times); four independent chains per stage hide each other.
+    auto issue_row = [&](int j, f32x4 (&RA)[4], f32x4 (&RB)[4]) {
         const bool mok = rm[j] < p.M;
-        const int iy = roy[j] * p.stride + kh - p.pad, ix = rox[j] * p.stride + kw - p.pad;
-        const bool xok = mok & ci_ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        bool xok = mok & ci_ok;
+        if (GEO == 1) xok = xok & ((unsigned)(roy[j] + dkh) < (unsigned)p.H) & ((unsigned)(rox[j] + dkw) < (unsigned)p.W);
+        else if (GEO <= 0) xok = xok & ((unsigned)riy[j] < (unsigned)p.H) & ((unsigned)rix[j] < (unsigned)p.W);
         // out-of-range rows get voffset -1 (= beyond num_records: the load returns 0); OR with an all-ones mask instead
         // of a select so the compiler cannot turn the address arithmetic into divergent control flow
         const int xmask = -(int)(!xok);
-        const int va = (rm[j] * p.Cout * 4 + cho) | -(int)(!(mok & co_ok));
-        const int vb = (((rn[j] * p.H + iy) * p.W + ix) * p.Cin * 4 + chi) | xmask;
-        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, va, 0, 0));
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vb, 0, 0));
+        if (!(ABL & 32)) {
+            RA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, va[j] | -(int)(!(mok & co_ok)), 0, 0));
+            RB[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vb[j] | xmask, 0, 0));
+        } else {   // address math only: keep it alive without issuing the loads
+            asm volatile("" ::"v"(va[j] | -(int)(!(mok & co_ok))), "v"(vb[j] | xmask));
+        }
         if (XF) {   // rows that must read as zero get a = b = 0 from the range check as well (branch-free)
-            const int vt = (rn[j] * p.Cin * 4 + chi) | xmask;
-            xa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ta, vt, 0, 0));
-            xb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_tb, vt, 0, 0));
+            xa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ta, vt[j] | xmask, 0, 0));
+            xb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_tb, vt[j] | xmask, 0, 0));
         }
-        rm[j] += WG_BK;
-        if (big_map) {               // 32 pixels cross at most one image boundary: select-only update
+    };
+    bool wcx[4], wcy[4];
+    // one micro-piece of the state update: (row j, stage) -- 12 per chunk, each behind its own MFMA.  Non-MFMA work has
+    // to be spread evenly: a slot holding more than ~10 VALU instructions outlasts its MFMA (64 cycles), and since the two
+    // workgroups of a CU run in lockstep nothing fills the matrix pipe meanwhile (cpr_wgrad_set_ablation 32 measured the
+    // whole update packed into 4 slots at 16 % of the kernel).
+    auto advance_row = [&](int j, int stage) {
+        if (ABL & 16) return;      // loads from a fixed address every chunk (cache hits, no address arithmetic)
+        if (!big_map) {            // tiny maps (unit-test sizes): decode from scratch, once
+            if (stage == 0) { rm[j] += WG_BK; decode_row(j); }
+            return;
+        }
+        if (GEO == 2) {            // 1x1 stride 1: linear; the image index only matters for the fused GroupNorm table
+            if (stage == 0) {
+                rm[j] += WG_BK;
+                va[j] += va_step;
+                vb[j] += vb_step;
+            } else if (stage == 1 && XF) {
+                const int rp = rox[j] + WG_BK;          // rox doubles as the pixel index inside the image
+                wcy[j] = rp >= ohw;
+                rox[j] = wcy[j] ? rp - ohw : rp;
+                vt[j] += wcy[j] ? pxb : 0;
+            }
+            return;
+        }
+        if (GEO == 1) {            // 'same' conv: linear addresses, (ox, oy) only for the border masks
+            if (stage == 0) {
+                rm[j] += WG_BK;
+                va[j] += va_step;
+                vb[j] += vb_step;
+                const int ox = rox[j] + r32;
+                wcx[j] = ox >= p.OW;
+                rox[j] = wcx[j] ? ox - p.OW : ox;
+            } else if (stage == 1) {
+                const int oy = roy[j] + q32 + (wcx[j] ? 1 : 0);
+                wcy[j] = oy >= p.OH;
+                roy[j] = wcy[j] ? oy - p.OH : oy;
+                if (XF) vt[j] += wcy[j] ? pxb : 0;
+            }
+            return;
+        }
+        if (stage == 0) {          // wrap flags and the output-pixel coordinates
+            rm[j] += WG_BK;
+            va[j] += va_step;
             const int ox = rox[j] + r32;
-            const int cx = ox >= p.OW ? 1 : 0;
-            const int oy = roy[j] + q32 + cx;
-            const int cy = oy >= p.OH ? 1 : 0;
-            rox[j] = ox - cx * p.OW;
-            roy[j] = oy - cy * p.OH;
-            rn[j] += cy;
-        } else {                     // tiny maps (unit-test sizes): decode from scratch
-            const int n = rm[j] / ohw, rem = rm[j] - n * ohw;
-            rn[j] = n;
-            roy[j] = rem / p.OW;
-            rox[j] = rem - roy[j] * p.OW;
+            wcx[j] = ox >= p.OW;
+            rox[j] = wcx[j] ? ox - p.OW : ox;
+            const int oy = roy[j] + q32 + (wcx[j] ? 1 : 0);
+            wcy[j] = oy >= p.OH;
+            roy[j] = wcy[j] ? oy - p.OH : oy;
+        } else if (stage == 1) {   // input coordinates
+            rix[j] += wcx[j] ? dX1 : dX0;
+            riy[j] += (wcx[j] ? dY1 : dY0) - (wcy[j] ? dYw : 0);
+        } else {                   // byte offsets
+            vb[j] += (wcx[j] ? bX1 + bY1 : bX0 + bY0) + (wcy[j] ? bN : 0);
+            vt[j] += wcy[j] ? pxb : 0;
         }
+    };
+    auto load_row = [&](int j, f32x4 (&RA)[4], f32x4 (&RB)[4]) {   // prologue form: issue + the whole advance
+        issue_row(j, RA, RB);
+        advance_row(j, 0); advance_row(j, 1); advance_row(j, 2);
     };
     const float relu_floor = p.in_relu ? 0.f : -INFINITY;
     // store piece z: z < 4 -> dY row z, else X row z-4 (with the fused GroupNorm affine + ReLU)
-    auto store_piece = [&](int buf, int z) {
+    auto store_piece = [&](int buf, int z, const f32x4 (&RA)[4], const f32x4 (&RB)[4]) {
         if (z < 4) {
-            *reinterpret_cast<f32x4*>(As + (buf * WG_BK + kr + 8 * z) * WG_LD + c4 * 4) = ra[z];
+            *reinterpret_cast<f32x4*>(As + (buf * WG_BK + kr + 8 * z) * WG_LD + c4 * 4) = RA[z];
         } else {
             const int j = z - 4;
-            f32x4 v = rb[j];
+            f32x4 v = RB[j];
             if (XF) {  // padded / out-of-range entries have a = b = 0 -> max(0, floor) = 0 for either floor
                 v = v * xa[j] + xb[j];
                 v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
@@ -134,8 +216,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int wm = wave & 1, wn = wave >> 1;
     const int half = lane >> 5;
-    const float* a_lds = As + half * WG_LD + wm * 64 + (lane & 31);
-    const float* b_lds = Bs + half * WG_LD + wn * 64 + (lane & 31);
+    // Four base pointers, each opaque to the compiler: fragment reads then compile to ds_read_b32 with a 16-bit immediate
+    // offset and NO per-read address arithmetic.  (With the two 32-channel sub-tiles addressed off one pointer the compiler
+    // pairs them into ds_read2_b32, whose 8-bit dword offsets cannot reach the next k row (264 dwords), so every read
+    // needed a v_add -- and each VALU instruction between two MFMAs costs ~12 cycles of matrix-pipe time here.)
+    int ia0 = half * WG_LD + wm * 64 + (lane & 31), ia1 = ia0 + 32;                       // dword indices into smem
+    int ib0 = 2 * WG_BK * WG_LD + half * WG_LD + wn * 64 + (lane & 31), ib1 = ib0 + 32;
+    asm volatile("" : "+v"(ia0), "+v"(ia1), "+v"(ib0), "+v"(ib1));
 
     // A "k-group" is 4 MFMA k-steps (8 pixels: lanes < 32 take the even pixel of a step, lanes >= 32 the odd one) =
     // 16 MFMAs.  Fragment sets: F[step][0..1] = A values of the two 32-row sub-tiles, F[step][2..3] = B values.
@@ -149,58 +236,73 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     float f0[4][4], f1[4][4];
 #define WG_FRAG(F, buf, g, z)                                                                         \
     do {                                                                                              \
-        const float* src_ = ((z) & 1 ? b_lds : a_lds) + ((buf) * WG_BK + (g) * 8 + ((z) >> 1) * 2) * WG_LD; \
-        F[(z) >> 1][((z) & 1) * 2] = src_[0];                                                         \
-        F[(z) >> 1][((z) & 1) * 2 + 1] = src_[32];                                                    \
+        const int off_ = ((buf) * WG_BK + (g) * 8 + ((z) >> 1) * 2) * WG_LD;                          \
+        F[(z) >> 1][((z) & 1) * 2] = smem[((z) & 1 ? ib0 : ia0) + off_];                              \
+        F[(z) >> 1][((z) & 1) * 2 + 1] = smem[((z) & 1 ? ib1 : ia1) + off_];                          \
     } while (0)
 #define WG_MFMA(F, q)                                                                                 \
     acc[((q) >> 1) & 1][(q) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(                              \
         F[(q) >> 2][((q) >> 1) & 1], F[(q) >> 2][2 + ((q) & 1)], acc[((q) >> 1) & 1][(q) & 1], 0, 0, 0)
+    // one chunk; SS = register set holding chunk c+1 (stored in g1) and receiving the next loads (g2)
+#define WG_CHUNK(c, SS)                                                                               \
+    do {                                                                                              \
+        const int buf = (c) & 1;                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                              \
+            WG_MFMA(f0, q);                                                                           \
+            if (q < 8 && !(ABL & 8)) WG_FRAG(f1, buf, 1, q);                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                              \
+            WG_MFMA(f1, q);                                                                           \
+            if (q < 8) { if (!(ABL & 8)) WG_FRAG(f0, buf, 2, q); }                                    \
+            else if (!(ABL & 2)) store_piece(buf ^ 1, q - 8, ra[SS], rb[SS]);                         \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                              \
+            WG_MFMA(f0, q);                                                                           \
+            if (q < 8) { if (!(ABL & 8)) WG_FRAG(f1, buf, 3, q); }                                    \
+            else if (q < 12) { if (!(ABL & 1)) issue_row(q - 8, ra[SS], rb[SS]); }                    \
+            else { if (!(ABL & 1)) advance_row(q - 12, 0); }                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        asm volatile("" ::: "memory"); /* no LDS access may be moved across the raw barrier */        \
+        __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) only: global loads stay in flight */        \
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                                 \
+        asm volatile("" ::: "memory");                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                              \
+            WG_MFMA(f1, q);                                                                           \
+            if (q < 8) { if (!(ABL & 8)) WG_FRAG(f0, buf ^ 1, 0, q); }                                \
+            else if (!(ABL & 1)) advance_row(q & 3, q < 12 ? 1 : 2);                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+    } while (0)
     if (nchunks > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_row(j);
+        for (int j = 0; j < 4; ++j) load_row(j, ra[0], rb[0]);                 // chunk 0
 #pragma unroll
-        for (int z = 0; z < 8; ++z) store_piece(0, z);
+        for (int z = 0; z < 8; ++z) store_piece(0, z, ra[0], rb[0]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_row(j);
+        for (int j = 0; j < 4; ++j) load_row(j, ra[NSET - 1], rb[NSET - 1]);   // chunk 1
+        if (NSET == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_row(j, ra[0], rb[0]);             // chunk 2
+        }
         __syncthreads();
 #pragma unroll
         for (int z = 0; z < 8; ++z) WG_FRAG(f0, 0, 0, z);
-        for (int c = 0; c < nchunks; ++c) {
-            const int buf = c & 1;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                WG_MFMA(f0, q);
-                if (q < 8) WG_FRAG(f1, buf, 1, q);
-                __builtin_amdgcn_sched_barrier(0);
+        if (NSET == 2) {   // chunk c stores chunk c+1 from set (c+1)&1 and refills it with chunk c+3
+            int c = 0;
+            for (; c + 1 < nchunks; c += 2) {
+                WG_CHUNK(c, NSET - 1);
+                WG_CHUNK(c + 1, 0);
             }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                WG_MFMA(f1, q);
-                if (q < 8) WG_FRAG(f0, buf, 2, q);
-                else store_piece(buf ^ 1, q - 8);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                WG_MFMA(f0, q);
-                if (q < 8) WG_FRAG(f1, buf, 3, q);
-                else if (q < 12) load_row(q - 8);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("" ::: "memory");       // no LDS access may be moved across the raw barrier by the compiler
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS traffic is done; global loads stay in flight
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                WG_MFMA(f1, q);
-                if (q < 8) WG_FRAG(f0, buf ^ 1, 0, q);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (c < nchunks) WG_CHUNK(c, NSET - 1);
+        } else {
+            for (int c = 0; c < nchunks; ++c) WG_CHUNK(c, 0);
         }
     }
+#undef WG_CHUNK
 #undef WG_FRAG
 #undef WG_MFMA
     // partial[slab][co][tap][ci]: col j = lane&31 (cin), row i = (r&3) + 8*(r>>2) + 4*half (cout)
@@ -263,6 +365,12 @@ static int wgrad_split(long long M, int Cout, int Cin, int KK) {
     }
     return (int)S;
 }
+static int wgrad_ablate = 0;   // benchmark-only (cpr_wgrad_set_ablation); 0 in production
+extern "C" int cpr_wgrad_set_ablation(int mode) {
+    CPR_CHECK_ARG(mode >= 0 && mode <= 32);
+    wgrad_ablate = mode;
+    return CPR_OK;
+}
 extern "C" int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {
     CPR_CHECK_ARG(N > 0 && OH > 0 && OW > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0);
     const int S = wgrad_split((long long)N * OH * OW, Cout, Cin, KH * KW);
@@ -295,8 +403,28 @@ extern "C" int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in
     p.chunks_per_slab = (chunks + p.S - 1) / p.S;
     const long long grid = (long long)p.tilesCo * KK * p.tilesCi * p.S;
     CPR_CHECK_ARG(grid < (1ll << 31));
-    if (in_a) hipLaunchKernelGGL((conv_wgrad_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    const int geo = (p.OH * p.OW < WG_BK) ? -1 : (KK == 1 && stride == 1 && pad == 0) ? 2
+                    : (stride == 1 && p.OH == H && p.OW == W) ? 1 : 0;
+#define WG_LAUNCH(XF_, ABL_, GEO_) \
+    hipLaunchKernelGGL((conv_wgrad_kernel<XF_, ABL_, GEO_>), dim3((unsigned)grid), dim3(256), 0, stream, p)
+    if (wgrad_ablate && !in_a && geo == 1) {
+        switch (wgrad_ablate) {
+            case 1: WG_LAUNCH(false, 1, 1); break;
+            case 2: WG_LAUNCH(false, 2, 1); break;
+            case 4: WG_LAUNCH(false, 4, 1); break;
+            case 8: WG_LAUNCH(false, 8, 1); break;
+            case 16: WG_LAUNCH(false, 16, 1); break;
+            case 32: WG_LAUNCH(false, 32, 1); break;
+            default: WG_LAUNCH(false, 15, 1); break;
+        }
+    } else if (in_a) {
+        if (geo == 2) WG_LAUNCH(true, 0, 2); else if (geo == 1) WG_LAUNCH(true, 0, 1);
+        else if (geo == 0) WG_LAUNCH(true, 0, 0); else WG_LAUNCH(true, 0, -1);
+    } else {
+        if (geo == 2) WG_LAUNCH(false, 0, 2); else if (geo == 1) WG_LAUNCH(false, 0, 1);
+        else if (geo == 0) WG_LAUNCH(false, 0, 0); else WG_LAUNCH(false, 0, -1);
+    }
+#undef WG_LAUNCH
     const long long total = (long long)Cout * KK * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, ws, grad_w, p.S, Cout,
                        KK, Cin, accumulate);

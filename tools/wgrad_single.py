@@ -17,7 +17,10 @@ ap.add_argument('--cout', type=int, default=256)
 ap.add_argument('--k', type=int, default=3)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--xf', action='store_true')
+ap.add_argument('--ablate', type=int, default=0)
 args = ap.parse_args()
+from pointtinybenchmark_amd import _lib  # noqa: E402
+_lib.call('cpr_wgrad_set_ablation', args.ablate)
 g = torch.Generator().manual_seed(0)
 x = torch.randn((args.batch, args.hw, args.hw, args.cin), generator=g).cuda()
 dy = torch.randn((args.batch, args.hw, args.hw, args.cout), generator=g).cuda()
@@ -37,4 +40,4 @@ e.record()
 torch.cuda.synchronize()
 t = s.elapsed_time(e) / args.iters
 fl = 2.0 * dy.numel() * args.cin * args.k * args.k
-print('wgrad %s on %s: %.3f ms, %.1f TFLOP/s' % (shape, tuple(x.shape), t, fl / t / 1e9))
+print('wgrad %s on %s ablate %d: %.3f ms, %.1f TFLOP/s' % (shape, tuple(x.shape), args.ablate, t, fl / t / 1e9))
