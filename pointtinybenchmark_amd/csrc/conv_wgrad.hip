@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     // selects of wave-uniform constants only (integer multiplies are quarter rate and sit in the MFMA shadow otherwise)
     const int q32 = WG_BK / p.OW, r32 = WG_BK - q32 * p.OW;
     constexpr bool big_map = GEO >= 0;      // 32 pixels cross at most one image boundary
-    const int cho = (co0 + c4 * 4) * 4, chi = (ci0 + c4 * 4) * 4;   // byte offsets of this thread's channel group
+    // byte offsets of this thread's channel group; a group beyond the tensor's channels gets 2^31, which puts every address
+    // built on it outside num_records (< 2^31) -- no per-load mask for the channel-tile overhang
+    const int cho = co_ok ? (co0 + c4 * 4) * 4 : (int)0x80000000, chi = ci_ok ? (ci0 + c4 * 4) * 4 : (int)0x80000000;
     const int pxb = p.Cin * 4, rowb = p.W * pxb;                    // bytes per input pixel / input row
     const int dX0 = r32 * p.stride, dX1 = (r32 - p.OW) * p.stride;  // input-x step without / with a row wrap
     const int dY0 = q32 * p.stride, dY1 = (q32 + 1) * p.stride, dYw = p.OH * p.stride;
@@ -111,18 +113,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     // one row's update as a single dependent VALU chain behind one MFMA costs 16 % of the kernel (the chain's
     // issue-to-use latencies add up to several MFMA times); four independent chains per stage hide each other.
     auto issue_row = [&](int j, f32x4 (&RA)[4], f32x4 (&RB)[4]) {
-        const bool mok = rm[j] < p.M;
-        bool xok = mok & ci_ok;
+        // No m < M test: rows past the last pixel lie beyond num_records of dY (and of X for the linear geometries), and
+        // whatever X row a negative tap shift still reaches there is multiplied by a dY row that read as zero.
+        bool xok = true;
         if (GEO == 1) xok = xok & ((unsigned)(roy[j] + dkh) < (unsigned)p.H) & ((unsigned)(rox[j] + dkw) < (unsigned)p.W);
         else if (GEO <= 0) xok = xok & ((unsigned)riy[j] < (unsigned)p.H) & ((unsigned)rix[j] < (unsigned)p.W);
         // out-of-range rows get voffset -1 (= beyond num_records: the load returns 0); OR with an all-ones mask instead
         // of a select so the compiler cannot turn the address arithmetic into divergent control flow
         const int xmask = -(int)(!xok);
         if (!(ABL & 32)) {
-            RA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, va[j] | -(int)(!(mok & co_ok)), 0, 0));
+            RA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, va[j], 0, 0));
             RB[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vb[j] | xmask, 0, 0));
         } else {   // address math only: keep it alive without issuing the loads
-            asm volatile("" ::"v"(va[j] | -(int)(!(mok & co_ok))), "v"(vb[j] | xmask));
+            asm volatile("" ::"v"(va[j]), "v"(vb[j] | xmask));
         }
         if (XF) {   // rows that must read as zero get a = b = 0 from the range check as well (branch-free)
             xa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ta, vt[j] | xmask, 0, 0));
