@@ -63,8 +63,13 @@ def main():
             elif name == 'conv2d_dgrad':
                 dy, pt = a[0], a[1]
                 st = a[3] if len(a) > 3 else k.get('stride', 1)
-                shp = 'dy%s ->%d k%d s%d' % (tuple(dy.shape), pt.Cout, pt.KH, st)
-                flops = 2.0 * dy.shape[0] * a[2][0] * a[2][1] * pt.Cout * pt.KH * pt.KW * dy.shape[3] / (st * st)
+                if isinstance(pt, ops.PhasedDgrad):      # stride-2: the taps are split over the four parity classes
+                    taps = sum(c[2].KH * c[2].KW for c in pt.classes)
+                    shp = 'dy%s ->%d phased(%d taps) s%d' % (tuple(dy.shape), pt.Cin, taps, st)
+                    flops = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * pt.Cin * taps * dy.shape[3]
+                else:
+                    shp = 'dy%s ->%d k%d s%d' % (tuple(dy.shape), pt.Cout, pt.KH, st)
+                    flops = 2.0 * dy.shape[0] * a[2][0] * a[2][1] * pt.Cout * pt.KH * pt.KW * dy.shape[3] / (st * st)
             elif a and isinstance(a[0], torch.Tensor):
                 shp = str(tuple(a[0].shape))
             events.append((name, shp, flops, s, e))
