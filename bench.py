@@ -214,6 +214,7 @@ def main():
     ap.add_argument('--mode', default='fwd_loss', choices=['fwd_loss', 'train'],
                     help="fwd_loss = BASELINE.json's metric; train = the full optimisation step (backward, bucketed RCCL "
                          "gradient all-reduce, clip + SGD) as the timed step")
+    ap.add_argument('--train-timeout', type=int, default=300, help='watchdog for the train_step extra (seconds)')
     ap.add_argument('--train-steps', type=int, default=3,
                     help='after the timed region also time this many full training steps (0 = skip); reported under '
                          '"train_step", never in "value"')
@@ -288,10 +289,12 @@ def main():
         elapsed = float(t.item())
     loss_vals = {k: float(v) for k, v in losses.items()}
 
-    # the step after the path: full training step incl. the RCCL gradient all-reduce at N > 1.
-    # Outside the timed region above; failures are reported, they do not take the headline number down.
-    train_info = None
-    if args.mode == 'fwd_loss' and args.train_steps > 0 and args.dtype == 'fp32':
+    def measure_train():
+        """The step after the path: full training step incl. the RCCL gradient all-reduce at N > 1.
+        Runs AFTER everything the headline line needs has been measured; failures are reported, never fatal."""
+        nonlocal trainer
+        if not (args.mode == 'fwd_loss' and args.train_steps > 0 and args.dtype == 'fp32'):
+            return None
         try:
             trainer = make_trainer()
             train_step()
@@ -305,14 +308,15 @@ def main():
                 t = torch.tensor([te], device='cuda', dtype=torch.float64)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
                 te = float(t.item())
-            train_info = {'value': args.batch * world * args.train_steps / te, 'unit': 'img/s',
-                          'ms_per_step': te / args.train_steps * 1e3, 'steps': args.train_steps,
-                          'what': 'forward + loss + backward (layer2-4, FPN, head) + bucketed gradient all-reduce + '
-                                  'clip_grad_norm(35) + SGD(momentum 0.9, wd 1e-4), fp32',
-                          'grad_norm': trainer.grad_norm(), 'loss': float(sum(v for k, v in tl.items() if 'loss' in k))}
+            return {'value': args.batch * world * args.train_steps / te, 'unit': 'img/s',
+                    'ms_per_step': te / args.train_steps * 1e3, 'steps': args.train_steps,
+                    'what': 'forward + loss + backward (layer2-4, FPN, head) + bucketed gradient all-reduce + '
+                            'clip_grad_norm(35) + SGD(momentum 0.9, wd 1e-4), fp32',
+                    'grad_norm': trainer.grad_norm(), 'loss': float(sum(v for k, v in tl.items() if 'loss' in k))}
         except Exception as e:   # noqa: BLE001 -- reported in the JSON line
-            train_info = {'error': repr(e)[:300]}
+            return {'error': repr(e)[:300]}
 
+    out = None
     if rank == 0:
         total_imgs = args.batch * world * args.steps
         out = {
@@ -328,8 +332,6 @@ def main():
                        'weights': 'random init (synthetic.locator_state_dict seed 0)'},
             'losses': loss_vals,
         }
-        if train_info is not None:
-            out['train_step'] = train_info
         if probe:
             summ = probe.summary()
             name = max(summ, key=lambda k: summ[k]['seconds'])      # dominant template instance by total time
@@ -354,6 +356,23 @@ def main():
                 out['hbm_kernels'] = {'error': repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(2, args.num_gts)
+    # last of all, under a watchdog: if the training step (first use of the collective library at N > 1) wedges, the headline
+    # line is still printed and every rank leaves
+    import threading
+
+    def bail():
+        if rank == 0:
+            out['train_step'] = {'error': 'no result within %d s' % args.train_timeout}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    timer = threading.Timer(args.train_timeout, bail)
+    timer.daemon = True
+    timer.start()
+    train_info = measure_train()
+    timer.cancel()
+    if rank == 0:
+        if train_info is not None:
+            out['train_step'] = train_info
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
