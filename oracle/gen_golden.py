@@ -104,6 +104,50 @@ CPR_CASES = {
 }
 
 
+GRAD_CASES = ('cpr_r18_c3_128', 'cpr_r50_c1_160_spread')
+
+
+def grad_sample_index(numel, k=256):
+    """Deterministic flat indices every consumer of the gradient fixtures re-derives (<= k entries, evenly spread)."""
+    return np.unique(np.linspace(0, numel - 1, min(k, numel)).round().astype(np.int64))
+
+
+def run_reference_cpr_grads(R, cfg):
+    """loss.backward() through the REFERENCE's own modules (torch autograd on CPU): the total of every key containing
+    'loss' (BaseDetector._parse_losses, base.py:179-212).  Per trainable tensor: L2 norm, sum and a strided sample."""
+    torch.manual_seed(0)
+    backbone, neck, head, sd = build_reference_cpr(R, cfg['depth'], cfg['num_classes'], cfg['start_level'],
+                                                   cfg['stride'], cfg['radius'], cfg['head_std'], cfg['seed'])
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'], cfg.get('ragged', False))
+    cls_feat, ins_feat = head(neck(backbone(batch['img'])))
+    losses = head.loss(cls_feat, ins_feat, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'])
+    total = sum(v for k, v in losses.items() if 'loss' in k)
+    total.backward()
+    out = {'total_loss': np.float64(float(total))}
+    n = 0
+    for prefix, mod in (('backbone.', backbone), ('neck.', neck), ('bbox_head.', head)):
+        for name, prm in mod.named_parameters():
+            if not prm.requires_grad:
+                continue
+            assert prm.grad is not None, prefix + name
+            g = prm.grad.detach().double().flatten()
+            key = prefix + name
+            out['norm:' + key] = np.float64(float(g.norm()))
+            out['sum:' + key] = np.float64(float(g.sum()))
+            out['sample:' + key] = g[torch.from_numpy(grad_sample_index(g.numel()))].numpy().astype(np.float32)
+            n += 1
+    out['num_tensors'] = np.int64(n)
+    return out
+
+
+def gen_cpr_grads(R):
+    for name in GRAD_CASES:
+        out = run_reference_cpr_grads(R, CPR_CASES[name])
+        np.savez_compressed(os.path.join(GOLDEN, 'cpr_grads_' + name + '.npz'), **out)
+        print('grads', name, 'tensors', int(out['num_tensors']), 'loss', float(out['total_loss']))
+
+
 def gen_cpr(R):
     for name, cfg in CPR_CASES.items():
         out = run_reference_cpr(R, cfg)
@@ -210,9 +254,11 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_loader.load()
-    which = sys.argv[1:] or ['cpr', 'assigners', 'p2p']
+    which = sys.argv[1:] or ['cpr', 'grads', 'assigners', 'p2p']
     if 'cpr' in which:
         gen_cpr(R)
+    if 'grads' in which:
+        gen_cpr_grads(R)
     if 'assigners' in which:
         gen_assigners(R)
     if 'p2p' in which:

@@ -102,3 +102,35 @@ def test_train_steps_match_torch_sgd():
         assert float(err) <= 5e-3 * max(float(upd), 1e-12) + 1e-7, (k, float(err), float(upd))
     # state dict keys/values still load strictly (parameters are views into the flat buffer)
     m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+
+
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
+def test_backward_matches_reference_autograd_golden(name):
+    """HIP gradients against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_grads_*.npz, produced
+    in the build container by oracle.gen_golden): total loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the
+    tensor's largest sampled entry."""
+    import numpy as np
+    from oracle.gen_golden import grad_sample_index
+    from pointtinybenchmark_amd.training import CprTrainer
+    cfg = CPR_CASES[name]
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cpr_grads_%s.npz' % name))
+    m, _ = build_hip_locator(cfg)
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'], cfg.get('ragged', False))
+    cb = to_cuda(batch)
+    tr = CprTrainer(m)
+    losses = tr.forward_backward(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+    torch.cuda.synchronize()
+    total = sum(float(v) for k, v in losses.items() if 'loss' in k)
+    assert abs(total - float(gold['total_loss'])) <= 1e-4 * max(1.0, abs(float(gold['total_loss'])))
+    params = dict(m.named_parameters())
+    keys = [k[len('norm:'):] for k in gold.files if k.startswith('norm:')]
+    assert sorted(keys) == sorted(k for k, p in params.items() if p.requires_grad)
+    gmax = max(float(gold['norm:' + k]) for k in keys)
+    for k in keys:
+        g = params[k].grad.detach().double().flatten().cpu()
+        ref_n = float(gold['norm:' + k])
+        assert abs(float(g.norm()) - ref_n) <= 2e-3 * ref_n + 1e-6 * gmax, (k, float(g.norm()), ref_n)
+        smp = g[torch.from_numpy(grad_sample_index(g.numel()))].numpy()
+        ref = gold['sample:' + k].astype(np.float64)
+        assert np.abs(smp - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-5 * gmax), k

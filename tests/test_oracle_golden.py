@@ -86,3 +86,34 @@ def test_hungarian_v2_matches_reference_fixture(golden_dir, case):
     assert np.array_equal(inds.numpy(), g['ha%d_gt_inds' % case])
     assert np.array_equal(lab.numpy(), g['ha%d_labels' % case])
     assert int((inds > 0).sum()) == min(k, (n_side * n_side) // G) * G
+
+
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
+def test_oracle_autograd_matches_reference_autograd(golden_dir, name):
+    """Pins the ORACLE's backward: torch autograd over oracle/cpr_oracle.py against loss.backward() through the reference's
+    own modules (fixtures from oracle.gen_golden.run_reference_cpr_grads): per-tensor norm, sum and strided samples."""
+    from oracle.gen_golden import CPR_CASES, grad_sample_index
+    cfg = CPR_CASES[name]
+    gold = _load(golden_dir, 'cpr_grads_' + name)
+    sd = synthetic.locator_state_dict(cfg['depth'], cfg['num_classes'], cfg['start_level'], 'cpr', cfg['seed'],
+                                      cfg['head_std'])
+    keys = [k[len('norm:'):] for k in gold.files if k.startswith('norm:')]
+    assert len(keys) == int(gold['num_tensors'])
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sd[k].requires_grad_(True)
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'], cfg.get('ragged', False))
+    losses, _, _ = O.locator_forward_train(sd, batch, cfg['depth'], cfg['start_level'], cfg['stride'], cfg['radius'],
+                                           cfg['num_classes'])
+    total = sum(v for k, v in losses.items() if 'loss' in k)
+    assert abs(float(total.detach()) - float(gold['total_loss'])) <= 1e-4 * max(1.0, abs(float(gold['total_loss'])))
+    total.backward()
+    gmax = max(float(gold['norm:' + k]) for k in keys)
+    for k in keys:
+        g = sd[k].grad.detach().double().flatten()
+        ref_n = float(gold['norm:' + k])
+        assert abs(float(g.norm()) - ref_n) <= 1e-3 * ref_n + 1e-7 * gmax, (k, float(g.norm()), ref_n)
+        smp = g[torch.from_numpy(grad_sample_index(g.numel()))].numpy()
+        ref = gold['sample:' + k].astype(np.float64)
+        assert np.abs(smp - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6 * gmax), k
