@@ -533,8 +533,12 @@ __global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int
                 const float gp = s;
                 dcls += gfocal_dp(gp, q, eps) * gtv * k_gt * gp * (1.f - gp);
             }
-            D[(size_t)k * J + c] = dcls;
-            D[(size_t)k * J + ins_off + c] = dins;
+            if (ins_off == 0) {   // ins_share_head_classifier: one logit plays both roles
+                D[(size_t)k * J + c] = dcls + dins;
+            } else {
+                D[(size_t)k * J + c] = dcls;
+                D[(size_t)k * J + ins_off + c] = dins;
+            }
         }
     }
 }

@@ -109,6 +109,12 @@ class CPRHead(nn.Module):
         self.strides = list(strides)
         self.ins_share_head_feat, self.ins_share_head_classifier = ins_share_head_feat, ins_share_head_classifier
         self.loss_cfg, self.loss_type, self.normal_cfg = dict(loss_cfg), loss_type, dict(normal_cfg)
+        # the three bag policies and the two gt_loss_type values only differ for num_refine > 1 (cpr_head.py:1159-1211);
+        # inputs with num_refine > 1 are rejected in _gt_tensors, so all of them run the same kernels here
+        assert self.loss_cfg.get('refine_bag_policy', 'independent_with_gt_bag') in (
+            'independent_with_gt_bag', 'merge_to_gt_bag', 'only_refine_bag'), self.loss_cfg['refine_bag_policy']
+        if self.loss_cfg.get('gt_loss_type', 'gt_refine') not in ('gt_refine', 'gt'):
+            raise NotImplementedError('gt_loss_type=%r (the reference raises too: cpr_head.py:1167)' % self.loss_cfg['gt_loss_type'])
         self.train_cfg, self.test_cfg, self.other_info = train_cfg, test_cfg, dict(other_info)
         self.cls_convs = nn.ModuleList()
         self.ins_convs = nn.ModuleList()

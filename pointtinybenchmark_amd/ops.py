@@ -151,7 +151,6 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
         part = torch.empty(((N * OH * OW + 63) // 64, pc.Cout, 2), device=x.device, dtype=torch.float32)
     if x.dtype == torch.bfloat16:
         assert not (res_mask or colsum), 'backward helpers are fp32'
-    if x.dtype == torch.bfloat16:
         assert in_ab is None, 'the bf16 kernel does not fuse the producer GroupNorm (materialise with gn_apply)'
         _lib.call('cpr_conv2d_fwd_bf16', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
                   _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding, pc.Kpad, int(relu),

@@ -69,6 +69,12 @@ def test_registry_names_and_state_dict_layout():
     'configs2/COCO/coarsepointv2/coarse_point_refine_r101_fpn_1x_coco400.py',
     'configs2/TinyPersonV2/p2p/p2p_r50_fpns4_1x_fl_sl1_TinyPersonV2_640.py',
     'configs2/TinyPersonV2/p2p/p2p_r50_fpns4_0.5x_fl_sl1_TinyPersonV2_640.py',
+    'configs2/COCO/p2p/p2p_r101_fpn_1x_fl_sl1_coco400_coarse.py',
+    'configs2/COCO/p2p/p2p_r50_fpn_1x_fl_sl1_coco400_coarse.py',
+    'configs2/COCO/p2p/p2p_r50_fpns4_1x_fl_sl1_coco.py',
+    'configs2/DOTA/coarsepointv2/coarse_point_refine_r50_fpns4_1x_DOTA_1024.py',
+    'configs2/DOTA/p2p/p2p_r50_fpn_1x_fl_sl1_DOTA_coarse.py',
+    'configs2/_base_/models/cpr/coarse_point_refine_r50_fpns4_1x.py',    # refine_bag_policy='only_refine_bag'
 ])
 def test_reference_configs_build_unmodified(rel):
     import pointtinybenchmark_amd as P
@@ -77,8 +83,10 @@ def test_reference_configs_build_unmodified(rel):
     m = P.build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
     keys = set(m.state_dict())
     assert 'backbone.layer4.2.conv3.weight' in keys and 'neck.lateral_convs.0.gn.weight' in keys
-    assert 'bbox_head.cls_convs.3.conv.weight' in keys and 'bbox_head.cls_out.weight' in keys
-    assert 'optimizer_config' in cfg and 'checkpoint_config' in cfg   # _base_ files merged
+    last = cfg.model.bbox_head.get('stacked_convs', 4) - 1
+    assert 'bbox_head.cls_convs.%d.conv.weight' % last in keys and 'bbox_head.cls_out.weight' in keys
+    if '_base_/models' not in rel:                                       # a bare model file has no schedule / runtime
+        assert 'optimizer_config' in cfg and 'checkpoint_config' in cfg   # _base_ files merged
     if 'TinyPersonV2' in rel:
         assert cfg.optimizer_config.grad_clip.max_norm == 35            # _delete_ override handled
     cfg.merge_from_dict({'model.backbone.depth': 18, 'data.samples_per_gpu': 4})
