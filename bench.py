@@ -67,6 +67,23 @@ def model_cfg(depth=50, num_classes=1):
             point_refiner=dict(merge_th=0.1, refine_th=0.1, classify_filter=True)))
 
 
+def p2p_model_cfg(depth=50, num_classes=1):
+    """Key/values of T/configs2/TinyPersonV2/p2p/p2p_r50_fpns4_1x_fl_sl1_TinyPersonV2_640.py (BASELINE.json configs[3])."""
+    cfg = model_cfg(depth, num_classes)
+    cfg['bbox_head'] = dict(
+        type='P2PHead', norm_cfg=GN, num_classes=num_classes, in_channels=256, feat_channels=256, stacked_convs=4,
+        strides=[4], point_anchor=[(0., 0.)],
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+        loss_reg=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=0.5), pts_gamma=1, reg_norm=1)
+    cfg['train_cfg'] = dict(neg_weight=1.0,
+                            assigner=dict(type='HungarianAssignerV2', cls_costs=dict(type='FocalLossCost', weight=2.0),
+                                          reg_costs=dict(type='DisCostV2', weight=0.1, norm_with_img_wh=False), topk_k=5),
+                            sampler=dict(type='PseudoSampler'))
+    cfg['test_cfg'] = dict(nms_pre=2000, min_bbox_size=0, score_thr=0.05, pseudo_wh=(16, 16),
+                           nms=dict(type='nms', iou_threshold=0.2), max_per_img=1000)
+    return cfg
+
+
 class ConvProbe:
     """HIP-event brackets around every conv launch of the timed region (events are recorded on the stream the
     kernels are launched on: torch's current stream)."""
@@ -211,7 +228,10 @@ def main():
                     help="fp32 = the headline metric (exact fp32 MFMA); bf16 = the bf16 compute mode of configs[4]")
     ap.add_argument('--depth', type=int, default=50)
     ap.add_argument('--size', type=int, default=640)
-    ap.add_argument('--mode', default='fwd_loss', choices=['fwd_loss', 'train'],
+    ap.add_argument('--model', default='cpr', choices=['cpr', 'p2p'],
+                    help="cpr = the headline (configs[1]); p2p = P2PNet R50-FPN (configs[3]): forward + Hungarian assignment + "
+                         "loss, or with --mode infer forward + top-k + pseudo-box NMS")
+    ap.add_argument('--mode', default='fwd_loss', choices=['fwd_loss', 'train', 'infer'],
                     help="fwd_loss = BASELINE.json's metric; train = the full optimisation step (backward, bucketed RCCL "
                          "gradient all-reduce, clip + SGD) as the timed step")
     ap.add_argument('--train-timeout', type=int, default=300, help='watchdog for the train_step extra (seconds)')
@@ -232,8 +252,14 @@ def main():
 
     import pointtinybenchmark_amd as P
     from pointtinybenchmark_amd import synthetic
-    model = P.build_detector(model_cfg(args.depth)).cuda()
-    model.load_state_dict(synthetic.locator_state_dict(args.depth, 1, 0, 'cpr', 0), strict=True)
+    if args.model == 'p2p':
+        assert args.mode in ('fwd_loss', 'infer'), 'the training step is built for the CPR head'
+        model = P.build_detector(p2p_model_cfg(args.depth)).cuda()
+        model.load_state_dict(synthetic.locator_state_dict(args.depth, 1, 0, 'p2p', 0, head_std=0.05), strict=True)
+    else:
+        assert args.mode != 'infer'
+        model = P.build_detector(model_cfg(args.depth)).cuda()
+        model.load_state_dict(synthetic.locator_state_dict(args.depth, 1, 0, 'cpr', 0), strict=True)
     model.train()
     model.set_compute_dtype(args.dtype)
     batch = synthetic.synthetic_batch(args.batch, args.size, args.size, args.num_gts, 1, seed=rank)   # per-rank shard
@@ -261,6 +287,9 @@ def main():
         if trainer is not None:
             return train_step()
         with torch.no_grad():
+            if args.mode == 'infer':
+                res = model.simple_test(img, metas)
+                return {'num_dets': torch.tensor(float(sum(len(d) for d, _ in res)))}
             return model.forward_train(img, metas, gtb, gtl)
 
     for _ in range(args.warmup):
@@ -287,13 +316,17 @@ def main():
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_vals = {k: float(v) for k, v in losses.items()}
+    def _val(v):
+        if isinstance(v, (list, tuple)):
+            return [_val(e) for e in v]
+        return float(v) if v.numel() == 1 else [float(e) for e in v.flatten()]
+    loss_vals = {k: _val(v) for k, v in losses.items()}
 
     def measure_train():
         """The step after the path: full training step incl. the RCCL gradient all-reduce at N > 1.
         Runs AFTER everything the headline line needs has been measured; failures are reported, never fatal."""
         nonlocal trainer
-        if not (args.mode == 'fwd_loss' and args.train_steps > 0 and args.dtype == 'fp32'):
+        if not (args.mode == 'fwd_loss' and args.model == 'cpr' and args.train_steps > 0 and args.dtype == 'fp32'):
             return None
         try:
             trainer = make_trainer()
@@ -320,13 +353,17 @@ def main():
     if rank == 0:
         total_imgs = args.batch * world * args.steps
         out = {
-            'metric': 'img/s (640x640) CPR R50-FPN fwd+loss' if args.mode == 'fwd_loss'
-            else 'img/s (640x640) CPR R50-FPN training step (NOT the headline metric)',
+            'metric': 'img/s (640x640) CPR R50-FPN fwd+loss' if (args.mode, args.model) == ('fwd_loss', 'cpr')
+            else 'img/s (640x640) %s R50-FPN %s (NOT the headline metric)' % (
+                args.model.upper(), {'train': 'training step', 'infer': 'forward + top-k + NMS',
+                                     'fwd_loss': 'forward + assignment + loss'}[args.mode]),
             'value': total_imgs / elapsed, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'CPR ResNet-%d + FPN(num_outs=1, stride 4) + CPRHead, %dx%d, forward + loss%s' % (
-                args.depth, args.size, args.size, ' (configs[1])' if (args.depth, args.size, args.dtype) == (50, 640, 'fp32')
+            'config': {'workload': '%s ResNet-%d + FPN(num_outs=1, stride 4) + %s, %dx%d, %s%s' % (
+                args.model.upper(), args.depth, 'CPRHead' if args.model == 'cpr' else 'P2PHead', args.size, args.size,
+                {'fwd_loss': 'forward + loss', 'train': 'training step', 'infer': 'inference'}[args.mode],
+                ' (configs[1])' if (args.model, args.mode, args.depth, args.size, args.dtype) == ('cpr', 'fwd_loss', 50, 640, 'fp32')
                 else ' (NOT the headline config)'), 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'gts_per_image': args.num_gts, 'parallelism': 'dp%d' % world,
                        'weights': 'random init (synthetic.locator_state_dict seed 0)'},
