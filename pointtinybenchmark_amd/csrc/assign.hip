@@ -190,6 +190,8 @@ __device__ __forceinline__ ArgD argd_min(ArgD a, ArgD b) {
     return b.it < a.it ? b : a;                    // first assigned in scan order
 }
 
+constexpr int LSA_MAX_VIS = 1024;   // columns one row search can scan = rows on the alternating path + 1 <= G + 1
+
 __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* __restrict__ m_of,
                                 const int* __restrict__ g_of, const long long* __restrict__ cost_off,
                                 const long long* __restrict__ col_off, const long long* __restrict__ row_off, int topk,
@@ -201,6 +203,7 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
                                 unsigned char* __restrict__ sr_all, int* __restrict__ status) {
     __shared__ ArgD sh[16];
     __shared__ int s_i, s_sink, s_fail, s_nact, s_nrem, s_base, s_wcnt[16];
+    __shared__ int s_nvis, s_vis[LSA_MAX_VIS], s_vidx[LSA_MAX_VIS], s_vlast[LSA_MAX_VIS];
     __shared__ double s_minval;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int M = m_of[b], G = g_of[b];
@@ -223,6 +226,10 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
     if (tid == 0) s_fail = 0;
     __syncthreads();
     if (G == 0 || M == 0) return;
+    if (G + 1 > LSA_MAX_VIS) {   // the visited-column log of a row search would not fit: refuse (status 2), never truncate
+        if (tid == 0 && status) status[b] = 2;
+        return;
+    }
 
     for (int round = 0; round < topk; ++round) {
         // ordered compaction of the still-active proposals: cols[c] = original index of the c-th active one
@@ -250,18 +257,21 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
         __syncthreads();
         const int Mc = s_nact;
         if (Mc / G == 0) break;  // cost_new.shape[0] // num_gts != 0
-        for (int c = tid; c < Mc; c += nt) { v[c] = 0.0; row4col[c] = -1; }
+        // per-round state of the column scan order (scipy's `remaining` array and its inverse) and the visited flags: set
+        // up once; every row search below undoes its own few edits instead of re-initialising 25 600 entries per gt
+        for (int c = tid; c < Mc; c += nt) {
+            v[c] = 0.0; row4col[c] = -1;
+            SC[c] = 0;
+            remaining[c] = Mc - 1 - c;  // remaining[it] = nc - it - 1
+            pos[c] = Mc - 1 - c;
+        }
         for (int i = tid; i < G; i += nt) { u[i] = 0.0; col4row[i] = -1; }
         __syncthreads();
         for (int cur = 0; cur < G; ++cur) {
-            for (int c = tid; c < Mc; c += nt) {
-                spc[c] = INFINITY; SC[c] = 0; path[c] = -1;
-                remaining[c] = Mc - 1 - c;  // remaining[it] = nc - it - 1
-                pos[c] = Mc - 1 - c;
-            }
             for (int i = tid; i < G; i += nt) SR[i] = 0;
-            if (tid == 0) { s_i = cur; s_sink = -1; s_minval = 0.0; s_nrem = Mc; }
+            if (tid == 0) { s_i = cur; s_sink = -1; s_minval = 0.0; s_nrem = Mc; s_nvis = 0; }
             __syncthreads();
+            bool first = true;   // first scan of this row: shortestPathCosts = inf, path = -1 for every column (not stored)
             while (true) {
                 const int i = s_i;
                 const double minval = s_minval, ui = u[i];
@@ -271,12 +281,14 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
                 for (int c = tid; c < Mc; c += nt) {
                     if (SC[c]) continue;
                     const double r = ((minval + (double)crow[cols[c]]) - ui) - v[c];
-                    double s = spc[c];
+                    double s = first ? (double)INFINITY : spc[c];
                     if (r < s) { path[c] = i; spc[c] = r; s = r; }
+                    else if (first) { path[c] = -1; spc[c] = s; }
                     ArgD x;
                     x.v = s; x.unassigned = (row4col[c] == -1) ? 1 : 0; x.it = pos[c]; x.c = c;
                     best = (best.c < 0) ? x : argd_min(best, x);
                 }
+                first = false;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     ArgD y;
@@ -303,6 +315,8 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
                         remaining[idx] = last;
                         pos[last] = idx;
                         s_nrem -= 1;
+                        s_vis[s_nvis] = r.c; s_vidx[s_nvis] = idx; s_vlast[s_nvis] = last;   // a search visits <= G columns
+                        s_nvis += 1;
                         if (row4col[r.c] == -1) s_sink = r.c; else s_i = row4col[r.c];
                     }
                 }
@@ -311,16 +325,20 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
             }
             if (s_fail) break;
             const double minval = s_minval;
+            const int nvis = s_nvis;
             for (int i = tid; i < G; i += nt) {
                 if (i == cur) u[i] += minval;
                 else if (SR[i]) u[i] += minval - spc[col4row[i]];
             }
             __syncthreads();
-            for (int c = tid; c < Mc; c += nt)
-                if (SC[c]) v[c] -= minval - spc[c];
+            if (tid < nvis) {            // v[j] -= minVal - shortestPathCosts[j] for the scanned columns only
+                const int c = s_vis[tid];
+                v[c] -= minval - spc[c];
+                SC[c] = 0;
+            }
             __syncthreads();
-            if (tid == 0) {  // augment along the path
-                int j = s_sink;
+            if (tid == 0) {
+                int j = s_sink;          // augment along the path
                 while (true) {
                     const int i = path[j];
                     row4col[j] = i;
@@ -328,6 +346,11 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
                     col4row[i] = j;
                     j = t;
                     if (i == cur) break;
+                }
+                for (int k = nvis - 1; k >= 0; --k) {   // put the scan order back (reverse of the swaps above)
+                    remaining[s_vidx[k]] = s_vis[k];
+                    pos[s_vlast[k]] = Mc - k - 1;
+                    pos[s_vis[k]] = s_vidx[k];
                 }
             }
             __syncthreads();
