@@ -221,6 +221,14 @@ int cpr_pack_weights(const float* w, const float* scale, float* out, int O, int 
  * inv_sigma (optional) = 1/sqrt(var+eps) */
 int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
                 float* shift, float* inv_sigma, int C, void* stream);
+/* gradient of sum_b (loss_cls[b] + loss_pts[b]) of cpr_p2p_loss wrt the class logits (B*M, C) and the regression output
+ * (p2p_head.py:220-248; sigmoid focal loss with its un-detached focal weight, SmoothL1 through
+ * pred = anchor + (point_anchor + reg*gamma_p)*stride).  npos: device scalar, positives in the batch.  dcls (B*M, Cp),
+ * dreg (B*M, Rp): channel-padded for the conv gradient kernels, padding columns written as zero. */
+int cpr_p2p_loss_bwd(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
+                     const int* gt_labels, const int* gt_start, const float* npos, float* dcls, float* dreg, int B, int M,
+                     int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w, float neg_w, float reg_norm,
+                     float w_cls, float w_reg, float gamma_p, void* stream);
 /* sum of squares of a flat gradient buffer into out[0] (double; accumulate across buffers); ws_partial 1024 doubles */
 int cpr_grad_sumsq(const float* g, long long n, double* ws_partial, double* out, int accumulate, void* stream);
 /* torch.optim.SGD step (momentum, weight decay) with clip_grad_norm_'s coefficient taken from norm2 on the device:

@@ -249,12 +249,38 @@ def gen_p2p(R):
     print('p2p', {k: v.shape for k, v in out.items() if 'det0' in k or 'loss' in k})
 
 
+def gen_p2p_grads(R):
+    """loss.backward() through the reference's own P2PHead (towers, output convs, focal + SmoothL1 on its scipy Hungarian
+    assignment): gradients of every head parameter and of the input feature map, as norm / sum / strided sample."""
+    out = {}
+    for ci, (C, hw, G, std) in enumerate([(1, 48, 6, 0.05), (2, 40, 9, 0.08)]):
+        head, sd = build_reference_p2p(R, C, std, seed=ci)
+        head.train()
+        g = torch.Generator().manual_seed(300 + ci)
+        feat = torch.randn((2, 256, hw, hw), generator=g).requires_grad_(True)
+        batch = synthetic.synthetic_batch(2, hw * 4, hw * 4, G, C, seed=300 + ci, ragged=True)
+        cls_outs, pts_outs = head((feat,))
+        losses = head.loss(cls_outs, pts_outs, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'],
+                           gt_bboxes_ignore=[torch.zeros((0, 4)) for _ in batch['gt_labels']])
+        total = sum(sum(v) if isinstance(v, (list, tuple)) else v for k, v in losses.items() if 'loss' in k)
+        total.backward()
+        out['p2p%d_total_loss' % ci] = np.float64(float(total.detach()))
+        tensors = [('bbox_head.' + n, p.grad) for n, p in head.named_parameters()] + [('feat', feat.grad)]
+        for key, gr in tensors:
+            gr = gr.detach().double().flatten()
+            out['p2p%d_norm:%s' % (ci, key)] = np.float64(float(gr.norm()))
+            out['p2p%d_sample:%s' % (ci, key)] = gr[torch.from_numpy(grad_sample_index(gr.numel()))].numpy().astype(np.float32)
+        out['p2p%d_cfg' % ci] = np.array([C, hw, G, int(std * 1000)])
+    np.savez_compressed(os.path.join(GOLDEN, 'p2p_grads.npz'), **out)
+    print('p2p grads', {k: float(v) for k, v in out.items() if 'total' in k})
+
+
 def main():
     assert ref_loader.available(), 'needs /root/reference'
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_loader.load()
-    which = sys.argv[1:] or ['cpr', 'grads', 'assigners', 'p2p']
+    which = sys.argv[1:] or ['cpr', 'grads', 'assigners', 'p2p', 'p2p_grads']
     if 'cpr' in which:
         gen_cpr(R)
     if 'grads' in which:
@@ -263,6 +289,8 @@ def main():
         gen_assigners(R)
     if 'p2p' in which:
         gen_p2p(R)
+    if 'p2p_grads' in which:
+        gen_p2p_grads(R)
 
 
 if __name__ == '__main__':

@@ -659,3 +659,65 @@ extern "C" int cpr_sgd_step(float* p, const float* grad, float* buf, const doubl
                        grad_scale, first);
     CPR_LAUNCH_STATUS();
 }
+
+// ------------------------------------------------------------------------------------------------ P2P loss backward
+// d(sum_b loss_cls[b] + loss_pts[b]) of cpr_p2p_loss (P2PHead.loss_single, p2p_head.py:220-248) wrt the class logits and
+// the regression output.  Sigmoid focal loss (py_sigmoid_focal_loss, focal_loss.py:11-56; the focal weight is NOT detached):
+//   d/dx [bce * at * pt^g] = at * [pt^g (p - t) + bce * g * pt^(g-1) * (1 - 2t) * p (1 - p)]
+// SmoothL1 on pred/stride/reg_norm with pred = anchor + (point_anchor + reg*gamma_p) * stride:
+//   d/dreg = (|e| < beta ? e/beta : sign(e)) * gamma_p / reg_norm,  e = (pred - gt)/stride/reg_norm
+// Both scaled by loss_weight / (number of positives in the batch, a device scalar).  Outputs use the padded channel counts
+// of the conv gradient kernels: dcls (B*M, Cp) with the first C columns live, dreg (B*M, Rp) with the first 2 live.
+__global__ void p2p_loss_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ pred,
+                                    const long long* __restrict__ gt_inds, const float* __restrict__ gt_pts,
+                                    const int* __restrict__ gt_labels, const int* __restrict__ gt_start,
+                                    const float* __restrict__ npos, float* __restrict__ dcls, float* __restrict__ dreg,
+                                    int M, int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w,
+                                    float neg_w, float reg_norm, float w_cls, float w_reg, float gamma_p) {
+    const int b = blockIdx.y;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const size_t r = (size_t)b * M + m;
+    const float inv_n = 1.f / fmaxf(npos[0], 1.f);
+    const long long gi = gt_inds[r];
+    const bool pos = gi > 0;
+    const int g = pos ? gt_start[b] + (int)gi - 1 : 0;
+    const int label = pos ? gt_labels[g] : C;
+    const float w = pos ? pos_w : (neg_w <= 0.f ? 1.f : neg_w);
+    for (int c = 0; c < Cp; ++c) {
+        float d = 0.f;
+        if (c < C) {
+            const float x = logits[r * C + c];
+            const float p = 1.f / (1.f + expf(-x));
+            const float t = (c == label) ? 1.f : 0.f;
+            const float pt = (1.f - p) * t + p * (1.f - t);
+            const float at = alpha * t + (1.f - alpha) * (1.f - t);
+            const float ptg = (gamma == 2.f) ? pt * pt : powf(pt, gamma);
+            const float ptg1 = (gamma == 2.f) ? pt : powf(pt, gamma - 1.f);
+            const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            d = at * (ptg * (p - t) + bce * gamma * ptg1 * (1.f - 2.f * t) * p * (1.f - p)) * w * w_cls * inv_n;
+        }
+        dcls[r * Cp + c] = d;
+    }
+    const float s = pred[r * 3 + 2];
+    for (int k = 0; k < Rp; ++k) {
+        float d = 0.f;
+        if (pos && k < 2) {
+            const float e = pred[r * 3 + k] / s / reg_norm - gt_pts[g * 2 + k] / s / reg_norm;
+            const float de = (fabsf(e) < beta) ? e / beta : (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+            d = de * gamma_p / reg_norm * w_reg * inv_n;
+        }
+        dreg[r * Rp + k] = d;
+    }
+}
+extern "C" int cpr_p2p_loss_bwd(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
+                                const int* gt_labels, const int* gt_start, const float* npos, float* dcls, float* dreg,
+                                int B, int M, int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w,
+                                float neg_w, float reg_norm, float w_cls, float w_reg, float gamma_p, hipStream_t stream) {
+    CPR_CHECK_ARG(B > 0 && M > 0 && C > 0 && Cp >= C && Rp >= 2 && beta > 0);
+    CPR_CHECK_ARG(logits && pred && gt_inds && gt_pts && gt_labels && gt_start && npos && dcls && dreg);
+    hipLaunchKernelGGL(p2p_loss_bwd_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, stream, logits, pred, gt_inds, gt_pts,
+                       gt_labels, gt_start, npos, dcls, dreg, M, C, Cp, Rp, alpha, gamma, beta, pos_w, neg_w, reg_norm,
+                       w_cls, w_reg, gamma_p);
+    CPR_LAUNCH_STATUS();
+}

@@ -76,12 +76,19 @@ class P2PHead(nn.Module):
         nn.init.constant_(self.cls_out.bias, float(-math.log((1 - 0.01) / 0.01)))
 
     # ------------------------------------------------------------------ forward (p2p_head.py:107-123)
-    def _tower(self, convs, out_conv, x):
+    def _tower(self, convs, out_conv, x, tape=None):
+        """tape (list): training mode -- one record per conv+GN layer and a final one for the output conv."""
         ab = None
         for m in convs:
-            x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=True, materialize=False)
+            rec = None
+            if tape is not None:
+                rec = dict(kind='tower')
+                tape.append(rec)
+            x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=True, materialize=False, save=rec)
         pc = packed_conv(self._cache, out_conv)
         H, W = x.shape[1:3]
+        if tape is not None:
+            tape.append(dict(kind='out', conv=out_conv, x=x, in_ab=ab))
         if (H * W) % 128 == 0:
             return ops.conv2d(x, pc, bias=out_conv.bias, in_ab=ab, in_relu=True)
         return ops.conv2d(ops.gn_apply(x, ab[0], ab[1], relu=True), pc, bias=out_conv.bias)
@@ -133,7 +140,7 @@ class P2PHead(nn.Module):
         inds, _ = ops.lsa_topk(costs, a.topk_k)
         return torch.stack(inds)
 
-    def loss(self, cls_outs, pts_outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+    def loss(self, cls_outs, pts_outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None, save=None):
         for gb in gt_bboxes:
             assert len(gb) > 0, gt_bboxes
         anchor, pred, valid, cls = self.get_pred_points(cls_outs, pts_outs, img_metas)
@@ -151,6 +158,9 @@ class P2PHead(nn.Module):
                            _get(self.train_cfg, 'neg_weight', 1.0), self.reg_norm, lc.get('loss_weight', 1.0),
                            lr.get('loss_weight', 1.0))
         B = out.shape[0]
+        if save is not None:      # what the loss backward re-reads (training.P2PTrainer)
+            save.update(cls=cls.contiguous(), pred=pred, gt_inds=gt_inds.contiguous(), gt_pts=torch.cat(gt_points).contiguous(),
+                        gt_labels=torch.cat(gt_labels).to(torch.int32).contiguous(), gt_start=start)
         return {'loss_cls': [out[b, 0] for b in range(B)], 'loss_pts': [out[b, 1] for b in range(B)]}
 
     def get_targets(self, pred_pts, valid_flag_list, cls_outs_list, gt_points, gt_labels, img_metas,

@@ -614,6 +614,19 @@ def cpr_loss_bwd(lmap, neg_mask, out5, bag_logits, valid, labels, bag_ws, center
     return dmap, dbag
 
 
+def p2p_loss_bwd(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, beta, pos_w, neg_w, reg_norm, w_cls,
+                 w_reg, gamma_p, Cp, Rp):
+    """-> (dcls (B,M,Cp), dreg (B,M,Rp)): gradient of the summed P2P losses wrt class logits / regression output."""
+    B, M, C = _check(logits).shape
+    npos = (gt_inds > 0).sum().to(torch.float32).reshape(1)          # device scalar, no host sync
+    dcls = torch.empty((B, M, Cp), device=logits.device, dtype=torch.float32)
+    dreg = torch.empty((B, M, Rp), device=logits.device, dtype=torch.float32)
+    _lib.call('cpr_p2p_loss_bwd', _ptr(logits), _ptr(_check(pred)), _ptr(gt_inds), _ptr(gt_pts), _ptr(gt_labels),
+              _ptr(gt_start), _ptr(npos), _ptr(dcls), _ptr(dreg), B, M, C, Cp, Rp, float(alpha), float(gamma), float(beta),
+              float(pos_w), float(neg_w), float(reg_norm), float(w_cls), float(w_reg), float(gamma_p), _stream())
+    return dcls, dreg
+
+
 def grad_sumsq(g, out, ws, accumulate):
     _lib.call('cpr_grad_sumsq', _ptr(_check(g)), g.numel(), _ptr(ws), _ptr(out), int(accumulate), _stream())
 

@@ -102,9 +102,7 @@ class CprTrainer:
             for p in ps:
                 if p is not None and p.requires_grad and all(p is not q for q in out):
                     out.append(p)
-        add(head.cls_out.weight, head.cls_out.bias, head.ins_out.weight, head.ins_out.bias)
-        for cm in reversed(list(head.cls_convs)):
-            add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
+        self._head_param_order(head, add)
         for cm in neck.fpn_convs:
             add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
         for cm in neck.lateral_convs:
@@ -117,6 +115,12 @@ class CprTrainer:
                 if blk.downsample is not None:
                     add(blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias)
         return out      # a trainable stem (frozen_stages < 0) has no backward rule and trips the constructor's check
+
+    @staticmethod
+    def _head_param_order(head, add):
+        add(head.cls_out.weight, head.cls_out.bias, head.ins_out.weight, head.ins_out.bias)
+        for cm in reversed(list(head.cls_convs)):
+            add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
 
     def _done(self, p):
         """The gradient of ``p`` (and of everything before it in the flat order) has been enqueued."""
@@ -147,13 +151,13 @@ class CprTrainer:
         batch_input_shape = tuple(img[0].size()[-2:])
         for meta in img_metas:
             meta['batch_input_shape'] = batch_input_shape
-        bb_tape, neck_tape, head_tape, lsave = [], [], [], {}
+        bb_tape, neck_tape = [], []
         feats = bb(img, tape=bb_tape)
         lazy = neck.forward_lazy(feats, tape=neck_tape)
-        losses = head.forward_train_lazy(lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes,
-                                         tape=head_tape, save=lsave)
+        losses, saved = self._forward_head(head, lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes)
         self.buckets.reset()
-        d_stage = self._backward_head_neck(head, neck, lsave, head_tape, neck_tape, feats)
+        dz = self._backward_head(head, saved)              # gradient wrt the (normalised) FPN output
+        d_stage = self._backward_neck(neck, neck_tape, dz)
         self._backward_backbone(bb, bb_tape, d_stage)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
@@ -174,7 +178,17 @@ class CprTrainer:
         pt = ops.dgrad_pack(w, cm.conv.stride[0], cm.conv.padding[0])
         return ops.conv2d_dgrad(draw, pt, (rec['x'].shape[1], rec['x'].shape[2]), cm.conv.stride[0])
 
-    def _backward_head_neck(self, head, neck, s, head_tape, neck_tape, feats):
+    # ------------------------------------------------------------------ CPR head
+    @staticmethod
+    def _forward_head(head, lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes):
+        tape, save = [], {}
+        losses = head.forward_train_lazy(lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes,
+                                         tape=tape, save=save)
+        save['tape'] = tape
+        return losses, save
+
+    def _backward_head(self, head, s):
+        head_tape = s['tape']
         C = head.num_classes
         cfg = head.loss_cfg
         J = s['lmap'].shape[-1]
@@ -204,7 +218,31 @@ class CprTrainer:
         for rec in reversed(head_tape):
             dz = self._gn_conv_backward(rec, dz, relu=True, need_dx=True)
             self._done(rec['module'].conv.weight)
-        # ---- FPN: output conv(s), then the top-down chain from the finest lateral to the coarsest
+        return dz
+
+    def _out_conv_backward(self, rec, dout_pad, n_out):
+        """Backward of a biased output conv (nn.Conv2d) reading the un-normalised last tower layer with its GroupNorm
+        affine (+ReLU) applied on load.  dout_pad (N,H,W,Cp): gradient wrt the conv output, channels padded to what the
+        conv gradient kernels take (first n_out live).  Returns the gradient wrt the normalised, activated input."""
+        conv = rec['conv']
+        w = conv.weight
+        Cp = dout_pad.shape[-1]
+        wpad = torch.zeros((Cp,) + tuple(w.shape[1:]), device=w.device, dtype=torch.float32)
+        wpad[:n_out] = w.detach()
+        x, ab = rec['x'], rec['in_ab']
+
+        def param_grads():
+            gw = ops.conv2d_wgrad(dout_pad, x, wpad.shape, conv.stride[0], conv.padding[0], in_ab=ab, in_relu=True)
+            _, gb = ops.relu_bwd_colsum(dout_pad, None, want_g=False)
+            w.grad.copy_(gw[:n_out])
+            conv.bias.grad.copy_(gb[:n_out])
+        self._param_side(param_grads, dout_pad)
+        return ops.conv2d_dgrad(dout_pad, ops.dgrad_pack(wpad, conv.stride[0], conv.padding[0]),
+                                (x.shape[1], x.shape[2]), conv.stride[0])
+
+    # ------------------------------------------------------------------ FPN
+    def _backward_neck(self, neck, neck_tape, dz):
+        """Output conv, then the top-down chain from the finest lateral to the coarsest -> {stage: d(stage output)}."""
         lat_recs = {r['level']: r for r in neck_tape if r['kind'] == 'lateral'}
         out_recs = {r['level']: r for r in neck_tape if r['kind'] == 'out'}
         assert list(out_recs) == [0], 'num_outs == 1 (every shipped CPR config)'
@@ -312,3 +350,52 @@ class CprTrainer:
         self.step(lr)
         loss, log_vars = self.model._parse_losses(losses)
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+
+class P2PTrainer(CprTrainer):
+    """The same training step for BasicLocator(P2PHead) (BASELINE.json configs[3]; T/configs2/**/p2p/*.py): two towers,
+    3x3 output convs with bias, sigmoid-focal + SmoothL1 loss on the device Hungarian assignment (the assignment itself
+    carries no gradient, as in the reference: it works on detached costs, hungarian_assigner.py:214-236)."""
+
+    @staticmethod
+    def _head_param_order(head, add):
+        add(head.reg_out.weight, head.reg_out.bias)
+        for cm in reversed(list(head.reg_convs)):
+            add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
+        add(head.cls_out.weight, head.cls_out.bias)
+        for cm in reversed(list(head.cls_convs)):
+            add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
+
+    @staticmethod
+    def _forward_head(head, lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes):
+        assert len(lazy) == 1 and head.num_points == 1, 'single level, one point per cell (the shipped P2P configs)'
+        raw, (a, b) = lazy[0]
+        x = ops.gn_apply(raw, a, b, relu=False)                   # FPN output, materialised once for the two towers
+        cls_tape, reg_tape, save = [], [], {}
+        cls = ops.as_nchw(head._tower(head.cls_convs, head.cls_out, x, tape=cls_tape))
+        reg = ops.as_nchw(head._tower(head.reg_convs, head.reg_out, x, tape=reg_tape))
+        losses = head.loss([cls], [reg], gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore, save=save)
+        save.update(cls_tape=cls_tape, reg_tape=reg_tape, hw=tuple(x.shape[1:3]))
+        return losses, save
+
+    def _backward_head(self, head, s):
+        from .dense_heads.p2p_head_impl import _get
+        lc, lr = head.loss_cls_cfg, head.loss_reg_cfg
+        B, M, C = s['cls'].shape
+        H, W = s['hw']
+        Cp = 4 if C <= 4 else (C + 31) // 32 * 32
+        dcls, dreg = ops.p2p_loss_bwd(s['cls'], s['pred'], s['gt_inds'], s['gt_pts'], s['gt_labels'], s['gt_start'],
+                                      lc.get('alpha', 0.25), lc.get('gamma', 2.0), lr.get('beta', 1.0),
+                                      _get(head.train_cfg, 'pos_weight', 1.0), _get(head.train_cfg, 'neg_weight', 1.0),
+                                      head.reg_norm, lc.get('loss_weight', 1.0), lr.get('loss_weight', 1.0),
+                                      head.pts_gamma, Cp, 4)
+        dz = None
+        for tape, dout, n_out, last in ((s['reg_tape'], dreg.view(B, H, W, 4), 2, head.reg_convs[0]),
+                                        (s['cls_tape'], dcls.view(B, H, W, Cp), C, head.cls_convs[0])):
+            d = self._out_conv_backward(tape[-1], dout, n_out)
+            self._done(tape[-1]['conv'].bias)
+            for rec in reversed(tape[:-1]):
+                d = self._gn_conv_backward(rec, d, relu=True, need_dx=True)
+                self._done(rec['module'].conv.weight)
+            dz = d if dz is None else ops.axpby(dz, d, 1.0, 1.0)
+        return dz
