@@ -164,3 +164,15 @@ def test_gradient_buckets_single_process_is_a_no_op():
     b = GradBuckets(flat, 4)
     b.ready(10)
     assert b.finish() == 1.0 and torch.equal(flat, torch.ones(10))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/cpr_hip.h is the C ABI: it must compile as C99 and as C++ without any HIP / torch header."""
+    import shutil
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "cpr_hip.h"\nint main(void) { return cpr_version() < 0; }\n')
+    inc = os.path.join(ROOT, 'include')
+    for cc, flags in (('gcc', ['-std=c99']), ('g++', ['-std=c++17', '-x', 'c++'])):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + ' not installed')
+        subprocess.check_call([cc, '-Wall', '-Werror', '-I', inc, '-c', str(src), '-o', str(tmp_path / (cc + '.o'))] + flags)
