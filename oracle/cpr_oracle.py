@@ -176,9 +176,20 @@ def mil_loss(bag_cls_prob, bag_ins_outs, labels, valid, loss_weight=1.0, eps=1e-
 def cpr_points_and_logits(sd, cls_feat, gt_bboxes, gt_labels, img_metas, stride, radius, num_classes,
                           prefix='bbox_head.'):
     """Extraction + scoring shared by loss and refine (cpr_head.py:614-662, 1045-1078), single FPN level,
-    num_refine=1, num_cls_fcs=0, ins_share_head_feat=True.  Returns per-image lists."""
+    num_refine=1, ins_share_head_feat=True; the optional FC stack (num_cls_fcs > 0, get_pts_outs.forward_with_fc
+    :1055-1059) is read off the state dict: relu(fc_i(...)) shared by the cls and ins classifiers.  Returns per-image lists."""
     Wc, bc = sd[prefix + 'cls_out.weight'], sd[prefix + 'cls_out.bias']
     Wi, bi = sd[prefix + 'ins_out.weight'], sd[prefix + 'ins_out.bias']
+    nfc = 0
+    while prefix + 'cls_fcs.%d.weight' % nfc in sd:
+        nfc += 1
+
+    def fcs(x):
+        shape = x.shape
+        x = x.flatten(0, -2)
+        for i in range(nfc):
+            x = F.relu(F.linear(x, sd[prefix + 'cls_fcs.%d.weight' % i], sd[prefix + 'cls_fcs.%d.bias' % i]))
+        return x.reshape(*shape[:-1], -1)
     out = []
     for b in range(len(gt_bboxes)):
         centers = (gt_bboxes[b][:, :2] + gt_bboxes[b][:, 2:]) / 2           # pseudo_bbox_to_center :1293-1301
@@ -189,7 +200,8 @@ def cpr_points_and_logits(sd, cls_feat, gt_bboxes, gt_labels, img_metas, stride,
         bag_feat = sample_bilinear(feat, pts / stride)                        # (G,K,256)
         h, w = feat.shape[2:]
         npts, nvalid = neg_valid_mask(h, w, stride, radius, centers, gt_labels[b], num_classes, ph, pw)
-        nfeat = feat.permute(0, 2, 3, 1)[0].flatten(0, 1)                     # (N,256)
+        nfeat = fcs(feat.permute(0, 2, 3, 1)[0].flatten(0, 1))                # (N,256) -> FC stack
+        bag_feat = fcs(bag_feat)
         out.append(dict(centers=centers, pts=pts, valid=valid,
                         cls_logit=F.linear(bag_feat, Wc, bc), ins_logit=F.linear(bag_feat, Wi, bi),
                         neg_pts=npts, neg_valid=nvalid, neg_logit=F.linear(nfeat, Wc, bc)))

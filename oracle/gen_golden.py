@@ -24,7 +24,7 @@ GN = dict(type='GN', num_groups=32, requires_grad=True)
 
 
 def build_reference_cpr(R, depth=50, num_classes=1, start_level=0, stride=4, radius=5, head_std=0.01, seed=0,
-                        policy='independent_with_gt_bag'):
+                        policy='independent_with_gt_bag', num_cls_fcs=0, fc_out_channels=1024):
     chans = synthetic.backbone_out_channels(depth)
     backbone = R.ResNet(depth=depth, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
                         norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch')
@@ -32,8 +32,8 @@ def build_reference_cpr(R, depth=50, num_classes=1, start_level=0, stride=4, rad
                  num_outs=1, norm_cfg=GN)
     alpha = 0.25
     head = R.CPRHead(
-        norm_cfg=GN, num_classes=num_classes, in_channels=256, feat_channels=256, stacked_convs=4, num_cls_fcs=0,
-        strides=[stride], loss_mil=dict(type='MILLoss', binary_ins=False, loss_weight=alpha), loss_type=0,
+        norm_cfg=GN, num_classes=num_classes, in_channels=256, feat_channels=256, stacked_convs=4,
+        num_cls_fcs=num_cls_fcs, fc_out_channels=fc_out_channels, strides=[stride], loss_mil=dict(type='MILLoss', binary_ins=False, loss_weight=alpha), loss_type=0,
         loss_cfg=dict(with_neg=True, neg_loss_weight=1 - alpha, refine_bag_policy=policy,
                       random_remove_rate=0.4, with_gt_loss=True, gt_loss_weight=alpha, with_mil_loss=True),
         normal_cfg=dict(prob_cls_type='sigmoid', out_bg_cls=False),
@@ -45,7 +45,8 @@ def build_reference_cpr(R, depth=50, num_classes=1, start_level=0, stride=4, rad
         point_refiner=dict(merge_th=0.1, refine_th=0.1, classify_filter=True),
         test_cfg=ref_loader.AttrDict(nms_pre=2000, min_bbox_size=0, score_thr=0.05,
                                      nms=dict(type='nms', iou_threshold=0.5), max_per_img=1000))
-    sd = synthetic.locator_state_dict(depth, num_classes, start_level, 'cpr', seed, head_std)
+    sd = synthetic.locator_state_dict(depth, num_classes, start_level, 'cpr', seed, head_std, num_cls_fcs=num_cls_fcs,
+                                      fc_out_channels=fc_out_channels)
     backbone.load_state_dict({k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}, strict=True)
     neck.load_state_dict({k[len('neck.'):]: v for k, v in sd.items() if k.startswith('neck.')}, strict=True)
     head.load_state_dict({k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}, strict=True)
@@ -57,7 +58,9 @@ def build_reference_cpr(R, depth=50, num_classes=1, start_level=0, stride=4, rad
 def run_reference_cpr(R, cfg):
     torch.manual_seed(0)
     backbone, neck, head, sd = build_reference_cpr(R, cfg['depth'], cfg['num_classes'], cfg['start_level'],
-                                                   cfg['stride'], cfg['radius'], cfg['head_std'], cfg['seed'])
+                                                   cfg['stride'], cfg['radius'], cfg['head_std'], cfg['seed'],
+                                                   num_cls_fcs=cfg.get('num_cls_fcs', 0),
+                                                   fc_out_channels=cfg.get('fc_out_channels', 1024))
     batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
                                       cfg['seed'], cfg.get('ragged', False))
     with torch.no_grad():
@@ -99,6 +102,9 @@ CPR_CASES = {
                                   batch=2, height=160, width=192, num_gts=7, ragged=True),
     'cpr_r18_c3_128': dict(depth=18, num_classes=3, start_level=0, stride=4, radius=5, head_std=0.3, seed=5, batch=2,
                            height=128, width=128, num_gts=9, ragged=True),
+    # num_cls_fcs > 0: two shared FC layers between the sampled features and the classifiers
+    'cpr_r18_c3_fc2': dict(depth=18, num_classes=3, start_level=0, stride=4, radius=5, head_std=0.05, seed=11, batch=2,
+                           height=128, width=160, num_gts=7, ragged=True, num_cls_fcs=2, fc_out_channels=64),
     'cpr_r50_c80_s8_r8': dict(depth=50, num_classes=80, start_level=1, stride=8, radius=8, head_std=0.3, seed=7,
                               batch=1, height=224, width=256, num_gts=8),
 }

@@ -100,8 +100,10 @@ class CPRHead(nn.Module):
                  conv_bias='auto', loss_cls=None, loss_bbox=None, conv_cfg=None, norm_cfg=None, train_cfg=None,
                  test_cfg=None):
         super().__init__()
-        assert num_cls_fcs == 0 and ins_share_head_feat and not loss_mil.get('binary_ins', False) and loss_type == 0, \
+        assert num_cls_fcs >= 0 and ins_share_head_feat and not loss_mil.get('binary_ins', False) and loss_type == 0, \
             'options outside the shipped configs are SURVEY.md §8f rank 4 ("next")'
+        assert num_cls_fcs == 0 or fc_out_channels % 32 == 0, 'fc_out_channels must be a multiple of 32'
+        self.num_cls_fcs, self.fc_out_channels = num_cls_fcs, fc_out_channels
         assert normal_cfg.get('prob_cls_type', 'sigmoid') == 'sigmoid' and not normal_cfg.get('out_bg_cls', False)
         assert norm_cfg is not None and norm_cfg['type'] == 'GN' and not dcn_on_last_conv and not debug
         self.num_classes = self.cls_out_channels = self.num_cls_out = num_classes
@@ -122,8 +124,11 @@ class CPRHead(nn.Module):
         for _ in range(stacked_convs):
             self.cls_convs.append(ConvModule(chn, feat_channels, 3, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg))
             chn = feat_channels
-        self.cls_fcs = nn.ModuleList()
+        self.cls_fcs = nn.ModuleList()     # shared by the cls and ins classifiers (ins_share_head_feat, cpr_head.py:999-1005)
         self.ins_fcs = nn.ModuleList()
+        for _ in range(num_cls_fcs):
+            self.cls_fcs.append(nn.Linear(chn, fc_out_channels))
+            chn = fc_out_channels
         self.cls_out = nn.Linear(chn, num_classes)
         self.ins_out = self.cls_out if ins_share_head_classifier else nn.Linear(chn, num_classes)
         self.loss_mil = build_loss(loss_mil)
@@ -194,10 +199,23 @@ class CPRHead(nn.Module):
                          gt_true_bboxes=gt_true_bboxes, save=save)
 
     # ------------------------------------------------------------------ shared extraction
+    def _fc_stack(self, rows_nhwc):
+        """get_pts_outs.forward_with_fc (cpr_head.py:1055-1059): relu(fc_i(.)) as 1x1 convs over an NHWC block of rows."""
+        x = rows_nhwc
+        for i, fc in enumerate(self.cls_fcs):
+            pc, bias = self._cache.get(('fc', i, x.dtype), [fc.weight, fc.bias], lambda fc=fc, x=x: (
+                ops.PackedConv(fc.weight.detach()[:, :, None, None], 1, 0, x.dtype), fc.bias.detach().float().contiguous()))
+            x = ops.conv2d(x, pc, bias=bias, relu=True)
+        return x
+
     def _logit_map(self, feat_nhwc, in_ab=None):
         """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C)] (or C when the classifier is shared).
-        in_ab: the input is the raw last-layer conv output and (a, b) its GroupNorm affine (+ReLU), applied on load."""
+        in_ab: the input is the raw last-layer conv output and (a, b) its GroupNorm affine (+ReLU), applied on load.
+        With num_cls_fcs > 0 the (materialised) input first runs through the shared FC stack."""
         dt = feat_nhwc.dtype
+        if self.num_cls_fcs > 0:
+            assert in_ab is None
+            feat_nhwc = self._fc_stack(feat_nhwc)
 
         def make():
             w = [self.cls_out.weight] + ([] if self.ins_share_head_classifier else [self.ins_out.weight])
@@ -210,6 +228,17 @@ class CPRHead(nn.Module):
             feat_nhwc, in_ab = ops.gn_apply(feat_nhwc, in_ab[0], in_ab[1], relu=True), None
         # the logit map is always fp32 (the loss / sampling kernels are shared by both compute modes)
         return ops.conv2d(feat_nhwc, pc, bias=bias, in_ab=in_ab, in_relu=True, out_dtype=torch.float32)
+
+    def _bags(self, feat, lmap, centers, gt_img, pad_hw, offsets, stride):
+        """Bag points, validity and bag logits (G,K,J).  num_cls_fcs == 0: Linear commutes with bilinear sampling, so the
+        logits are sampled from the projected map.  Otherwise the 256-channel features are sampled and run through the FC
+        stack + classifiers (the ReLUs in between do not commute with the interpolation)."""
+        if self.num_cls_fcs == 0:
+            return ops.bag_sample(lmap, centers, gt_img, pad_hw, offsets, stride)
+        pts, valid, bag_feat = ops.bag_sample(feat, centers, gt_img, pad_hw, offsets, stride)
+        G, K, Cf = bag_feat.shape
+        logits = self._logit_map(bag_feat.view(1, G * K, 1, Cf))
+        return pts, valid, logits.view(G, K, -1)
 
     def _gt_tensors(self, gt_bboxes, gt_labels, img_metas, device, shape_key):
         counts = [int(len(l)) for l in gt_labels]
@@ -245,10 +274,13 @@ class CPRHead(nn.Module):
         else:
             feat, ab = ops.from_nchw(cls_feat[0]), None
         dev = feat.device
+        if self.num_cls_fcs > 0 and ab is not None:       # the FC path samples the normalised, activated features
+            assert save is None, 'the training step is built for num_cls_fcs == 0'
+            feat, ab = ops.gn_apply(feat, ab[0], ab[1], relu=True), None
         lmap = self._logit_map(feat, ab)
         centers, labels, gt_start, gt_img, pad_hw, _ = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev,
                                                                         'pad_shape')
-        _, valid, bag_logits = ops.bag_sample(lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
+        _, valid, bag_logits = self._bags(feat, lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
         cfg = self.loss_cfg
         partial = neg_mask = None
         if cfg.get('with_neg', True):
@@ -289,7 +321,7 @@ class CPRHead(nn.Module):
                                                                              'pad_shape')
         img_hw = torch.tensor([[m['img_shape'][0], m['img_shape'][1]] for m in img_metas], dtype=torch.int32,
                               device=dev).reshape(-1)
-        pts, valid, bag_logits = ops.bag_sample(lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
+        pts, valid, bag_logits = self._bags(feat, lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
         # the grid (negative) branch is computed but unused by the reference at refine time (cpr_head.py:794-804)
         nr_in = None if not_refine is None else torch.cat(list(not_refine)).to(torch.uint8).to(dev).contiguous()
         rp, sc, nr, chosen = ops.refine(bag_logits, pts, valid, centers, labels, gt_img, gt_start, img_hw, C,

@@ -97,7 +97,7 @@ def fpn_state_dict(in_channels, out_channels=256, start_level=0, num_outs=1, see
 
 
 def cpr_head_state_dict(num_classes=1, in_channels=256, feat_channels=256, stacked_convs=4, seed=2,
-                        prefix='bbox_head.', std=0.01):
+                        prefix='bbox_head.', std=0.01, num_cls_fcs=0, fc_out_channels=1024):
     """Normal(0, std) on Conv2d/Linear, cls_out bias = bias_init_with_prob(0.01)
     (T/mmdet/models/point/dense_heads/cpr_head.py:939-948).  ``std`` larger than the reference's
     0.01 makes the synthetic logits spread out (used by tests to exercise the refine filters)."""
@@ -108,6 +108,10 @@ def cpr_head_state_dict(num_classes=1, in_channels=256, feat_channels=256, stack
         sd['%scls_convs.%d.conv.weight' % (prefix, i)] = torch.randn((feat_channels, chn, 3, 3), generator=g) * 0.01
         _gn(sd, '%scls_convs.%d.gn' % (prefix, i), feat_channels, g)
         chn = feat_channels
+    for i in range(num_cls_fcs):          # cpr_head.py:999-1005 (ins_share_head_feat: no separate ins_fcs)
+        sd['%scls_fcs.%d.weight' % (prefix, i)] = torch.randn((fc_out_channels, chn), generator=g) * (2.0 / chn) ** 0.5
+        sd['%scls_fcs.%d.bias' % (prefix, i)] = torch.randn((fc_out_channels,), generator=g) * 0.1
+        chn = fc_out_channels
     sd[prefix + 'cls_out.weight'] = torch.randn((num_classes, chn), generator=g) * std
     sd[prefix + 'cls_out.bias'] = torch.full((num_classes,), -math.log((1 - 0.01) / 0.01))
     sd[prefix + 'ins_out.weight'] = torch.randn((num_classes, chn), generator=g) * std
@@ -133,11 +137,13 @@ def p2p_head_state_dict(num_classes=1, num_points=1, in_channels=256, feat_chann
     return sd
 
 
-def locator_state_dict(depth=50, num_classes=1, start_level=0, head='cpr', seed=0, head_std=0.01, num_points=1):
+def locator_state_dict(depth=50, num_classes=1, start_level=0, head='cpr', seed=0, head_std=0.01, num_points=1,
+                       num_cls_fcs=0, fc_out_channels=1024):
     sd = resnet_state_dict(depth, seed)
     sd.update(fpn_state_dict(backbone_out_channels(depth), 256, start_level, 1, seed + 1))
     if head == 'cpr':
-        sd.update(cpr_head_state_dict(num_classes, seed=seed + 2, std=head_std))
+        sd.update(cpr_head_state_dict(num_classes, seed=seed + 2, std=head_std, num_cls_fcs=num_cls_fcs,
+                                      fc_out_channels=fc_out_channels))
     else:
         sd.update(p2p_head_state_dict(num_classes, num_points, seed=seed + 3, std=head_std))
     return sd

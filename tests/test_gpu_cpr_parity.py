@@ -27,7 +27,8 @@ def build_hip_locator(cfg):
                   start_level=cfg['start_level'], add_extra_convs='on_input', num_outs=1, norm_cfg=GN),
         bbox_head=dict(
             type='CPRHead', norm_cfg=GN, num_classes=cfg['num_classes'], in_channels=256, feat_channels=256,
-            stacked_convs=4, num_cls_fcs=0, strides=[cfg['stride']],
+            stacked_convs=4, num_cls_fcs=cfg.get('num_cls_fcs', 0), fc_out_channels=cfg.get('fc_out_channels', 1024),
+            strides=[cfg['stride']],
             loss_mil=dict(type='MILLoss', binary_ins=False, loss_weight=alpha), loss_type=0,
             loss_cfg=dict(with_neg=True, neg_loss_weight=1 - alpha, refine_bag_policy='independent_with_gt_bag',
                           random_remove_rate=0.4, with_gt_loss=True, gt_loss_weight=alpha, with_mil_loss=True),
@@ -40,7 +41,8 @@ def build_hip_locator(cfg):
             point_refiner=dict(merge_th=0.1, refine_th=0.1, classify_filter=True)))
     m = P.build_detector(model).cuda()
     sd = synthetic.locator_state_dict(cfg['depth'], cfg['num_classes'], cfg['start_level'], 'cpr', cfg['seed'],
-                                      cfg['head_std'])
+                                      cfg['head_std'], num_cls_fcs=cfg.get('num_cls_fcs', 0),
+                                      fc_out_channels=cfg.get('fc_out_channels', 1024))
     m.load_state_dict(sd, strict=True)
     m.train()
     return m, sd
@@ -71,8 +73,8 @@ def run_hip(cfg):
         centers, labels, gt_start, gt_img, pad_hw, _ = head._gt_tensors(cb['gt_bboxes'], cb['gt_labels'],
                                                                        cb['img_metas'], feat.device, 'pad_shape')
         ex = head.train_pts_extractor
-        pts, valid, bag = ops.bag_sample(lmap, centers, gt_img, pad_hw, ex.offsets(cfg['stride'], feat.device),
-                                         cfg['stride'])
+        pts, valid, bag = head._bags(feat, lmap, centers, gt_img, pad_hw, ex.offsets(cfg['stride'], feat.device),
+                                     cfg['stride'])
         mask, _ = ops.neg_mask_loss(lmap, centers, labels, gt_start, pad_hw, cfg['num_classes'], cfg['stride'],
                                     head._d2_threshold(cfg['stride'], ex.neg_radius), 1e-6, ex.neg_class_wise)
         torch.cuda.synchronize()

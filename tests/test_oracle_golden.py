@@ -20,7 +20,8 @@ def test_cpr_path_matches_reference_fixture(golden_dir, name):
     cfg = CPR_CASES[name]
     g = _load(golden_dir, name)
     sd = synthetic.locator_state_dict(cfg['depth'], cfg['num_classes'], cfg['start_level'], 'cpr', cfg['seed'],
-                                      cfg['head_std'])
+                                      cfg['head_std'], num_cls_fcs=cfg.get('num_cls_fcs', 0),
+                                      fc_out_channels=cfg.get('fc_out_channels', 1024))
     batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
                                       cfg['seed'], cfg.get('ragged', False))
     torch.set_num_threads(8)
@@ -96,7 +97,8 @@ def test_oracle_autograd_matches_reference_autograd(golden_dir, name):
     cfg = CPR_CASES[name]
     gold = _load(golden_dir, 'cpr_grads_' + name)
     sd = synthetic.locator_state_dict(cfg['depth'], cfg['num_classes'], cfg['start_level'], 'cpr', cfg['seed'],
-                                      cfg['head_std'])
+                                      cfg['head_std'], num_cls_fcs=cfg.get('num_cls_fcs', 0),
+                                      fc_out_channels=cfg.get('fc_out_channels', 1024))
     keys = [k[len('norm:'):] for k in gold.files if k.startswith('norm:')]
     assert len(keys) == int(gold['num_tensors'])
     sd = {k: v.clone() for k, v in sd.items()}
