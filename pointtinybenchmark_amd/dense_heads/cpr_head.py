@@ -284,7 +284,8 @@ class CPRHead(nn.Module):
         cfg = self.loss_cfg
         partial = neg_mask = None
         if cfg.get('with_neg', True):
-            assert not ex.neg_is_anchor
+            # the reference cannot train with it either: loss0 unpacks a (H, W, C) tensor into two dims (cpr_head.py:1221)
+            assert not ex.neg_is_anchor, 'AnchorPtFeatGenerator is a refine-time generator only'
             neg_mask, partial = ops.neg_mask_loss(lmap, centers, labels, gt_start, pad_hw, C, stride,
                                            self._d2_threshold(stride, ex.neg_radius), self.loss_mil.eps,
                                            ex.neg_class_wise)
