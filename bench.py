@@ -199,10 +199,12 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0):
     t_start = time.perf_counter()
     one(min(16, avail))                                            # warm-up (allocator, oneDNN primitive cache)
     trials = {}
+    worse = 0
     for t in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
-        if time.perf_counter() - t_start > seconds_budget * 0.6:
-            break
+        if time.perf_counter() - t_start > seconds_budget * 0.6 or worse >= 2:
+            break      # out of budget, or two thread counts in a row slower than the best (256 threads took ~55 s/step here)
         trials[t] = one(t)
+        worse = worse + 1 if trials[t] > min(trials.values()) else 0
     best = min(trials, key=trials.get)
     times = [trials[best]]
     while len(times) < 4 and time.perf_counter() - t_start < seconds_budget:
