@@ -134,3 +134,42 @@ def test_backward_matches_reference_autograd_golden(name):
         smp = g[torch.from_numpy(grad_sample_index(g.numel()))].numpy()
         ref = gold['sample:' + k].astype(np.float64)
         assert np.abs(smp - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-5 * gmax), k
+
+
+@pytest.mark.parametrize('kind', ['cpr', 'p2p'])
+def test_bucket_ready_points_only_cover_finished_gradients(kind):
+    """The multi-GPU overlap contract, checked on one GPU: whenever the backward declares ``gradients [0, end) are final``
+    (the point where a bucket's all-reduce may be launched), every gradient in that range has really been written -- on
+    either stream.  The flat gradient buffer is poisoned with NaN before the backward; at every ready point the prefix
+    must be NaN-free, and at the end the whole buffer."""
+    import pointtinybenchmark_amd as P
+    from pointtinybenchmark_amd import training
+    cfg = CPR_CASES['cpr_r18_c3_128']
+    if kind == 'cpr':
+        m, _ = build_hip_locator(cfg)
+        base = training.CprTrainer
+    else:
+        from bench import p2p_model_cfg
+        m = P.build_detector(p2p_model_cfg(18)).cuda()
+        m.load_state_dict(synthetic.locator_state_dict(18, 1, 0, 'p2p', 3, head_std=0.05), strict=True)
+        m.train()
+        base = training.P2PTrainer
+    seen = []
+
+    class Checked(base):
+        def _done(self, p):
+            end = self.offset[id(p)][1]
+            torch.cuda.synchronize()          # what wait_stream(side) + stream order give the collective
+            bad = torch.isnan(self.flat_g[:end])
+            assert not bool(bad.any()), 'gradient prefix [0, %d) declared final with %d unwritten entries (first at %d)' % (
+                end, int(bad.sum()), int(bad.nonzero()[0]))
+            seen.append(end)
+    tr = Checked(m)
+    tr.flat_g.fill_(float('nan'))
+    C = 1 if kind == 'p2p' else cfg['num_classes']
+    batch = synthetic.synthetic_batch(2, 128, 160, 6, C, seed=8)
+    cb = to_cuda(batch)
+    tr.forward_backward(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(tr.flat_g).any()), 'some trainable parameter never received a gradient'
+    assert seen and max(seen) == tr.flat_g.numel() and seen == sorted(seen), 'ready points must sweep the buffer front to back'
