@@ -23,8 +23,10 @@ class GradBuckets:
     fully below ``end`` is all-reduced asynchronously (on the process group's own stream).  Works on CPU tensors with
     gloo (tests) and on device tensors with nccl (= RCCL)."""
 
-    def __init__(self, flat, bucket_elems, group=None):
-        self.flat, self.group = flat, group
+    def __init__(self, flat, bucket_elems, group=None, force=False):
+        """force: issue the collectives even in a 1-rank group (a sum over one rank is the identity) -- lets a single GPU
+        exercise the real RCCL path (tests)."""
+        self.flat, self.group, self.force = flat, group, force
         n = flat.numel()
         self.bounds = list(range(0, n, bucket_elems)) + [n]
         if len(self.bounds) > 2 and self.bounds[-1] - self.bounds[-2] < bucket_elems // 4:
@@ -38,11 +40,17 @@ class GradBuckets:
     def reset(self):
         self.next, self.pending = 0, []
 
+    @property
+    def active(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self.world_size > 1 or self.force
+
     def would_launch(self, end):
-        return self.world_size > 1 and self.next + 1 < len(self.bounds) and self.bounds[self.next + 1] <= end
+        return self.active and self.next + 1 < len(self.bounds) and self.bounds[self.next + 1] <= end
 
     def ready(self, end):
-        if self.world_size == 1:
+        if not self.active:
             return
         while self.next + 1 < len(self.bounds) and self.bounds[self.next + 1] <= end:
             lo, hi = self.bounds[self.next], self.bounds[self.next + 1]
@@ -62,7 +70,7 @@ class GradBuckets:
 
 class CprTrainer:
     def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_mb=25.0, group=None,
-                 two_streams=True):
+                 two_streams=True, force_collectives=False):
         self.model = model
         self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
         order = self._backward_order()
@@ -83,7 +91,7 @@ class CprTrainer:
             p.grad = self.flat_g[off:off + k].view(p.shape)
             self.offset[id(p)] = (off, off + k)
             off += k
-        self.buckets = GradBuckets(self.flat_g, max(1, int(bucket_mb * (1 << 20) / 4)), group)
+        self.buckets = GradBuckets(self.flat_g, max(1, int(bucket_mb * (1 << 20) / 4)), group, force=force_collectives)
         self.norm2 = torch.zeros((1,), device=dev, dtype=torch.float64)
         self._ws = torch.empty((1024,), device=dev, dtype=torch.float64)
         self.steps = 0

@@ -173,3 +173,34 @@ def test_bucket_ready_points_only_cover_finished_gradients(kind):
     torch.cuda.synchronize()
     assert not bool(torch.isnan(tr.flat_g).any()), 'some trainable parameter never received a gradient'
     assert seen and max(seen) == tr.flat_g.numel() and seen == sorted(seen), 'ready points must sweep the buffer front to back'
+
+
+def test_rccl_bucket_path_single_rank():
+    """The real collective path on one GPU: a 1-rank `nccl` (= RCCL) process group with the collectives forced on.  Bucketed
+    async all-reduce of device slices, the wait before the optimizer and the 1/world scale must leave the step equal to the
+    non-distributed one (a sum over one rank is the identity)."""
+    import torch.distributed as dist
+    from pointtinybenchmark_amd.training import CprTrainer
+    cfg = CPR_CASES['cpr_r18_c3_128']
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'], 5, True)
+    cb = to_cuda(batch)
+    data = dict(img=cb['img'], img_metas=cb['img_metas'], gt_bboxes=cb['gt_bboxes'], gt_labels=cb['gt_labels'])
+
+    def run(force):
+        m, _ = build_hip_locator(cfg)
+        tr = CprTrainer(m, lr=0.01, bucket_mb=4.0, force_collectives=force)
+        outs = [tr.train_step(dict(data))['log_vars']['loss'] for _ in range(2)]
+        torch.cuda.synchronize()
+        return outs, tr.flat_p.clone(), len(tr.buckets.bounds) - 1
+    ref_losses, ref_p, _ = run(False)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        losses, p, nb = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert nb >= 3, 'several buckets must be in play (%d)' % nb
+    # not bit-equal even run to run: the bilinear scatter of the loss backward sums with float atomics
+    assert losses[0] == ref_losses[0] and abs(losses[1] - ref_losses[1]) <= 1e-5 * abs(ref_losses[1]), (losses, ref_losses)
+    assert float((p - ref_p).abs().max()) <= 1e-5 * float(ref_p.abs().max())
