@@ -246,10 +246,26 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
-    if world > 1:
+    # launched by torch.distributed.run (RANK in the environment): take the distributed code path even with one rank, so the
+    # N-GPU plumbing (process group, barriers, max-over-ranks, gradient collectives) can be exercised on a 1-GPU box
+    distributed = world > 1 or 'RANK' in os.environ
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)  # backend "nccl" is RCCL on ROCm
+        # RCCL prints a version banner on STDOUT when the first communicator is created; stdout must carry exactly one JSON
+        # line, so the group is created and warmed (one barrier) with fd 1 pointed at stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', rank=rank, world_size=world,      # backend "nccl" is RCCL on ROCm
+                                    device_id=torch.device('cuda', local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     import pointtinybenchmark_amd as P
@@ -275,7 +291,8 @@ def main():
         from pointtinybenchmark_amd.training import CprTrainer, P2PTrainer
         cls = P2PTrainer if args.model == 'p2p' else CprTrainer
         return cls(model, lr=1e-3 if args.model == 'cpr' else 1e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0,
-                          two_streams=os.environ.get('CPR_TRAIN_STREAMS', '2') != '1')
+                          two_streams=os.environ.get('CPR_TRAIN_STREAMS', '2') != '1',
+                          force_collectives=distributed and world == 1)
 
     def train_step():
         losses = trainer.forward_backward(img, metas, gtb, gtl)
@@ -302,7 +319,7 @@ def main():
         probe.install()
 
     def barrier():
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -314,7 +331,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if probe:
         probe.remove()
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -339,7 +356,7 @@ def main():
                 tl = train_step()
             barrier()
             te = time.perf_counter() - t1
-            if world > 1:
+            if distributed:
                 t = torch.tensor([te], device='cuda', dtype=torch.float64)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
                 te = float(t.item())
@@ -413,7 +430,7 @@ def main():
         if train_info is not None:
             out['train_step'] = train_info
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         torch.distributed.destroy_process_group()
 
 
