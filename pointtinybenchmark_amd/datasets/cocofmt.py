@@ -100,48 +100,37 @@ class CocoFmtDataset:
 
     # ------------------------------------------------------------------ cocofmt.py:157-225
     def _parse_ann_info(self, img_info, ann_info):
-        gt_bboxes, gt_labels, gt_bboxes_ignore, gt_masks_ann = [], [], [], []
-        true_bboxes, anns_id = [], []
-        for ann in ann_info:
-            if self.train_ignore_as_bg and ann.get('ignore', False):
-                continue
-            x1, y1, w, h = ann['bbox']
-            inter_w = max(0, min(x1 + w, img_info['width']) - max(x1, 0))
-            inter_h = max(0, min(y1 + h, img_info['height']) - max(y1, 0))
-            if inter_w * inter_h == 0:
-                continue
-            if ann['area'] <= 0 or w < 1 or h < 1:
-                continue
-            if ann['category_id'] not in self.cat_ids:
-                continue
-            bbox = [x1, y1, x1 + w, y1 + h]
-            if ann.get('iscrowd', False):
-                gt_bboxes_ignore.append(bbox)
-            else:
-                gt_bboxes.append(bbox)
-                gt_labels.append(self.cat2label[ann['category_id']])
-                gt_masks_ann.append(ann.get('segmentation', None))
-                if 'true_bbox' in ann:
-                    tx, ty, tw, th = ann['true_bbox']
-                    true_bboxes.append([tx, ty, tx + tw, ty + th])
-                anns_id.append(ann['id'])
-        if len(true_bboxes) > 0:
-            true_bboxes = np.array(true_bboxes, dtype=np.float32)
-            anns_id = np.array(anns_id, dtype=np.int64)
-        if gt_bboxes:
-            gt_bboxes = np.array(gt_bboxes, dtype=np.float32)
-            gt_labels = np.array(gt_labels, dtype=np.int64)
-        else:
-            gt_bboxes = np.zeros((0, 4), dtype=np.float32)
-            gt_labels = np.array([], dtype=np.int64)
-        if gt_bboxes_ignore:
-            gt_bboxes_ignore = np.array(gt_bboxes_ignore, dtype=np.float32)
-        else:
-            gt_bboxes_ignore = np.zeros((0, 4), dtype=np.float32)
-        ann = dict(bboxes=gt_bboxes, labels=gt_labels, anns_id=anns_id, bboxes_ignore=gt_bboxes_ignore,
-                   masks=gt_masks_ann, seg_map=img_info['filename'].replace('jpg', 'png'))
-        if len(true_bboxes) > 0:
-            ann['true_bboxes'] = true_bboxes
+        """One image's annotations -> the ``ann_info`` dict of the reference (same keys, dtypes and the same quirk: ``anns_id``
+        stays a plain list unless some annotation carries a ``true_bbox``)."""
+        W, H = img_info['width'], img_info['height']
+
+        def usable(a):
+            if self.train_ignore_as_bg and a.get('ignore', False):
+                return False
+            x, y, w, h = a['bbox']
+            clipped_w = max(0, min(x + w, W) - max(x, 0))
+            clipped_h = max(0, min(y + h, H) - max(y, 0))
+            return clipped_w * clipped_h != 0 and a['area'] > 0 and w >= 1 and h >= 1 and a['category_id'] in self.cat2label
+
+        def xyxy(box):
+            x, y, w, h = box
+            return [x, y, x + w, y + h]
+        kept = [a for a in ann_info if usable(a)]
+        crowd = [a for a in kept if a.get('iscrowd', False)]
+        real = [a for a in kept if not a.get('iscrowd', False)]
+        true_boxes = [xyxy(a['true_bbox']) for a in real if 'true_bbox' in a]
+        ids = [a['id'] for a in real]
+
+        def boxes(rows):
+            return np.array(rows, dtype=np.float32) if rows else np.zeros((0, 4), dtype=np.float32)
+        ann = dict(bboxes=boxes([xyxy(a['bbox']) for a in real]),
+                   labels=np.array([self.cat2label[a['category_id']] for a in real], dtype=np.int64),
+                   anns_id=np.array(ids, dtype=np.int64) if true_boxes else ids,
+                   bboxes_ignore=boxes([xyxy(a['bbox']) for a in crowd]),
+                   masks=[a.get('segmentation', None) for a in real],
+                   seg_map=img_info['filename'].replace('jpg', 'png'))
+        if true_boxes:
+            ann['true_bboxes'] = np.array(true_boxes, dtype=np.float32)
         return ann
 
     # ------------------------------------------------------------------ sample assembly (custom.py:185-215 + LoadAnnotations)

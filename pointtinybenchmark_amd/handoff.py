@@ -78,25 +78,20 @@ def load_res_bbox(dataset, anns):
     return res
 
 
-def xywh2centerwh(xywh):
-    x1, y1, w, h = xywh
-    return [x1 + w / 2, y1 + h / 2, w, h]
-
-
-def centerwh2xywh(centerwh):
-    xc, yc, w, h = centerwh
-    return [xc - w / 2, yc - h / 2, w, h]
+def _centre(xywh):
+    return xywh[0] + xywh[2] / 2, xywh[1] + xywh[3] / 2
 
 
 def turn_bbox_wh(bbox, new_wh):
-    """Re-size a box around its centre (result2ann.py:44-54)."""
-    if new_wh[0] > 0 and new_wh[1] > 0:
-        xc, yc, _, _ = xywh2centerwh(bbox)
-        new_bbox = centerwh2xywh([xc, yc, new_wh[0], new_wh[1]])
-        cb1, cb2 = xywh2centerwh(new_bbox)[:2], xywh2centerwh(bbox)[:2]
-        assert round(cb1[0]) == round(cb2[0]) and round(cb1[1]) == round(cb2[1]), (bbox, new_bbox)
-        bbox = new_bbox
-    return bbox
+    """Re-size a box around its centre when both target sides are positive (result2ann.py:44-54); the centre must survive
+    to the pixel."""
+    if not (new_wh[0] > 0 and new_wh[1] > 0):
+        return bbox
+    cx, cy = _centre(bbox)
+    out = [cx - new_wh[0] / 2, cy - new_wh[1] / 2, new_wh[0], new_wh[1]]
+    ox, oy = _centre(out)
+    assert round(ox) == round(cx) and round(oy) == round(cy), (bbox, out)
+    return out
 
 
 def result2ann(ori_dataset, det_results, wh=-1):
@@ -126,7 +121,7 @@ def result2ann(ori_dataset, det_results, wh=-1):
     for im_id in img_with_anns:
         for ann_res in res_by_img.get(im_id, []):
             ori = by_id[ann_res['ann_id']]
-            oc, nc = xywh2centerwh(ori['bbox'])[:2], xywh2centerwh(ann_res['bbox'])[:2]
+            oc, nc = _centre(ori['bbox']), _centre(ann_res['bbox'])
             assert round(oc[0]) == round(nc[0]) and round(oc[1]) == round(nc[1])
             for key in ('segmentation', 'area'):
                 assert ori[key] == ann_res[key], key
