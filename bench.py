@@ -164,6 +164,28 @@ def hbm_probe(batch, size):
          lambda: ops.gn_bwd(x, dz, a, b, mean, rstd, gam, True), 5 * nb),
         ('relu_bwd_colsum_kernel (ReLU backward + column sums)', lambda: ops.relu_bwd_colsum(dz, x), 3 * nb),
     ]
+    # the CPR-specific stage on its real shapes (C = 1, 32 gts per image): these launches move a few MB and finish in tens of
+    # microseconds, i.e. they are launch-latency bound -- listed so that the stage is accounted for, not as roofline claims
+    from pointtinybenchmark_amd.dense_heads.cpr_head import circle_offsets, sqrt_threshold
+    G = 32 * batch
+    lmap = torch.randn((batch, h, h, 2), device=dev, generator=g)
+    ctr = torch.rand((G, 2), device=dev, generator=g) * (size - 16) + 8
+    lab = torch.zeros((G,), device=dev, dtype=torch.int32)
+    gt_img = torch.arange(batch, device=dev, dtype=torch.int32).repeat_interleave(32)
+    gt_start = torch.arange(batch + 1, device=dev, dtype=torch.int32) * 32
+    pad_hw = torch.full((batch * 2,), size, device=dev, dtype=torch.int32)
+    offs = circle_offsets(5, 4).to(dev)
+    thr = sqrt_threshold(20.0)
+    _, valid_b, bag_l = ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, 4)
+    K = bag_l.shape[1]
+    cases += [
+        ('neg_mask_loss_kernel (negative grid: distance mask + sigmoid + gfocal partials)',
+         lambda: ops.neg_mask_loss(lmap, ctr, lab, gt_start, pad_hw, 1, 4, thr, 1e-6, True), lmap.numel() * 4 + batch * h * h),
+        ('bag_sample_kernel (bag points + bilinear samples of the logit map)',
+         lambda: ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, 4), G * K * (4 * 2 * 4 + 2 * 4 + 8 + 1)),
+        ('mil_bag + loss_finalize kernels (MIL / gt losses, one wave per bag)',
+         lambda: ops.mil_loss(bag_l, 1, valid_b, lab, 1, None, 0.25, 0.25, 0.75), G * K * (2 * 4 + 1)),
+    ]
     out = []
     for name, fn, byts in cases:
         for _ in range(3):
