@@ -80,34 +80,64 @@ int cpr_gn_apply(const float* x, const float* a, const float* b, const float* up
  * pseudo_bbox_to_center (cpr_head.py:1293-1301): boxes (n,4) -> centers (n,2) */
 int cpr_box_centers(const float* boxes, float* centers, int n, void* stream);
 
+/* Probability types of CPRHead.get_cls_prob (cpr_head.py:1080-1099), argument `prob_type` below:
+ *   0 sigmoid   1 softmax over the class dim   2 normed_sigmoid (sigmoid, then L_p normalisation over the class dim,
+ *   p = norm_p)   3 (cpr_mil_loss only) the cls channels already hold probabilities. */
+#define CPR_PROB_SIGMOID 0
+#define CPR_PROB_SOFTMAX 1
+#define CPR_PROB_NORMED_SIGMOID 2
+#define CPR_PROB_IDENTITY 3
+
 /* OutCirclePtFeatGenerator.generate + neg branch of CPRHead.loss0 (cpr_head.py:254-290,1219-1228):
- * logit (N,H,W,J) (class logits in channels [0,C)); gts in CSR form (centers (G,2), labels (G), gt_start (N+1));
+ * logit (N,H,W,J) (class logits in channels [0,C)); annotated points in CSR form (centers (P,2), labels (P),
+ * gt_start (N+1)) -- with num_refine > 1 every refine point is a row, carrying its gt's label;
  * pad_hw (N,2) int32.  mask (N*H*W, C) uint8 = the reference's neg `valid`; partial[] (double, N*ceil(H*W*C/256))
- * = block partial sums of gfocal(sigmoid(logit), 0, valid).  d2_thr = smallest fp32 whose torch-CPU sqrt is
+ * = block partial sums of gfocal(prob(logit), 0, valid).  d2_thr = smallest fp32 whose torch-CPU sqrt is
  * >= stride*radius (the reference thresholds cdist, i.e. a sqrt).  n_partial [host, may be NULL] receives the count. */
 int cpr_neg_mask_loss(const float* logit, int J, const float* centers, const int* labels, const int* gt_start,
                       const int* pad_hw, unsigned char* mask, double* partial, int N, int H, int W, int C,
-                      float stride, float d2_thr, float eps, int class_wise, int* n_partial, void* stream);
+                      float stride, float d2_thr, float eps, int class_wise, int prob_type, float norm_p,
+                      int* n_partial, void* stream);
 
-/* CirclePtFeatGenerator.generate (cpr_head.py:453-497,172-199): bag points (rings + centre last), validity and
- * bilinear samples of a J-channel NHWC map.  offsets (K-1,2) from the host.  pts (G,K,2) valid (G,K) out (G,K,J) */
+/* CirclePtFeatGenerator.generate (cpr_head.py:453-497,172-199): bag points (rings + the point itself last), validity
+ * and bilinear samples of a J-channel NHWC map, one bag per annotated / refine point.  offsets (K-1,2) from the host.
+ * pts (G,K,2) valid (G,K) out (G,K,J) */
 int cpr_bag_sample(const float* map, int J, const float* centers, const int* gt_img, const int* pad_hw,
                    const float* offsets, float* pts, unsigned char* valid, float* out, int G, int K, int H, int W,
                    float stride, void* stream);
 
-/* MILLoss.forward + gt loss + neg normalisation (multi_instance_learning_loss.py:153-203, cpr_head.py:1159-1228).
- * logits (G,K,J): cls in [0,C), ins in [ins_off, ins_off+C).  bag_ws (G,5) workspace.
- * out5 = {gt_loss, pos_loss, bag_acc, neg_loss, num_pos} (device scalars, no host sync). */
-int cpr_mil_loss(const float* logits, int J, int ins_off, const unsigned char* valid, const int* labels,
-                 const float* gt_weight, float* bag_ws, const double* neg_partial, int n_partial, int G, int K, int C,
-                 float eps, float w_mil, float w_gt, float w_neg, float* out5, void* stream);
+/* GridCirclesPtFeatGenerator.generate (cpr_head.py:296-352,405-438): per gt (R refine points each, points (G*R,2),
+ * gt_img (G)) every grid point within radius_px of any of its refine points, row-major, zero-padded to Kmax, then the R
+ * refine points in reversed order.  pts (G,Kmax+R,2), valid (G,Kmax+R) u8, out (G,Kmax+R,J) (grid entries = map value of
+ * the cell, refine points = bilinear samples, padding slots = pad_value (J) or 0 when NULL: the reference pads with zero
+ * FEATURES, i.e. the projection's bias on a logit map), count (G) int32 = grid points found (> Kmax: the reference raises),
+ * ws_cell (G,Kmax+R) int32 workspace. */
+int cpr_grid_bag(const float* map, int J, const float* points, const int* gt_img, int R, int Kmax, float radius_px,
+                 const float* pad_value, float* pts, unsigned char* valid, int* ws_cell, int* count, float* out, int G,
+                 int H, int W, float stride, void* stream);
 
-/* PointRefiner.refine_single (cpr_head.py:711-850): refine_pts (G,2), scores (G), not_refine (G) u8, chosen (G,K) u8 */
-int cpr_refine(const float* logits, int J, const float* pts, const unsigned char* valid, const float* centers,
-               const int* labels, const int* gt_img, const int* gt_start, const int* img_hw,
+/* MILLoss.forward / AllPosLoss.forward + gt loss + neg normalisation (multi_instance_learning_loss.py:153-243,
+ * cpr_head.py:1159-1228).  logits (entries,J): cls in [0,C), ins in [ins_off, ins_off + C*(1+binary_ins)).
+ * Bag b = entries [b*bag_stride + bag_off, + bag_len): covers refine_bag_policy independent_with_gt_bag (stride K),
+ * merge_to_gt_bag (stride R*K, len R*K) and only_refine_bag (off si*K) without re-packing.  Annotated-point ("gt") loss
+ * entries of bag b: b*bag_stride + ctr_off + j*ctr_stride (j < ctr_count), used when b % ctr_mod == 0.
+ * labels / gt_weight are per bag.  allpos = AllPosLoss instead of MILLoss.  bag_ws (num_bags,5) workspace.
+ * out5 = {gt_loss, pos_loss, bag_acc, neg_loss, num_sample} (device scalars, no host sync); neg_from_gt: average the
+ * negative loss over the gt count instead of num_sample (with_mil_loss = False). */
+int cpr_mil_loss(const float* logits, int J, int ins_off, const unsigned char* valid, const int* labels,
+                 const float* gt_weight, float* bag_ws, const double* neg_partial, int n_partial, int num_bags,
+                 int bag_stride, int bag_off, int bag_len, int ctr_off, int ctr_stride, int ctr_count, int ctr_mod,
+                 int C, float eps, int prob_type, float norm_p, int binary_ins, int allpos, float w_mil, float w_gt,
+                 float w_neg, int neg_from_gt, float* out5, void* stream);
+
+/* PointRefiner.refine_single (cpr_head.py:711-850).  A gt owns Kt = Rv*Kv bag entries (Rv sub-bags of Kv; entry Kv-1 is
+ * the annotated point); centers holds ctr_stride points per gt of which the first Rv take part in the nearest filter.
+ * refine_pts (G,2), scores (G), not_refine (G) u8, chosen (G,Kt) u8 */
+int cpr_refine(const float* logits, int J, const float* pts, const unsigned char* valid, const float* centers, int Rv,
+               int ctr_stride, const int* labels, const int* gt_img, const int* gt_start, const int* img_hw,
                const unsigned char* not_refine_in, float* refine_pts, float* scores, unsigned char* not_refine,
-               unsigned char* chosen, int G, int K, int C, float gt_alpha, float merge_th, float refine_th,
-               int use_nearest, int use_classify, void* stream);
+               unsigned char* chosen, int G, int Kt, int Kv, int C, int prob_type, float norm_p, float gt_alpha,
+               float merge_th, float refine_th, int use_nearest, int use_classify, void* stream);
 
 /* ---- assigners -------------------------------------------------------------------------------------------------
  * PointAssigner.assign (T/mmdet/core/bbox/assigners/point_assigner.py:23-133): points (n,3)=(x,y,stride),

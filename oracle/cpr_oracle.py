@@ -317,11 +317,36 @@ def point_assign(points, gt_bboxes, gt_labels=None, scale=4, pos_num=3):
     return inds, lab
 
 
-def focal_loss_cost(cls_pred, gt_labels, weight=1.0, alpha=0.25, gamma=2, eps=1e-12):
-    """FocalLossCost.__call__ (T/mmdet/core/bbox/match_costs/match_cost.py:84-100)."""
-    p = cls_pred.sigmoid()
-    neg = -(1 - p + eps).log() * (1 - alpha) * p.pow(gamma)
-    pos = -(p + eps).log() * alpha * (1 - p).pow(gamma)
+def _log_cr(x):
+    """Correctly rounded fp32 log.  torch's CPU ``log`` goes through MKL VML, whose last bit depends on the HOST (Xeon /
+    AVX-512 kernel: 0.007 % of values 1 ulp off this; EPYC kernel: 1.7 %, measured with tools/log_probe.py,
+    profiles/round2_log_probe.txt), so the reference's cost bits are not machine independent.  This is the
+    host-independent limit both approximate and what the HIP cost kernel computes ((float)log((double)x), checked against
+    glibc on 2^22 inputs: tools/diag/logcr.hip).  Evaluated in x87 extended precision (glibc logl, 64-bit mantissa) and
+    rounded ONCE to fp32 -- torch's own float64 log is MKL as well and not accurate enough on every host to be the judge."""
+    v = np.log(x.detach().numpy().astype(np.longdouble)).astype(np.float32)
+    return torch.from_numpy(v)
+
+
+def _sigmoid_vector_path(x):
+    """torch.sigmoid as ATen's VECTOR loop computes it (1 / (1 + Sleef_expf_u10(-x))) for EVERY element.  On a contiguous
+    tensor ATen runs the last numel mod (2 x vector width) elements through the scalar lambda instead (glibc expf), whose
+    last bit can differ: the same logit gives 0x1.cd0e34p-5 as element 9987 of 10000 and 0x1.cd0e30p-5 inside a longer
+    tensor.  Padding to a multiple of 64 keeps every real element in the vector body.  (P2P score maps hold
+    H/4 * W/4 * C elements with H, W multiples of 32, i.e. a multiple of 64: the reference has no tail there.)"""
+    flat = x.reshape(-1)
+    pad = (-flat.numel()) % 64
+    return torch.cat([flat, flat.new_zeros(pad + 64)]).sigmoid()[:flat.numel()].reshape(x.shape)
+
+
+def focal_loss_cost(cls_pred, gt_labels, weight=1.0, alpha=0.25, gamma=2, eps=1e-12, log_mode='host'):
+    """FocalLossCost.__call__ (T/mmdet/core/bbox/match_costs/match_cost.py:84-100).
+    log_mode='host': torch's CPU ops as the reference executes them on THIS machine;
+    'cr': the host- and shape-independent statement of the same formula (correctly rounded log, vector-path sigmoid)."""
+    log = _log_cr if log_mode == 'cr' else torch.log
+    p = _sigmoid_vector_path(cls_pred) if log_mode == 'cr' else cls_pred.sigmoid()
+    neg = -log(1 - p + eps) * (1 - alpha) * p.pow(gamma)
+    pos = -log(p + eps) * alpha * (1 - p).pow(gamma)
     return (pos[:, gt_labels] - neg[:, gt_labels]) * weight
 
 
@@ -360,7 +385,7 @@ def lsa_topk(cost, topk_k):
 
 
 def hungarian_assign_v2(pred_pts, cls_pred, gt_pts, gt_labels, img_shape, topk_k=5,
-                        cls_weight=2.0, dis_weight=0.1, dis_norm=False):
+                        cls_weight=2.0, dis_weight=0.1, dis_norm=False, log_mode='host', p=1):
     """HungarianAssignerV2.assign (hungarian_assigner.py:166-270) with the P2P config's costs
     (T/configs2/TinyPersonV2/p2p/p2p_r50_fpns4_1x_fl_sl1_TinyPersonV2_640.py:55-63):
     FocalLossCost(weight=2.0) + DisCostV2(weight=0.1, p=1)."""
@@ -368,8 +393,8 @@ def hungarian_assign_v2(pred_pts, cls_pred, gt_pts, gt_labels, img_shape, topk_k
     labels = torch.full((M,), -1, dtype=torch.long)
     if G == 0 or M == 0:
         return torch.full((M,), 0 if G == 0 else -1, dtype=torch.long), labels, None
-    cost = focal_loss_cost(cls_pred, gt_labels, cls_weight) + dis_cost_v2(pred_pts, gt_pts, img_shape, dis_weight,
-                                                                          dis_norm, 1)
+    cost = focal_loss_cost(cls_pred, gt_labels, cls_weight, log_mode=log_mode) + dis_cost_v2(
+        pred_pts, gt_pts, img_shape, dis_weight, dis_norm, p)
     inds = lsa_topk(cost, topk_k)
     pos = inds > 0
     labels[pos] = gt_labels[inds[pos] - 1]

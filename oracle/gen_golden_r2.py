@@ -1,0 +1,284 @@
+"""Round-2 fixtures from the REFERENCE's own classes (build container only).  TEST INFRASTRUCTURE ONLY.
+
+  python -m oracle.gen_golden_r2 [refine] [options] [costs]
+
+  refine   tests/golden/refine.npz        PointRefiner internals (refine points, scores, not_refine, the chosen-point
+                                          masks) of every CPR case + the out_geo / cascade_out_fmt / not_refine-input /
+                                          rescale output formats of CPRHead.get_bboxes (cpr_head.py:780-864,1231-1283)
+  options  tests/golden/cpr_options.npz   the CPRHead options no shipped config uses: num_refine > 1
+                                          with the three bag policies / two gt_loss_type values, GridCirclesPtFeatGenerator,
+                                          softmax / normed_sigmoid probabilities, binary_ins, AllPosLoss
+  costs    tests/golden/assigner_costs.npz  the reference's own fp32 cost matrices of the HungarianAssignerV2 fixtures
+                                          (FocalLossCost + DisCostV2 evaluated by the reference classes on THIS host)
+Inputs and weights come from ``pointtinybenchmark_amd.synthetic`` (seeded, regenerated at test time)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import ref_loader  # noqa: E402
+from oracle.gen_golden import CPR_CASES, GN, GOLDEN, assigner_inputs  # noqa: E402
+from pointtinybenchmark_amd import synthetic  # noqa: E402
+
+HA_CASES = [(40, 7, 1, 5), (40, 7, 1, 1), (32, 20, 3, 5), (24, 100, 1, 5), (160, 32, 1, 5)]   # = gen_golden.gen_assigners
+
+BASE = dict(depth=18, num_classes=3, start_level=0, stride=4, radius=5, head_std=0.3, seed=41, batch=2, height=128,
+            width=160, num_gts=7, ragged=True)
+# name: overrides of BASE + head options
+OPTION_CASES = {
+    'r2_independent': dict(num_refine=2, policy='independent_with_gt_bag', gt_loss_type='gt_refine'),
+    'r2_merge_gt': dict(num_refine=2, policy='merge_to_gt_bag', gt_loss_type='gt', seed=42),
+    'r3_only_refine': dict(num_refine=3, policy='only_refine_bag', gt_loss_type='gt_refine', seed=43),
+    'softmax': dict(prob='softmax', seed=44),
+    'normed_sigmoid_p1': dict(prob='normed_sigmoid', norm_p=1, seed=45),
+    'normed_sigmoid_p2': dict(prob='normed_sigmoid', norm_p=2, seed=46),
+    'binary_ins': dict(binary_ins=True, seed=47),
+    'allpos': dict(loss='AllPosLoss', seed=48),
+    'grid_circles': dict(pos='GridCirclesPtFeatGenerator', radius=3, seed=49),
+    'grid_circles_r2': dict(pos='GridCirclesPtFeatGenerator', radius=3, num_refine=2, max_pos_num=160, seed=50),
+    'no_mil_loss': dict(with_mil_loss=False, seed=51),
+}
+
+
+def option_cfg(name):
+    cfg = dict(BASE)
+    cfg.update(OPTION_CASES[name])
+    return cfg
+
+
+def cpr_head_kwargs(cfg):
+    """CPRHead constructor arguments of a case -- plain dicts, accepted unchanged by the reference's CPRHead and by
+    pointtinybenchmark_amd's (the tests build the HIP head from the same dict)."""
+    alpha, r = 0.25, cfg['radius']
+    pos = dict(type=cfg.get('pos', 'CirclePtFeatGenerator'), radius=r)
+    if 'max_pos_num' in cfg:
+        pos['max_pos_num'] = cfg['max_pos_num']
+    normal = dict(prob_cls_type=cfg.get('prob', 'sigmoid'), out_bg_cls=False)
+    if 'norm_p' in cfg:
+        normal['normed_sigmoid_p'] = cfg['norm_p']
+    loss_cfg = dict(with_neg=True, neg_loss_weight=1 - alpha, refine_bag_policy=cfg.get('policy', 'independent_with_gt_bag'),
+                    random_remove_rate=0.4, with_gt_loss=True, gt_loss_weight=alpha,
+                    with_mil_loss=cfg.get('with_mil_loss', True))
+    if 'gt_loss_type' in cfg:
+        loss_cfg['gt_loss_type'] = cfg['gt_loss_type']
+    return dict(
+        norm_cfg=GN, num_classes=cfg['num_classes'], in_channels=256, feat_channels=256, stacked_convs=4,
+        num_cls_fcs=cfg.get('num_cls_fcs', 0), fc_out_channels=cfg.get('fc_out_channels', 1024), strides=[cfg['stride']],
+        loss_mil=dict(type=cfg.get('loss', 'MILLoss'), binary_ins=cfg.get('binary_ins', False), loss_weight=alpha),
+        loss_type=0, loss_cfg=loss_cfg, normal_cfg=normal,
+        train_pts_extractor=dict(pos_generator=dict(pos),
+                                 neg_generator=dict(type='OutCirclePtFeatGenerator', radius=r, class_wise=True)),
+        refine_pts_extractor=dict(pos_generator=dict(pos),
+                                  neg_generator=dict(type='OutCirclePtFeatGenerator', radius=r, keep_wh=True,
+                                                     class_wise=True)),
+        point_refiner=dict(merge_th=0.1, refine_th=0.1, classify_filter=True))
+
+
+def case_inputs(cfg):
+    sd = synthetic.locator_state_dict(cfg['depth'], cfg['num_classes'], cfg['start_level'], 'cpr', cfg['seed'],
+                                      cfg['head_std'], num_cls_fcs=cfg.get('num_cls_fcs', 0),
+                                      fc_out_channels=cfg.get('fc_out_channels', 1024),
+                                      binary_ins=cfg.get('binary_ins', False))
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'], cfg.get('ragged', False))
+    batch = synthetic.with_refine_points(batch, cfg.get('num_refine', 1), cfg['seed'])
+    return sd, batch
+
+
+def not_refine_input(batch, seed):
+    """A seeded not_refine input for get_bboxes (one bool per gt), shared with the tests."""
+    g = torch.Generator().manual_seed(seed + 500)
+    return [torch.rand(len(l), generator=g) < 0.3 for l in batch['gt_labels']]
+
+
+def build_reference(R, cfg):
+    chans = synthetic.backbone_out_channels(cfg['depth'])
+    backbone = R.ResNet(depth=cfg['depth'], num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                        norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch')
+    neck = R.FPN(in_channels=chans, out_channels=256, start_level=cfg['start_level'], add_extra_convs='on_input',
+                 num_outs=1, norm_cfg=GN)
+    head = R.CPRHead(**cpr_head_kwargs(cfg),
+                     test_cfg=ref_loader.AttrDict(nms_pre=2000, min_bbox_size=0, score_thr=0.05,
+                                                  nms=dict(type='nms', iou_threshold=0.5), max_per_img=1000))
+    sd, batch = case_inputs(cfg)
+    backbone.load_state_dict({k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}, strict=True)
+    neck.load_state_dict({k[len('neck.'):]: v for k, v in sd.items() if k.startswith('neck.')}, strict=True)
+    head.load_state_dict({k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}, strict=True)
+    for m in (backbone, neck, head):
+        m.train()
+    return backbone, neck, head, batch
+
+
+class RefineCapture:
+    """Records what PointRefiner.refine_single returns for every image (cpr_head.py:780-850) and turns its chosen-point
+    LISTS back into (num_gts, num_refine*num_chosen) masks by matching them, in order, against the bag points."""
+
+    def __init__(self, head):
+        self.rec = []
+        pr = head.point_refiner
+        orig = pr.refine_single
+
+        def wrapped(bag_data, grid_data, gt_r_points, gt_labels, img_meta, gt_true_bboxes, not_refine=None):
+            out = orig(bag_data, grid_data, gt_r_points, gt_labels, img_meta, gt_true_bboxes, not_refine)
+            refine_pts, scores, nr, chosen_pts, geos = out
+            flat = bag_data.pts[0].reshape(len(gt_labels), -1, 3)
+            mask = torch.zeros(flat.shape[:2], dtype=torch.bool)
+            for i, cp in enumerate(chosen_pts):
+                j = 0
+                for q in cp:
+                    while not bool((flat[i, j] == q).all()):
+                        j += 1
+                    mask[i, j] = True
+                    j += 1
+            self.rec.append(dict(refine_pts=refine_pts.clone(), scores=scores.clone(), not_refine=nr.clone(), chosen=mask,
+                                 bag_pts=flat[..., :2].clone(), bag_valid=bag_data.valid[0].reshape(len(gt_labels), -1).clone(),
+                                 bag_cls_logit=bag_data.cls_outs[0].reshape(len(gt_labels), flat.shape[1], -1).clone()))
+            return out
+        pr.refine_single = wrapped
+
+    def collect(self):
+        rec, self.rec = self.rec, []
+        return {k: torch.cat([r[k] for r in rec]) for k in rec[0]}
+
+
+def _refine_outputs(head, cls_feat, ins_feat, batch, seed, prefix, out):
+    """All get_bboxes output formats of one case into ``out`` (keys prefixed)."""
+    cap = RefineCapture(head)
+    kw = dict(gt_bboxes=batch['gt_bboxes'], gt_labels=batch['gt_labels'], gt_anns_id=batch['gt_anns_id'])
+    metas = batch['img_metas']
+    dets = head.get_bboxes(cls_feat, ins_feat, metas, rescale=False, **kw)
+    c = cap.collect()
+    out[prefix + 'dets'] = np.concatenate([d[0].numpy() for d in dets])
+    out[prefix + 'det_labels'] = np.concatenate([d[1].numpy() for d in dets])
+    out[prefix + 'refine_pts'] = c['refine_pts'].numpy()
+    out[prefix + 'scores'] = c['scores'].numpy()
+    out[prefix + 'not_refine'] = c['not_refine'].numpy()
+    out[prefix + 'chosen'] = np.packbits(c['chosen'].numpy().astype(np.uint8), axis=None)
+    out[prefix + 'chosen_shape'] = np.array(c['chosen'].shape)
+    out[prefix + 'bag_pts'] = c['bag_pts'].numpy()
+    out[prefix + 'bag_valid'] = np.packbits(c['bag_valid'].numpy().astype(np.uint8), axis=None)
+    out[prefix + 'bag_cls_logit'] = c['bag_cls_logit'].numpy()
+    # out_geo (cpr_head.py:1268-1269): the rows of different images have different widths -> one array per image
+    head.other_info = dict(out_geo=True)
+    dg = head.get_bboxes(cls_feat, ins_feat, metas, rescale=False, **kw)
+    cap.collect()
+    for b, d in enumerate(dg):
+        out[prefix + 'dets_geo%d' % b] = d[0].numpy()
+    # rescale=True with a non-unit scale factor (boxes and geo points are divided, cpr_head.py:1259-1262,1285-1288)
+    metas2 = [dict(m, scale_factor=[1.25, 1.6, 1.25, 1.6]) for m in metas]
+    dr = head.get_bboxes(cls_feat, ins_feat, metas2, rescale=True, **kw)
+    cap.collect()
+    for b, d in enumerate(dr):
+        out[prefix + 'dets_geo_rescaled%d' % b] = d[0].numpy()
+    head.other_info = dict()
+    # not_refine input + cascade_out_fmt (cpr_head.py:839,1273-1274)
+    nr_in = not_refine_input(batch, seed)
+    dc, nr_out = head.get_bboxes(cls_feat, ins_feat, metas, rescale=False, not_refine=nr_in, cascade_out_fmt=True, **kw)
+    cap.collect()
+    out[prefix + 'cascade_dets'] = np.concatenate([d[0].numpy() for d in dc])
+    out[prefix + 'cascade_not_refine'] = np.concatenate([n.numpy() for n in nr_out])
+
+
+def gen_refine(R):
+    out = {}
+    for name, cfg in CPR_CASES.items():
+        torch.manual_seed(0)
+        backbone, neck, head, batch = build_reference(R, dict(cfg))
+        with torch.no_grad():
+            cls_feat, ins_feat = head(neck(backbone(batch['img'])))
+            _refine_outputs(head, cls_feat, ins_feat, batch, cfg['seed'], name + ':', out)
+        print('refine', name, 'gts', len(out[name + ':scores']), 'chosen', int(np.unpackbits(out[name + ':chosen']).sum()),
+              'not_refine', int(out[name + ':not_refine'].sum()))
+    np.savez_compressed(os.path.join(GOLDEN, 'refine.npz'), **out)
+
+
+def gen_options(R):
+    out = {}
+    for name in OPTION_CASES:
+        cfg = option_cfg(name)
+        torch.manual_seed(0)
+        backbone, neck, head, batch = build_reference(R, cfg)
+        with torch.no_grad():
+            cls_feat, ins_feat = head(neck(backbone(batch['img'])))
+            losses = head.loss(cls_feat, ins_feat, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'])
+            gt_points = head.pseudo_bbox_to_center(batch['gt_bboxes'])
+            gt_r = [p.reshape(len(l), -1, 2) for p, l in zip(gt_points, batch['gt_labels'])]
+            pos, neg = head.train_pts_extractor(cls_feat, ins_feat, gt_r, batch['gt_labels'], batch['img_metas'], None, True)
+            pos.cls_outs, pos.ins_outs = head.get_pts_outs(pos.cls_feats, pos.ins_feats)
+            p = name + ':'
+            for k, v in losses.items():
+                out[p + 'loss_' + k] = np.float32(float(v.mean()))      # AllPosLoss returns a tensor; _parse_losses means it
+            out[p + 'pos_pts'] = pos.pts[0][..., :2].numpy()
+            out[p + 'pos_valid'] = pos.valid[0][..., 0].numpy()
+            out[p + 'pos_cls_logit'] = pos.cls_outs[0].numpy()
+            out[p + 'pos_ins_logit'] = pos.ins_outs[0].numpy()
+            out[p + 'neg_valid'] = np.packbits(neg.valid[0].numpy().astype(np.uint8), axis=None)
+            out[p + 'neg_valid_count'] = np.int64(neg.valid[0].sum().item())
+            try:
+                _refine_outputs(head, cls_feat, ins_feat, batch, cfg['seed'], p, out)
+            except AssertionError:
+                # PointRefiner.refine_single asserts that every refine point of a gt coincides with its first one when the
+                # bags come from CirclePtFeatGenerator (cpr_head.py:809): get_bboxes cannot run on such num_refine > 1
+                # inputs in the reference -> loss only (the grid generators keep one annotated point per bag and do run)
+                assert cfg.get('num_refine', 1) > 1 and 'pos' not in cfg
+                for k in [k for k in out if k.startswith(p) and not (k.startswith(p + 'loss_') or k.startswith(p + 'pos_')
+                                                                      or k.startswith(p + 'neg_'))]:
+                    del out[k]
+                out[p + 'refine_asserts_in_reference'] = np.array(True)
+        print('options', name, {k[len(p):]: float(v) for k, v in out.items() if k.startswith(p + 'loss_')},
+              'pos', out[p + 'pos_pts'].shape, 'chosen', int(np.unpackbits(out[p + 'chosen']).sum()) if p + 'chosen' in out else 'n/a')
+    # the one generator that cannot run in the reference (documented in pointtinybenchmark_amd/dense_heads/cpr_head.py)
+    try:
+        cfg = dict(BASE, pos='GridEllipsePtFeatGenerator', num_refine=2)
+        kw = cpr_head_kwargs(cfg)
+        for ex in ('train_pts_extractor', 'refine_pts_extractor'):
+            kw[ex]['pos_generator'] = dict(type='GridEllipsePtFeatGenerator', a_minus_c=2.0)
+        head = R.CPRHead(**kw)
+        sd, batch = case_inputs(cfg)
+        feat = torch.randn(2, 256, 32, 40)
+        head.loss([feat], [feat], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'])
+        out['grid_ellipse_reference_error'] = np.array('none')
+    except Exception as e:  # noqa: BLE001
+        out['grid_ellipse_reference_error'] = np.array('%s: %s' % (type(e).__name__, str(e)[:200]))
+    print('GridEllipsePtFeatGenerator in the reference ->', out['grid_ellipse_reference_error'])
+    np.savez_compressed(os.path.join(GOLDEN, 'cpr_options.npz'), **out)
+
+
+def gen_assigner_costs(R):
+    """cost = sum(cls_costs) + sum(reg_costs) exactly as HungarianAssignerV2.assign forms it (hungarian_assigner.py:222-227),
+    from the reference's own FocalLossCost / DisCostV2 objects; float32 bits as computed on the build host."""
+    out = {}
+    for case, (n_side, G, C, k) in enumerate(HA_CASES):
+        pred, logits, gt, labels, shp = assigner_inputs(200 + case, n_side, 4, G, C)
+        ha = R.HungarianAssignerV2(cls_costs=dict(type='FocalLossCost', weight=2.0),
+                                   reg_costs=dict(type='DisCostV2', weight=0.1, norm_with_img_wh=False), topk_k=k)
+        cls_costs = [c(logits, labels) for c in ha.cls_costs]
+        reg_costs = [c(pred, gt, dict(img_shape=shp)) for c in ha.reg_costs]
+        cost = sum(cls_costs) + sum(reg_costs)
+        out['ha%d_cost' % case] = cost.numpy()
+        res = ha.assign(pred, logits, gt, labels, dict(img_shape=shp))
+        g = np.load(os.path.join(GOLDEN, 'assigners.npz'))
+        assert np.array_equal(res.gt_inds.numpy(), g['ha%d_gt_inds' % case]), 'fixture host changed its log bits?'
+    np.savez_compressed(os.path.join(GOLDEN, 'assigner_costs.npz'), **out)
+    print('assigner costs', {k: v.shape for k, v in out.items()})
+
+
+def main():
+    assert ref_loader.available(), 'needs /root/reference'
+    torch.set_num_threads(8)
+    R = ref_loader.load()
+    which = sys.argv[1:] or ['refine', 'options', 'costs']
+    if 'refine' in which:
+        gen_refine(R)
+    if 'options' in which:
+        gen_options(R)
+    if 'costs' in which:
+        gen_assigner_costs(R)
+
+
+if __name__ == '__main__':
+    main()

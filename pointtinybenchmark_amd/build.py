@@ -11,6 +11,12 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcprhip.so')
 SOURCES = ['conv_mfma.hip', 'conv_mfma_bf16.hip', 'conv_wgrad.hip', 'norm_pool.hip', 'cpr_points.hip', 'assign.hip',
            'postproc.hip', 'backward.hip', 'preprocess.hip', 'pack.hip']
+# Kernels whose integer / mask / index outputs are held bit-exact against the reference's CPU arithmetic restate it
+# operation by operation.  hipcc's default -ffp-contract=fast fuses a*b+c into one fma EVEN ACROSS the __fmul_rn/__fadd_rn
+# intrinsics (plain operators in the HIP headers), which changes the last bit (round 1 shipped a Hungarian cost whose
+# pos - neg had become fma(t, q, -neg): 24 % of the entries 1 ulp off).  These files are compiled with contraction off;
+# where the reference itself uses an fma, the source says __fmaf_rn explicitly.
+EXACT_SOURCES = {'cpr_points.hip', 'assign.hip', 'postproc.hip', 'preprocess.hip'}
 
 
 def _hipcc():
@@ -37,7 +43,8 @@ def build(force=False, verbose=True):
         if not os.path.exists(src):
             continue
         obj = os.path.join(CSRC, s.replace('.hip', '.o'))
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj]
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + \
+            (['-ffp-contract=off'] if s in EXACT_SOURCES else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -113,24 +113,6 @@ extern "C" int cpr_point_assign(const float* points, const float* gt_bboxes, int
 //    Sleef routine operation for operation: 0 mismatches against torch.sigmoid on 2^20 random inputs)
 //  * log goes through MKL VML (HA mode, ~correctly rounded: 0.1 % of values differ from the correctly rounded result);
 //    log_cr() evaluates in float64 and rounds once, i.e. the correctly rounded value.
-__device__ __forceinline__ float sleef_expf_u10(float d) {
-    const float q = rintf(__fmul_rn(d, 1.442695040888963407359924681001892137426645954152985934135449406931f));
-    float s = __fmaf_rn(q, -0.693145751953125f, d);
-    s = __fmaf_rn(q, -1.428606765330187045e-06f, s);
-    float u = 0.000198527617612853646278381f;
-    u = __fmaf_rn(u, s, 0.00139304355252534151077271f);
-    u = __fmaf_rn(u, s, 0.00833336077630519866943359f);
-    u = __fmaf_rn(u, s, 0.0416664853692054748535156f);
-    u = __fmaf_rn(u, s, 0.166666671633720397949219f);
-    u = __fmaf_rn(u, s, 0.5f);
-    u = __fadd_rn(1.0f, __fmaf_rn(__fmul_rn(s, s), u, s));
-    const int qi = (int)q, h = qi >> 1;                      // ldexp2kf: two exact power-of-two scalings
-    u = __fmul_rn(u, __int_as_float((h + 127) << 23));
-    u = __fmul_rn(u, __int_as_float((qi - h + 127) << 23));
-    if (d < -104.f) u = 0.f;
-    if (d > 104.f) u = INFINITY;
-    return u;
-}
 __device__ __forceinline__ float log_cr(float x) { return (float)log((double)x); }
 __global__ void hungarian_cost_kernel(const float* __restrict__ pred, int pred_stride,
                                       const float* __restrict__ logits, int C, const float* __restrict__ gt,
@@ -142,7 +124,7 @@ __global__ void hungarian_cost_kernel(const float* __restrict__ pred, int pred_s
     if (m >= M) return;
     const int l = labels[g];
     const float x = logits[(size_t)m * C + l];
-    const float p = __fdiv_rn(1.f, __fadd_rn(1.f, sleef_expf_u10(-x)));   // torch.sigmoid on CPU, bit for bit
+    const float p = sigmoid_torch_cpu(x);   // torch.sigmoid on CPU, bit for bit
     const float pg = (gamma == 2.f) ? __fmul_rn(p, p) : powf(p, gamma);
     const float q1 = __fsub_rn(1.f, p);
     const float qg = (gamma == 2.f) ? __fmul_rn(q1, q1) : powf(q1, gamma);

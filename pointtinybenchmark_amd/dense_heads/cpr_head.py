@@ -3,13 +3,15 @@
 Same registry name, constructor keys and method signatures as the reference; the work is done by HIP kernels:
   forward        4 x [conv3x3 -> GN32 -> ReLU] on the MFMA conv kernel; GN statistics ride in the conv epilogue
                  and GN-apply+ReLU is folded into the NEXT conv's input load (only the last layer materialises)
-  loss           ONE 1x1 conv projects the head features to a (N,H,W,2C) logit map ([cls ++ ins]); the negative
-                 grid mask + sigmoid + gfocal run on that map, positive bags are bilinear-sampled from it
+  loss           ONE 1x1 conv projects the head features to a (N,H,W,J) logit map ([cls ++ ins]); the negative
+                 grid mask + probabilities + gfocal run on that map, positive bags are sampled from it
                  (valid because num_cls_fcs == 0: Linear and bilinear sampling commute), MIL + gt loss in one
                  wave per bag; no host sync, the four scalars stay on the device
   get_bboxes     same extraction, then PointRefiner as one wave per gt.
-Single FPN level and num_refine == 1, like every shipped config (the reference asserts the single level itself:
-cpr_head.py:799,1152)."""
+Single FPN level like every shipped config (the reference asserts the single level itself: cpr_head.py:799,1152).
+Options beyond the shipped configs, all on the same kernels: num_refine > 1 inputs with the three
+``refine_bag_policy`` values and both ``gt_loss_type`` values, ``GridCirclesPtFeatGenerator`` bags, ``softmax`` /
+``normed_sigmoid`` class probabilities, ``binary_ins``, ``AllPosLoss``, ``num_cls_fcs > 0``."""
 import math
 
 import numpy as np
@@ -20,8 +22,7 @@ from .. import ops
 from ..layers import ConvModule, _PackCache, conv_gn
 from ..registry import HEADS, build_loss
 
-_GENERATORS = ('CirclePtFeatGenerator', 'OutCirclePtFeatGenerator', 'OutGridCirclesPtFeatGenerator',
-               'AnchorPtFeatGenerator')
+_NEG_GENERATORS = ('OutCirclePtFeatGenerator', 'OutGridCirclesPtFeatGenerator', 'AnchorPtFeatGenerator')
 
 
 def circle_offsets(radius, stride, base_num_point=8, start_angle=0, same_num_all_radius=False):
@@ -58,17 +59,31 @@ def sqrt_threshold(thr):
 
 
 class _Extractor:
-    """Parsed ``train_pts_extractor`` / ``refine_pts_extractor`` config (PointExtractor, cpr_head.py:602-662)."""
+    """Parsed ``train_pts_extractor`` / ``refine_pts_extractor`` config (PointExtractor, cpr_head.py:602-662).
+    pos generator: CirclePtFeatGenerator (rings around every annotated / refine point, bilinear samples) or
+    GridCirclesPtFeatGenerator (the grid points inside the circles, cpr_head.py:405-438)."""
 
     def __init__(self, pos_generator, neg_generator, strides, num_classes):
         pg, ng = dict(pos_generator), dict(neg_generator)
-        assert pg.pop('type') == 'CirclePtFeatGenerator', 'pos generator: only CirclePtFeatGenerator is built'
-        ntype = ng.pop('type')
-        assert ntype in _GENERATORS, ntype
+        ptype, ntype = pg.pop('type'), ng.pop('type')
+        if ptype == 'GridEllipsePtFeatGenerator':
+            # the reference class cannot run: `c` is a (num_gts, 2) unit vector where a focal distance was meant, so
+            # `2 * a.reshape(-1, 1, 1)` has 2*num_gts rows against (num_gts, H, W) distances and get_max_pos_num returns a
+            # tensor that torch.zeros() rejects (cpr_head.py:368-402) -- there is no behaviour to reproduce
+            raise NotImplementedError('GridEllipsePtFeatGenerator raises inside the reference itself (cpr_head.py:382-402)')
+        assert ptype in ('CirclePtFeatGenerator', 'GridCirclesPtFeatGenerator'), ptype
+        assert ntype in _NEG_GENERATORS, ntype
+        assert not pg.pop('align_corners', False) and not ng.get('align_corners', False), 'align_corners=True is not built'
+        self.pos_is_grid = ptype == 'GridCirclesPtFeatGenerator'
         self.pos_radius = pg.pop('radius')
-        self.pos_kw = dict(start_angle=pg.pop('start_angle', 0), base_num_point=pg.pop('base_num_point', 8),
-                           same_num_all_radius=pg.pop('same_num_all_radius', False))
-        assert pg.pop('append_center', True) and not pg, pg
+        if self.pos_is_grid:
+            mp = pg.pop('max_pos_num', -1)
+            self.max_pos_num = mp if mp > 0 else 2 * (2 * self.pos_radius) ** 2          # cpr_head.py:434-438
+            assert pg.pop('scale_factor', None) in (None, 1.0) and not pg, pg
+        else:
+            self.pos_kw = dict(start_angle=pg.pop('start_angle', 0), base_num_point=pg.pop('base_num_point', 8),
+                               same_num_all_radius=pg.pop('same_num_all_radius', False))
+            assert pg.pop('append_center', True) and not pg, pg
         self.neg_is_anchor = ntype == 'AnchorPtFeatGenerator'
         self.neg_radius = ng.get('radius', 0)
         self.neg_class_wise = ng.get('class_wise', False)
@@ -80,6 +95,13 @@ class _Extractor:
         if key not in self._off:
             self._off[key] = circle_offsets(self.pos_radius, stride, **self.pos_kw).to(device)
         return self._off[key]
+
+
+class _Gts:
+    """The annotated / refine points of a batch in the kernels' CSR form.  With num_refine = R > 1 an image brings
+    (num_gts*R, 4) pseudo boxes (cpr_head.py:1240-1246): ``points`` holds all of them (gt-major), ``pt_*`` describe points,
+    the un-prefixed fields describe gts."""
+    pass
 
 
 @HEADS.register_module()
@@ -100,19 +122,26 @@ class CPRHead(nn.Module):
                  conv_bias='auto', loss_cls=None, loss_bbox=None, conv_cfg=None, norm_cfg=None, train_cfg=None,
                  test_cfg=None):
         super().__init__()
-        assert num_cls_fcs >= 0 and ins_share_head_feat and not loss_mil.get('binary_ins', False) and loss_type == 0, \
-            'options outside the shipped configs are SURVEY.md §8f rank 4 ("next")'
+        # ins_share_head_feat=False (a second, instance-only tower) and loss_type != 0 exist in no config of the reference
+        assert num_cls_fcs >= 0 and ins_share_head_feat and loss_type == 0, \
+            'ins_share_head_feat=False / loss_type != 0 are not built'
         assert num_cls_fcs == 0 or fc_out_channels % 32 == 0, 'fc_out_channels must be a multiple of 32'
         self.num_cls_fcs, self.fc_out_channels = num_cls_fcs, fc_out_channels
-        assert normal_cfg.get('prob_cls_type', 'sigmoid') == 'sigmoid' and not normal_cfg.get('out_bg_cls', False)
+        self.prob_type = normal_cfg.get('prob_cls_type', 'sigmoid')
+        self.norm_p = float(normal_cfg.get('normed_sigmoid_p', 1))
+        if self.prob_type not in ('sigmoid', 'softmax', 'normed_sigmoid'):
+            raise ValueError(self.prob_type)                     # as get_cls_prob does (cpr_head.py:1097)
+        # out_bg_cls=True cannot run in the reference for C > 1 (the (.., C) validity mask meets (.., C+1) probabilities in
+        # gfocal_loss, cpr_head.py:1226) and no config sets it
+        assert not normal_cfg.get('out_bg_cls', False), 'out_bg_cls=True is not built'
         assert norm_cfg is not None and norm_cfg['type'] == 'GN' and not dcn_on_last_conv and not debug
         self.num_classes = self.cls_out_channels = self.num_cls_out = num_classes
         self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
         self.strides = list(strides)
         self.ins_share_head_feat, self.ins_share_head_classifier = ins_share_head_feat, ins_share_head_classifier
+        self.binary_ins = bool(loss_mil.get('binary_ins', False))
+        assert not (self.binary_ins and ins_share_head_classifier)            # cpr_head.py:1012
         self.loss_cfg, self.loss_type, self.normal_cfg = dict(loss_cfg), loss_type, dict(normal_cfg)
-        # the three bag policies and the two gt_loss_type values only differ for num_refine > 1 (cpr_head.py:1159-1211);
-        # inputs with num_refine > 1 are rejected in _gt_tensors, so all of them run the same kernels here
         assert self.loss_cfg.get('refine_bag_policy', 'independent_with_gt_bag') in (
             'independent_with_gt_bag', 'merge_to_gt_bag', 'only_refine_bag'), self.loss_cfg['refine_bag_policy']
         if self.loss_cfg.get('gt_loss_type', 'gt_refine') not in ('gt_refine', 'gt'):
@@ -130,7 +159,8 @@ class CPRHead(nn.Module):
             self.cls_fcs.append(nn.Linear(chn, fc_out_channels))
             chn = fc_out_channels
         self.cls_out = nn.Linear(chn, num_classes)
-        self.ins_out = self.cls_out if ins_share_head_classifier else nn.Linear(chn, num_classes)
+        self.ins_out = self.cls_out if ins_share_head_classifier else \
+            nn.Linear(chn, num_classes * 2 if self.binary_ins else num_classes)      # cpr_head.py:1009-1011
         self.loss_mil = build_loss(loss_mil)
         self.loss_cls = self.loss_mil
         self.train_pts_extractor = _Extractor(**train_pts_extractor, strides=self.strides, num_classes=num_classes)
@@ -138,11 +168,16 @@ class CPRHead(nn.Module):
         pr = dict(gt_alpha=0.5, merge_th=0.05, refine_th=0.05, classify_filter=False, return_score_type='mean',
                   nearest_filter=True)
         pr.update(point_refiner)
-        assert pr['return_score_type'] == 'mean'
+        assert pr['return_score_type'] == 'mean', "return_score_type='max' is not built"
         self.point_refiner = pr
         self._cache = _PackCache()
         self._thr = {}
         self.init_weights()
+
+    def train_step_supported(self):
+        """The hand-written backward (training.CprTrainer) covers the shipped configs' options."""
+        return (self.prob_type == 'sigmoid' and not self.binary_ins and not self.loss_mil.allpos and
+                self.num_cls_fcs == 0 and not self.train_pts_extractor.pos_is_grid)
 
     # ------------------------------------------------------------------ init (cpr_head.py:939-948)
     def init_weights(self):
@@ -208,8 +243,18 @@ class CPRHead(nn.Module):
             x = ops.conv2d(x, pc, bias=bias, relu=True)
         return x
 
+    def _proj(self, dt):
+        """The classifiers as ONE packed 1x1 conv: rows [cls_out ++ ins_out] (cls_out alone when the classifier is shared)."""
+        def make():
+            w = [self.cls_out.weight] + ([] if self.ins_share_head_classifier else [self.ins_out.weight])
+            b = [self.cls_out.bias] + ([] if self.ins_share_head_classifier else [self.ins_out.bias])
+            wt = torch.cat(w, 0).detach()[:, :, None, None]
+            return ops.PackedConv(wt, 1, 0, dt), torch.cat(b, 0).detach().float().contiguous()
+        srcs = [self.cls_out.weight, self.cls_out.bias, self.ins_out.weight, self.ins_out.bias]
+        return self._cache.get(('proj', dt), srcs, make)
+
     def _logit_map(self, feat_nhwc, in_ab=None):
-        """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C)] (or C when the classifier is shared).
+        """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C, or 2C with binary_ins)] (or C when the classifier is shared).
         in_ab: the input is the raw last-layer conv output and (a, b) its GroupNorm affine (+ReLU), applied on load.
         With num_cls_fcs > 0 the (materialised) input first runs through the shared FC stack."""
         dt = feat_nhwc.dtype
@@ -217,51 +262,92 @@ class CPRHead(nn.Module):
             assert in_ab is None
             feat_nhwc = self._fc_stack(feat_nhwc)
 
-        def make():
-            w = [self.cls_out.weight] + ([] if self.ins_share_head_classifier else [self.ins_out.weight])
-            b = [self.cls_out.bias] + ([] if self.ins_share_head_classifier else [self.ins_out.bias])
-            wt = torch.cat(w, 0).detach()[:, :, None, None]
-            return ops.PackedConv(wt, 1, 0, dt), torch.cat(b, 0).detach().float().contiguous()
-        srcs = [self.cls_out.weight, self.cls_out.bias, self.ins_out.weight, self.ins_out.bias]
-        pc, bias = self._cache.get(('proj', dt), srcs, make)
+        pc, bias = self._proj(dt)
         if in_ab is not None and ((feat_nhwc.shape[1] * feat_nhwc.shape[2]) % 128 != 0 or dt != torch.float32):
             feat_nhwc, in_ab = ops.gn_apply(feat_nhwc, in_ab[0], in_ab[1], relu=True), None
         # the logit map is always fp32 (the loss / sampling kernels are shared by both compute modes)
         return ops.conv2d(feat_nhwc, pc, bias=bias, in_ab=in_ab, in_relu=True, out_dtype=torch.float32)
 
-    def _bags(self, feat, lmap, centers, gt_img, pad_hw, offsets, stride):
-        """Bag points, validity and bag logits (G,K,J).  num_cls_fcs == 0: Linear commutes with bilinear sampling, so the
-        logits are sampled from the projected map.  Otherwise the 256-channel features are sampled and run through the FC
-        stack + classifiers (the ReLUs in between do not commute with the interpolation)."""
-        if self.num_cls_fcs == 0:
-            return ops.bag_sample(lmap, centers, gt_img, pad_hw, offsets, stride)
-        pts, valid, bag_feat = ops.bag_sample(feat, centers, gt_img, pad_hw, offsets, stride)
-        G, K, Cf = bag_feat.shape
-        logits = self._logit_map(bag_feat.view(1, G * K, 1, Cf))
-        return pts, valid, logits.view(G, K, -1)
+    def _bags(self, ex, feat, lmap, gts, stride):
+        """Bag points (E,2), validity (E) and bag logits (E,J) of the positive generator, E = G * entries-per-gt, plus
+        the bag view (sub_bags per gt, entries per sub-bag).  num_cls_fcs == 0: Linear commutes with bilinear sampling, so
+        the logits are sampled from the projected map.  Otherwise the 256-channel features are sampled and run through the
+        FC stack + classifiers (the ReLUs in between do not commute with the interpolation)."""
+        src = lmap if self.num_cls_fcs == 0 else feat
+        if ex.pos_is_grid:
+            # the reference pads to max_pos_num + num_refine grid slots and THEN appends the num_refine points (cpr_head.py:325-349)
+            kmax = ex.max_pos_num + gts.R
+            # padding slots hold zero features in the reference (:323-324): on the projected map that is the projection's bias
+            pad = self._proj(src.dtype)[1] if self.num_cls_fcs == 0 else None
+            pts, valid, out, count = ops.grid_bag(src, gts.points, gts.gt_img, gts.R, kmax, ex.pos_radius * stride, stride,
+                                                  pad_value=pad)
+            # the reference fails inside generate() when a bag overflows (cpr_head.py:331-333: shape mismatch on assignment)
+            worst = int(count.max().item()) if count.numel() else 0
+            if worst > kmax:
+                raise RuntimeError('GridCirclesPtFeatGenerator: %d grid points in one bag > max_pos_num + num_refine = %d'
+                                   % (worst, kmax))
+            view = (1, kmax + gts.R)
+        else:
+            pts, valid, out = ops.bag_sample(src, gts.points, gts.pt_img, gts.pad_hw, ex.offsets(stride, src.device), stride)
+            view = (gts.R, pts.shape[1])
+        if self.num_cls_fcs > 0:
+            E, K, Cf = out.shape
+            out = self._logit_map(out.view(1, E * K, 1, Cf)).view(E, K, -1)
+        G = gts.G
+        return pts.view(G, -1, 2), valid.view(G, -1), out.view(G, -1, out.shape[-1]), view
 
-    def _gt_tensors(self, gt_bboxes, gt_labels, img_metas, device, shape_key):
+    def _gt_tensors(self, gt_bboxes, gt_labels, img_metas, device, shape_key='pad_shape'):
         counts = [int(len(l)) for l in gt_labels]
         assert len(counts) > 0 and all(c > 0 for c in counts), 'CPRHead does not support empty-gt images ' \
             '(the reference asserts too: cpr_head.py:1102,1242)'
+        R = gt_bboxes[0].shape[0] // counts[0]
         for b, c in zip(gt_bboxes, counts):
-            assert b.shape[0] == c, 'num_refine > 1 inputs are not built (SURVEY.md §8f rank 4)'
+            assert b.shape[0] == c * R and R >= 1, 'every image must bring num_gts * num_refine pseudo boxes'
+        g = _Gts()
+        g.R, g.counts, g.G = R, counts, sum(counts)
         boxes = torch.cat([b.float() for b in gt_bboxes]).contiguous()
         labels = torch.cat(list(gt_labels)).to(torch.int32).contiguous()
         start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         gt_img = np.repeat(np.arange(len(counts), dtype=np.int32), counts)
         hw = np.array([[m[shape_key][0], m[shape_key][1]] for m in img_metas], dtype=np.int32).reshape(-1)
-        meta = torch.from_numpy(np.concatenate([start, gt_img, hw])).to(device)
-        nb = len(counts)
-        gt_start, gt_img_t, hw_t = meta[:nb + 1], meta[nb + 1:nb + 1 + len(gt_img)], meta[nb + 1 + len(gt_img):]
-        centers = ops.box_centers(boxes.to(device))
-        return centers, labels.to(device), gt_start, gt_img_t, hw_t, counts
+        ihw = np.array([[m['img_shape'][0], m['img_shape'][1]] for m in img_metas], dtype=np.int32).reshape(-1)
+        parts = [start, gt_img, hw, ihw] + ([start * R, np.repeat(gt_img, R)] if R > 1 else [])
+        meta = torch.from_numpy(np.concatenate(parts)).to(device)
+        cuts = np.cumsum([0] + [len(p) for p in parts])
+        g.gt_start, g.gt_img, g.pad_hw, g.img_hw = [meta[cuts[i]:cuts[i + 1]] for i in range(4)]
+        g.pt_start, g.pt_img = (meta[cuts[4]:cuts[5]], meta[cuts[5]:cuts[6]]) if R > 1 else (g.gt_start, g.gt_img)
+        g.points = ops.box_centers(boxes.to(device))              # (G*R, 2), gt-major
+        g.labels = labels.to(device)
+        g.pt_labels = g.labels.repeat_interleave(R).contiguous() if R > 1 else g.labels
+        return g
 
     def _d2_threshold(self, stride, radius):
         key = (stride, radius)
         if key not in self._thr:
             self._thr[key] = sqrt_threshold(stride * radius)
         return self._thr[key]
+
+    def _loss_geometry(self, gts, view, gt_weights, dev):
+        """Bag / annotated-point geometry of loss0 (cpr_head.py:1159-1211) for ops.mil_loss, plus per-bag labels / weights."""
+        Rv, Kv = view
+        G, cfg = gts.G, self.loss_cfg
+        w = None if gt_weights is None else torch.cat(list(gt_weights)).float().to(dev).contiguous()
+        policy = cfg.get('refine_bag_policy', 'independent_with_gt_bag')
+        only_first = cfg.get('gt_loss_type', 'gt_refine') == 'gt'
+        if Rv == 1 or policy == 'independent_with_gt_bag':
+            bags = (G * Rv, Kv, 0, Kv)
+            centres = (Kv - 1, Kv, 1, Rv if only_first else 1)
+            labels = gts.pt_labels if Rv > 1 else gts.labels
+            if w is not None and Rv > 1:
+                w = w.repeat_interleave(Rv).contiguous()
+        else:
+            si = 1 if policy == 'only_refine_bag' else 0
+            bags = (G, Rv * Kv, si * Kv, (Rv - si) * Kv)
+            centres = (Kv - 1, Kv, 1 if only_first else Rv, 1)
+            labels = gts.labels
+        if not cfg.get('with_gt_loss', False):
+            centres = (0, 1, 0, 1)
+        return bags, centres, labels, w
 
     # ------------------------------------------------------------------ loss (cpr_head.py:1101-1229)
     def loss(self, cls_feat, ins_feat, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None, gt_true_bboxes=None,
@@ -278,59 +364,71 @@ class CPRHead(nn.Module):
             assert save is None, 'the training step is built for num_cls_fcs == 0'
             feat, ab = ops.gn_apply(feat, ab[0], ab[1], relu=True), None
         lmap = self._logit_map(feat, ab)
-        centers, labels, gt_start, gt_img, pad_hw, _ = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev,
-                                                                        'pad_shape')
-        _, valid, bag_logits = self._bags(feat, lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
+        gts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev)
+        _, valid, bag_logits, view = self._bags(ex, feat, lmap, gts, stride)
         cfg = self.loss_cfg
+        with_mil, with_gt, with_neg = cfg.get('with_mil_loss', True), cfg.get('with_gt_loss', False), cfg.get('with_neg', True)
+        assert with_mil or with_gt, 'loss0 needs num_pos from the MIL or the gt loss (cpr_head.py:1180,1213,1227)'
         partial = neg_mask = None
-        if cfg.get('with_neg', True):
+        if with_neg:
             # the reference cannot train with it either: loss0 unpacks a (H, W, C) tensor into two dims (cpr_head.py:1221)
             assert not ex.neg_is_anchor, 'AnchorPtFeatGenerator is a refine-time generator only'
-            neg_mask, partial = ops.neg_mask_loss(lmap, centers, labels, gt_start, pad_hw, C, stride,
-                                           self._d2_threshold(stride, ex.neg_radius), self.loss_mil.eps,
-                                           ex.neg_class_wise)
-        w = None if gt_weights is None else torch.cat(list(gt_weights)).float().to(dev).contiguous()
+            neg_mask, partial = ops.neg_mask_loss(lmap, gts.points, gts.pt_labels, gts.pt_start, gts.pad_hw, C, stride,
+                                                  self._d2_threshold(stride, ex.neg_radius), self.loss_mil.eps,
+                                                  ex.neg_class_wise, self.prob_type, self.norm_p)
+        bags, centres, labels, w = self._loss_geometry(gts, view, gt_weights, dev)
         ins_off = 0 if self.ins_share_head_classifier else C
         out = self.loss_mil.forward_logits(bag_logits, ins_off, valid, labels, C, w, partial,
                                            cfg.get('gt_loss_weight', 1.0), cfg.get('neg_loss_weight', 1.0),
-                                           want_bag_ws=save is not None)
+                                           want_bag_ws=save is not None, bags=bags, centres=centres,
+                                           prob_type=self.prob_type, norm_p=self.norm_p, neg_from_gt=not with_mil)
         if save is not None:
+            assert self.train_step_supported() and gts.R == 1, \
+                'the hand-written backward covers the shipped configs (sigmoid, MILLoss, circle bags, num_refine = 1)'
             out, bag_ws = out
             save.update(feat=feat, ab=ab, lmap=lmap, neg_mask=neg_mask, out5=out, bag_logits=bag_logits, valid=valid,
-                        labels=labels, gt_weight=w, bag_ws=bag_ws, centers=centers, gt_img=gt_img,
+                        labels=labels, gt_weight=w, bag_ws=bag_ws, centers=gts.points, gt_img=gts.gt_img,
                         offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride)
         losses = {}
-        if cfg.get('with_gt_loss', False):
+        if with_gt:
             losses['gt_loss'] = out[0]
-        if cfg.get('with_mil_loss', True):
+        if with_mil:
             losses['pos_loss'], losses['bag_acc'] = out[1], out[2]
-        if cfg.get('with_neg', True):
+        if with_neg:
             losses['neg_loss'] = out[3]
         return losses
 
     # ------------------------------------------------------------------ refine (cpr_head.py:1231-1283)
-    def get_bboxes(self, cls_feat, ins_feat, img_metas, cfg=None, rescale=False, with_nms=True, gt_bboxes=None,
-                   gt_labels=None, gt_bboxes_ignore=None, gt_true_bboxes=None, gt_anns_id=None, not_refine=None,
-                   cascade_out_fmt=False):
-        assert gt_labels is not None and len(gt_labels) > 0 and gt_anns_id is not None
+    def refine_points(self, cls_feat, img_metas, gt_bboxes, gt_labels, not_refine=None):
+        """Extraction + PointRefiner of get_bboxes: returns the kernel outputs for all gts of the batch
+        (gts, bag pts (G,Kt,2), refine_pts (G,2), scores (G), not_refine (G) u8, chosen (G,Kt) u8)."""
         assert len(cls_feat) == 1
         ex, C, stride, pr = self.refine_pts_extractor, self.num_classes, self.strides[0], self.point_refiner
         feat = ops.from_nchw(cls_feat[0])
         dev = feat.device
         lmap = self._logit_map(feat)
-        centers, labels, gt_start, gt_img, pad_hw, counts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev,
-                                                                             'pad_shape')
-        img_hw = torch.tensor([[m['img_shape'][0], m['img_shape'][1]] for m in img_metas], dtype=torch.int32,
-                              device=dev).reshape(-1)
-        pts, valid, bag_logits = self._bags(feat, lmap, centers, gt_img, pad_hw, ex.offsets(stride, dev), stride)
+        gts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev)
+        # PointRefiner.refine_single asserts gt_r_pts == gt_r_points[:, :1] (cpr_head.py:809): with CirclePtFeatGenerator
+        # bags it only accepts one point per gt; the grid generators keep one annotated point per bag and take R > 1
+        assert ex.pos_is_grid or gts.R == 1, 'num_refine > 1 inputs cannot be refined (the reference asserts: cpr_head.py:809)'
+        pts, valid, bag_logits, (Rv, Kv) = self._bags(ex, feat, lmap, gts, stride)
         # the grid (negative) branch is computed but unused by the reference at refine time (cpr_head.py:794-804)
         nr_in = None if not_refine is None else torch.cat(list(not_refine)).to(torch.uint8).to(dev).contiguous()
-        rp, sc, nr, chosen = ops.refine(bag_logits, pts, valid, centers, labels, gt_img, gt_start, img_hw, C,
-                                        pr['gt_alpha'], pr['merge_th'], pr['refine_th'], pr['nearest_filter'],
-                                        pr['classify_filter'], nr_in)
+        rp, sc, nr, chosen = ops.refine(bag_logits, pts, valid, gts.points, gts.labels, gts.gt_img, gts.gt_start,
+                                        gts.img_hw, C, pr['gt_alpha'], pr['merge_th'], pr['refine_th'],
+                                        pr['nearest_filter'], pr['classify_filter'], nr_in, sub_bags=Rv,
+                                        ctr_stride=gts.R, prob_type=self.prob_type, norm_p=self.norm_p)
+        return gts, pts, rp, sc, nr, chosen
+
+    def get_bboxes(self, cls_feat, ins_feat, img_metas, cfg=None, rescale=False, with_nms=True, gt_bboxes=None,
+                   gt_labels=None, gt_bboxes_ignore=None, gt_true_bboxes=None, gt_anns_id=None, not_refine=None,
+                   cascade_out_fmt=False):
+        assert gt_labels is not None and len(gt_labels) > 0 and gt_anns_id is not None
+        gts, pts, rp, sc, nr, chosen = self.refine_points(cls_feat, img_metas, gt_bboxes, gt_labels, not_refine)
+        dev = rp.device
         boxes = torch.cat([rp - 8.0, rp + 8.0], dim=-1)          # center_to_pseudo_bbox, 16x16 (:1303-1309)
         out, nr_list, s = [], [], 0
-        for b, n in enumerate(counts):
+        for b, n in enumerate(gts.counts):
             bx = boxes[s:s + n]
             if rescale:
                 bx = bx / bx.new_tensor(img_metas[b]['scale_factor'])
@@ -349,18 +447,16 @@ class CPRHead(nn.Module):
 
     @staticmethod
     def _geo(pts, chosen, rp, img_meta, rescale):
-        """get_geo_output (cpr_head.py:852-864): [refined pt, chosen pts...] padded with -1."""
+        """get_geo_output + scale_geos + fill_list_to_tensor (cpr_head.py:852-864,1285-1288,54-60): per gt
+        [refined pt, chosen pts...], rescaled, then padded with -1 to the longest row of the IMAGE."""
         G, K, _ = pts.shape
         m = int(chosen.sum(dim=1).max().item()) if G else 0
-        geo = pts.new_full((G, m + 1, 2), -1.0)
-        geo[:, 0] = rp
         order = torch.argsort(chosen.to(torch.int16), dim=1, descending=True, stable=True)[:, :m]
-        sel = torch.gather(pts, 1, order[..., None].expand(-1, -1, 2))
-        keep = torch.gather(chosen, 1, order).bool()
-        geo[:, 1:][keep] = sel[keep]
+        sel = torch.cat([rp[:, None], torch.gather(pts, 1, order[..., None].expand(-1, -1, 2))], dim=1)
+        keep = torch.cat([chosen.new_ones((G, 1)), torch.gather(chosen, 1, order)], dim=1).bool()
         if rescale:
-            sf = geo.new_tensor(img_meta['scale_factor'][:2])
-            geo = torch.where(geo >= 0, geo / sf, geo)
+            sel = sel / sel.new_tensor(img_meta['scale_factor'][:2])
+        geo = torch.where(keep[..., None], sel, sel.new_full((), -1.0))
         return geo.reshape(G, -1)
 
     def simple_test(self, feats, img_metas, rescale=False, **gt_kwargs):

@@ -257,22 +257,26 @@ def box_centers(boxes):
     return out
 
 
+PROB_TYPES = {'sigmoid': 0, 'softmax': 1, 'normed_sigmoid': 2, 'identity': 3}
+
+
 def neg_mask_loss(logit_map, centers, labels, gt_start, pad_hw, num_classes, stride, d2_thr, eps=1e-6,
-                  class_wise=True):
-    """logit_map (N,H,W,J) -> mask (N*H*W, C) uint8, partial sums (double)."""
+                  class_wise=True, prob_type='sigmoid', norm_p=1.0):
+    """logit_map (N,H,W,J) -> mask (N*H*W, C) uint8, partial sums (double).  centers/labels/gt_start: the annotated
+    points in CSR form (with num_refine > 1: every refine point, carrying its gt's label)."""
     N, H, W, J = _check(logit_map).shape
     C = num_classes
     mask = torch.empty((N * H * W, C), device=logit_map.device, dtype=torch.uint8)
     nblk = (H * W * C + 255) // 256
     partial = torch.empty((N * nblk,), device=logit_map.device, dtype=torch.float64)
     _lib.call('cpr_neg_mask_loss', _ptr(logit_map), J, _ptr(centers), _ptr(labels), _ptr(gt_start), _ptr(pad_hw),
-              _ptr(mask), _ptr(partial), N, H, W, C, float(stride), float(d2_thr), float(eps), int(class_wise), None,
-              _stream())
+              _ptr(mask), _ptr(partial), N, H, W, C, float(stride), float(d2_thr), float(eps), int(class_wise),
+              PROB_TYPES[prob_type], float(norm_p), None, _stream())
     return mask, partial
 
 
 def bag_sample(fmap, centers, gt_img, pad_hw, offsets, stride):
-    """fmap (N,H,W,J); returns pts (G,K,2), valid (G,K) uint8, sampled (G,K,J)."""
+    """fmap (N,H,W,J); one bag per row of centers; returns pts (G,K,2), valid (G,K) uint8, sampled (G,K,J)."""
     N, H, W, J = _check(fmap).shape
     G = centers.shape[0]
     K = (offsets.shape[0] if offsets is not None else 0) + 1
@@ -284,30 +288,66 @@ def bag_sample(fmap, centers, gt_img, pad_hw, offsets, stride):
     return pts, valid, out
 
 
-def mil_loss(logits, ins_off, valid, labels, num_classes, neg_partial, w_mil, w_gt, w_neg, gt_weight=None, eps=1e-6):
-    """-> (5,) tensor {gt_loss, pos_loss, bag_acc, neg_loss, num_pos} and the per-bag workspace (G,5)."""
+def grid_bag(fmap, points, gt_img, num_refine, max_pos_num, radius_px, stride, pad_value=None):
+    """GridCirclesPtFeatGenerator bags: fmap (N,H,W,J), points (G*R,2), gt_img (G) -> pts (G,Kmax+R,2),
+    valid (G,Kmax+R) uint8, sampled (G,Kmax+R,J), count (G) int32 (grid points found per gt).  pad_value (J,): what the
+    padding slots hold (default zeros)."""
+    N, H, W, J = _check(fmap).shape
+    R = int(num_refine)
+    G = points.shape[0] // R
+    Kt = int(max_pos_num) + R
+    dev = fmap.device
+    pts = torch.empty((G, Kt, 2), device=dev, dtype=torch.float32)
+    valid = torch.empty((G, Kt), device=dev, dtype=torch.uint8)
+    cell = torch.empty((G, Kt), device=dev, dtype=torch.int32)
+    count = torch.empty((G,), device=dev, dtype=torch.int32)
+    out = torch.empty((G, Kt, J), device=dev, dtype=torch.float32)
+    assert pad_value is None or pad_value.numel() == J
+    _lib.call('cpr_grid_bag', _ptr(fmap), J, _ptr(_check(points)), _ptr(gt_img), R, int(max_pos_num), float(radius_px),
+              _ptr(pad_value), _ptr(pts), _ptr(valid), _ptr(cell), _ptr(count), _ptr(out), G, H, W, float(stride), _stream())
+    return pts, valid, out, count
+
+
+def mil_loss(logits, ins_off, valid, labels, num_classes, neg_partial, w_mil, w_gt, w_neg, gt_weight=None, eps=1e-6,
+             bags=None, centres=None, prob_type='sigmoid', norm_p=1.0, binary_ins=False, allpos=False,
+             neg_from_gt=False):
+    """logits (G,K,J) [entries = G*K rows], valid (G,K).  bags = (num_bags, stride, off, len) in entries (default: one bag
+    per row of the (G,K) layout); centres = (off, stride, count, mod): the annotated-point loss entries of a bag (default:
+    the last entry of every bag).  labels / gt_weight are per bag.
+    -> (5,) tensor {gt_loss, pos_loss, bag_acc, neg_loss, num_sample} and the per-bag workspace (num_bags,5)."""
     G, K, J = _check(logits).shape
-    bag = torch.empty((G, 5), device=logits.device, dtype=torch.float32)
+    nb, bstride, boff, blen = bags if bags is not None else (G, K, 0, K)
+    coff, cstride, ccount, cmod = centres if centres is not None else (K - 1, K, 1, 1)
+    assert labels.numel() == nb and (gt_weight is None or gt_weight.numel() == nb)
+    assert (nb - 1) * bstride + boff + blen <= G * K
+    bag = torch.empty((nb, 5), device=logits.device, dtype=torch.float32)
     out = torch.empty((5,), device=logits.device, dtype=torch.float32)
     npart = 0 if neg_partial is None else neg_partial.numel()
     _lib.call('cpr_mil_loss', _ptr(logits), J, ins_off, _ptr(valid), _ptr(labels), _ptr(gt_weight), _ptr(bag),
-              _ptr(neg_partial), npart, G, K, num_classes, float(eps), float(w_mil), float(w_gt), float(w_neg),
-              _ptr(out), _stream())
+              _ptr(neg_partial), npart, nb, bstride, boff, blen, coff, cstride, ccount, cmod, num_classes, float(eps),
+              PROB_TYPES[prob_type], float(norm_p), int(binary_ins), int(allpos), float(w_mil), float(w_gt),
+              float(w_neg), int(neg_from_gt), _ptr(out), _stream())
     return out, bag
 
 
 def refine(logits, pts, valid, centers, labels, gt_img, gt_start, img_hw, num_classes, gt_alpha, merge_th, refine_th,
-           use_nearest=True, use_classify=False, not_refine_in=None):
-    G, K, J = _check(logits).shape
+           use_nearest=True, use_classify=False, not_refine_in=None, sub_bags=1, ctr_stride=None, prob_type='sigmoid',
+           norm_p=1.0):
+    """logits (G,Kt,J): a gt owns Kt = sub_bags*Kv entries; centers holds ctr_stride points per gt (default sub_bags)."""
+    G, Kt, J = _check(logits).shape
+    Rv = int(sub_bags)
+    assert Kt % Rv == 0
+    ctr_stride = Rv if ctr_stride is None else int(ctr_stride)
+    assert centers.shape[0] == G * ctr_stride
     dev = logits.device
     rp = torch.empty((G, 2), device=dev, dtype=torch.float32)
     sc = torch.empty((G,), device=dev, dtype=torch.float32)
     nr = torch.empty((G,), device=dev, dtype=torch.uint8)
-    chosen = torch.empty((G, K), device=dev, dtype=torch.uint8)
-    _lib.call('cpr_refine', _ptr(logits), J, _ptr(pts), _ptr(valid), _ptr(centers), _ptr(labels), _ptr(gt_img),
-              _ptr(gt_start), _ptr(img_hw), _ptr(not_refine_in), _ptr(rp), _ptr(sc), _ptr(nr), _ptr(chosen), G, K,
-              num_classes, float(gt_alpha), float(merge_th), float(refine_th), int(use_nearest), int(use_classify),
-              _stream())
+    chosen = torch.empty((G, Kt), device=dev, dtype=torch.uint8)
+    _lib.call('cpr_refine', _ptr(logits), J, _ptr(pts), _ptr(valid), _ptr(centers), Rv, ctr_stride, _ptr(labels),
+              _ptr(gt_img), _ptr(gt_start), _ptr(img_hw), _ptr(not_refine_in), _ptr(rp), _ptr(sc), _ptr(nr),
+              _ptr(chosen), G, Kt, Kt // Rv, num_classes, PROB_TYPES[prob_type], float(norm_p), float(gt_alpha),
+              float(merge_th), float(refine_th), int(use_nearest), int(use_classify), _stream())
     return rp, sc, nr, chosen
 
 

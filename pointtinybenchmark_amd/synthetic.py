@@ -97,7 +97,7 @@ def fpn_state_dict(in_channels, out_channels=256, start_level=0, num_outs=1, see
 
 
 def cpr_head_state_dict(num_classes=1, in_channels=256, feat_channels=256, stacked_convs=4, seed=2,
-                        prefix='bbox_head.', std=0.01, num_cls_fcs=0, fc_out_channels=1024):
+                        prefix='bbox_head.', std=0.01, num_cls_fcs=0, fc_out_channels=1024, binary_ins=False):
     """Normal(0, std) on Conv2d/Linear, cls_out bias = bias_init_with_prob(0.01)
     (T/mmdet/models/point/dense_heads/cpr_head.py:939-948).  ``std`` larger than the reference's
     0.01 makes the synthetic logits spread out (used by tests to exercise the refine filters)."""
@@ -114,8 +114,9 @@ def cpr_head_state_dict(num_classes=1, in_channels=256, feat_channels=256, stack
         chn = fc_out_channels
     sd[prefix + 'cls_out.weight'] = torch.randn((num_classes, chn), generator=g) * std
     sd[prefix + 'cls_out.bias'] = torch.full((num_classes,), -math.log((1 - 0.01) / 0.01))
-    sd[prefix + 'ins_out.weight'] = torch.randn((num_classes, chn), generator=g) * std
-    sd[prefix + 'ins_out.bias'] = torch.zeros(num_classes)
+    n_ins = num_classes * 2 if binary_ins else num_classes          # cpr_head.py:1009-1011
+    sd[prefix + 'ins_out.weight'] = torch.randn((n_ins, chn), generator=g) * std
+    sd[prefix + 'ins_out.bias'] = torch.zeros(n_ins)
     return sd
 
 
@@ -138,12 +139,12 @@ def p2p_head_state_dict(num_classes=1, num_points=1, in_channels=256, feat_chann
 
 
 def locator_state_dict(depth=50, num_classes=1, start_level=0, head='cpr', seed=0, head_std=0.01, num_points=1,
-                       num_cls_fcs=0, fc_out_channels=1024):
+                       num_cls_fcs=0, fc_out_channels=1024, binary_ins=False):
     sd = resnet_state_dict(depth, seed)
     sd.update(fpn_state_dict(backbone_out_channels(depth), 256, start_level, 1, seed + 1))
     if head == 'cpr':
         sd.update(cpr_head_state_dict(num_classes, seed=seed + 2, std=head_std, num_cls_fcs=num_cls_fcs,
-                                      fc_out_channels=fc_out_channels))
+                                      fc_out_channels=fc_out_channels, binary_ins=binary_ins))
     else:
         sd.update(p2p_head_state_dict(num_classes, num_points, seed=seed + 3, std=head_std))
     return sd
@@ -174,3 +175,27 @@ def synthetic_batch(batch=2, height=640, width=640, num_gts=32, num_classes=1, s
                               ori_shape=(height, width, 3), scale_factor=[1.0, 1.0, 1.0, 1.0],
                               filename='synthetic_%d' % b, flip=False))
     return dict(img=img, img_metas=img_metas, gt_bboxes=gt_bboxes, gt_labels=gt_labels, gt_anns_id=gt_anns_id)
+
+
+def with_refine_points(batch, num_refine, seed=0, jitter=6.0):
+    """num_refine > 1 inputs (cpr_head.py:1240-1246): every gt brings R pseudo boxes, gt-major ((num_gts*R, 4) per image):
+    refine 0 is the annotated point, the others are seeded perturbations of it (as a previous refinement round would
+    supply), kept inside the image.  Returns a copy of ``batch`` with the wider ``gt_bboxes``."""
+    if num_refine == 1:
+        return batch
+    g = torch.Generator().manual_seed(seed + 77)
+    out = dict(batch)
+    boxes = []
+    for b, bb in enumerate(batch['gt_bboxes']):
+        h, w = batch['img_metas'][b]['img_shape'][:2]
+        ctr = (bb[:, :2] + bb[:, 2:]) / 2
+        pts = [ctr]
+        for _ in range(num_refine - 1):
+            p = ctr + torch.randn(ctr.shape, generator=g) * jitter
+            p[:, 0] = p[:, 0].clamp(1, w - 2)
+            p[:, 1] = p[:, 1].clamp(1, h - 2)
+            pts.append(p)
+        pts = torch.stack(pts, dim=1).reshape(-1, 2)                       # (G, R, 2) -> (G*R, 2)
+        boxes.append(torch.cat([pts - 8, pts + 8], dim=1))
+    out['gt_bboxes'] = boxes
+    return out

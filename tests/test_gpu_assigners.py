@@ -42,51 +42,101 @@ def _ha(k):
                                reg_costs=dict(type='DisCostV2', weight=0.1, norm_with_img_wh=False), topk_k=k)
 
 
+def _ulp_diff(a, b):
+    """|a - b| in units of the last place for same-sign finite fp32 arrays (0 where bit-identical)."""
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    return np.abs(ia - ib)
+
+
+def _check_hungarian(pred, logits, gt, labels, shp, k, record_property, tag, ref_cost=None, ref_inds=None):
+    """The a13 gate.  The reference's cost bits depend on the HOST it runs on (its fp32 log is MKL VML, whose last bit
+    differs between the Xeon build host and the EPYC GPU-box host: profiles/round2_log_probe.txt), so parity is stated as
+    a chain of exact links plus a measured residual:
+      1. device cost == the reference formula with a correctly rounded log, BIT FOR BIT (host independent);
+      2. device indices == scipy.linear_sum_assignment run on the device's own cost matrix, BIT FOR BIT, always;
+      3. device LSA on the reference's own cost bits == the reference's indices, BIT FOR BIT (fixtures only);
+      4. residual vs what the reference computes on a given host: a 1-ulp difference of either log term moves a cost
+         entry by <= 2^-23 * |2 * term| (many ulps of the entry when pos - neg cancels) plus one rounding of the sum, so the
+         bound is |diff| <= 1e-6 + 2^-23 |entry|; the number of differing entries / indices is recorded."""
+    ha = _ha(k)
+    meta = dict(img_shape=shp)
+    costT = ha.cost_t(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), meta)
+    dev_cost = costT.t().contiguous().cpu()
+    got = ha.assign(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), meta).gt_inds.cpu()
+    # 1. cost bits against the correctly-rounded-log statement of the reference formula
+    inds_cr, _, cost_cr = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=k, log_mode='cr')
+    n_cr = int((dev_cost != cost_cr).sum())
+    assert n_cr == 0, '%s: %d of %d device cost entries differ from the correctly-rounded-log formula' % (
+        tag, n_cr, dev_cost.numel())
+    # 2. the device LSA is scipy on the device's own costs, tie for tie
+    own = O.lsa_topk(dev_cost, k)
+    n_own = int((got != own).sum())
+    assert n_own == 0, '%s: %d indices differ from scipy on the device cost matrix' % (tag, n_own)
+    assert torch.equal(got, inds_cr)
+    # 4. residual against the host-dependent reference bits
+    if ref_cost is None:
+        ref_inds_t, _, ref_cost_t = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=k)   # this host's log
+        ref_cost, ref_inds = ref_cost_t.numpy(), ref_inds_t.numpy()
+    ulp = _ulp_diff(dev_cost.numpy(), ref_cost)
+    n_ent, n_idx = int((ulp > 0).sum()), int((got.numpy() != ref_inds).sum())
+    record_property(tag + '_n_diff_cost_entries', n_ent)
+    record_property(tag + '_n_diff_indices', n_idx)
+    _RESIDUALS.append(dict(case=tag, entries=int(ulp.size), n_diff_cost_entries=n_ent, max_ulp=int(ulp.max()),
+                           n_diff_indices=n_idx, positives=int((got > 0).sum())))
+    aerr = np.abs(dev_cost.numpy().astype(np.float64) - ref_cost.astype(np.float64))
+    worst = float((aerr - 2.0 ** -23 * np.abs(ref_cost.astype(np.float64))).max())
+    assert worst <= 1e-6, '%s: a cost entry is %.3e (beyond one rounding) from the reference' % (tag, worst)
+    assert n_ent <= 0.08 * ulp.size, '%s: %d of %d cost entries differ' % (tag, n_ent, ulp.size)
+    return got, n_ent, n_idx
+
+
+_RESIDUALS = []
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _dump_residuals():
+    """gpurun_out/assigner_residuals.json: the measured host-log residual per case (pulled back by the driver)."""
+    yield
+    if _RESIDUALS:
+        import json
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'assigner_residuals.json'), 'w') as f:
+            json.dump(_RESIDUALS, f, indent=1)
+
+
 @pytest.mark.parametrize('case', range(5))
-def test_hungarian_v2_vs_reference_fixture(golden_dir, case):
+def test_hungarian_v2_vs_reference_fixture(golden_dir, case, record_property):
+    """Fixtures = the reference's own HungarianAssignerV2 run on the build host (indices AND its fp32 cost matrix)."""
+    from pointtinybenchmark_amd import ops
     g = np.load(os.path.join(golden_dir, 'assigners.npz'))
+    gc = np.load(os.path.join(golden_dir, 'assigner_costs.npz'))
     n_side, G, C, k = [int(v) for v in g['ha%d_cfg' % case]]
     pred, logits, gt, labels, shp = assigner_inputs(200 + case, n_side, 4, G, C)
-    ha = _ha(k)
-    res = ha.assign(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
-    got = res.gt_inds.cpu().numpy()
-    ref = g['ha%d_gt_inds' % case]
-    nbad = int((got != ref).sum())
-    if nbad:
-        # The L1 cost makes exactly tied optima common; which one is returned hangs on the last bit of every cost
-        # entry.  sigmoid is reproduced bit-exactly, log is MKL-VML on the host (0.1 % of values 1 ulp off the correctly
-        # rounded result the kernel uses), so a tie can still flip.  Accept ONLY tie-equivalent answers: same positives
-        # per gt and the same total cost (to fp32 rounding) under the reference's own cost matrix.
-        _, _, cost = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=k)
-        c = cost.double().numpy()
-        tot = lambda a: sum(c[m, a[m] - 1] for m in np.nonzero(a > 0)[0])
-        assert np.array_equal(np.bincount(got, minlength=G + 1), np.bincount(ref, minlength=G + 1))
-        assert abs(tot(got) - tot(ref)) <= 1e-6 * abs(tot(ref)), \
-            '%d of %d indices differ and the assignment is NOT cost-equivalent (%.9g vs %.9g)' % (
-                nbad, got.size, tot(got), tot(ref))
-        costT = ha.cost_t(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
-        nbits = int((costT.t().cpu() != cost).sum())
-        print('hungarian fixture %d: %d tie-equivalent index differences; %d of %d cost entries differ in the last bit'
-              % (case, nbad, nbits, cost.numel()))
-    else:
-        assert np.array_equal(res.labels.cpu().numpy(), g['ha%d_labels' % case])
+    ref_cost, ref_inds = gc['ha%d_cost' % case], g['ha%d_gt_inds' % case]
+    # 3. the device LSA on the reference's own cost bits reproduces the reference's indices, unconditionally
+    (on_ref,), status = ops.lsa_topk([torch.from_numpy(ref_cost).t().contiguous().cuda()], k)
+    assert int(status[0]) == 0
+    assert np.array_equal(on_ref.cpu().numpy(), ref_inds), '%d indices differ on identical cost bits' % int(
+        (on_ref.cpu().numpy() != ref_inds).sum())
+    got, n_ent, n_idx = _check_hungarian(pred, logits, gt, labels, shp, k, record_property, 'ha%d' % case, ref_cost, ref_inds)
+    # the build host's MKL log is within 2 entries in 819 200 of the correctly rounded one on these inputs, and none of
+    # those touches a tie: the device indices ARE the reference's
+    assert n_idx == 0, 'ha%d: %d indices differ from the reference fixture (%d cost entries 1 ulp apart)' % (case, n_idx, n_ent)
+    labels_ref = g['ha%d_labels' % case]
+    res = _ha(k).assign(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
+    assert np.array_equal(res.labels.cpu().numpy(), labels_ref)
 
 
 @pytest.mark.parametrize('seed', range(8))
-def test_hungarian_v2_vs_oracle_seeds(seed):
+def test_hungarian_v2_vs_oracle_seeds(seed, record_property):
+    """Extra seeds against the oracle executed on THIS host (the GPU box's CPU: its MKL log differs from the correctly
+    rounded one in ~2-5 % of the cost entries, so links 1-2 carry the proof and the residual is recorded)."""
     n_side, G, C, k = [(48, 12, 1, 5), (64, 30, 1, 5), (40, 5, 2, 3), (30, 64, 1, 5), (100, 40, 1, 5),
                        (20, 3, 1, 1), (160, 100, 1, 5), (56, 17, 5, 4)][seed]
     pred, logits, gt, labels, shp = assigner_inputs(900 + seed, n_side, 4, G, C)
-    ha = _ha(k)
-    costT = ha.cost_t(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
-    inds, lab, cost = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=k)
-    cerr = float((costT.t().cpu() - cost).abs().max())
-    assert cerr <= 1e-5, 'cost matrix max abs err %.3e' % cerr
-    res = ha.assign(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
-    got = res.gt_inds.cpu()
-    assert int((got > 0).sum()) == int((inds > 0).sum())
-    nbad = int((got != inds).sum())
-    assert nbad == 0, '%d of %d indices differ from scipy' % (nbad, got.numel())
+    got, n_ent, n_idx = _check_hungarian(pred, logits, gt, labels, shp, k, record_property, 'seed%d' % seed)
+    assert int((got > 0).sum()) == min(k, (n_side * n_side) // G) * G
 
 
 @pytest.mark.parametrize('case', range(5))
@@ -102,8 +152,6 @@ def test_device_lsa_reproduces_scipy_on_identical_costs(golden_dir, case):
     assert int(status[0]) == 0
     assert torch.equal(got.cpu(), inds), '%d indices differ from scipy run on the same cost matrix' % int(
         (got.cpu() != inds).sum())
-    if np.array_equal(inds.numpy(), g['ha%d_gt_inds' % case]):     # host CPU reproduces the fixture's cost bits
-        assert np.array_equal(got.cpu().numpy(), g['ha%d_gt_inds' % case])
 
 
 def test_device_lsa_batched_problems():

@@ -70,17 +70,18 @@ def run_hip(cfg):
         head = m.bbox_head
         feat = ops.from_nchw(cls_feat[0])
         lmap = head._logit_map(feat)
-        centers, labels, gt_start, gt_img, pad_hw, _ = head._gt_tensors(cb['gt_bboxes'], cb['gt_labels'],
-                                                                       cb['img_metas'], feat.device, 'pad_shape')
+        gts = head._gt_tensors(cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'], feat.device)
         ex = head.train_pts_extractor
-        pts, valid, bag = head._bags(feat, lmap, centers, gt_img, pad_hw, ex.offsets(cfg['stride'], feat.device),
-                                     cfg['stride'])
-        mask, _ = ops.neg_mask_loss(lmap, centers, labels, gt_start, pad_hw, cfg['num_classes'], cfg['stride'],
-                                    head._d2_threshold(cfg['stride'], ex.neg_radius), 1e-6, ex.neg_class_wise)
+        pts, valid, bag, _ = head._bags(ex, feat, lmap, gts, cfg['stride'])
+        mask, _ = ops.neg_mask_loss(lmap, gts.points, gts.pt_labels, gts.pt_start, gts.pad_hw, cfg['num_classes'],
+                                    cfg['stride'], head._d2_threshold(cfg['stride'], ex.neg_radius), 1e-6,
+                                    ex.neg_class_wise)
+        refined = head.refine_points(cls_feat, cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
         torch.cuda.synchronize()
     return dict(model=m, sd=sd, batch=batch, c=[t.cpu() for t in c], fpn=feats[0].cpu(), cls_feat=cls_feat[0].cpu(),
                 losses={k: float(v) for k, v in losses.items()}, dets=[(d.cpu(), l.cpu()) for d, l in dets],
-                lmap=lmap.cpu(), pts=pts.cpu(), valid=valid.cpu(), bag=bag.cpu(), mask=mask.cpu())
+                lmap=lmap.cpu(), pts=pts.cpu(), valid=valid.cpu(), bag=bag.cpu(), mask=mask.cpu(),
+                refined=[t.cpu() for t in refined[2:]])
 
 
 def _relerr(a, b):

@@ -1,0 +1,261 @@
+"""-m gpu: (a) PointRefiner selections held bit-exact -- the kernel on the REFERENCE's own bag logits must reproduce the
+reference's chosen-point masks / not_refine flags exactly, and end to end (HIP conv stack -> logits -> refine) the masks
+must agree except where a probability sits within the logit tolerance of a threshold; (b) every get_bboxes output format
+(out_geo, rescale, not_refine input, cascade_out_fmt); (c) the CPRHead options no shipped config uses (num_refine > 1 bag
+policies, GridCirclesPtFeatGenerator, softmax / normed_sigmoid, binary_ins, AllPosLoss) against fixtures produced by the
+reference's own classes (oracle/gen_golden_r2.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.gen_golden import CPR_CASES
+from oracle.gen_golden_r2 import OPTION_CASES, case_inputs, cpr_head_kwargs, not_refine_input, option_cfg
+from pointtinybenchmark_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+GN = dict(type='GN', num_groups=32, requires_grad=True)
+
+
+def build_hip(cfg):
+    import pointtinybenchmark_amd as P
+    model = dict(
+        type='BasicLocator',
+        backbone=dict(type='ResNet', depth=cfg['depth'], num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                      norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'),
+        neck=dict(type='FPN', in_channels=synthetic.backbone_out_channels(cfg['depth']), out_channels=256,
+                  start_level=cfg['start_level'], add_extra_convs='on_input', num_outs=1, norm_cfg=GN),
+        bbox_head=dict(type='CPRHead', **cpr_head_kwargs(cfg)))
+    m = P.build_detector(model).cuda()
+    sd, batch = case_inputs(cfg)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    return m, batch
+
+
+def cuda_batch(batch):
+    return dict(img=batch['img'].cuda(), img_metas=batch['img_metas'], gt_bboxes=[b.cuda() for b in batch['gt_bboxes']],
+                gt_labels=[l.cuda() for l in batch['gt_labels']], gt_anns_id=[a.cuda() for a in batch['gt_anns_id']])
+
+
+def _mask(g, key, shape_key=None, shape=None):
+    shape = tuple(g[shape_key]) if shape is None else shape
+    return np.unpackbits(g[key])[:int(np.prod(shape))].reshape(shape).astype(bool)
+
+
+def _kernel_on_reference_logits(g, p, cfg, batch, head):
+    """ops.refine fed with the reference's bag logits / points / validity: selections must be bit-exact."""
+    from pointtinybenchmark_amd import ops
+    cb = cuda_batch(batch)
+    gts = head._gt_tensors(cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'], torch.device('cuda'))
+    chosen_ref = _mask(g, p + 'chosen', p + 'chosen_shape')
+    G, Kt = chosen_ref.shape
+    logits = torch.from_numpy(g[p + 'bag_cls_logit']).cuda().contiguous()
+    pts = torch.from_numpy(g[p + 'bag_pts']).cuda().contiguous()
+    valid = torch.from_numpy(_mask(g, p + 'bag_valid', shape=(G, Kt)).astype(np.uint8)).cuda()
+    pr = head.point_refiner
+    rp, sc, nr, chosen = ops.refine(logits, pts, valid, gts.points, gts.labels, gts.gt_img, gts.gt_start, gts.img_hw,
+                                    cfg['num_classes'], pr['gt_alpha'], pr['merge_th'], pr['refine_th'],
+                                    pr['nearest_filter'], pr['classify_filter'], None, sub_bags=1, ctr_stride=gts.R,
+                                    prob_type=head.prob_type, norm_p=head.norm_p)
+    nbad = int((chosen.cpu().numpy().astype(bool) != chosen_ref).sum())
+    assert nbad == 0, '%d of %d chosen flags differ from the reference on identical logits' % (nbad, chosen_ref.size)
+    assert np.array_equal(nr.cpu().numpy().astype(bool), g[p + 'not_refine'])
+    np.testing.assert_allclose(rp.cpu().numpy(), g[p + 'refine_pts'], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(sc.cpu().numpy(), g[p + 'scores'], rtol=1e-5, atol=1e-7)
+    return chosen_ref
+
+
+def _near_threshold(g, p, head, labels):
+    """Entries whose class probability lies within the logit tolerance (1e-4 on the logit -> < 3e-5 on the probability) of
+    a PointRefiner threshold: the only places where the end-to-end selection may legitimately differ."""
+    lg = torch.from_numpy(g[p + 'bag_cls_logit'])                                  # (G, Kt, C)
+    if head.prob_type == 'sigmoid':
+        prob = lg.sigmoid()
+    elif head.prob_type == 'softmax':
+        prob = lg.softmax(-1)
+    else:
+        prob = torch.nn.functional.normalize(lg.sigmoid(), p=head.norm_p, dim=-1)
+    G = lg.shape[0]
+    pl = prob[torch.arange(G), :, labels]
+    gate = pl[:, -1:] * head.point_refiner['gt_alpha']
+    top2 = prob.topk(min(2, prob.shape[-1]), dim=-1)[0]
+    margin = (top2[..., 0] - top2[..., -1]) if prob.shape[-1] > 1 else torch.ones_like(pl)
+    tol = 5e-5
+    return ((pl - head.point_refiner['merge_th']).abs() < tol) | ((pl - gate).abs() < tol) | (margin < tol)
+
+
+def _end_to_end_refine(g, p, cfg, m, batch, seed):
+    head = m.bbox_head
+    cb = cuda_batch(batch)
+    kw = dict(gt_bboxes=cb['gt_bboxes'], gt_labels=cb['gt_labels'], gt_anns_id=cb['gt_anns_id'])
+    with torch.no_grad():
+        cls_feat, ins_feat = head(m.neck(m.backbone(cb['img'])))
+        gts, pts, rp, sc, nr, chosen = head.refine_points(cls_feat, cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+        dets = head.get_bboxes(cls_feat, ins_feat, cb['img_metas'], rescale=False, **kw)
+        head.other_info = dict(out_geo=True)
+        dg = head.get_bboxes(cls_feat, ins_feat, cb['img_metas'], rescale=False, **kw)
+        metas2 = [dict(mm, scale_factor=[1.25, 1.6, 1.25, 1.6]) for mm in cb['img_metas']]
+        dr = head.get_bboxes(cls_feat, ins_feat, metas2, rescale=True, **kw)
+        head.other_info = dict()
+        nr_in = [t.cuda() for t in not_refine_input(batch, seed)]
+        dc, nr_out = head.get_bboxes(cls_feat, ins_feat, cb['img_metas'], rescale=False, not_refine=nr_in,
+                                     cascade_out_fmt=True, **kw)
+        torch.cuda.synchronize()
+    chosen_ref = _mask(g, p + 'chosen', p + 'chosen_shape')
+    assert np.array_equal(pts.cpu().numpy(), g[p + 'bag_pts']), 'bag points must be bit-exact'
+    err = float(np.abs(head_logits(head, cls_feat, gts, cfg)[..., :cfg['num_classes']] - g[p + 'bag_cls_logit']).max())
+    assert err <= 1e-4, 'bag logits %.3e (bar 1e-4)' % err
+    diff = chosen.cpu().numpy().astype(bool) != chosen_ref
+    labels = torch.cat(batch['gt_labels'])
+    near = _near_threshold(g, p, head, labels).numpy()
+    # a gate / classify decision of the annotated point's own probability moves a whole row: rows where the gate itself is
+    # near a threshold are excused as a whole
+    assert not (diff & ~near).any(), '%d chosen flags differ away from any threshold (of %d; %d near-threshold entries)' % (
+        int((diff & ~near).sum()), diff.size, int(near.sum()))
+    same_rows = ~diff.any(axis=1)
+    nr_ref = g[p + 'not_refine']
+    assert np.array_equal(nr.cpu().numpy().astype(bool)[same_rows], nr_ref[same_rows])
+    np.testing.assert_allclose(rp.cpu().numpy()[same_rows], g[p + 'refine_pts'][same_rows], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(sc.cpu().numpy()[same_rows], g[p + 'scores'][same_rows], rtol=1e-4, atol=1e-5)
+    d = torch.cat([x for x, _ in dets]).cpu().numpy()
+    assert np.array_equal(torch.cat([l for _, l in dets]).cpu().numpy(), g[p + 'det_labels'])
+    assert np.array_equal(d[:, 5], g[p + 'dets'][:, 5])                                # ann ids
+    np.testing.assert_allclose(d[same_rows, :5], g[p + 'dets'][same_rows, :5], rtol=1e-4, atol=2e-3)
+    s = 0
+    for b, (x, _) in enumerate(dg):                       # out_geo rows: [box, score, ann_id, refined pt, chosen pts.., -1 pad]
+        x, ref = x.cpu().numpy(), g[p + 'dets_geo%d' % b]
+        rows = same_rows[s:s + len(ref)]
+        if rows.all():
+            assert x.shape == ref.shape, (x.shape, ref.shape)
+            assert np.array_equal(x[:, 8:], ref[:, 8:]), 'chosen-point columns of the geo output must be bit-exact'
+            np.testing.assert_allclose(x[:, :8], ref[:, :8], rtol=1e-4, atol=2e-3)
+            xr, rr = dr[b][0].cpu().numpy(), g[p + 'dets_geo_rescaled%d' % b]
+            assert xr.shape == rr.shape
+            np.testing.assert_allclose(xr, rr, rtol=1e-4, atol=2e-3)
+            assert np.array_equal(xr[:, 8:] == -1, rr[:, 8:] == -1)
+        s += len(ref)
+    nro = torch.cat(nr_out).cpu().numpy()
+    assert np.array_equal(nro[same_rows], g[p + 'cascade_not_refine'][same_rows])
+    dcc = torch.cat([x for x, _ in dc]).cpu().numpy()
+    np.testing.assert_allclose(dcc[same_rows, :5], g[p + 'cascade_dets'][same_rows, :5], rtol=1e-4, atol=2e-3)
+    return int(diff.sum()), int(near.sum())
+
+
+def head_logits(head, cls_feat, gts, cfg):
+    from pointtinybenchmark_amd import ops
+    feat = ops.from_nchw(cls_feat[0])
+    lmap = head._logit_map(feat)
+    return head._bags(head.refine_pts_extractor, feat, lmap, gts, cfg['stride'])[2].cpu().numpy()
+
+
+@pytest.mark.parametrize('name', list(CPR_CASES))
+def test_refine_selections_vs_reference(golden_dir, name, record_property):
+    from tests.test_gpu_cpr_parity import build_hip_locator
+    cfg = dict(CPR_CASES[name])
+    g = np.load(os.path.join(golden_dir, 'refine.npz'))
+    p = name + ':'
+    m, _ = build_hip_locator(cfg)
+    _, batch = case_inputs(cfg)
+    if cfg.get('num_cls_fcs', 0) == 0:
+        _kernel_on_reference_logits(g, p, cfg, batch, m.bbox_head)
+    ndiff, nnear = _end_to_end_refine(g, p, cfg, m, batch, cfg['seed'])
+    record_property('chosen_flags_differing_near_threshold', ndiff)
+    record_property('near_threshold_entries', nnear)
+
+
+@pytest.mark.parametrize('name', list(OPTION_CASES))
+def test_cpr_options_vs_reference(golden_dir, name, record_property):
+    cfg = option_cfg(name)
+    g = np.load(os.path.join(golden_dir, 'cpr_options.npz'))
+    p = name + ':'
+    m, batch = build_hip(cfg)
+    head, C = m.bbox_head, cfg['num_classes']
+    cb = cuda_batch(batch)
+    from pointtinybenchmark_amd import ops
+    with torch.no_grad():
+        cls_feat, ins_feat = head(m.neck(m.backbone(cb['img'])))
+        losses = head.loss(cls_feat, ins_feat, cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'])
+        feat = ops.from_nchw(cls_feat[0])
+        lmap = head._logit_map(feat)
+        gts = head._gt_tensors(cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'], feat.device)
+        ex = head.train_pts_extractor
+        pts, valid, bag, view = head._bags(ex, feat, lmap, gts, cfg['stride'])
+        mask, _ = ops.neg_mask_loss(lmap, gts.points, gts.pt_labels, gts.pt_start, gts.pad_hw, C, cfg['stride'],
+                                    head._d2_threshold(cfg['stride'], ex.neg_radius), 1e-6, ex.neg_class_wise,
+                                    head.prob_type, head.norm_p)
+        torch.cuda.synchronize()
+    ref_pts = g[p + 'pos_pts']                                  # (G, R|1, K, 2)
+    G = ref_pts.shape[0]
+    assert np.array_equal(pts.cpu().numpy().reshape(ref_pts.shape), ref_pts), 'bag points must be bit-exact'
+    assert np.array_equal(valid.cpu().numpy().astype(bool).reshape(g[p + 'pos_valid'].shape), g[p + 'pos_valid'])
+    bagn = bag.cpu().numpy()
+    ec = float(np.abs(bagn[..., :C].reshape(g[p + 'pos_cls_logit'].shape) - g[p + 'pos_cls_logit']).max())
+    ei = float(np.abs(bagn[..., C:].reshape(g[p + 'pos_ins_logit'].shape) - g[p + 'pos_ins_logit']).max())
+    assert ec <= 1e-4 and ei <= 1e-4, 'bag logits: cls %.3e ins %.3e (bar 1e-4)' % (ec, ei)
+    gv = np.unpackbits(g[p + 'neg_valid'])[:mask.numel()].reshape(mask.shape).astype(bool)
+    assert int((mask.cpu().numpy().astype(bool) != gv).sum()) == 0, 'negative mask must be bit-exact'
+    for k, v in losses.items():
+        ref = float(g[p + 'loss_' + k])
+        assert abs(float(v) - ref) <= 3e-4 * max(abs(ref), 1e-6), '%s: hip %.8g ref %.8g' % (k, float(v), ref)
+    assert set('loss_' + k for k in losses) == set(k[len(p):] for k in g.files if k.startswith(p + 'loss_'))
+    if (p + 'refine_asserts_in_reference') in g.files:
+        with pytest.raises(AssertionError):                     # same contract as cpr_head.py:809
+            head.get_bboxes(cls_feat, ins_feat, cb['img_metas'], gt_bboxes=cb['gt_bboxes'], gt_labels=cb['gt_labels'],
+                            gt_anns_id=cb['gt_anns_id'])
+        return
+    _kernel_on_reference_logits(g, p, cfg, batch, head)
+    ndiff, nnear = _end_to_end_refine(g, p, cfg, m, batch, cfg['seed'])
+    record_property('chosen_flags_differing_near_threshold', ndiff)
+    record_property('near_threshold_entries', nnear)
+
+
+def test_grid_ellipse_generator_raises_like_the_reference(golden_dir):
+    """GridEllipsePtFeatGenerator cannot run in the reference (fixture records its RuntimeError); ours refuses at build."""
+    from pointtinybenchmark_amd.registry import build_head
+    g = np.load(os.path.join(golden_dir, 'cpr_options.npz'))
+    assert 'RuntimeError' in str(g['grid_ellipse_reference_error'])
+    kw = cpr_head_kwargs(option_cfg('softmax'))
+    kw['train_pts_extractor']['pos_generator'] = dict(type='GridEllipsePtFeatGenerator', a_minus_c=2.0)
+    with pytest.raises(NotImplementedError):
+        build_head(dict(type='CPRHead', **kw))
+
+
+def test_mil_loss_reference_signature_matches_formula():
+    """MILLoss.forward / AllPosLoss.forward with the reference's (prob, ins logits, labels, valid) signature against the
+    formulas of multi_instance_learning_loss.py:153-243 evaluated in torch on the CPU."""
+    import torch.nn.functional as F
+    from pointtinybenchmark_amd.losses.mil_loss import AllPosLoss, MILLoss
+    g = torch.Generator().manual_seed(3)
+    B, N, C = 9, 37, 4
+    prob = torch.rand((B, N, C), generator=g)
+    labels = torch.randint(0, C, (B,), generator=g)
+    valid = (torch.rand((B, N, 1), generator=g) > 0.3).float()
+    valid[2] = 0                                            # a bag without any valid point
+    for binary in (False, True):
+        ins = torch.randn((B, N, C * (2 if binary else 1)), generator=g)
+        loss, acc, ns = MILLoss(binary_ins=binary, loss_weight=0.7)(prob.cuda(), ins.cuda(), labels.cuda(), valid.cuda())
+        pi = ins.reshape(B, N, C, -1).softmax(dim=1) * valid.unsqueeze(-1)
+        pi = F.normalize(pi, dim=1, p=1)
+        pb = (prob.unsqueeze(-1) * pi).sum(dim=1)                       # (B, C, 1|2)
+        lw = (valid.sum(dim=1) > 0).float()
+        onehot = F.one_hot(labels, C).float()
+        num = max(float((lw.sum(-1) > 0).sum()), 1.0)
+        gf = lambda p_, q_, w_: -(((p_ - q_) ** 2) * (q_ * (p_ + 1e-6).log() + (1 - q_) * (1 - p_ + 1e-6).log()) * w_).sum(-1)
+        ref = gf(pb[..., 0], onehot, lw).sum()
+        if binary:
+            ref = ref + gf(pb[..., 1], torch.zeros_like(onehot), lw).sum()
+        ref = ref / num * 0.7
+        assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)), (binary, float(loss), float(ref))
+        assert float(ns) == num
+        racc = float((pb[..., 0].argmax(-1) == labels).float().mean() * 100)
+        assert abs(float(acc) - racc) < 1e-3
+    ins = torch.randn((B, N, C), generator=g)
+    loss, acc, ns = AllPosLoss(loss_weight=0.3)(prob.cuda(), ins.cuda(), labels.cuda(), valid.cuda())
+    pr, lab, v = prob.reshape(B * N, C), labels.unsqueeze(-1).repeat(1, N).flatten(), valid.reshape(B * N, 1)
+    num = max(float((v.sum(-1) > 0).sum()), 1.0)
+    ref = gf(pr, F.one_hot(lab, C).float(), v).sum() / num * 0.3
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    assert float(ns) == num
+    assert abs(float(acc) - float((pr.argmax(-1) == lab).float().mean() * 100)) < 1e-3

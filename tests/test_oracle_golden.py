@@ -119,3 +119,47 @@ def test_oracle_autograd_matches_reference_autograd(golden_dir, name):
         smp = g[torch.from_numpy(grad_sample_index(g.numel()))].numpy()
         ref = gold['sample:' + k].astype(np.float64)
         assert np.abs(smp - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6 * gmax), k
+
+
+@pytest.mark.parametrize('name', list(CPR_CASES))
+def test_oracle_refine_internals_match_reference(golden_dir, name):
+    """PointRefiner internals of the restatement (chosen-point masks, not_refine, refined points, scores) against what the
+    reference's own refine_single returned (tests/golden/refine.npz, oracle/gen_golden_r2.py): masks bit-exact."""
+    cfg = CPR_CASES[name]
+    g = _load(golden_dir, 'refine')
+    p = name + ':'
+    sd = synthetic.locator_state_dict(cfg['depth'], cfg['num_classes'], cfg['start_level'], 'cpr', cfg['seed'],
+                                      cfg['head_std'], num_cls_fcs=cfg.get('num_cls_fcs', 0),
+                                      fc_out_channels=cfg.get('fc_out_channels', 1024))
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'], cfg.get('ragged', False))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        feats = O.fpn_forward(sd, O.resnet_forward(sd, batch['img'], cfg['depth']), cfg['start_level'], 1)
+        cls_feat, _ = O.cpr_head_forward(sd, feats)
+        ref = O.cpr_refine(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['gt_anns_id'],
+                           batch['img_metas'], cfg['stride'], cfg['radius'], cfg['num_classes'])
+    mv = torch.cat([r['merge_valid'] for r in ref]).numpy()
+    chosen = np.unpackbits(g[p + 'chosen'])[:mv.size].reshape(mv.shape).astype(bool)
+    assert np.array_equal(mv, chosen)
+    assert np.array_equal(torch.cat([r['not_refine'] for r in ref]).numpy(), g[p + 'not_refine'])
+    np.testing.assert_allclose(torch.cat([r['refine_pts'] for r in ref]).numpy(), g[p + 'refine_pts'], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(torch.cat([r['scores'] for r in ref]).numpy(), g[p + 'scores'], rtol=1e-6, atol=1e-7)
+
+
+def test_correctly_rounded_log_cost_vs_reference_cost_fixture(golden_dir):
+    """The reference's own fp32 cost matrices (tests/golden/assigner_costs.npz, computed by its FocalLossCost/DisCostV2 on
+    the build host) against the restated formula with a CORRECTLY ROUNDED log -- what the HIP cost kernel computes and what
+    is host independent: at most a handful of entries 1 ulp apart (the build host's MKL log), indices identical."""
+    g, gc = _load(golden_dir, 'assigners'), _load(golden_dir, 'assigner_costs')
+    total_diff = 0
+    for case in range(5):
+        n_side, G, C, k = [int(v) for v in g['ha%d_cfg' % case]]
+        pred, logits, gt, labels, shp = assigner_inputs(200 + case, n_side, 4, G, C)
+        inds, _, cost = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=k, log_mode='cr')
+        ref = gc['ha%d_cost' % case]
+        ulp = np.abs(cost.numpy().view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1
+        total_diff += int((ulp > 0).sum())
+        assert np.array_equal(inds.numpy(), g['ha%d_gt_inds' % case])
+    assert total_diff <= 8, total_diff
