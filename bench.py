@@ -27,16 +27,27 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); only used with --dtype bf16
 
 
+def kernel_source_sha16():
+    """Content hash of the conv kernel source: profiles/pmc_dominant_kernel.json is stamped with it (tools/pmc_to_json.py),
+    so a PMC figure measured on an older kernel is never replayed into a newer bench line."""
+    import hashlib
+    src = os.path.join(ROOT, 'pointtinybenchmark_amd', 'csrc', 'conv_mfma.hip')
+    return hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
+
+
 def pmc_traffic(kernel_name, batch):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_dominant_kernel.json,
     produced by tools/gpu_pmc.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950
     note of MI355X_MICROARCH.md).  Counters cannot be read from inside the timed run, so this is the profile's figure,
-    scaled linearly if the batch differs; null when no profile of this kernel is committed."""
+    scaled linearly if the batch differs; null when no profile of this kernel INSTANCE and this kernel SOURCE is committed
+    (the JSON carries the template instance name and the sha of conv_mfma.hip it was measured on)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
     if d.get('kernel', '').replace(' ', '') != kernel_name.replace(' ', ''):
+        return None
+    if d.get('source_sha16') != kernel_source_sha16():
         return None
     return d['hbm_bytes_per_launch'] * batch / d['batch']
 GN = dict(type='GN', num_groups=32, requires_grad=True)
@@ -85,11 +96,18 @@ def p2p_model_cfg(depth=50, num_classes=1):
 
 
 class ConvProbe:
-    """HIP-event brackets around every conv launch of the timed region (events are recorded on the stream the
-    kernels are launched on: torch's current stream)."""
+    """HIP-event brackets around conv launches (events are recorded on the stream the kernels are launched on: torch's
+    current stream).  Two uses: a FULL pass over every launch of a few untimed steps (per-instance table), and -- inside
+    the timed region -- only the launches of the dominant instance's shapes (``only``), so that the ~110 extra event
+    records per step of the full probe (1.4 % of a step) are not charged to the headline value."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []
+        self.only = only      # set of shape keys to bracket, or None = every launch
+
+    @staticmethod
+    def key(x, pc):
+        return (tuple(x.shape), pc.Cout, pc.KH, pc.stride)
 
     def install(self):
         from pointtinybenchmark_amd import _lib, ops
@@ -98,6 +116,8 @@ class ConvProbe:
         probe = self
 
         def conv2d(x, pc, *a, **k):
+            if probe.only is not None and probe.key(x, pc) not in probe.only:
+                return probe._orig(x, pc, *a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             out = probe._orig(x, pc, *a, **k)
@@ -112,7 +132,7 @@ class ConvProbe:
                 variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
                                                                       'true' if v // 10 % 10 else 'false', v % 10)
             kreal = pc.KH * pc.KW * (3 if pc.Cin == 4 else pc.Cin)
-            probe.records.append((variant, 2.0 * N * OH * OW * pc.Cout * kreal, s, e))
+            probe.records.append((variant, 2.0 * N * OH * OW * pc.Cout * kreal, s, e, probe.key(x, pc)))
             return out
         ops.conv2d = conv2d   # callers use ``ops.conv2d(...)`` through the module object, so they see the probe
 
@@ -122,47 +142,57 @@ class ConvProbe:
 
     def summary(self):
         agg = {}
-        for variant, flops, s, e in self.records:
-            d = agg.setdefault(variant, [0.0, 0.0, 0])
+        for variant, flops, s, e, key in self.records:
+            d = agg.setdefault(variant, [0.0, 0.0, 0, set()])
             d[0] += flops
             d[1] += s.elapsed_time(e) * 1e-3
             d[2] += 1
-        return {v: dict(flops=d[0], seconds=d[1], launches=d[2], tflops=d[0] / d[1] / 1e12 if d[1] > 0 else 0.0)
+            d[3].add(key)
+        return {v: dict(flops=d[0], seconds=d[1], launches=d[2], tflops=d[0] / d[1] / 1e12 if d[1] > 0 else 0.0, keys=d[3])
                 for v, d in agg.items()}
 
 
 def hbm_probe(batch, size):
     """The HBM-bound kernels of the step, each timed alone with HIP events on its real shape: algorithmic bytes (one read
     of every input, one write of every output) / time vs the 8 TB/s roof (reported separately from the
-    MFMA-bound convs)."""
+    MFMA-bound convs).  Every case rotates over enough distinct copies of its tensors that consecutive launches touch
+    more than 1 GiB: the 256 MB Infinity Cache cannot serve the re-reads, so the figures are HBM rates, not L3 rates."""
     from pointtinybenchmark_amd import ops
     dev = 'cuda'
     h = size // 4
     g = torch.Generator(device=dev).manual_seed(0)
-    x = torch.randn((batch, h, h, 256), device=dev, generator=g)
+    gam, bet = torch.ones(256, device=dev), torch.zeros(256, device=dev)
     a = torch.rand((batch, 256), device=dev, generator=g) + 0.5
     b = torch.randn((batch, 256), device=dev, generator=g)
-    img = torch.randn((batch, 3, size, size), device=dev, generator=g)
-    stem = torch.randn((batch, size // 2, size // 2, 64), device=dev, generator=g)
-    dz = torch.randn_like(x)
-    part = ops.gn_stats(x)
-    gam, bet = torch.ones(256, device=dev), torch.zeros(256, device=dev)
-    _, _, mean, rstd = ops.gn_finalize(part, gam, bet, batch, h * h, 32, 1e-5, want_stats=True)
-    u8 = torch.randint(0, 256, (batch, size, size, 3), device=dev, dtype=torch.uint8, generator=g)
-    pre_out = torch.empty((batch, size, size, 4), device=dev)
     from pointtinybenchmark_amd.datasets import GpuImagePipeline
     pipe = GpuImagePipeline(device=dev)
-    nb = x.numel() * 4
+    nb = batch * h * h * 256 * 4
+
+    def rot(working_set_bytes):
+        return max(2, min(16, -(-(1 << 30) // max(int(working_set_bytes), 1))))
+
+    def maps(n, k=1):
+        return [tuple(torch.randn((batch, h, h, 256), device=dev, generator=g) for _ in range(k)) for _ in range(n)]
+    xs = maps(rot(2 * nb))
+    x0 = xs[0][0]
+    part = ops.gn_stats(x0)
+    _, _, mean, rstd = ops.gn_finalize(part, gam, bet, batch, h * h, 32, 1e-5, want_stats=True)
+    x2 = maps(rot(5 * nb), 2)
+    stems = [torch.randn((batch, size // 2, size // 2, 64), device=dev, generator=g) for _ in range(rot(batch * size * size * 80))]
+    imgs = [torch.randn((batch, 3, size, size), device=dev, generator=g) for _ in range(rot(batch * size * size * 28))]
+    u8s = [torch.randint(0, 256, (batch, size, size, 3), device=dev, dtype=torch.uint8, generator=g)
+           for _ in range(rot(batch * size * size * 19))]
+    pre_outs = [torch.empty((batch, size, size, 4), device=dev) for _ in u8s]
     cases = [
-        ('gn_apply_kernel (GroupNorm apply + ReLU, head map)', lambda: ops.gn_apply(x, a, b, relu=True), 2 * nb),
-        ('gn_stats_kernel (statistics pass)', lambda: ops.gn_stats(x), nb),
-        ('maxpool3x3s2_kernel (stem)', lambda: ops.maxpool3x3s2(stem), stem.numel() * 4 * 1.25),
-        ('nchw_to_nhwc4_kernel (network input)', lambda: ops.nchw_to_nhwc(img), img.numel() * 4 * (1 + 4 / 3)),
-        ('preprocess_u8_kernel (uint8 HWC -> normalised NHWC4)',
-         lambda: pipe._launch(u8, None, pre_out, batch, size, size, size, size), u8.numel() + pre_out.numel() * 4),
-        ('gn_bwd (stats + apply passes of the GroupNorm backward)',
-         lambda: ops.gn_bwd(x, dz, a, b, mean, rstd, gam, True), 5 * nb),
-        ('relu_bwd_colsum_kernel (ReLU backward + column sums)', lambda: ops.relu_bwd_colsum(dz, x), 3 * nb),
+        ('gn_apply_kernel (GroupNorm apply + ReLU, head map)', len(xs), lambda i: ops.gn_apply(xs[i][0], a, b, relu=True), 2 * nb),
+        ('gn_stats_kernel (statistics pass)', len(xs), lambda i: ops.gn_stats(xs[i][0]), nb),
+        ('maxpool3x3s2_kernel (stem)', len(stems), lambda i: ops.maxpool3x3s2(stems[i]), stems[0].numel() * 4 * 1.25),
+        ('nchw_to_nhwc4_kernel (network input)', len(imgs), lambda i: ops.nchw_to_nhwc(imgs[i]), imgs[0].numel() * 4 * (1 + 4 / 3)),
+        ('preprocess_u8_kernel (uint8 HWC -> normalised NHWC4)', len(u8s),
+         lambda i: pipe._launch(u8s[i], None, pre_outs[i], batch, size, size, size, size), u8s[0].numel() + pre_outs[0].numel() * 4),
+        ('gn_bwd (stats + apply passes of the GroupNorm backward)', len(x2),
+         lambda i: ops.gn_bwd(x2[i][0], x2[i][1], a, b, mean, rstd, gam, True), 5 * nb),
+        ('relu_bwd_colsum_kernel (ReLU backward + column sums)', len(x2), lambda i: ops.relu_bwd_colsum(x2[i][1], x2[i][0]), 3 * nb),
     ]
     # the CPR-specific stage on its real shapes (C = 1, 32 gts per image): these launches move a few MB and finish in tens of
     # microseconds, i.e. they are launch-latency bound -- listed so that the stage is accounted for, not as roofline claims
@@ -178,45 +208,86 @@ def hbm_probe(batch, size):
     thr = sqrt_threshold(20.0)
     _, valid_b, bag_l = ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, 4)
     K = bag_l.shape[1]
+    feat = xs[0][0]
+    head_ab = (a, b)
     cases += [
-        ('neg_mask_loss_kernel (negative grid: distance mask + sigmoid + gfocal partials)',
-         lambda: ops.neg_mask_loss(lmap, ctr, lab, gt_start, pad_hw, 1, 4, thr, 1e-6, True), lmap.numel() * 4 + batch * h * h),
-        ('bag_sample_kernel (bag points + bilinear samples of the logit map)',
-         lambda: ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, 4), G * K * (4 * 2 * 4 + 2 * 4 + 8 + 1)),
-        ('mil_bag + loss_finalize kernels (MIL / gt losses, one wave per bag)',
-         lambda: ops.mil_loss(bag_l, 1, valid_b, lab, 1, None, 0.25, 0.25, 0.75), G * K * (2 * 4 + 1)),
+        ('logit projection (256 -> 2C channels of the head map, GroupNorm + ReLU applied on load)', len(xs),
+         lambda i: ops.logit_project(xs[i][0], proj_w, proj_b, head_ab) if hasattr(ops, 'logit_project') else None, nb + batch * h * h * 8),
+        ('neg_mask_loss_kernel (negative grid: distance mask + sigmoid + gfocal partials)', 1,
+         lambda i: ops.neg_mask_loss(lmap, ctr, lab, gt_start, pad_hw, 1, 4, thr, 1e-6, True), lmap.numel() * 4 + batch * h * h),
+        ('bag_sample_kernel (bag points + bilinear samples of the logit map)', 1,
+         lambda i: ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, 4), G * K * (4 * 2 * 4 + 2 * 4 + 8 + 1)),
+        ('mil_bag + loss_finalize kernels (MIL / gt losses, one wave per bag)', 1,
+         lambda i: ops.mil_loss(bag_l, 1, valid_b, lab, 1, None, 0.25, 0.25, 0.75), G * K * (2 * 4 + 1)),
     ]
+    proj_w = torch.randn((2, 256), device=dev, generator=g) * 0.01
+    proj_b = torch.zeros((2,), device=dev)
     out = []
-    for name, fn, byts in cases:
-        for _ in range(3):
-            fn()
+    for name, n, fn, byts in cases:
+        if fn(0) is None and 'projection' in name:
+            continue
+        for i in range(3):
+            fn(i % n)
+        reps = max(10, 2 * n)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(10):
-            fn()
+        for i in range(reps):
+            fn(i % n)
         e.record()
         torch.cuda.synchronize()
-        t = s.elapsed_time(e) / 10 * 1e-3
-        out.append({'kernel': name, 'bytes': byts, 'ms': t * 1e3, 'GB/s': byts / t / 1e9, 'frac_of_8TBs': byts / t / 8e12})
+        t = s.elapsed_time(e) / reps * 1e-3
+        out.append({'kernel': name, 'bytes': byts, 'ms': t * 1e3, 'GB/s': byts / t / 1e9, 'frac_of_8TBs': byts / t / 8e12,
+                    'rotating_buffers': n})
     return out
 
 
-def cpu_baseline(batch_size, num_gts, seconds_budget=30.0):
+def host_cpu_info():
+    model, phys = 'unknown', None
+    try:
+        cores = set()
+        phys_id = core_id = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name') and model == 'unknown':
+                model = line.split(':', 1)[1].strip()
+            elif line.startswith('physical id'):
+                phys_id = line.split(':', 1)[1].strip()
+            elif line.startswith('core id'):
+                core_id = line.split(':', 1)[1].strip()
+                cores.add((phys_id, core_id))
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return model, phys
+
+
+def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None):
     """The CPU oracle on this box's host cores: same synthetic workload, bounded sample.  The box reports 256 logical
     CPUs but torch/oneDNN throughput is far from monotone in the thread count there (cgroup quota, SMT, NUMA), so the
-    whole step is timed once at several thread counts and the fastest is kept and re-timed."""
+    whole step is timed once at several thread counts and the fastest is kept and re-timed, with the backbone / neck /
+    head towers / point stage split.  ``hip_losses_fn(batch)``: the HIP path on the SAME sample -- the
+    parity gate of the bench run (losses of the two paths side by side)."""
     from oracle import cpr_oracle as O
     from pointtinybenchmark_amd import synthetic
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     sd = synthetic.locator_state_dict(50, 1, 0, 'cpr', 0)
     batch = synthetic.synthetic_batch(batch_size, 640, 640, num_gts, 1, 0)
+    last = {}
 
     def one(threads):
         torch.set_num_threads(threads)
         with torch.no_grad():
             t0 = time.perf_counter()
-            O.locator_forward_train(sd, batch, 50, 0, 4, 5, 1)
-            return time.perf_counter() - t0
+            c = O.resnet_forward(sd, batch['img'], 50)
+            t1 = time.perf_counter()
+            feats = O.fpn_forward(sd, c, 0, 1)
+            t2 = time.perf_counter()
+            cls_feat, _ = O.cpr_head_forward(sd, feats)
+            t3 = time.perf_counter()
+            losses, _ = O.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], 4, 5, 1)
+            t4 = time.perf_counter()
+        last.update(split=dict(backbone=t1 - t0, neck=t2 - t1, head_towers=t3 - t2, points_and_losses=t4 - t3),
+                    losses={k: float(v) for k, v in losses.items()})
+        return t4 - t0
 
     t_start = time.perf_counter()
     one(min(16, avail))                                            # warm-up (allocator, oneDNN primitive cache)
@@ -232,11 +303,67 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0):
     while len(times) < 4 and time.perf_counter() - t_start < seconds_budget:
         times.append(one(best))
     dt = sorted(times)[len(times) // 2]
-    return dict(value=batch_size / dt, unit='img/s', cores=best, kind='port',
-                sample='median of %d step(s) of B=%d 640x640 tiles at %d threads (%.2f s/step); thread count = fastest of '
-                       '%s s/step out of %d logical CPUs; oracle = torch-CPU restatement executing the reference op '
-                       'sequence' % (len(times), batch_size, best, dt,
-                                     {k: round(v, 2) for k, v in trials.items()}, os.cpu_count() or 1))
+    model, phys = host_cpu_info()
+    out = dict(value=batch_size / dt, unit='img/s', cores=best, kind='port',
+               sample='median of %d step(s) of B=%d 640x640 tiles at %d threads (%.2f s/step); thread count = fastest of '
+                      '%s s/step out of %d logical CPUs; oracle = torch-CPU restatement executing the reference op '
+                      'sequence' % (len(times), batch_size, best, dt,
+                                    {k: round(v, 2) for k, v in trials.items()}, os.cpu_count() or 1),
+               host_cpu=model, physical_cores=phys, logical_cpus=os.cpu_count() or 1,
+               split_s={k: round(v, 4) for k, v in last['split'].items()})
+    if hip_losses_fn is not None:          # parity gate: the HIP path on the very sample the oracle was timed on
+        try:
+            hip = hip_losses_fn(batch)
+            rel = {k: abs(hip[k] - v) / max(abs(v), 1e-12) for k, v in last['losses'].items() if k in hip}
+            out['parity_gate'] = dict(oracle_losses=last['losses'], hip_losses=hip, max_rel_err=max(rel.values()),
+                                      passed=bool(max(rel.values()) <= 5e-4), bar=5e-4)
+        except Exception as e:   # noqa: BLE001
+            out['parity_gate'] = dict(error=repr(e)[:200])
+    return out
+
+
+def measure_small_batch(model, b, size, num_gts, steps=30, graph_too=True):
+    """The reference's own per-GPU batch (samples_per_gpu = 2, T/configs2/TinyPersonV2/coarsepointv2/
+    coarse_point_refine_base_TinyPersonV2_640.py:50).  ~150 launches of a few microseconds: launch-bound when issued one by
+    one, so the step is also timed as ONE hipGraph replay (backbone .. logit projection) + the eager 5-launch loss tail."""
+    from pointtinybenchmark_amd import synthetic
+    batch = synthetic.synthetic_batch(b, size, size, num_gts, 1, seed=123)
+    img, metas = batch['img'].cuda(), batch['img_metas']
+    gtb, gtl = [x.cuda() for x in batch['gt_bboxes']], [x.cuda() for x in batch['gt_labels']]
+    res = {'B': b}
+    keep = model.use_graph
+    try:
+        for graph in ((False, True) if graph_too else (False,)):
+            model.use_graph = graph
+            with torch.no_grad():
+                for _ in range(5):
+                    losses = model.forward_train(img, metas, gtb, gtl)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    losses = model.forward_train(img, metas, gtb, gtl)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+            key = 'hipgraph' if graph else 'eager'
+            res[key] = {'img_per_s': b / dt, 'ms_per_step': dt * 1e3, 'losses': {k: float(v) for k, v in losses.items()}}
+        res['img_per_s'] = max(v['img_per_s'] for k, v in res.items() if isinstance(v, dict))
+        res['what'] = 'forward + loss at the reference batch size; hipgraph = one graph replay (backbone .. projection) + eager loss tail'
+    except Exception as e:   # noqa: BLE001
+        res['error'] = repr(e)[:300]
+    model.use_graph = keep
+    return res
+
+
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -244,7 +371,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('CPR_BENCH_BATCH', 16)), help='images per GPU')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('CPR_BENCH_BATCH', 64)),
+                    help='images per GPU.  SURVEY.md 8d: the reference batch (samples_per_gpu = 2) is reported under '
+                         '"small_batch", the headline uses the best batch: 64 (567 img/s; 16 -> 553, 32 -> 559: the 160x160 '
+                         'layers run 6400 / 12800 / 25600 tiles over 512 resident workgroups, i.e. 12.5 / 25 / 50 rounds, '
+                         'and the deeper layers fill the chip better)')
+    ap.add_argument('--batch-sweep', default='16', help='other per-GPU batches to report under "batch_sweep" (comma list, "" = none)')
     ap.add_argument('--num-gts', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
@@ -258,12 +390,19 @@ def main():
     ap.add_argument('--mode', default='fwd_loss', choices=['fwd_loss', 'train', 'infer'],
                     help="fwd_loss = BASELINE.json's metric; train = the full optimisation step (backward, bucketed RCCL "
                          "gradient all-reduce, clip + SGD) as the timed step")
+    ap.add_argument('--graph', action='store_true', help='replay backbone..projection as one hipGraph (forward + loss only)')
+    ap.add_argument('--small-batch', type=int, default=2,
+                    help="also report this per-GPU batch (the reference's samples_per_gpu) as 'small_batch' (0 = skip)")
     ap.add_argument('--train-timeout', type=int, default=300, help='watchdog for the train_step extra (seconds)')
     ap.add_argument('--train-steps', type=int, default=3,
                     help='after the timed region also time this many full training steps (0 = skip); reported under '
                          '"train_step", never in "value"')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1) and pass the single JSON line of rank 0 through
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -301,6 +440,7 @@ def main():
         model.load_state_dict(synthetic.locator_state_dict(args.depth, 1, 0, 'cpr', 0), strict=True)
     model.train()
     model.set_compute_dtype(args.dtype)
+    model.use_graph = bool(args.graph)
     batch = synthetic.synthetic_batch(args.batch, args.size, args.size, args.num_gts, 1, seed=rank)   # per-rank shard
     img = batch['img'].cuda()
     gtb = [b.cuda() for b in batch['gt_bboxes']]
@@ -335,9 +475,19 @@ def main():
 
     for _ in range(args.warmup):
         losses = step()
-    probe = None
+    probe = full = None
     if not args.no_probe:
-        probe = ConvProbe()
+        # untimed: every conv launch of two steps bracketed -> per-instance table and the dominant instance's shapes
+        full = ConvProbe()
+        full.install()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        full.remove()
+        fsum = full.summary()
+        dom_name = max(fsum, key=lambda k: fsum[k]['seconds'])
+        # timed: only the dominant instance's launches carry events
+        probe = ConvProbe(only=fsum[dom_name]['keys'])
         probe.install()
 
     def barrier():
@@ -412,11 +562,11 @@ def main():
         }
         if probe:
             summ = probe.summary()
-            name = max(summ, key=lambda k: summ[k]['seconds'])      # dominant template instance by total time
-            dom = summ[name]
+            name = dom_name if dom_name in summ else max(summ, key=lambda k: summ[k]['seconds'])
+            dom = summ[name]                                   # dominant template instance, launches of the TIMED region
             ach = dom['tflops']
-            conv_s = sum(v['seconds'] for v in summ.values())
-            conv_f = sum(v['flops'] for v in summ.values())
+            conv_s = sum(v['seconds'] for v in fsum.values()) / 2   # per step, from the untimed full-probe pass
+            conv_f = sum(v['flops'] for v in fsum.values()) / 2
             peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in name else PEAK_FP32_MFMA_TFLOPS
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': ach / peak, 'traffic': pmc_traffic(name, args.batch), 'kernel': name,
@@ -424,16 +574,32 @@ def main():
                                'avg_launch_ms': dom['seconds'] / dom['launches'] * 1e3,
                                'share_of_step_time': dom['seconds'] / elapsed,
                                'all_conv_instances_tflops': conv_f / conv_s / 1e12,
-                               'per_instance_tflops': {k: round(v['tflops'], 2) for k, v in summ.items()}}
-            out['conv_time_frac'] = conv_s / elapsed
-            out['end_to_end_tflops'] = conv_f / args.steps / (elapsed / args.steps) / 1e12   # conv FLOPs of a step / step time
+                               'per_instance_tflops': {k: round(v['tflops'], 2) for k, v in fsum.items()},
+                               'per_instance_source': 'every conv launch of 2 untimed steps bracketed with HIP events; '
+                                                      'achieved/avg_launch_ms: the dominant instance inside the timed region'}
+            out['conv_time_frac'] = conv_s / (elapsed / args.steps)
+            out['end_to_end_tflops'] = conv_f / (elapsed / args.steps) / 1e12   # conv FLOPs of a step / step time
         if world == 1 and not args.no_probe:
             try:
                 out['hbm_kernels'] = hbm_probe(args.batch, args.size)
             except Exception as e:   # noqa: BLE001
                 out['hbm_kernels'] = {'error': repr(e)[:200]}
+        if world == 1 and args.small_batch > 0 and (args.model, args.mode) == ('cpr', 'fwd_loss'):
+            out['small_batch'] = measure_small_batch(model, args.small_batch, args.size, args.num_gts)
+        if world == 1 and args.batch_sweep and (args.model, args.mode) == ('cpr', 'fwd_loss'):
+            out['batch_sweep'] = {}
+            for bs in [int(v) for v in args.batch_sweep.split(',') if v and int(v) != args.batch]:
+                r = measure_small_batch(model, bs, args.size, args.num_gts, steps=8, graph_too=False)
+                out['batch_sweep'][str(bs)] = r.get('eager', r)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(2, args.num_gts)
+            def hip_losses(b):
+                with torch.no_grad():
+                    model.use_graph = False
+                    r = model.forward_train(b['img'].cuda(), b['img_metas'], [x.cuda() for x in b['gt_bboxes']],
+                                            [x.cuda() for x in b['gt_labels']])
+                    return {k: float(v) for k, v in r.items()}
+            out['cpu_baseline'] = cpu_baseline(2, args.num_gts, hip_losses_fn=hip_losses if (
+                args.model, args.dtype, args.depth, args.size) == ('cpr', 'fp32', 50, 640) else None)
     # last of all, under a watchdog: if the training step (first use of the collective library at N > 1) wedges, the headline
     # line is still printed and every rank leaves
     import threading
@@ -457,4 +623,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

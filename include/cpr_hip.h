@@ -88,6 +88,13 @@ int cpr_box_centers(const float* boxes, float* centers, int n, void* stream);
 #define CPR_PROB_NORMED_SIGMOID 2
 #define CPR_PROB_IDENTITY 3
 
+/* CPRHead.get_pts_outs for EVERY pixel (cls_out / ins_out = nn.Linear(Cin -> C), cpr_head.py:1007-1014,1045-1078) as one
+ * HBM-streaming pass: x (N,HW,Cin) fp32 NHWC, w (J,Cin), bias (J) -> out (N,HW,J); in_a/in_b (N,Cin) optional: the input
+ * is read as relu?(x*a+b) (GroupNorm-apply of the last tower layer fused into the load).  Small J only: returns
+ * CPR_ERR_UNSUPPORTED when J > 8 or Cin is not 64, 128, 192 or 256 (the caller then uses cpr_conv2d_fwd). */
+int cpr_logit_project(const float* x, const float* w, const float* bias, const float* in_a, const float* in_b,
+                      float* out, int N, int HW, int Cin, int J, int in_relu, void* stream);
+
 /* OutCirclePtFeatGenerator.generate + neg branch of CPRHead.loss0 (cpr_head.py:254-290,1219-1228):
  * logit (N,H,W,J) (class logits in channels [0,C)); annotated points in CSR form (centers (P,2), labels (P),
  * gt_start (N+1)) -- with num_refine > 1 every refine point is a row, carrying its gt's label;
@@ -181,6 +188,8 @@ int cpr_p2p_decode(const float* reg, const float* point_anchor, float* pred, flo
                    float stride, float gamma, void* stream);
 /* max_c sigmoid(logits[m][c]) -> out (M): the score P2PHead._get_bboxes_single ranks with (p2p_head.py:362-369) */
 int cpr_rowmax_sigmoid(const float* logits, float* out, long long M, int C, void* stream);
+/* elementwise sigmoid with the bits of torch's CPU kernel (p2p_head.py:362: the scores that order top-k and NMS) */
+int cpr_sigmoid(const float* x, float* y, long long n, void* stream);
 /* P2PHead.loss_single + sample_result_to_target (p2p_head.py:220-248,308-328): sigmoid focal loss
  * (T/mmdet/models/losses/focal_loss.py:11-56) + SmoothL1 (smooth_l1_loss.py:11-28) straight from gt_inds (B,M) int64.
  * ws_partial (B*ceil(M/256)*3) double; out (B,2) = per image {loss_cls, loss_pts}, averaged by the batch's positives. */

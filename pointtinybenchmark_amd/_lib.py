@@ -34,6 +34,7 @@ SIGNATURES = {
     'cpr_gn_finalize': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     'cpr_gn_apply': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_box_centers': [_p, _p, _i, _p],
+    'cpr_logit_project': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'cpr_neg_mask_loss': [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _f, _p, _p],
     'cpr_bag_sample': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     'cpr_grid_bag': [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
@@ -46,6 +47,7 @@ SIGNATURES = {
     'cpr_nms': [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
     'cpr_p2p_decode': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'cpr_rowmax_sigmoid': [_p, _p, ctypes.c_longlong, _i, _p],
+    'cpr_sigmoid': [_p, _p, ctypes.c_longlong, _p],
     'cpr_p2p_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p],
     # training step: backward + optimizer
     'cpr_conv2d_wgrad_workspace': [_i] * 7,

@@ -243,9 +243,23 @@ __global__ void rowmax_sigmoid_kernel(const float* __restrict__ logits, float* _
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= M) return;
     float m = -INFINITY;
-    for (int c = 0; c < C; ++c) m = fmaxf(m, 1.f / (1.f + expf(-logits[i * C + c])));
+    for (int c = 0; c < C; ++c) m = fmaxf(m, sigmoid_torch_cpu(logits[i * C + c]));   // torch's CPU sigmoid bit for bit: decides top-k / NMS order
     out[i] = m;
 }
+// cls_score.sigmoid() of P2PHead._get_bboxes_single (p2p_head.py:362), elementwise, with torch's CPU bits (the scores
+// order the candidates of top-k and NMS, so a last-bit difference can swap two detections)
+__global__ void sigmoid_exact_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < n) y[i] = sigmoid_torch_cpu(x[i]);
+}
+extern "C" int cpr_sigmoid(const float* x, float* y, long long n, hipStream_t stream) {
+    CPR_CHECK_ARG(n >= 0);
+    if (n == 0) return CPR_OK;
+    CPR_CHECK_ARG(x && y);
+    hipLaunchKernelGGL(sigmoid_exact_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, stream, x, y, n);
+    CPR_LAUNCH_STATUS();
+}
+
 extern "C" int cpr_rowmax_sigmoid(const float* logits, float* out, long long M, int C, hipStream_t stream) {
     CPR_CHECK_ARG(M >= 0 && C > 0);
     if (M == 0) return CPR_OK;

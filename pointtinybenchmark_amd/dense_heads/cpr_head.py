@@ -197,15 +197,16 @@ class CPRHead(nn.Module):
             ins.append(f[1])
         return cls, ins
 
-    def _tower(self, x, ab=None, in_relu=True, tape=None):
-        """4 x [conv3x3 -> GN -> ReLU]; returns the LAST layer un-normalised: (raw, (a, b))."""
+    def _tower(self, x, ab=None, in_relu=True, tape=None, own_input=False):
+        """4 x [conv3x3 -> GN -> ReLU]; returns the LAST layer un-normalised: (raw, (a, b)).
+        own_input: nobody else reads ``x`` (its pending GroupNorm may be applied in place)."""
         for i, m in enumerate(self.cls_convs):
             rec = None
             if tape is not None:
                 rec = dict(kind='tower', level=i)
                 tape.append(rec)
             x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=(in_relu if i == 0 else True), materialize=False,
-                            save=rec)
+                            save=rec, consume_input=(own_input or i > 0))
         return x, ab
 
     def forward_single(self, x):
@@ -229,7 +230,7 @@ class CPRHead(nn.Module):
         projection) apply the GroupNorm affine (+ReLU) on load.  Same arithmetic as forward() + loss()."""
         assert len(lazy_feats) == 1
         raw, ab = lazy_feats[0]
-        raw, ab = self._tower(raw, ab, in_relu=False, tape=tape)
+        raw, ab = self._tower(raw, ab, in_relu=False, tape=tape, own_input=True)
         return self.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
                          gt_true_bboxes=gt_true_bboxes, save=save)
 
@@ -249,7 +250,8 @@ class CPRHead(nn.Module):
             w = [self.cls_out.weight] + ([] if self.ins_share_head_classifier else [self.ins_out.weight])
             b = [self.cls_out.bias] + ([] if self.ins_share_head_classifier else [self.ins_out.bias])
             wt = torch.cat(w, 0).detach()[:, :, None, None]
-            return ops.PackedConv(wt, 1, 0, dt), torch.cat(b, 0).detach().float().contiguous()
+            return (ops.PackedConv(wt, 1, 0, dt), torch.cat(b, 0).detach().float().contiguous(),
+                    wt[:, :, 0, 0].float().contiguous())
         srcs = [self.cls_out.weight, self.cls_out.bias, self.ins_out.weight, self.ins_out.bias]
         return self._cache.get(('proj', dt), srcs, make)
 
@@ -262,10 +264,15 @@ class CPRHead(nn.Module):
             assert in_ab is None
             feat_nhwc = self._fc_stack(feat_nhwc)
 
-        pc, bias = self._proj(dt)
+        pc, bias, w_rows = self._proj(dt)
         if in_ab is not None and ((feat_nhwc.shape[1] * feat_nhwc.shape[2]) % 128 != 0 or dt != torch.float32):
             feat_nhwc, in_ab = ops.gn_apply(feat_nhwc, in_ab[0], in_ab[1], relu=True), None
         # the logit map is always fp32 (the loss / sampling kernels are shared by both compute modes)
+        if dt == torch.float32 and feat_nhwc.shape[0] * feat_nhwc.shape[1] * feat_nhwc.shape[2] >= 4096:
+            # few output channels: a pure HBM stream (csrc/project.hip) instead of a mostly-empty MFMA tile
+            out = ops.logit_project(feat_nhwc, w_rows, bias, in_ab, in_relu=True)
+            if out is not None:
+                return out
         return ops.conv2d(feat_nhwc, pc, bias=bias, in_ab=in_ab, in_relu=True, out_dtype=torch.float32)
 
     def _bags(self, ex, feat, lmap, gts, stride):
@@ -351,7 +358,7 @@ class CPRHead(nn.Module):
 
     # ------------------------------------------------------------------ loss (cpr_head.py:1101-1229)
     def loss(self, cls_feat, ins_feat, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None, gt_true_bboxes=None,
-             gt_weights=None, save=None):
+             gt_weights=None, save=None, lmap=None):
         assert len(gt_labels) > 0
         assert len(cls_feat) == 1, 'single FPN level (the reference asserts the same: cpr_head.py:1152)'
         ex, C, stride = self.train_pts_extractor, self.num_classes, self.strides[0]
@@ -363,7 +370,8 @@ class CPRHead(nn.Module):
         if self.num_cls_fcs > 0 and ab is not None:       # the FC path samples the normalised, activated features
             assert save is None, 'the training step is built for num_cls_fcs == 0'
             feat, ab = ops.gn_apply(feat, ab[0], ab[1], relu=True), None
-        lmap = self._logit_map(feat, ab)
+        if lmap is None:                            # (a caller that replays a hipGraph hands the projected map over)
+            lmap = self._logit_map(feat, ab)
         gts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev)
         _, valid, bag_logits, view = self._bags(ex, feat, lmap, gts, stride)
         cfg = self.loss_cfg

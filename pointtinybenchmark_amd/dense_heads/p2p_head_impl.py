@@ -203,7 +203,7 @@ class P2PHead(nn.Module):
         if 0 < nms_pre < logits.shape[0]:
             _, topk_inds = ops.topk_desc(ops.rowmax_sigmoid(logits), nms_pre)
             logits, pred_pts = logits[topk_inds], pred_pts[topk_inds]
-        scores = ops.rowmax_sigmoid(logits)[:, None] if self.num_cls_out == 1 else logits.sigmoid()
+        scores = ops.rowmax_sigmoid(logits)[:, None] if self.num_cls_out == 1 else ops.sigmoid_exact(logits)
         x = pred_pts[:, 0].clamp(min=0, max=img_shape[1])
         y = pred_pts[:, 1].clamp(min=0, max=img_shape[0])
         pts = torch.stack([x, y], dim=-1)

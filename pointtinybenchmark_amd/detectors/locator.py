@@ -79,10 +79,48 @@ class BasicLocator(nn.Module):
             out.append(t.permute(0, 3, 1, 2))
         return out, out
 
+    # Small per-GPU batches (the reference trains with samples_per_gpu = 2) are launch-bound: ~150 kernel launches of a few
+    # microseconds each.  ``model.use_graph = True`` (or CPR_GRAPH=1) captures backbone -> neck -> head towers -> logit
+    # projection into ONE hipGraph per input shape and replays it; only the ragged, gt-dependent tail (bag sampling, masks,
+    # losses: 5 launches) stays eager.  Forward + loss only: weights must not change between replays (the training step
+    # re-packs them every iteration and does not use the graph).
+    use_graph = False
+
+    def _graphed_logit_map(self, img):
+        head = self.bbox_head
+        key = (tuple(img.shape), img.dtype, self.backbone.compute_dtype)
+        if not hasattr(self, '_graphs'):
+            self._graphs = {}
+        entry = self._graphs.get(key)
+        if entry is None:
+            def run(x):
+                raw, ab = head._tower(*self.neck.forward_lazy(self.backbone(x))[0], in_relu=False, own_input=True)
+                return raw, ab, head._logit_map(raw, ab)
+            static_img = img.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):       # warm-up off the capture: packs weights, fills the allocator
+                for _ in range(2):
+                    run(static_img)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()      # a hipGraph on ROCm
+            with torch.cuda.graph(graph):
+                outs = run(static_img)
+            entry = self._graphs[key] = (graph, static_img, outs)
+        graph, static_img, outs = entry
+        static_img.copy_(img)
+        graph.replay()
+        return outs
+
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
         batch_input_shape = tuple(img[0].size()[-2:])
         for m in img_metas:
             m['batch_input_shape'] = batch_input_shape
+        if (self.use_graph or os.environ.get('CPR_GRAPH', '0') == '1') and img.is_cuda and not torch.is_grad_enabled() \
+                and hasattr(self.bbox_head, 'forward_train_lazy') and getattr(self.bbox_head, 'num_cls_fcs', 1) == 0:
+            raw, ab, lmap = self._graphed_logit_map(img)
+            return self.bbox_head.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas,
+                                       gt_bboxes_ignore=gt_bboxes_ignore, gt_true_bboxes=gt_true_bboxes, lmap=lmap)
         k = int(os.environ.get('CPR_STREAMS', self.num_streams))
         if k > 1 and img.is_cuda and hasattr(self.bbox_head, 'loss'):
             outs = self._towers_multistream(img, k)

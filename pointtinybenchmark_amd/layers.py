@@ -3,6 +3,8 @@
 nn.Conv2d / nn.BatchNorm2d / nn.GroupNorm objects are used ONLY as parameter holders so the state-dict
 keys match the reference checkpoint layout; their ``forward`` is never called -- all
 compute goes through ``ops`` (HIP kernels)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -90,7 +92,7 @@ class ConvModule(nn.Module):
         return getattr(self, self.norm_name) if self.norm_name else None
 
 
-def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None, save=None):
+def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None, save=None, consume_input=False):
     """Run a ConvModule(conv, GN[, ReLU]) on an NHWC tensor.
 
     The GroupNorm statistics come out of the conv epilogue when the map is tile-aligned (no extra pass);
@@ -98,6 +100,12 @@ def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None, s
     the CONSUMER conv applies normalisation + ReLU while loading its input tile (no apply pass either).
     ``save`` (dict): training mode -- records what the backward needs (conv input and its pending affine, raw output,
     GroupNorm affine and statistics) and keeps the raw output intact (the apply pass goes out of place).
+    ``consume_input``: the caller owns ``x`` and nobody else reads it -- a pending producer-GroupNorm may be applied in place.
+
+    Fused-on-load vs one streaming apply pass (forward only; the training step keeps the fused form because its backward
+    needs the raw map): a KxK consumer re-transforms every input element K*K x (cout tiles) times behind its MFMAs
+    (3x3 256->256 at 160x160, B=16: 3.52 ms fused vs 3.30 ms plain), while gn_apply touches it once at HBM speed
+    (0.14 ms) -- so 3x3 consumers take the materialised input, 1x1 consumers fuse (CPR_GN_FUSE_IN=1 forces the fused form).
     """
     pc = packed_conv(cache, m.conv, x.dtype)
     gn = m.norm
@@ -106,8 +114,10 @@ def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None, s
     fused_stats = (OH * OW) % 128 == 0
     fuse_in = in_ab is not None and (H * W) % 128 == 0 and pc.stride == 1 and (OH, OW) == (H, W) \
         and x.dtype == torch.float32   # the bf16 kernel does not fuse the producer GN (see conv_mfma_bf16.hip)
+    if fuse_in and save is None and pc.KH * pc.KW > 1 and os.environ.get('CPR_GN_FUSE_IN', '0') != '1':
+        fuse_in = False
     if in_ab is not None and not fuse_in:
-        x = ops.gn_apply(x, in_ab[0], in_ab[1], relu=in_relu)
+        x = ops.gn_apply(x, in_ab[0], in_ab[1], relu=in_relu, out=x if (consume_input and save is None) else None)
         in_ab = None
     bias = m.conv.bias
     if fused_stats:

@@ -257,6 +257,20 @@ def box_centers(boxes):
     return out
 
 
+def logit_project(x, w, bias, in_ab=None, in_relu=True):
+    """x (N,H,W,Cin) fp32, w (J,Cin), bias (J) -> (N,H,W,J): the streaming projection kernel (J <= 8, Cin in {64, 128,
+    192, 256}); returns None when the shape is outside what it covers (the caller uses the MFMA conv)."""
+    N, H, W, Cin = _check(x).shape
+    J = w.shape[0]
+    if J > 8 or Cin > 256 or Cin % 64:
+        return None
+    out = torch.empty((N, H, W, J), device=x.device, dtype=torch.float32)
+    a, b = in_ab if in_ab is not None else (None, None)
+    _lib.call('cpr_logit_project', _ptr(x), _ptr(_check(w)), _ptr(_check(bias)), _ptr(a), _ptr(b), _ptr(out), N, H * W, Cin, J,
+              int(in_relu), _stream())
+    return out
+
+
 PROB_TYPES = {'sigmoid': 0, 'softmax': 1, 'normed_sigmoid': 2, 'identity': 3}
 
 
@@ -454,6 +468,14 @@ def p2p_decode(reg_nhwc, point_anchor, stride, gamma, want_anchor=False):
     _lib.call('cpr_p2p_decode', _ptr(reg_nhwc), _ptr(_check(point_anchor)), _ptr(pred), _ptr(anchor), N, H, W, k,
               float(stride), float(gamma), _stream())
     return (pred, anchor) if want_anchor else pred
+
+
+def sigmoid_exact(x):
+    """Elementwise sigmoid with torch's CPU bits (the scores that order top-k / NMS candidates)."""
+    x = _check(x.contiguous())
+    y = torch.empty_like(x)
+    _lib.call('cpr_sigmoid', _ptr(x), _ptr(y), x.numel(), _stream())
+    return y
 
 
 def rowmax_sigmoid(logits):

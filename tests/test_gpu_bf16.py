@@ -89,7 +89,10 @@ def test_bf16_aux_kernels():
          num_gts=8),
     dict(depth=101, num_classes=3, start_level=0, stride=4, radius=5, head_std=0.3, seed=53, batch=1, height=384,
          width=320, num_gts=10),
-], ids=['r50_256', 'r101_384x320'])
+    # BASELINE.json configs[4] at its own size: ResNet-101 + FPN, 1024x1024, bf16 compute mode, one image
+    dict(depth=101, num_classes=1, start_level=0, stride=4, radius=5, head_std=0.3, seed=45, batch=1, height=1024,
+         width=1024, num_gts=32),
+], ids=['r50_256', 'r101_384x320', 'r101_1024'])
 def test_bf16_path_vs_fp32_oracle(cfg):
     from pointtinybenchmark_amd import ops
     m, sd = build_hip_locator(cfg)

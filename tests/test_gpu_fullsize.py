@@ -119,9 +119,13 @@ def test_full_size_conv_linearity():
     # aligned, so this also covers the unfused GroupNorm-statistics path at full size.
     ('coco_style_800x1344', dict(depth=50, num_classes=80, start_level=1, stride=8, radius=8, head_std=0.3, seed=41,
                                  batch=1, height=800, width=1344, num_gts=24)),
-    # configs[4] backbone: ResNet-101 (fp32; the bf16 variant of that config is not built yet)
+    # configs[4] backbone at a small size (fast) ...
     ('r101_384', dict(depth=101, num_classes=1, start_level=0, stride=4, radius=5, head_std=0.3, seed=43, batch=1,
                       height=384, width=384, num_gts=12)),
+    # ... and BASELINE.json configs[4] at ITS OWN size: ResNet-101 + FPN, 1024x1024, one image, in the fp32 parity mode
+    # (the bf16 compute mode of the same config: tests/test_gpu_bf16.py::test_bf16_path_vs_fp32_oracle[r101_1024])
+    ('r101_1024', dict(depth=101, num_classes=1, start_level=0, stride=4, radius=5, head_std=0.3, seed=45, batch=1,
+                       height=1024, width=1024, num_gts=32)),
 ])
 def test_other_baseline_configs_parity_with_oracle(name, cfg):
     m, sd = build_hip_locator(cfg)
@@ -143,3 +147,48 @@ def test_other_baseline_configs_parity_with_oracle(name, cfg):
         assert abs(a - b) <= 5e-4 * max(abs(b), 1e-6), (name, k, a, b)
     np.testing.assert_allclose(torch.cat([d for d, _ in dets]).cpu().numpy(),
                                torch.cat([r['dets'] for r in ref]).numpy(), rtol=1e-4, atol=5e-3)
+
+
+def test_p2p_r50_640_full_network_vs_oracle():
+    """BASELINE.json configs[3] at its own size, through the WHOLE network (ResNet-50 -> FPN -> P2PHead towers -> Hungarian
+    targets -> losses, and top-k + pseudo-box NMS), one 640x640 image with 32 gts: tower outputs against the oracle on the
+    same weights (1e-4 logits), assignment bit-exact on the device's own predictions, detections against the oracle."""
+    import pointtinybenchmark_amd as P
+    from bench import p2p_model_cfg
+    m = P.build_detector(p2p_model_cfg(50)).cuda()
+    sd = synthetic.locator_state_dict(50, 1, 0, 'p2p', 61, head_std=0.05)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    batch = synthetic.synthetic_batch(1, 640, 640, 32, 1, seed=61)
+    cb = to_cuda(batch)
+    head = m.bbox_head
+    with torch.no_grad():
+        cls_outs, pts_outs = head(m.neck(m.backbone(cb['img'])))
+        losses = head.loss(cls_outs, pts_outs, cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'])
+        anchor, pred, valid, cls = head.get_pred_points(cls_outs, pts_outs, cb['img_metas'])
+        gtp = head.pseudo_bbox_to_center(cb['gt_bboxes'])
+        gt_inds = head.assign_batch(pred, cls, gtp, cb['gt_labels'], cb['img_metas'])
+        res = head.get_bboxes(cls_outs, pts_outs, cb['img_metas'])
+        torch.cuda.synchronize()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        feats = O.fpn_forward(sd, O.resnet_forward(sd, batch['img'], 50), 0, 1)
+        rc, rp = O.p2p_head_forward(sd, feats)
+    ec = float((cls_outs[0].cpu() - rc[0]).abs().max())
+    ep = float((pts_outs[0].cpu() - rp[0]).abs().max())
+    assert ec <= 1e-4 and ep <= 1e-4, 'P2P tower outputs at 640x640: cls %.3e pts %.3e (bar 1e-4)' % (ec, ep)
+    inds, lab, cost = O.hungarian_assign_v2(pred[0, :, :2].cpu(), cls[0].cpu(), gtp[0].cpu(), cb['gt_labels'][0].cpu(),
+                                            (640, 640, 3), topk_k=5, log_mode='cr')
+    got = gt_inds[0].cpu()
+    assert int((got > 0).sum()) == 160 and int((got != inds).sum()) == 0, 'Hungarian indices differ: %d' % int((got != inds).sum())
+    dets, labels, topk_inds, keep = O.p2p_get_points_single(cls[0].cpu(), pred[0, :, :2].cpu(), None, (640, 640, 3))
+    got_d = res[0][0].cpu()
+    assert got_d.shape[0] == dets.shape[0], (got_d.shape, dets.shape)
+    ref_boxes = torch.cat([dets[:, :2] - 8, dets[:, :2] + 8, dets[:, 2:]], dim=1)
+
+    def canon(d):     # detections arrive sorted by score; the order INSIDE a run of bit-equal scores is unspecified in the
+        d = d.numpy()  # reference (an unstable sort inside mmcv's nms) -> compare with ties ordered by (x1, y1)
+        return d[np.lexsort((d[:, 1], d[:, 0], -d[:, 4]))]
+    assert np.array_equal(got_d.numpy()[:, 4], ref_boxes.numpy()[:, 4]), 'scores (bit-exact sigmoid) must agree in order'
+    np.testing.assert_allclose(canon(got_d), canon(ref_boxes), rtol=1e-5, atol=1e-4)
+    assert all(bool(torch.isfinite(v[0] if isinstance(v, (list, tuple)) else v).all()) for v in losses.values())

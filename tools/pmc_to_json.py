@@ -34,5 +34,8 @@ out = {
     'lds_bank_conflict_cycles': res['SQ_LDS_BANK_CONFLICT'], 'duration_us': res['duration_us_sq'],
     'wait_any_frac': res['SQ_WAIT_ANY'] / res['SQ_WAVE_CYCLES'], 'source': 'tools/gpu_pmc.sh (rocprofv3 --pmc, 3 passes)',
 }
+sys.path.insert(0, root)
+from bench import kernel_source_sha16  # noqa: E402
+out['source_sha16'] = kernel_source_sha16()      # bench.py only replays this figure for the same kernel source
 json.dump(out, open(os.path.join(root, 'profiles', 'pmc_dominant_kernel.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
