@@ -113,6 +113,7 @@ class ConvProbe:
         from pointtinybenchmark_amd import _lib, ops
         self._orig = ops.conv2d
         self._lib = _lib
+        ops.TRACE_CONV_VARIANT[0] = True
         probe = self
 
         def conv2d(x, pc, *a, **k):
@@ -124,11 +125,10 @@ class ConvProbe:
             e.record()
             N, H, W, _ = x.shape
             OH, OW = pc.out_hw(H, W)
-            if x.dtype == torch.bfloat16:
-                v = probe._lib.load().cpr_conv_bf16_last_variant()
+            kind, v = ops.TRACE_CONV_VARIANT[1]          # what the launcher returned through its out-parameter
+            if kind == 'bf16':
                 variant = 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
             else:
-                v = probe._lib.load().cpr_conv_last_variant()
                 variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
                                                                       'true' if v // 10 % 10 else 'false', v % 10)
             kreal = pc.KH * pc.KW * (3 if pc.Cin == 4 else pc.Cin)
@@ -139,6 +139,7 @@ class ConvProbe:
     def remove(self):
         from pointtinybenchmark_amd import ops
         ops.conv2d = self._orig
+        ops.TRACE_CONV_VARIANT[0] = False
 
     def summary(self):
         agg = {}

@@ -4,7 +4,10 @@
  *   - every function returns 0, CPR_ERR_ARG (-1001, shape/pointer check failed), CPR_ERR_UNSUPPORTED (-1002) or
  *     -(hipError_t); nothing is thrown; the Python host raises RuntimeError on non-zero
  *   - all pointers are DEVICE pointers unless marked [host]; the caller allocates every output and workspace
- *     (no hidden allocation, no ownership transfer); functions are stateless and re-entrant
+ *     (no hidden allocation, no ownership transfer); the library keeps NO mutable state: every call is a pure function of
+ *     its arguments and may be issued from any host thread on any stream (what a launch did -- e.g. which template instance
+ *     the tile heuristic picked -- comes back through [host] out-parameters, never through a "last call" global).
+ *     The only exception is the measurement build (-DCPR_BENCH_HOOKS, libcprhip_bench.so, see the end of this file)
  *   - work is enqueued on `stream` (a hipStream_t passed as void*); no host synchronisation inside
  *   - activations are NHWC fp32; index outputs are int64 (torch long) where the reference returns long
  * Each entry cites the reference interface it replaces (T/ = TOV_mmdetection/).
@@ -30,30 +33,25 @@ int cpr_version(void);
  * epilogue  y = acc*scale[c] + bias[c] (+ residual[m][c]) (ReLU);   scale/bias/residual may be NULL
  * in_a/in_b (N,Cin) optional: input is read as relu?(x*a+b) (fused GroupNorm-apply of the producer; needs H*W%128==0)
  * gn_part optional [N*OH*OW/128][Cout][2]: per-tile per-channel (sum, sumsq) of the output (needs OH*OW%128==0)
- * Cin must be a multiple of 32, or 4 (3-channel stem padded with a zero channel). */
+ * Cin must be a multiple of 32, or 4 (3-channel stem padded with a zero channel).
+ * flags: CPR_CONV_* bits below.  variant_out [host, may be NULL]: bm*1e6 + bn*1e3 + mode*100 + xf*10 + pipe of the template
+ * instance that was launched (for profilers; with CPR_CONV_COLSUM the caller needs bm to size the partials). */
+#define CPR_CONV_RELU 1     /* ReLU in the epilogue */
+#define CPR_CONV_OUT_BF16 2 /* write bf16 (the 3-channel stem runs on the fp32 kernel and hands bf16 to the bf16 layers) */
+#define CPR_CONV_RES_MASK 4 /* residual is a ReLU mask source: out = residual > 0 ? v : 0 (backward of a fused ReLU) */
+#define CPR_CONV_COLSUM 8   /* gn_part [ceil(M/bm)][Cout][2] holds per-tile per-channel sums for a whole-tensor column sum */
 int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
                    const float* residual, const float* in_a, const float* in_b, float* gn_part, int N, int H, int W,
-                   int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int relu, int in_relu,
-                   void* stream);
-
-/* test / benchmark hook: force the conv output tile (bm, bn in {0 = heuristic, 64, 128}) */
-int cpr_conv_force_tile(int bm, int bn);
-/* K-loop schedule: 1 = interleaved (default), 0 = phase-separated (kept for A/B measurements) */
-int cpr_conv_set_pipeline(int mode);
-/* benchmark-only ablation of the K loop (bit0 no loads/LDS writes, bit1 no fragment reads, bit2 no barrier); results are
- * wrong when non-zero; 0 = product behaviour */
-int cpr_conv_set_ablation(int mode);
-/* template instance of the last cpr_conv2d_fwd launch: bm*1e6 + bn*1e3 + mode*100 + xf*10 + pipe (for profilers) */
-int cpr_conv_last_variant(void);
+                   int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int flags, int in_relu,
+                   int* variant_out, void* stream);
 
 /* bf16 compute mode (BASELINE.json configs[4]): bf16 activations / weights / residual, fp32 accumulate
  * (v_mfma_f32_32x32x16_bf16), K chunks of 64 (Cin % 64 == 0, Kpad == KH*KW*Cin), output bf16 or fp32 (out_fp32).
- * No fused producer-GroupNorm input; GroupNorm statistics come from the fp32 accumulators.  In cpr_conv2d_fwd the
- * `relu` argument's bit 1 requests a bf16 output (the 3-channel stem runs on the fp32 kernel and hands over bf16). */
+ * No fused producer-GroupNorm input; GroupNorm statistics come from the fp32 accumulators.
+ * variant_out [host, may be NULL]: bm*1000 + bn of the launched instance. */
 int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                         const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                        int stride, int pad, int Kpad, int relu, int out_fp32, void* stream);
-int cpr_conv_bf16_last_variant(void); /* bm*1000 + bn of the last cpr_conv2d_fwd_bf16 launch */
+                        int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, void* stream);
 int cpr_maxpool3x3s2_bf16(const void* in, void* out, int N, int H, int W, int C, void* stream);
 int cpr_gn_stats_bf16(const void* x, float* part, int N, int HW, int C, int P, void* stream);
 int cpr_gn_apply_bf16(const void* x, const float* a, const float* b, const void* up, void* y, int N, int H, int W,
@@ -153,10 +151,11 @@ int cpr_point_assign(const float* points, const float* gt_bboxes, int n, int k, 
                      long long* gt_inds, float* ws_best, int* ws_lvl, void* stream);
 
 /* FocalLossCost + DisCostV2 (T/mmdet/core/bbox/match_costs/match_cost.py:84-100,197-214):
- * costT (G,M) = transpose of the reference's (M,G) cost; pred (M,pred_stride>=2), logits (M,C), gt (G,2) */
+ * costT (G,M) = transpose of the reference's (M,G) cost; pred (M,pred_stride>=2), logits (M,C), gt (G,2);
+ * p_norm = DisCostV2's p: 1 (|dx|+|dy|) or 2 (torch.cdist's Euclidean forms) */
 int cpr_hungarian_cost(const float* pred, int pred_stride, const float* logits, int C, const float* gt,
                        const int* labels, float* costT, int M, int G, float w_cls, float alpha, float gamma,
-                       float eps, float w_dis, float fx, float fy, void* stream);
+                       float eps, float w_dis, float fx, float fy, int p_norm, void* stream);
 
 /* The linear_sum_assignment loop of HungarianAssignerV2.assign (hungarian_assigner.py:229-268; replaces scipy and
  * the device->host->device round trip), including scipy's tie-breaking order.  A batch of problems, one workgroup
@@ -208,7 +207,6 @@ int cpr_p2p_loss(const float* logits, const float* pred, const long long* gt_ind
  * GroupNorm(+ReLU) the forward applied on load).  ws: cpr_conv2d_wgrad_workspace(...) floats.  Cin%4==0, Cout%4==0. */
 /* benchmark hook: main-loop ablations of the plain weight-gradient kernel (1 no loads, 2 no LDS stores, 4 no barrier,
  * 8 no fragment reads, 3 = 1|2, 15 = all); results are wrong by construction, 0 restores the product kernel */
-int cpr_wgrad_set_ablation(int mode);
 int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
 int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w, float* ws,
                      int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int in_relu,
@@ -283,9 +281,21 @@ int cpr_sgd_step(float* p, const float* grad, float* buf, const double* norm2, l
  * device flags or NULL. */
 int cpr_preprocess_u8(const unsigned char* img, const int* flip, const float* mean3, const float* stdinv3, int to_rgb,
                       float* out, int N, int H, int W, int Hp, int Wp, void* stream);
-/* RandomFlip.bbox_flip, horizontal (transforms.py:397-415), in place: boxes (n,4) xyxy, img_of (n) image index,
- * flip / widths per image (width = img_shape[1]) */
-int cpr_flip_boxes(float* boxes, const int* img_of, const int* flip, const int* widths, int n, void* stream);
+/* Box side of Resize(scale 1) -> RandomFlip, in place: clip every box to its image when `clip` (Resize._resize_bboxes,
+ * bbox_clip_border=True, transforms.py:241-249), then mirror it when flip[img] (RandomFlip.bbox_flip, :397-415).
+ * boxes (n,4) xyxy, img_of (n) image index, flip (N), img_hw (N,2) int32 = img_shape[:2] */
+int cpr_clip_flip_boxes(float* boxes, const int* img_of, const int* flip, const int* img_hw, int n, int clip,
+                        void* stream);
+
+/* ---- measurement build only (-DCPR_BENCH_HOOKS; python -m pointtinybenchmark_amd.build --bench-hooks) ------------------
+ * Process-global, not thread-safe switches used by the scripts under tools/ to A/B the conv kernels.  NOT part of the
+ * product library. */
+#ifdef CPR_BENCH_HOOKS
+int cpr_conv_force_tile(int bm, int bn); /* force the conv output tile (0 = heuristic, 64, 128) */
+int cpr_conv_set_pipeline(int mode);     /* K-loop schedule: 1 = interleaved (product), 0 = phase-separated */
+int cpr_conv_set_ablation(int mode);     /* loop ablations: results are WRONG when non-zero */
+int cpr_wgrad_set_ablation(int mode);    /* same for the weight-gradient kernel */
+#endif
 
 #ifdef __cplusplus
 }

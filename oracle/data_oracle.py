@@ -72,8 +72,8 @@ def reference_parse(ds, classes, min_gt_size, train_ignore_as_bg=True):
     exec(base + '\n' + sub, ns)
     d = ns['Sub']()
     d.coco = _Coco(ds)
-    by_name = {c['name']: c['id'] for c in ds['categories']}
-    d.cat_ids = [by_name[n] for n in classes]
+    # self.coco.get_cat_ids(cat_names=CLASSES) = pycocotools getCatIds: the json's categories filtered by name, JSON order
+    d.cat_ids = [c['id'] for c in ds['categories'] if c['name'] in classes]
     d.cat2label = {c: i for i, c in enumerate(d.cat_ids)}
     d.img_ids = [im['id'] for im in ds['images']]
     d.data_infos = [dict(im, filename=im['file_name']) for im in ds['images']]
@@ -89,6 +89,24 @@ def reference_bbox_flip(boxes, img_shape):
     exec('class F:\n' + textwrap.indent(_method(T + 'datasets/pipelines/transforms.py', 'class RandomFlip', 'bbox_flip'),
                                         '    '), ns)
     return ns['F']().bbox_flip(boxes, img_shape, 'horizontal')
+
+
+def reference_resize_bboxes(boxes, img_shape, scale_factor=(1.0, 1.0, 1.0, 1.0)):
+    """Resize._resize_bboxes (transforms.py:241-249) executed from the reference source, bbox_clip_border=True."""
+    ns = {'np': np}
+    exec('class R:\n    bbox_clip_border = True\n' + textwrap.indent(
+        _method(T + 'datasets/pipelines/transforms.py', 'class Resize', '_resize_bboxes'), '    '), ns)
+    res = dict(bbox_fields=['b'], b=boxes.copy(), scale_factor=np.array(scale_factor, dtype=np.float32), img_shape=img_shape)
+    ns['R']()._resize_bboxes(res)
+    return res['b']
+
+
+def resize_clip_bboxes(boxes, img_shape):
+    """Resize._resize_bboxes at scale 1 with bbox_clip_border=True, restated (pinned by tests/golden/data_side.json)."""
+    b = boxes * np.array([1.0, 1.0, 1.0, 1.0], dtype=np.float32)
+    b[:, 0::2] = np.clip(b[:, 0::2], 0, img_shape[1])
+    b[:, 1::2] = np.clip(b[:, 1::2], 0, img_shape[0])
+    return b
 
 
 def bbox_flip(boxes, img_shape):
@@ -133,13 +151,21 @@ def _jsonable(o):
 def main():
     out = {}
     for name, classes, mgs, seed in (('all3_min2', ['person', 'rider', 'other'], 2, 0), ('person_only', ['person'], 2, 1),
-                                     ('no_min', ['person', 'rider'], None, 2)):
+                                     ('no_min', ['person', 'rider'], None, 2),
+                                     # CLASSES in another order than the json's categories: labels follow the JSON order
+                                     ('permuted_classes', ['other', 'person'], 2, 3)):
         ds = synthetic_dataset(seed)
         ids, parsed = reference_parse(ds, classes, mgs)
         out[name] = dict(seed=seed, classes=classes, min_gt_size=mgs, img_ids=ids, parsed=_jsonable(parsed))
     rng = np.random.RandomState(0)
     b = rng.uniform(0, 600, (9, 4)).astype(np.float32)
     out['bbox_flip'] = dict(boxes=b.tolist(), width=633, flipped=reference_bbox_flip(b, (480, 633)).tolist())
+    # pseudo boxes overhanging the image border (points closer than pseudo_wh/2 to an edge): Resize clips them before the flip
+    c = rng.uniform(-12, 652, (40, 2)).astype(np.float32)
+    ob = np.concatenate([c - 8, c + 8], axis=1).astype(np.float32)
+    clipped = reference_resize_bboxes(ob, (480, 633, 3))
+    out['resize_clip'] = dict(boxes=ob.tolist(), img_shape=[480, 633, 3], clipped=clipped.tolist(),
+                              clipped_then_flipped=reference_bbox_flip(clipped, (480, 633)).tolist())
     json.dump(out, open(GOLDEN, 'w'))
     print('wrote', GOLDEN, {k: len(v.get('img_ids', [])) for k, v in out.items()})
 

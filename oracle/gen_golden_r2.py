@@ -1,6 +1,6 @@
 """Round-2 fixtures from the REFERENCE's own classes (build container only).  TEST INFRASTRUCTURE ONLY.
 
-  python -m oracle.gen_golden_r2 [refine] [options] [costs]
+  python -m oracle.gen_golden_r2 [refine] [options] [costs] [p2p_edge]
 
   refine   tests/golden/refine.npz        PointRefiner internals (refine points, scores, not_refine, the chosen-point
                                           masks) of every CPR case + the out_geo / cascade_out_fmt / not_refine-input /
@@ -10,6 +10,8 @@
                                           softmax / normed_sigmoid probabilities, binary_ins, AllPosLoss
   costs    tests/golden/assigner_costs.npz  the reference's own fp32 cost matrices of the HungarianAssignerV2 fixtures
                                           (FocalLossCost + DisCostV2 evaluated by the reference classes on THIS host)
+  p2p_edge tests/golden/p2p_edge.npz      P2PHead targets / losses on a batch with invalid feature-map cells (an image padded
+                                          less than the batch maximum) and with a gt-less image (p2p_head.py:275-328,451-463)
 Inputs and weights come from ``pointtinybenchmark_amd.synthetic`` (seeded, regenerated at test time)."""
 import os
 import sys
@@ -267,17 +269,66 @@ def gen_assigner_costs(R):
     print('assigner costs', {k: v.shape for k, v in out.items()})
 
 
+def p2p_edge_inputs():
+    """Shared with the tests: a 2-image batch whose second image is padded LESS than the batch maximum (its feature-map
+    cells beyond ceil(pad_shape / stride) are invalid, p2p_head.py:451-463) and a variant with a gt-less image."""
+    hw, C, G = 48, 2, 7
+    g = torch.Generator().manual_seed(910)
+    feat = torch.randn((2, 256, hw, hw), generator=g)
+    batch = synthetic.synthetic_batch(2, hw * 4, hw * 4, G, C, seed=910, ragged=True)
+    metas = [dict(m) for m in batch['img_metas']]
+    metas[1]['pad_shape'] = (160, 176, 3)             # -> 40 x 44 valid cells of the 48 x 48 map
+    metas[1]['img_shape'] = (150, 170, 3)
+    keep = [(b[:, 2] < 168) & (b[:, 3] < 148) for b in batch['gt_bboxes']]
+    keep[0][:] = True
+    gtb = [b[k] for b, k in zip(batch['gt_bboxes'], keep)]
+    gtl = [l[k] for l, k in zip(batch['gt_labels'], keep)]
+    assert all(len(x) > 0 for x in gtl)
+    return feat, metas, gtb, gtl, C, hw
+
+
+def gen_p2p_edge(R):
+    from oracle.gen_golden import build_reference_p2p
+    feat, metas, gtb, gtl, C, hw = p2p_edge_inputs()
+    head, sd = build_reference_p2p(R, C, 0.08, seed=5)
+    out = {}
+    with torch.no_grad():
+        cls_outs, pts_outs = head((feat,))
+        losses = head.loss(cls_outs, pts_outs, gtb, gtl, metas, gt_bboxes_ignore=[torch.zeros((0, 4)) for _ in gtl])
+        anchor, pred, vflag, co = head.get_pred_points(cls_outs, pts_outs, metas)
+        gtp = head.pseudo_bbox_to_center(gtb)
+        lab, lw, bgt, pw = head.get_targets(pred[..., :2], vflag, co, gtp, gtl, metas)
+        # an image without gts is legal for get_targets (HungarianAssignerV2's no-gt branch, hungarian_assigner.py:207-219)
+        gtp0 = [gtp[0], gtp[1][:0]]
+        gtl0 = [gtl[0], gtl[1][:0]]
+        lab0, lw0, bgt0, pw0 = head.get_targets(pred[..., :2], vflag, co, gtp0, gtl0, metas)
+    out['valid_flag'] = vflag.numpy()
+    out['loss_cls'] = np.array([float(v) for v in losses['loss_cls']], dtype=np.float32)
+    out['loss_pts'] = np.array([float(v) for v in losses['loss_pts']], dtype=np.float32)
+    out['labels'] = torch.stack(lab).numpy().astype(np.int32)
+    out['label_weights'] = torch.stack(lw).numpy()
+    out['target_pts'] = torch.stack(bgt).numpy()
+    out['target_weights'] = torch.stack(pw).numpy()
+    out['nogt_labels'] = torch.stack(lab0).numpy().astype(np.int32)
+    out['nogt_label_weights'] = torch.stack(lw0).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, 'p2p_edge.npz'), **out)
+    print('p2p_edge: invalid cells', int((~vflag).sum()), 'losses', out['loss_cls'], out['loss_pts'],
+          'positives', int((out['labels'] < C).sum()), 'no-gt image positives', int((out['nogt_labels'][1] < C).sum()))
+
+
 def main():
     assert ref_loader.available(), 'needs /root/reference'
     torch.set_num_threads(8)
     R = ref_loader.load()
-    which = sys.argv[1:] or ['refine', 'options', 'costs']
+    which = sys.argv[1:] or ['refine', 'options', 'costs', 'p2p_edge']
     if 'refine' in which:
         gen_refine(R)
     if 'options' in which:
         gen_options(R)
     if 'costs' in which:
         gen_assigner_costs(R)
+    if 'p2p_edge' in which:
+        gen_p2p_edge(R)
 
 
 if __name__ == '__main__':

@@ -17,13 +17,8 @@ _l = ctypes.c_longlong
 # name -> argtypes (restype is always int: 0 ok, <0 error).  Mirrors include/cpr_hip.h one to one.
 SIGNATURES = {
     'cpr_version': [],
-    'cpr_conv2d_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    'cpr_conv_force_tile': [_i, _i],
-    'cpr_conv_set_pipeline': [_i],
-    'cpr_conv_set_ablation': [_i],
-    'cpr_conv_last_variant': [],
-    'cpr_conv2d_fwd_bf16': [_p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p],
-    'cpr_conv_bf16_last_variant': [],
+    'cpr_conv2d_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
+    'cpr_conv2d_fwd_bf16': [_p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p, _p],
     'cpr_maxpool3x3s2_bf16': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_gn_stats_bf16': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_gn_apply_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -41,7 +36,7 @@ SIGNATURES = {
     'cpr_mil_loss': [_p, _i, _i, _p, _p, _p, _p, _p] + [_i] * 10 + [_f, _i, _f, _i, _i, _f, _f, _f, _i, _p, _p],
     'cpr_refine': [_p, _i, _p, _p, _p, _i, _i] + [_p] * 9 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _i, _p],
     'cpr_point_assign': [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p],
-    'cpr_hungarian_cost': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p],
+    'cpr_hungarian_cost': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _p],
     'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i] + [_p] * 15,
     'cpr_topk_desc': [_p, _i, _i, _p, _p, _p],
     'cpr_nms': [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
@@ -51,7 +46,6 @@ SIGNATURES = {
     'cpr_p2p_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p],
     # training step: backward + optimizer
     'cpr_conv2d_wgrad_workspace': [_i] * 7,
-    'cpr_wgrad_set_ablation': [_i],
     'cpr_conv2d_wgrad': [_p] * 6 + [_i] * 11 + [_p],
     'cpr_gn_bwd': [_p] * 12 + [_i] * 7 + [_p],
     'cpr_upsample_add_bwd': [_p, _p] + [_i] * 7 + [_p],
@@ -64,13 +58,22 @@ SIGNATURES = {
     'cpr_loss_bwd': [_p] * 13 + [_i] * 9 + [_f] * 5 + [_p],
     # data side
     'cpr_preprocess_u8': [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
-    'cpr_flip_boxes': [_p, _p, _p, _p, _i, _p],
+    'cpr_clip_flip_boxes': [_p, _p, _p, _p, _i, _i, _p],
     'cpr_pack_weights': [_p, _p, _p] + [_i] * 7 + [_p],
     'cpr_bn_fold': [_p, _p, _p, _p, _f, _p, _p, _p, _i, _p],
     'cpr_p2p_loss_bwd': [_p] * 9 + [_i] * 5 + [_f] * 9 + [_p],
     'cpr_grad_sumsq': [_p, _l, _p, _p, _i, _p],
     'cpr_sgd_step': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p],
 }
+
+# measurement build only (-DCPR_BENCH_HOOKS -> libcprhip_bench.so, tools/*.py): NOT part of the product library
+BENCH_SIGNATURES = {
+    'cpr_conv_force_tile': [_i, _i],
+    'cpr_conv_set_pipeline': [_i],
+    'cpr_conv_set_ablation': [_i],
+    'cpr_wgrad_set_ablation': [_i],
+}
+BENCH_LIB_PATH = os.path.join(_HERE, 'csrc', 'libcprhip_bench.so')
 
 _lib = None
 
@@ -85,14 +88,18 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise CprHipError('%s not found: run `python -m pointtinybenchmark_amd.build` (no CPU fallback exists)'
-                          % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, argtypes in SIGNATURES.items():
+    path, sigs = LIB_PATH, dict(SIGNATURES)
+    if os.environ.get('CPR_BENCH_HOOKS', '0') == '1':      # tools/*.py: the measurement build with its global switches
+        path = BENCH_LIB_PATH
+        sigs.update(BENCH_SIGNATURES)
+    if not os.path.exists(path):
+        raise CprHipError('%s not found: run `python -m pointtinybenchmark_amd.build%s` (no CPU fallback exists)'
+                          % (path, ' --bench-hooks' if path == BENCH_LIB_PATH else ''))
+    lib = ctypes.CDLL(path)
+    for name, argtypes in sigs.items():
         fn = getattr(lib, name, None)
         if fn is None:
-            raise CprHipError('symbol %s missing from %s (stale build?)' % (name, LIB_PATH))
+            raise CprHipError('symbol %s missing from %s (stale build?)' % (name, path))
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     _lib = lib

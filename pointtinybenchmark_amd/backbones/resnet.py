@@ -96,6 +96,8 @@ class ResNet(nn.Module):
         self.feat_dim = inplanes
         self.compute_dtype = torch.float32   # torch.bfloat16 = bf16 activations/weights from the stem output on
         self._cache = _PackCache()
+        self.zero_init_residual = zero_init_residual
+        self.init_weights()
         self._freeze_stages()
 
     def _freeze_stages(self):  # resnet.py:612-628
@@ -113,7 +115,24 @@ class ResNet(nn.Module):
         return self
 
     def init_weights(self):
-        pass
+        """The reference's default init_cfg when no checkpoint is given (resnet.py:404-424; the configs name
+        torchvision://resnet50, which is not available offline, so weights normally arrive through load_state_dict):
+        Kaiming normal (fan_out, relu) on every conv, BatchNorm weight 1 / bias 0, and -- zero_init_residual -- weight 0 on
+        the last norm of every block."""
+        from ..layers import bump_weight_epoch
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual:
+            for name in self.res_layers:
+                for blk in getattr(self, name):
+                    nn.init.constant_((blk.bn3 if blk.kind == 'bottleneck' else blk.bn2).weight, 0)
+        bump_weight_epoch()
 
     def forward(self, x, tape=None):
         """x: (N,3,H,W) -> tuple of NCHW-shaped (channels_last) stage outputs.

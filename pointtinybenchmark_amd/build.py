@@ -34,28 +34,44 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
+BENCH_LIB = os.path.join(CSRC, 'libcprhip_bench.so')
+HOOK_SOURCES = {'conv_mfma.hip', 'conv_wgrad.hip'}     # the files that carry #ifdef CPR_BENCH_HOOKS code
+
+
+def build(force=False, verbose=True, bench_hooks=False):
+    """bench_hooks=True builds libcprhip_bench.so (-DCPR_BENCH_HOOKS: forced tiles, schedule A/B, loop ablations) for
+    tools/*.py next to the product library; the product library never contains those switches."""
+    lib = BENCH_LIB if bench_hooks else LIB
+    if not force and not (needs_build() if not bench_hooks else (
+            not os.path.exists(lib) or any(os.path.getmtime(os.path.join(CSRC, s)) > os.path.getmtime(lib)
+                                           for s in SOURCES + ['common.h']))):
+        return lib
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         if not os.path.exists(src):
             continue
-        obj = os.path.join(CSRC, s.replace('.hip', '.o'))
+        hooked = bench_hooks and s in HOOK_SOURCES
+        obj = os.path.join(CSRC, s.replace('.hip', '.bench.o' if hooked else '.o'))
+        if bench_hooks and not hooked and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src) \
+                and os.path.getmtime(obj) >= os.path.getmtime(os.path.join(CSRC, 'common.h')):
+            objs.append(obj)          # identical object as in the product build
+            continue
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + \
-            (['-ffp-contract=off'] if s in EXACT_SOURCES else []) + ['-c', src, '-o', obj]
+            (['-ffp-contract=off'] if s in EXACT_SOURCES else []) + (['-DCPR_BENCH_HOOKS'] if hooked else []) + \
+            ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(LIB)
+    print(build(force='--force' in sys.argv))
+    if '--bench-hooks' in sys.argv:
+        print(build(force='--force' in sys.argv, bench_hooks=True))

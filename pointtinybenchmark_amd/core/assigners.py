@@ -59,7 +59,7 @@ class FocalLossCost:
 @MATCH_COST.register_module()
 class DisCostV2:
     def __init__(self, weight=1., norm_with_img_wh=True, p=1):
-        assert p == 1, 'only the L1 distance of the shipped P2P config is built'
+        assert p in (1, 2), 'DisCostV2: p = 1 (the shipped P2P config) or 2'
         self.weight, self.norm_with_img_wh, self.p = weight, norm_with_img_wh, p
 
 
@@ -106,7 +106,7 @@ class HungarianAssignerV2:
             fx, fy = float(w), float(h)
         return ops.hungarian_cost(bbox_pred.float().contiguous(), cls_pred.float().contiguous(),
                                   gt_bboxes.float().contiguous(), gt_labels.to(torch.int32).contiguous(), cc.weight,
-                                  cc.alpha, float(cc.gamma), cc.eps, rc.weight, fx, fy)
+                                  cc.alpha, float(cc.gamma), cc.eps, rc.weight, fx, fy, rc.p)
 
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None, eps=1e-7):
         assert gt_bboxes_ignore is None, 'Only case when gt_bboxes_ignore is None is supported.'

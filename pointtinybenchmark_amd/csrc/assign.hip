@@ -118,7 +118,7 @@ __global__ void hungarian_cost_kernel(const float* __restrict__ pred, int pred_s
                                       const float* __restrict__ logits, int C, const float* __restrict__ gt,
                                       const int* __restrict__ labels, float* __restrict__ costT, int M, int G,
                                       float w_cls, float alpha, float gamma, float eps, float w_dis, float fx,
-                                      float fy) {
+                                      float fy, int p_norm) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;
     if (m >= M) return;
@@ -131,20 +131,30 @@ __global__ void hungarian_cost_kernel(const float* __restrict__ pred, int pred_s
     const float neg = __fmul_rn(__fmul_rn(-log_cr(__fadd_rn(q1, eps)), 1.f - alpha), pg);
     const float pos = __fmul_rn(__fmul_rn(-log_cr(__fadd_rn(p, eps)), alpha), qg);
     const float cls = __fmul_rn(__fsub_rn(pos, neg), w_cls);
-    const float dx = fabsf(__fsub_rn(__fdiv_rn(pred[(size_t)m * pred_stride], fx), __fdiv_rn(gt[g * 2], fx)));
-    const float dy = fabsf(__fsub_rn(__fdiv_rn(pred[(size_t)m * pred_stride + 1], fy), __fdiv_rn(gt[g * 2 + 1], fy)));
-    const float dis = __fmul_rn(__fadd_rn(dx, dy), w_dis);
+    const float px = __fdiv_rn(pred[(size_t)m * pred_stride], fx), py = __fdiv_rn(pred[(size_t)m * pred_stride + 1], fy);
+    const float gx = __fdiv_rn(gt[g * 2], fx), gy = __fdiv_rn(gt[g * 2 + 1], fy);
+    float dist;
+    if (p_norm == 1) {              // torch.cdist(p=1): |dx| + |dy|
+        dist = __fadd_rn(fabsf(__fsub_rn(px, gx)), fabsf(__fsub_rn(py, gy)));
+    } else if (M > 25 || G > 25) {  // torch.cdist(p=2), matmul form (use_mm_for_euclid_dist_if_necessary), IEEE sqrt
+        dist = __fsqrt_rn(fmaxf(d2_chain(px, py, sq_norm(px, py), gx, gy, sq_norm(gx, gy)), 0.f));
+    } else {                        // small problems: the direct kernel sqrt(dx^2 + dy^2)
+        const float dx = __fsub_rn(px, gx), dy = __fsub_rn(py, gy);
+        dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    }
+    const float dis = __fmul_rn(dist, w_dis);
     costT[(size_t)g * M + m] = __fadd_rn(cls, dis);
 }
 
 extern "C" int cpr_hungarian_cost(const float* pred, int pred_stride, const float* logits, int C, const float* gt,
                                   const int* labels, float* costT, int M, int G, float w_cls, float alpha,
-                                  float gamma, float eps, float w_dis, float fx, float fy, hipStream_t stream) {
-    CPR_CHECK_ARG(M >= 0 && G >= 0 && C > 0 && pred_stride >= 2);
+                                  float gamma, float eps, float w_dis, float fx, float fy, int p_norm,
+                                  hipStream_t stream) {
+    CPR_CHECK_ARG(M >= 0 && G >= 0 && C > 0 && pred_stride >= 2 && (p_norm == 1 || p_norm == 2));
     if (M == 0 || G == 0) return CPR_OK;
     CPR_CHECK_ARG(pred && logits && gt && labels && costT);
     hipLaunchKernelGGL(hungarian_cost_kernel, dim3(cdiv(M, 256), G), dim3(256), 0, stream, pred, pred_stride, logits,
-                       C, gt, labels, costT, M, G, w_cls, alpha, gamma, eps, w_dis, fx, fy);
+                       C, gt, labels, costT, M, G, w_cls, alpha, gamma, eps, w_dis, fx, fy, p_norm);
     CPR_LAUNCH_STATUS();
 }
 

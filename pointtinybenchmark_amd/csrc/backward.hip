@@ -683,7 +683,7 @@ __global__ void p2p_loss_bwd_kernel(const float* __restrict__ logits, const floa
     const bool pos = gi > 0;
     const int g = pos ? gt_start[b] + (int)gi - 1 : 0;
     const int label = pos ? gt_labels[g] : C;
-    const float w = pos ? pos_w : (neg_w <= 0.f ? 1.f : neg_w);
+    const float w = (gi < 0) ? 0.f : pos ? pos_w : (neg_w <= 0.f ? 1.f : neg_w);   // gi < 0: invalid cell, label weight 0
     for (int c = 0; c < Cp; ++c) {
         float d = 0.f;
         if (c < C) {

@@ -7,6 +7,12 @@
 #define CPR_ERR_ARG (-1001)   // bad shape / pointer argument
 #define CPR_ERR_UNSUPPORTED (-1002)
 
+// cpr_conv2d_fwd `flags` (mirrors include/cpr_hip.h)
+#define CPR_CONV_RELU 1       // ReLU in the epilogue
+#define CPR_CONV_OUT_BF16 2   // write bf16 (the fp32 stem hands a bf16 map to the bf16 layers)
+#define CPR_CONV_RES_MASK 4   // `residual` is a ReLU mask source: out = residual > 0 ? v : 0 (backward of a fused ReLU)
+#define CPR_CONV_COLSUM 8     // gn_part receives per-tile per-channel sums that are only reduced over the whole tensor
+
 #define CPR_CHECK_ARG(cond) \
     do {                    \
         if (!(cond)) return CPR_ERR_ARG; \
@@ -66,6 +72,21 @@ __device__ __forceinline__ float sleef_expf_u10(float d) {
     return u;
 }
 __device__ __forceinline__ float sigmoid_torch_cpu(float x) { return __fdiv_rn(1.f, __fadd_rn(1.f, sleef_expf_u10(-x))); }
+
+// torch.cdist(p=2) for > 25 rows (what every call site on this path has) is the matmul form
+// [-2x, -2y, |p|^2, 1] . [cx, cy, 1, |c|^2] evaluated by MKL sgemm as a k-ordered fp32 FMA chain, then clamp_min(0), sqrt.
+// d2_chain() is that chain operation for operation (the files that use it are compiled with -ffp-contract=off).
+__device__ __forceinline__ float sq_norm(float x, float y) {
+    // x.pow(2).sum(-1): each square rounded, then one add (cpr_head.py:277 via torch.cdist)
+    return __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y));
+}
+__device__ __forceinline__ float d2_chain(float px, float py, float pn, float cx, float cy, float cn) {
+    float acc = __fmul_rn(-2.f * px, cx);
+    acc = __fmaf_rn(-2.f * py, cy, acc);
+    acc = __fadd_rn(pn, acc);
+    acc = __fadd_rn(acc, cn);
+    return acc;
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

@@ -434,11 +434,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 }
 
 // C-ABI ------------------------------------------------------------------------------------------
-static int force_tile_bm = 0, force_tile_bn = 0;  // test/bench hook (cpr_conv_force_tile), 0 = heuristic
+// The product library holds no mutable state.  The benchmark hooks (forced tile, K-loop schedule A/B, loop ablations --
+// the latter give WRONG results by design) exist only in builds with -DCPR_BENCH_HOOKS (python -m
+// pointtinybenchmark_amd.build --bench-hooks -> libcprhip_bench.so, used by tools/); they are process-global and not
+// thread-safe, which is acceptable for a single-threaded measurement script and for nothing else.
+#ifdef CPR_BENCH_HOOKS
+static int force_tile_bm = 0, force_tile_bn = 0;  // cpr_conv_force_tile, 0 = heuristic
 static int conv_pipeline = 1;                      // 1 = interleaved K loop (default), 0 = phase-separated (A/B reference)
-static int conv_ablate = 0;                        // benchmark-only (cpr_conv_set_ablation); 0 in production
-static int last_variant = 0;                       // bm*1e6 + bn*1e3 + mode*100 + xf*10 + pipe of the last launch
-extern "C" int cpr_conv_last_variant(void) { return last_variant; }
+static int conv_ablate = 0;                        // cpr_conv_set_ablation
 extern "C" int cpr_conv_set_ablation(int mode) {
     CPR_CHECK_ARG(mode >= 0 && mode <= 16);
     conv_ablate = mode;
@@ -455,11 +458,14 @@ extern "C" int cpr_conv_force_tile(int bm, int bn) {
     force_tile_bn = bn;
     return CPR_OK;
 }
+#else
+constexpr int force_tile_bm = 0, force_tile_bn = 0, conv_pipeline = 1, conv_ablate = 0;
+#endif
 
 extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
                               const float* residual, const float* in_a, const float* in_b, float* gn_part, int N,
                               int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad,
-                              int relu, int in_relu, hipStream_t stream) {
+                              int flags, int in_relu, int* variant_out, hipStream_t stream) {
     CPR_CHECK_ARG(in && wgt && out);
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     CPR_CHECK_ARG(Kpad % BK == 0);
@@ -467,9 +473,10 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     p.in = in; p.wgt = wgt; p.out = out; p.scale = scale; p.bias = bias; p.residual = residual;
     p.in_a = in_a; p.in_b = in_b; p.gn_part = gn_part;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
-    p.Kpad = Kpad; p.relu = relu & 1; p.in_relu = in_relu; p.out_bf16 = (relu >> 1) & 1;  // relu bit1 = bf16 output
-    p.res_mask = (relu >> 2) & 1;          // bit2: residual is a ReLU mask source
-    const bool colsum_mode = (relu >> 3) & 1;   // bit3: gn_part partials are only summed over the whole tensor (any tile)
+    CPR_CHECK_ARG((flags & ~15) == 0);
+    p.Kpad = Kpad; p.relu = flags & CPR_CONV_RELU; p.in_relu = in_relu; p.out_bf16 = (flags & CPR_CONV_OUT_BF16) ? 1 : 0;
+    p.res_mask = (flags & CPR_CONV_RES_MASK) ? 1 : 0;
+    const bool colsum_mode = (flags & CPR_CONV_COLSUM) != 0;   // gn_part partials are only summed over the whole tensor (any tile)
     if (p.res_mask) CPR_CHECK_ARG(residual != nullptr);
     p.OH = (H + 2 * pad - KH) / stride + 1;
     p.OW = (W + 2 * pad - KW) / stride + 1;
@@ -499,11 +506,12 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     }
     if (force_tile_bm > 0 && (!gn_part || colsum_mode) && !in_a && !mode1) { bm = force_tile_bm; }
     if (force_tile_bn > 0 && Cout > 64 && !mode1) { bn = force_tile_bn; }
-    last_variant = bm * 1000000 + bn * 1000 + (mode1 ? 100 : 0) + (in_a ? 10 : 0) + conv_pipeline;
+    if (variant_out) *variant_out = bm * 1000000 + bn * 1000 + (mode1 ? 100 : 0) + (in_a ? 10 : 0) + conv_pipeline;
     p.tilesM = (p.M + bm - 1) / bm;
     p.tilesN = (Cout + bn - 1) / bn;
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
+#ifdef CPR_BENCH_HOOKS
 #define LAUNCH(BM_, BN_, MODE_, XF_)                                                                               \
     do {                                                                                                           \
         if (conv_pipeline == 0)                                                                                    \
@@ -511,6 +519,11 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
         else                                                                                                       \
             hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 1>), dim3(grid), dim3(256), 0, stream, p); \
     } while (0)
+#else
+#define LAUNCH(BM_, BN_, MODE_, XF_) \
+    hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 1>), dim3(grid), dim3(256), 0, stream, p)
+#endif
+#ifdef CPR_BENCH_HOOKS
     if (conv_ablate && !mode1 && !in_a && bm == 128 && bn == 128) {
         switch (conv_ablate) {
             case 1: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 1>), dim3(grid), dim3(256), 0, stream, p); break;
@@ -521,7 +534,9 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
             case 16: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 16>), dim3(grid), dim3(256), 0, stream, p); break;
             default: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 7>), dim3(grid), dim3(256), 0, stream, p); break;
         }
-    } else if (mode1) {
+    } else
+#endif
+    if (mode1) {
         if (bn == 64) LAUNCH(128, 64, 1, false); else LAUNCH(128, 128, 1, false);
     } else if (in_a) {
         if (bn == 64) LAUNCH(128, 64, 0, true); else LAUNCH(128, 128, 0, true);

@@ -300,12 +300,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
     }
 }
 
-static int last_variant_bf16 = 0;  // bm*1000 + bn of the last launch (for profilers)
-extern "C" int cpr_conv_bf16_last_variant(void) { return last_variant_bf16; }
-
 extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                                    const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
-                                   int KW, int stride, int pad, int Kpad, int relu, int out_fp32, hipStream_t stream) {
+                                   int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream) {
     CPR_CHECK_ARG(in && wgt && out);
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     CPR_CHECK_ARG(Cin % BKH == 0 && Kpad == KH * KW * Cin);
@@ -327,7 +324,7 @@ extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, c
     const int bm = big ? 128 : 64, bn = big ? 128 : 64;
     p.tilesM = (int)((M + bm - 1) / bm);
     p.tilesN = (Cout + bn - 1) / bn;
-    last_variant_bf16 = bm * 1000 + bn;
+    if (variant_out) *variant_out = bm * 1000 + bn;
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
     if (big) hipLaunchKernelGGL((conv_mfma_bf16_kernel<128, 128>), dim3(grid), dim3(256), 0, stream, p);

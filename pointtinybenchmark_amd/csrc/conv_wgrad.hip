@@ -368,12 +368,14 @@ static int wgrad_split(long long M, int Cout, int Cin, int KK) {
     }
     return (int)S;
 }
-static int wgrad_ablate = 0;   // benchmark-only (cpr_wgrad_set_ablation); 0 in production
+#ifdef CPR_BENCH_HOOKS   // benchmark-only loop ablations (results are wrong by construction): tools builds only
+static int wgrad_ablate = 0;
 extern "C" int cpr_wgrad_set_ablation(int mode) {
     CPR_CHECK_ARG(mode >= 0 && mode <= 32);
     wgrad_ablate = mode;
     return CPR_OK;
 }
+#endif
 extern "C" int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {
     CPR_CHECK_ARG(N > 0 && OH > 0 && OW > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0);
     const int S = wgrad_split((long long)N * OH * OW, Cout, Cin, KH * KW);
@@ -410,6 +412,7 @@ extern "C" int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in
                     : (stride == 1 && p.OH == H && p.OW == W) ? 1 : 0;
 #define WG_LAUNCH(XF_, ABL_, GEO_) \
     hipLaunchKernelGGL((conv_wgrad_kernel<XF_, ABL_, GEO_>), dim3((unsigned)grid), dim3(256), 0, stream, p)
+#ifdef CPR_BENCH_HOOKS
     if (wgrad_ablate && !in_a && geo == 1) {
         switch (wgrad_ablate) {
             case 1: WG_LAUNCH(false, 1, 1); break;
@@ -420,7 +423,9 @@ extern "C" int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in
             case 32: WG_LAUNCH(false, 32, 1); break;
             default: WG_LAUNCH(false, 15, 1); break;
         }
-    } else if (in_a) {
+    } else
+#endif
+    if (in_a) {
         if (geo == 2) WG_LAUNCH(true, 0, 2); else if (geo == 1) WG_LAUNCH(true, 0, 1);
         else if (geo == 0) WG_LAUNCH(true, 0, 0); else WG_LAUNCH(true, 0, -1);
     } else {

@@ -15,17 +15,6 @@
 
 #define MAX_GT_LDS 1024
 
-__device__ __forceinline__ float sq_norm(float x, float y) {
-    // x.pow(2).sum(-1): each square rounded, then one add (cpr_head.py:277 via torch.cdist)
-    return __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y));
-}
-__device__ __forceinline__ float d2_chain(float px, float py, float pn, float cx, float cy, float cn) {
-    float acc = __fmul_rn(-2.f * px, cx);
-    acc = __fmaf_rn(-2.f * py, cy, acc);
-    acc = __fadd_rn(pn, acc);
-    acc = __fadd_rn(acc, cn);
-    return acc;
-}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------

@@ -287,7 +287,9 @@ __global__ void p2p_loss_kernel(const float* __restrict__ logits, const float* _
         const bool pos = gi > 0;
         const int g = pos ? gt_start[b] + (int)gi - 1 : 0;
         const int label = pos ? gt_labels[g] : C;
-        const float w = pos ? pos_w : (neg_w <= 0.f ? 1.f : neg_w);
+        // gi < 0: a cell outside the padded image (valid_flags false): the reference un-maps it with label weight 0
+        // (p2p_head.py:300-305, unmap fill 0), i.e. it contributes to neither loss
+        const float w = (gi < 0) ? 0.f : pos ? pos_w : (neg_w <= 0.f ? 1.f : neg_w);
         for (int c = 0; c < C; ++c) {
             const float x = logits[r * C + c];
             const float p = 1.f / (1.f + expf(-x));

@@ -43,23 +43,32 @@ extern "C" int cpr_preprocess_u8(const unsigned char* img, const int* flip, cons
     CPR_LAUNCH_STATUS();
 }
 
-// RandomFlip.bbox_flip, horizontal (transforms.py:397-415): boxes (n,4) xyxy of image `img_of[i]`, flipped when flip[img]
-__global__ void flip_boxes_kernel(float* __restrict__ boxes, const int* __restrict__ img_of, const int* __restrict__ flip,
-                                  const int* __restrict__ widths, int n) {
+// Box side of Resize (scale 1) -> RandomFlip: Resize._resize_bboxes clips every bbox field to the image
+// (bbox_clip_border=True: x to [0, W], y to [0, H]; transforms.py:241-249) BEFORE RandomFlip.bbox_flip mirrors it
+// (transforms.py:397-415).  boxes (n,4) xyxy of image `img_of[i]`; hw (N,2) int32 = img_shape[:2]; flipped when flip[img].
+__global__ void clip_flip_boxes_kernel(float* __restrict__ boxes, const int* __restrict__ img_of,
+                                       const int* __restrict__ flip, const int* __restrict__ hw, int n, int clip) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int im = img_of[i];
-    if (!flip[im]) return;
-    const float w = (float)widths[im];
-    const float x1 = boxes[i * 4], x2 = boxes[i * 4 + 2];
-    boxes[i * 4] = __fsub_rn(w, x2);
-    boxes[i * 4 + 2] = __fsub_rn(w, x1);
+    const float h = (float)hw[im * 2], w = (float)hw[im * 2 + 1];
+    float x1 = boxes[i * 4], y1 = boxes[i * 4 + 1], x2 = boxes[i * 4 + 2], y2 = boxes[i * 4 + 3];
+    if (clip) {
+        x1 = fminf(fmaxf(x1, 0.f), w); x2 = fminf(fmaxf(x2, 0.f), w);
+        y1 = fminf(fmaxf(y1, 0.f), h); y2 = fminf(fmaxf(y2, 0.f), h);
+    }
+    if (flip[im]) {
+        const float t = x1;
+        x1 = __fsub_rn(w, x2);
+        x2 = __fsub_rn(w, t);
+    }
+    boxes[i * 4] = x1; boxes[i * 4 + 1] = y1; boxes[i * 4 + 2] = x2; boxes[i * 4 + 3] = y2;
 }
-extern "C" int cpr_flip_boxes(float* boxes, const int* img_of, const int* flip, const int* widths, int n,
-                              hipStream_t stream) {
+extern "C" int cpr_clip_flip_boxes(float* boxes, const int* img_of, const int* flip, const int* img_hw, int n, int clip,
+                                   hipStream_t stream) {
     CPR_CHECK_ARG(n >= 0);
     if (n == 0) return CPR_OK;
-    CPR_CHECK_ARG(boxes && img_of && flip && widths);
-    hipLaunchKernelGGL(flip_boxes_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, boxes, img_of, flip, widths, n);
+    CPR_CHECK_ARG(boxes && img_of && flip && img_hw);
+    hipLaunchKernelGGL(clip_flip_boxes_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, boxes, img_of, flip, img_hw, n, clip);
     CPR_LAUNCH_STATUS();
 }

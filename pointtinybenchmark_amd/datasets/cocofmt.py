@@ -51,8 +51,9 @@ class CocoFmtDataset:
             self.img_to_anns.setdefault(a['image_id'], []).append(a)
         if self.CLASSES is None:
             self.CLASSES = [c['name'] for c in ds['categories']]
-        by_name = {c['name']: c['id'] for c in ds['categories']}
-        self.cat_ids = [by_name[n] for n in self.CLASSES if n in by_name]
+        # COCO.getCatIds(catNms=CLASSES) filters the json's category list: ids come in the JSON's order, "will not change
+        # with the order of the CLASSES" (cocofmt.py:117-119; pycocotools is un-vendored, published algorithm)
+        self.cat_ids = [c['id'] for c in ds['categories'] if c['name'] in self.CLASSES]
         self.cat2label = {cid: i for i, cid in enumerate(self.cat_ids)}
         self.img_ids = [im['id'] for im in ds['images']]
         infos = []

@@ -1,7 +1,8 @@
 """Device tail of the train / test image pipeline of the CPR configs
 (configs2/TinyPersonV2/coarsepointv2/coarse_point_refine_base_TinyPersonV2_640.py:17-50):
 
-    Resize(scale_factor=1.0, keep_ratio=True)   identity at the shipped scale (asserted)
+    Resize(scale_factor=1.0, keep_ratio=True)   pixels: identity at the shipped scale (asserted); boxes: clipped to the image
+                                                (bbox_clip_border=True, transforms.py:241-249) -- same kernel as the flip
     RandomFlip(flip_ratio)                      decision on the host, pixels + boxes flipped on the device
     Normalize(mean, std, to_rgb) -> Pad(size_divisor) -> DefaultFormatBundle -> collate
                                                 ONE kernel: uint8 HWC -> (N,Hp,Wp,4) fp32 channels-last (cpr_preprocess_u8)
@@ -25,7 +26,7 @@ def pil_bgr_loader(path):
 class GpuImagePipeline:
     def __init__(self, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True, size_divisor=32,
                  flip_ratio=0.0, scale_factor=1.0, device='cuda',
-                 keys=('img', 'gt_bboxes', 'gt_labels', 'gt_bboxes_ignore', 'gt_true_bboxes')):
+                 keys=('img', 'gt_bboxes', 'gt_labels', 'gt_bboxes_ignore', 'gt_true_bboxes'), bbox_clip_border=True):
         assert float(scale_factor) == 1.0, 'the shipped CPR/P2P configs resize with scale_factor=[1.0]'
         self.mean = np.array(mean, dtype=np.float32)
         self.std = np.array(std, dtype=np.float32)
@@ -33,6 +34,7 @@ class GpuImagePipeline:
         self.stdinv = (1.0 / np.float64(self.std)).astype(np.float32)
         self.to_rgb, self.size_divisor, self.flip_ratio = bool(to_rgb), int(size_divisor), float(flip_ratio)
         self.device, self.keys = device, tuple(keys)
+        self.bbox_clip_border = bool(bbox_clip_border)       # Resize's default (transforms.py:66)
 
     def __call__(self, samples, rng=None):
         """samples: list of dicts with ``img`` (uint8 HxWx3 BGR, numpy or torch) and the gt_* numpy fields."""
@@ -65,11 +67,11 @@ class GpuImagePipeline:
                               flip_direction='horizontal' if flips[i] else None,
                               img_norm_cfg=dict(mean=self.mean, std=self.std, to_rgb=self.to_rgb)))
         batch = dict(img=ops.as_nchw(out), img_metas=metas)
-        widths = torch.tensor([s[1] for s in shapes], dtype=torch.int32, device=dev)
+        img_hw = torch.tensor([[s[0], s[1]] for s in shapes], dtype=torch.int32, device=dev).reshape(-1)
         flips_d = torch.from_numpy(flips).to(dev)
-        for key in ('gt_bboxes', 'gt_bboxes_ignore', 'gt_true_bboxes'):
+        for key in ('gt_bboxes', 'gt_bboxes_ignore', 'gt_true_bboxes'):   # = the pipeline's bbox_fields (loading.py:246-278)
             if key in self.keys and all(key in s for s in samples):
-                batch[key] = self._boxes([s[key] for s in samples], flips_d, widths)
+                batch[key] = self._boxes([s[key] for s in samples], flips_d, img_hw)
         for key in ('gt_labels', 'gt_anns_id'):
             if key in self.keys and all(key in s for s in samples):
                 batch[key] = [torch.from_numpy(np.asarray(s[key], dtype=np.int64)).to(dev) for s in samples]
@@ -83,13 +85,13 @@ class GpuImagePipeline:
         _lib.call('cpr_preprocess_u8', ops._ptr(img_u8), ops._ptr(flips), ctypes.cast(m, ctypes.c_void_p),
                   ctypes.cast(s, ctypes.c_void_p), int(self.to_rgb), ops._ptr(out), n, H, W, Hp, Wp, ops._stream())
 
-    def _boxes(self, per_img, flips_d, widths):
+    def _boxes(self, per_img, flips_d, img_hw):
         counts = [len(b) for b in per_img]
         flat = np.concatenate([np.asarray(b, dtype=np.float32).reshape(-1, 4) for b in per_img]) if sum(counts) else \
             np.zeros((0, 4), np.float32)
         t = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
         if len(flat):
             img_of = torch.from_numpy(np.repeat(np.arange(len(counts), dtype=np.int32), counts)).to(self.device)
-            _lib.call('cpr_flip_boxes', ops._ptr(t), ops._ptr(img_of), ops._ptr(flips_d), ops._ptr(widths), len(flat),
-                      ops._stream())
+            _lib.call('cpr_clip_flip_boxes', ops._ptr(t), ops._ptr(img_of), ops._ptr(flips_d), ops._ptr(img_hw), len(flat),
+                      int(self.bbox_clip_border), ops._stream())
         return list(torch.split(t, counts))

@@ -113,14 +113,26 @@ class P2PHead(nn.Module):
         reg = ops.from_nchw(pts_outs[0])
         B, H, W, _ = cls.shape
         stride = self.strides[0]
-        for m in img_metas:  # valid_flags (p2p_head.py:451-463): every cell must lie inside the padded image
-            ph, pw = m['pad_shape'][:2]
-            if min(int(np.ceil(ph / stride)), H) != H or min(int(np.ceil(pw / stride)), W) != W:
-                raise NotImplementedError('feature map larger than the padded image (invalid cells) is not built')
         pa = self._cache.get('pa', [], lambda: self.point_anchor.to(cls.device).contiguous())
         pred, anchor = ops.p2p_decode(reg, pa, stride, self.pts_gamma, want_anchor=True)
         cls = cls.reshape(B, H * W * self.num_points, self.num_cls_out)
-        valid = torch.ones((B, H * W * self.num_points), dtype=torch.bool, device=cls.device)
+        # valid_flags (p2p_head.py:451-463, PointGenerator.valid_flags): cells beyond ceil(pad_shape / stride) -- an image
+        # padded less than the batch maximum -- are invalid: not assigned, label weight 0
+        valid = None
+        for b, m in enumerate(img_metas):
+            ph, pw = m['pad_shape'][:2]
+            vh, vw = min(int(np.ceil(ph / stride)), H), min(int(np.ceil(pw / stride)), W)
+            if vh != H or vw != W:
+                if valid is None:
+                    valid = torch.ones((B, H, W, self.num_points), dtype=torch.bool)
+                valid[b, vh:] = False
+                valid[b, :, vw:] = False
+        if valid is None:
+            valid = torch.ones((B, H * W * self.num_points), dtype=torch.bool, device=cls.device)
+            valid.all_valid = True
+        else:
+            valid = valid.reshape(B, -1).to(cls.device)
+            valid.all_valid = False
         return anchor, pred, valid, cls
 
     @staticmethod
@@ -128,17 +140,42 @@ class P2PHead(nn.Module):
         return [ops.box_centers(b.float().contiguous()) for b in gt_bboxes]
 
     # ------------------------------------------------------------------ loss (p2p_head.py:172-328)
-    def assign_batch(self, proposals, cls, gt_points, gt_labels, img_metas):
-        """All images' Hungarian problems in one LSA launch.  Returns gt_inds (B, M) int64."""
+    def assign_batch(self, proposals, cls, gt_points, gt_labels, img_metas, valid=None):
+        """All images' Hungarian problems in one LSA launch.  Returns gt_inds (B, M) int64: j+1 = gt j, 0 = background,
+        -1 = invalid cell (``valid`` false: not offered to the assigner, label weight 0 -- p2p_head.py:288-305).
+        Degenerate images follow HungarianAssignerV2.assign (hungarian_assigner.py:207-219,251): no gts -> all background;
+        fewer proposals than gts with topk_k > 1 -> the loop never runs, all background."""
         a = self.assigner
         B, M = proposals.shape[:2]
-        costs = []
+        all_valid = True if valid is None else getattr(valid, 'all_valid', None)
+        if all_valid is None:
+            all_valid = bool(valid.all())
+        masked = not all_valid
+        out = proposals.new_zeros((B, M), dtype=torch.long)
+        costs, where = [], []
         for b in range(B):
-            if M < gt_points[b].shape[0]:
-                raise NotImplementedError('fewer proposals than gts')
-            costs.append(a.cost_t(proposals[b], cls[b], gt_points[b], gt_labels[b], img_metas[b]))
-        inds, _ = ops.lsa_topk(costs, a.topk_k)
-        return torch.stack(inds)
+            idx = torch.nonzero(valid[b], as_tuple=False).squeeze(1) if masked else None
+            if masked:
+                out[b][~valid[b]] = -1
+            props, c = (proposals[b][idx], cls[b][idx]) if masked else (proposals[b], cls[b])
+            G, Mb = gt_points[b].shape[0], props.shape[0]
+            if G == 0 or Mb == 0:
+                continue
+            if Mb < G:
+                if a.topk_k == 1:
+                    raise NotImplementedError('fewer proposals than gts with topk_k == 1 (scipy solves the transposed '
+                                              'problem there; the device LSA needs M >= G)')
+                continue
+            costs.append(a.cost_t(props.contiguous(), c.contiguous(), gt_points[b], gt_labels[b], img_metas[b]))
+            where.append((b, idx))
+        if costs:
+            inds, _ = ops.lsa_topk(costs, a.topk_k)
+            for (b, idx), gi in zip(where, inds):
+                if idx is None:
+                    out[b] = gi
+                else:
+                    out[b][idx] = gi
+        return out
 
     def loss(self, cls_outs, pts_outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None, save=None):
         for gb in gt_bboxes:
@@ -148,7 +185,7 @@ class P2PHead(nn.Module):
         gt_points = self.pseudo_bbox_to_center([b.to(dev) for b in gt_bboxes])
         gt_labels = [l.to(dev) for l in gt_labels]
         proposals = anchor if self.assign_before_pred else pred
-        gt_inds = self.assign_batch(proposals, cls, gt_points, gt_labels, img_metas)
+        gt_inds = self.assign_batch(proposals, cls, gt_points, gt_labels, img_metas, valid)
         counts = [len(l) for l in gt_labels]
         start = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(dev)
         lc, lr = self.loss_cls_cfg, self.loss_reg_cfg
@@ -166,7 +203,8 @@ class P2PHead(nn.Module):
     def get_targets(self, pred_pts, valid_flag_list, cls_outs_list, gt_points, gt_labels, img_metas,
                     gt_points_ignore=None, unmap_outputs=True):
         """Reference-format targets (p2p_head.py:250-328) derived from the device assignment."""
-        gt_inds = self.assign_batch(pred_pts, cls_outs_list, gt_points, gt_labels, img_metas)
+        valid = valid_flag_list if torch.is_tensor(valid_flag_list) else torch.stack(list(valid_flag_list))
+        gt_inds = self.assign_batch(pred_pts, cls_outs_list, gt_points, gt_labels, img_metas, valid)
         labels, lw, tgt, w = [], [], [], []
         pos_w = _get(self.train_cfg, 'pos_weight', 1.0)
         neg_w = _get(self.train_cfg, 'neg_weight', 1.0)
@@ -181,6 +219,9 @@ class P2PHead(nn.Module):
             ww[pos] = 1.0
             l_w = pred_pts.new_full(gi.shape, 1.0 if neg_w <= 0 else neg_w)
             l_w[pos] = pos_w
+            inv = gi < 0                       # unmap(fill=0) of the reference: label 0, weight 0 on invalid cells
+            lab[inv] = 0
+            l_w[inv] = 0
             labels.append(lab), lw.append(l_w), tgt.append(t), w.append(ww)
         return labels, lw, tgt, w
 

@@ -33,9 +33,16 @@ class FPN(nn.Module):
         extra = num_outs - self.backbone_end_level + start_level
         assert extra < 1, 'extra pyramid levels are not used by the CPR/P2P configs (num_outs=1)'
         self._cache = _PackCache()
+        self.init_weights()
 
     def init_weights(self):
-        pass
+        """init_cfg=dict(type='Xavier', layer='Conv2d', distribution='uniform') (fpn.py:81-82): Xavier-uniform conv
+        weights, zero biases; GroupNorm keeps weight 1 / bias 0."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
 
     def _run(self, inputs, lazy, tape=None):
         assert len(inputs) == len(self.in_channels)

@@ -126,6 +126,12 @@ class PackedConv:
                 (W + 2 * self.padding - self.KW) // self.stride + 1)
 
 
+CONV_RELU, CONV_OUT_BF16, CONV_RES_MASK, CONV_COLSUM = 1, 2, 4, 8      # include/cpr_hip.h CPR_CONV_*
+# profilers (bench.py) set [0] = True; the template instance of the last conv launch is then left in [1] as
+# (kind, code).  Host-side, single-threaded bookkeeping of a value the C ABI returns through an out-parameter.
+TRACE_CONV_VARIANT = [False, None]
+
+
 def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, in_relu=False, gn_part=False,
            out=None, out_dtype=None, res_mask=False, colsum=False):
     """x (N,H,W,Cin) -> (N,OH,OW,Cout).  Epilogue: *scale[c] + bias[c] (+residual) (ReLU).
@@ -149,22 +155,29 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
         part = torch.empty((N * OH * OW // 128, pc.Cout, 2), device=x.device, dtype=torch.float32)
     if colsum:
         part = torch.empty(((N * OH * OW + 63) // 64, pc.Cout, 2), device=x.device, dtype=torch.float32)
+    variant = ctypes.c_int(0) if (colsum or TRACE_CONV_VARIANT[0]) else None   # [host] out-parameter of the launcher
+    vref = ctypes.byref(variant) if variant is not None else None
     if x.dtype == torch.bfloat16:
         assert not (res_mask or colsum), 'backward helpers are fp32'
         assert in_ab is None, 'the bf16 kernel does not fuse the producer GroupNorm (materialise with gn_apply)'
         _lib.call('cpr_conv2d_fwd_bf16', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
                   _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding, pc.Kpad, int(relu),
-                  int(odt == torch.float32), _stream())
+                  int(odt == torch.float32), vref, _stream())
+        if variant is not None:
+            TRACE_CONV_VARIANT[1] = ('bf16', variant.value)
         return (out, part) if gn_part else out
     a = b = None
     if in_ab is not None:
         a, b = in_ab
-    flags = int(relu) | (2 if odt == torch.bfloat16 else 0) | (4 if res_mask else 0) | (8 if colsum else 0)
+    flags = (CONV_RELU if relu else 0) | (CONV_OUT_BF16 if odt == torch.bfloat16 else 0) | \
+        (CONV_RES_MASK if res_mask else 0) | (CONV_COLSUM if colsum else 0)
     _lib.call('cpr_conv2d_fwd', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias),
               _ptr(residual), _ptr(a), _ptr(b), _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride,
-              pc.padding, pc.Kpad, flags, int(in_relu), _stream())
+              pc.padding, pc.Kpad, flags, int(in_relu), vref, _stream())
+    if variant is not None:
+        TRACE_CONV_VARIANT[1] = ('fp32', variant.value)
     if colsum:
-        bm = _lib.call('cpr_conv_last_variant', positive=True) // 1000000     # tile edge the launcher picked
+        bm = variant.value // 1000000     # tile edge the launcher picked
         return out, TilePartials(part, (N * OH * OW + bm - 1) // bm, pc.Cout)
     return (out, part) if gn_part else out
 
@@ -380,13 +393,13 @@ def point_assign(points, gt_bboxes, scale=4, pos_num=3):
 
 
 def hungarian_cost(pred, logits, gt, labels, w_cls=2.0, alpha=0.25, gamma=2.0, eps=1e-12, w_dis=0.1, fx=1.0,
-                   fy=1.0):
+                   fy=1.0, p=1):
     """-> cost^T (G, M) fp32 (column-major view of the reference's (M, G) cost)."""
     M, G = pred.shape[0], gt.shape[0]
     costT = torch.empty((G, M), device=pred.device, dtype=torch.float32)
     _lib.call('cpr_hungarian_cost', _ptr(_check(pred)), pred.shape[1], _ptr(_check(logits)), logits.shape[1],
               _ptr(_check(gt)), _ptr(labels), _ptr(costT), M, G, float(w_cls), float(alpha), float(gamma),
-              float(eps), float(w_dis), float(fx), float(fy), _stream())
+              float(eps), float(w_dis), float(fx), float(fy), int(p), _stream())
     return costT
 
 

@@ -68,10 +68,51 @@ class GradBuckets:
         return 1.0 / self.world_size
 
 
+class StepLrSchedule:
+    """The reference's learning-rate policy (``lr_config = dict(policy='step', warmup='linear', warmup_iters=500,
+    warmup_ratio=0.001, step=[8, 11])``, T/configs2/TinyPersonV2/coarsepointv2/coarse_point_refine_base_TinyPersonV2_640.py:
+    101-106, T/configs/_base_/schedules/schedule_1x.py:5-11) as a pure function of the iteration.  The hooks that implement
+    it live in mmcv (StepLrUpdaterHook / LrUpdaterHook, un-vendored, mmcv-full 1.3.x): restated from the published
+    algorithm -- parity unpinned --
+        regular lr of epoch e      base_lr * gamma ** #{s in step : e >= s}
+        iteration i < warmup_iters regular_lr * (1 - (1 - i / warmup_iters) * (1 - warmup_ratio))     ('linear')
+    by_epoch=True: the epoch of iteration i is i // iters_per_epoch."""
+
+    def __init__(self, base_lr, iters_per_epoch, step=(8, 11), gamma=0.1, warmup='linear', warmup_iters=500,
+                 warmup_ratio=0.001):
+        assert warmup in (None, 'linear', 'constant', 'exp') and iters_per_epoch > 0
+        self.base_lr, self.iters_per_epoch, self.step, self.gamma = base_lr, int(iters_per_epoch), tuple(step), gamma
+        self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
+
+    @classmethod
+    def from_config(cls, optimizer, lr_config, iters_per_epoch):
+        cfg = dict(lr_config)
+        assert cfg.pop('policy') == 'step', 'only the step policy of the CPR / P2P configs is built'
+        return cls(optimizer['lr'], iters_per_epoch, **cfg)
+
+    def regular_lr(self, epoch):
+        return self.base_lr * self.gamma ** sum(1 for s in self.step if epoch >= s)
+
+    def lr(self, it):
+        reg = self.regular_lr(it // self.iters_per_epoch)
+        if self.warmup is None or it >= self.warmup_iters:
+            return reg
+        if self.warmup == 'constant':
+            return reg * self.warmup_ratio
+        if self.warmup == 'exp':
+            return reg * self.warmup_ratio ** (1 - it / self.warmup_iters)
+        return reg * (1 - (1 - it / self.warmup_iters) * (1 - self.warmup_ratio))
+
+
 class CprTrainer:
     def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_mb=25.0, group=None,
-                 two_streams=True, force_collectives=False):
+                 two_streams=True, force_collectives=False, schedule=None):
+        """schedule: a StepLrSchedule (or any object with ``lr(iteration)``); ``lr`` is then only the fallback of
+        ``step(lr=...)``.  Constructing the trainer re-homes every trainable parameter: ``p.data`` becomes a view of ONE
+        flat buffer (``flat_p``) and ``p.grad`` a view of ``flat_g``; do not re-bind them afterwards (``model.to()``,
+        ``.float()``, ``p.data = ...``) -- ``step`` checks and refuses.  ``state_dict()`` below returns detached clones."""
         self.model = model
+        self.schedule = schedule
         self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
         order = self._backward_order()
         seen = {id(p) for p in order}
@@ -98,7 +139,36 @@ class CprTrainer:
         # weight gradients run on a second stream: they are off the critical path (nothing downstream of the backward
         # chain reads them) and the deep layers' launches are too small to fill 256 CUs on their own
         self.side = torch.cuda.Stream(device=dev) if two_streams and dev.type == 'cuda' else None
+        self.group = group
+        self.sync_initial_state()
         bump_weight_epoch()
+
+    def sync_initial_state(self, src=0):
+        """What MMDistributedDataParallel does at construction (T/mmdet/apis/train.py:75-86): every rank starts from rank
+        ``src``'s module state -- parameters (trainable: the flat buffer in one collective; frozen ones singly) and buffers
+        (BatchNorm running statistics).  Without it, unseeded per-process initialisation leaves the replicas on different
+        weights for ever, because only gradients are averaged."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        dist.broadcast(self.flat_p, src=src, group=self.group)
+        dist.broadcast(self.flat_m, src=src, group=self.group)
+        flat_ids = set(self.offset)
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            if id(t) not in flat_ids and t.numel() > 0:
+                dist.broadcast(t.data, src=src, group=self.group)
+
+    def check_bindings(self):
+        """A parameter that no longer aliases the flat buffers would be updated into stale memory: refuse."""
+        lo, hi = self.flat_p.data_ptr(), self.flat_p.data_ptr() + self.flat_p.numel() * 4
+        for p in (self.params[0], self.params[len(self.params) // 2], self.params[-1]):
+            assert lo <= p.data_ptr() < hi and p.grad is not None and \
+                self.flat_g.data_ptr() <= p.grad.data_ptr() < self.flat_g.data_ptr() + self.flat_g.numel() * 4, \
+                'a parameter was re-bound after CprTrainer took it over (model.to() / .float() / p.data = ...): ' \
+                'build the trainer AFTER moving the model and load weights with load_state_dict (in place)'
+
+    def state_dict(self):
+        """Detached clones of the model's tensors (saving the views would serialise the whole flat storage per key)."""
+        return {k: v.detach().clone() for k, v in self.model.state_dict().items()}
 
     # ------------------------------------------------------------------ parameter order = gradient completion order
     def _backward_order(self):
@@ -339,7 +409,12 @@ class CprTrainer:
 
     # ------------------------------------------------------------------ optimizer
     def step(self, lr=None):
-        """Wait for the gradient buckets, clip by the global norm, SGD-momentum update of every trainable parameter."""
+        """Wait for the gradient buckets, clip by the global norm, SGD-momentum update of every trainable parameter.
+        lr: explicit override; else the schedule's value for this iteration; else the constructor's constant."""
+        self.check_bindings()
+        if lr is None and self.schedule is not None:
+            lr = self.schedule.lr(self.steps)
+        self.last_lr = self.lr if lr is None else lr
         grad_scale = self.buckets.finish()
         if self.max_norm and self.max_norm > 0:
             ops.grad_sumsq(self.flat_g, self.norm2, self._ws, accumulate=False)

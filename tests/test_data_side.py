@@ -19,7 +19,7 @@ def _arr(o):
     return np.array(o['data'], dtype=o['dtype']).reshape(o['shape']) if isinstance(o, dict) and 'dtype' in o else o
 
 
-@pytest.mark.parametrize('name', ['all3_min2', 'person_only', 'no_min'])
+@pytest.mark.parametrize('name', ['all3_min2', 'person_only', 'no_min', 'permuted_classes'])
 def test_cocofmt_parse_matches_reference_methods(name):
     from pointtinybenchmark_amd.datasets import CocoFmtDataset
     g = GOLD[name]
@@ -41,6 +41,18 @@ def test_box_flip_oracle_is_the_reference_formula():
     g = GOLD['bbox_flip']
     b = np.array(g['boxes'], np.float32)
     assert np.array_equal(DO.bbox_flip(b, (480, g['width'])), np.array(g['flipped'], np.float32))
+
+
+def test_resize_clip_oracle_is_the_reference_formula():
+    """Resize._resize_bboxes at scale 1 (bbox_clip_border=True) clips boxes that overhang the image BEFORE the flip
+    (fixture: the reference's own method body on border-overhanging 16x16 pseudo boxes)."""
+    g = GOLD['resize_clip']
+    b = np.array(g['boxes'], np.float32)
+    shp = tuple(g['img_shape'])
+    clipped = DO.resize_clip_bboxes(b, shp)
+    assert np.array_equal(clipped, np.array(g['clipped'], np.float32))
+    assert (clipped != b).any(), 'the fixture must contain overhanging boxes'
+    assert np.array_equal(DO.bbox_flip(clipped, shp[:2]), np.array(g['clipped_then_flipped'], np.float32))
 
 
 def _samples(n, shapes, seed=0):
@@ -90,10 +102,28 @@ def test_gpu_pipeline_bit_exact(shapes):
         m = batch['img_metas'][i]
         assert m['flip'] == flip and m['img_shape'] == s['img'].shape and m['pad_shape'] == (h, w, 3)
         for key in ('gt_bboxes', 'gt_true_bboxes'):
-            want = DO.bbox_flip(s[key], s['img'].shape[:2]) if flip else s[key]
+            want = DO.resize_clip_bboxes(s[key], s['img'].shape)        # Resize (scale 1) clips to the image first
+            want = DO.bbox_flip(want, s['img'].shape[:2]) if flip else want
             assert np.array_equal(batch[key][i].cpu().numpy(), want), key
         assert torch.equal(batch['gt_anns_id'][i].cpu(), torch.from_numpy(s['gt_anns_id']))
         assert batch['gt_bboxes_ignore'][i].shape == (0, 4)
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_clips_overhanging_boxes_like_resize():
+    """The reference fixture (border-overhanging pseudo boxes through Resize._resize_bboxes, then bbox_flip) through the
+    device pipeline, flipped and not flipped."""
+    from pointtinybenchmark_amd.datasets import GpuImagePipeline
+    g = GOLD['resize_clip']
+    h, w, _ = g['img_shape']
+    boxes = np.array(g['boxes'], np.float32)
+    sample = dict(img=np.zeros((h, w, 3), np.uint8), gt_bboxes=boxes, gt_labels=np.zeros(len(boxes), np.int64),
+                  gt_bboxes_ignore=np.zeros((0, 4), np.float32), gt_true_bboxes=boxes.copy())
+    pipe = GpuImagePipeline(flip_ratio=0.5)
+    for draw, key in ((0.9, 'clipped'), (0.1, 'clipped_then_flipped')):
+        batch = pipe([sample], _Rng([draw]))
+        assert np.array_equal(batch['gt_bboxes'][0].cpu().numpy(), np.array(g[key], np.float32)), key
+        assert np.array_equal(batch['gt_true_bboxes'][0].cpu().numpy(), np.array(g[key], np.float32)), key
 
 
 @pytest.mark.gpu

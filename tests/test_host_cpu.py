@@ -18,12 +18,23 @@ def test_library_exports_every_declared_symbol():
     from pointtinybenchmark_amd import _lib, build
     build.build(verbose=False)
     hdr = open(os.path.join(ROOT, 'include', 'cpr_hip.h')).read()
-    declared = set(re.findall(r'^\s*int\s+(cpr_\w+)\s*\(', hdr, flags=re.M))
+    product, hooks = hdr.split('#ifdef CPR_BENCH_HOOKS')
+    declared = set(re.findall(r'^\s*int\s+(cpr_\w+)\s*\(', product, flags=re.M))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.cpr_version() >= 1
+    # the measurement switches (process-global state, results wrong by design) are NOT in the product library
+    hook_names = set(re.findall(r'^\s*int\s+(cpr_\w+)\s*\(', hooks, flags=re.M))
+    assert hook_names == set(_lib.BENCH_SIGNATURES)
+    import ctypes
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in hook_names:
+        assert not hasattr(raw, name), '%s must only exist in libcprhip_bench.so' % name
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r'\b(cpr_\w+)$', out, flags=re.M))
+    assert exported == declared, exported ^ declared
 
 
 def test_product_package_never_imports_the_oracle():
@@ -176,3 +187,66 @@ def test_header_is_plain_c(tmp_path):
         if shutil.which(cc) is None:
             pytest.skip(cc + ' not installed')
         subprocess.check_call([cc, '-Wall', '-Werror', '-I', inc, '-c', str(src), '-o', str(tmp_path / (cc + '.o'))] + flags)
+
+
+_SYNC_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(sys.argv[1]); os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[2]
+dist.init_process_group('gloo', rank=rank, world_size=2)
+import pointtinybenchmark_amd as P
+from pointtinybenchmark_amd.training import CprTrainer
+from bench import model_cfg
+torch.manual_seed(100 + rank)                       # different per-rank initialisation, as unseeded processes would have
+cfg = model_cfg(18)
+model = P.build_detector(cfg)                       # CPU: construction only, no kernel runs
+for b in model.buffers():
+    if b.dtype.is_floating_point:
+        b.add_(0.01 * rank)                         # buffers (BN running statistics) differ too
+before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+tr = CprTrainer(model, two_streams=False)           # constructor broadcasts rank 0's state
+flat = torch.cat([t.detach().reshape(-1).float() for t in list(model.parameters()) + list(model.buffers())])
+ref = flat.clone(); dist.broadcast(ref, src=0)
+assert torch.equal(flat, ref), 'rank %%d differs from rank 0 after CprTrainer()' %% rank
+if rank == 1:
+    after = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert not torch.equal(before, after), 'the ranks were supposed to start from different weights'
+tr.check_bindings()
+sd = tr.state_dict()
+assert all(v.untyped_storage().nbytes() == v.numel() * v.element_size() for v in sd.values())   # clones, not flat views
+p0 = tr.params[0]; p0.data = p0.data.clone()        # re-binding must be caught
+try:
+    tr.check_bindings(); raise SystemExit('re-bound parameter not detected')
+except AssertionError:
+    pass
+dist.barrier(); dist.destroy_process_group(); print('rank', rank, 'ok')
+'''
+
+
+def test_two_rank_gloo_trainer_broadcasts_initial_state(tmp_path):
+    """CprTrainer replaces MMDistributedDataParallel: like DDP it must start every rank from rank 0's parameters and
+    buffers (only gradients are averaged afterwards).  Also: the re-binding guard and the cloning state_dict()."""
+    script = tmp_path / 'sworker.py'
+    script.write_text(_SYNC_WORKER % ROOT)
+    port = str(33500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+def test_step_lr_schedule_matches_the_published_policy():
+    """lr_config of the CPR configs (policy='step', warmup='linear', warmup_iters=500, warmup_ratio=0.001, step=[8, 11]) with
+    optimizer lr 0.01 (coarse_point_refine_base_TinyPersonV2_640.py:99-106): values of mmcv's StepLrUpdaterHook formulas."""
+    from pointtinybenchmark_amd.training import StepLrSchedule
+    s = StepLrSchedule.from_config(dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=0.0001),
+                                   dict(policy='step', warmup='linear', warmup_iters=500, warmup_ratio=0.001, step=[8, 11]),
+                                   iters_per_epoch=1000)
+    assert abs(s.lr(0) - 0.01 * 0.001) < 1e-12                       # first iteration: base * warmup_ratio
+    assert abs(s.lr(250) - 0.01 * (1 - 0.5 * 0.999)) < 1e-12         # half way through the warm-up
+    assert s.lr(500) == 0.01 and s.lr(7999) == 0.01                  # regular lr until epoch 8
+    assert abs(s.lr(8000) - 0.001) < 1e-15 and abs(s.lr(10999) - 0.001) < 1e-15
+    assert abs(s.lr(11000) - 0.0001) < 1e-15
+    short = StepLrSchedule(0.02, iters_per_epoch=10, step=(8, 11))   # warm-up longer than 8 epochs: both factors apply
+    assert abs(short.lr(85) - 0.002 * (1 - (1 - 85 / 500) * 0.999)) < 1e-15

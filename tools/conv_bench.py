@@ -1,8 +1,9 @@
 """Per-layer timing of every distinct conv launch of the CPR R50-FPN forward (HIP events, 20 launches each).
 Prints flops, minimum HBM bytes, time, TFLOP/s, GB/s and the fraction of min(MFMA roof, HBM roof)."""
+import os
+os.environ.setdefault('CPR_BENCH_HOOKS', '1')   # measurement build (libcprhip_bench.so: python -m pointtinybenchmark_amd.build --bench-hooks)
 import argparse
 import json
-import os
 import sys
 
 import torch

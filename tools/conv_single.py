@@ -1,7 +1,8 @@
 """Runs one conv shape repeatedly (for rocprofv3 --pmc passes).  Default: the CPR head's 3x3 256->256 conv on a
 (B,160,160,256) map with the fused GN-apply input and GN-stats epilogue, exactly as the forward launches it."""
-import argparse
 import os
+os.environ.setdefault('CPR_BENCH_HOOKS', '1')   # measurement build (libcprhip_bench.so: python -m pointtinybenchmark_amd.build --bench-hooks)
+import argparse
 import sys
 
 import torch

@@ -1,7 +1,8 @@
 """Runs one weight-gradient shape repeatedly (for rocprofv3 --pmc passes / quick A-B timing).  Default: the CPR head's
 3x3 256->256 layer on a (B,160,160,256) map, plain input."""
-import argparse
 import os
+os.environ.setdefault('CPR_BENCH_HOOKS', '1')   # measurement build (libcprhip_bench.so: python -m pointtinybenchmark_amd.build --bench-hooks)
+import argparse
 import sys
 
 import torch
