@@ -136,6 +136,37 @@ def image_tail(img_u8_bgr, flip, mean, std, to_rgb=True, size_divisor=32):
     return out
 
 
+def reference_group_sampler(flags, samples_per_gpu, num_replicas, rank, seed, epoch):
+    """The reference's DistributedGroupSampler class (samplers/group_sampler.py:51-148, pure torch / numpy) executed from
+    its source on a dataset stub that only has ``flag``; mmcv's get_dist_info is not needed when rank / num_replicas are given."""
+    import math
+    import torch
+    from torch.utils.data import Sampler
+    src = open(T + 'datasets/samplers/group_sampler.py').read()
+    cls = src[src.index('class DistributedGroupSampler'):]
+    ns = dict(math=math, np=np, torch=torch, Sampler=Sampler, get_dist_info=lambda: (0, 1))
+    exec(cls, ns)
+    ds = type('D', (), {})()
+    ds.flag = np.asarray(flags, dtype=np.uint8)
+    smp = ns['DistributedGroupSampler'](ds, samples_per_gpu, num_replicas, rank, seed)
+    smp.set_epoch(epoch)
+    return list(iter(smp)), len(smp)
+
+
+def reference_load_annotations(ann_info):
+    """LoadAnnotations._load_bboxes / ._load_labels (pipelines/loading.py:246-278) executed from the reference source:
+    which ann_info fields become which pipeline keys (gt_true_bboxes falls back to bboxes; gt_anns_id)."""
+    ns = {'np': np}
+    path = T + 'datasets/pipelines/loading.py'
+    exec('class L:\n' + textwrap.indent(_method(path, 'class LoadAnnotations', '_load_bboxes'), '    ') + '\n' +
+         textwrap.indent(_method(path, 'class LoadAnnotations', '_load_labels'), '    '), ns)
+    res = dict(ann_info=ann_info, bbox_fields=[])
+    ld = ns['L']()
+    ld._load_bboxes(res)
+    ld._load_labels(res)
+    return {k: v for k, v in res.items() if k != 'ann_info'}
+
+
 def _jsonable(o):
     if isinstance(o, dict):
         return {k: _jsonable(v) for k, v in o.items()}
@@ -166,8 +197,20 @@ def main():
     clipped = reference_resize_bboxes(ob, (480, 633, 3))
     out['resize_clip'] = dict(boxes=ob.tolist(), img_shape=[480, 633, 3], clipped=clipped.tolist(),
                               clipped_then_flipped=reference_bbox_flip(clipped, (480, 633)).tolist())
+    # DistributedGroupSampler index streams: two aspect-ratio groups, 2 ranks, two epochs
+    flags = [int(v) for v in (np.random.RandomState(5).rand(23) < 0.35)]
+    out['group_sampler'] = dict(flags=flags, cases=[])
+    for spg, world, seed, epoch in ((2, 2, 0, 0), (2, 2, 0, 3), (3, 2, 7, 1), (2, 1, 0, 0), (4, 3, 1, 2)):
+        for rank in range(world):
+            idx, n = reference_group_sampler(flags, spg, world, rank, seed, epoch)
+            out['group_sampler']['cases'].append(dict(samples_per_gpu=spg, num_replicas=world, rank=rank, seed=seed, epoch=epoch,
+                                                      indices=[int(i) for i in idx], length=n))
+    # LoadAnnotations key mapping, with and without true_bboxes
+    ds = synthetic_dataset(0)
+    _, parsed = reference_parse(ds, ['person', 'rider', 'other'], 2)
+    out['load_annotations'] = [_jsonable(reference_load_annotations(p)) for p in parsed[:2]]
     json.dump(out, open(GOLDEN, 'w'))
-    print('wrote', GOLDEN, {k: len(v.get('img_ids', [])) for k, v in out.items()})
+    print('wrote', GOLDEN, sorted(out))
 
 
 if __name__ == '__main__':

@@ -3,9 +3,11 @@ json -> per-image ``ann_info`` with the fork's extra fields (``true_bboxes``, ``
 ``gt_true_bboxes`` / ``gt_anns_id`` (pipelines/loading.py:246-278, formating.py:210).  Host-side, pure Python + numpy; the
 pycocotools index (third party, not vendored) is replaced by three dict look-ups.
 
-Not built (they live in the un-vendored ``huicv`` package and only rewrite annotation FILES before training):
-``corner_kwargs`` (640x640 tile generation with overlap) and ``noise_kwargs`` (pseudo-box synthesis) -- the shipped CPR
-configs point ``ann_file`` at the already generated files and pass neither."""
+``corner_kwargs`` (640x640 tile generation with overlap, cocofmt.py:22-43) is served by ``datasets/tiles.py`` (restated from the
+documented parameters; the generator itself lives in the un-vendored ``huicv`` package -- parity unpinned); tile entries carry
+``corner = [l, u, r, b]`` and ``load_sample`` crops the decoded image like LoadImageFromFile does (loading.py:63-68).
+Not built: ``noise_kwargs`` (pseudo-box synthesis around noisy points, also ``huicv``; it only rewrites annotation FILES before
+training and the shipped CPR configs point ``ann_file`` at the generated files)."""
 import json
 import os
 
@@ -23,10 +25,15 @@ class CocoFmtDataset:
     def __init__(self, ann_file, pipeline=None, classes=None, data_root=None, img_prefix='', test_mode=False,
                  filter_empty_gt=True, corner_kwargs=None, train_ignore_as_bg=True, noise_kwargs=None,
                  merge_after_infer_kwargs=None, min_gt_size=None, image_loader=None):
-        assert corner_kwargs is None and noise_kwargs is None, \
-            'corner / noise file generation lives in huicv (not vendored); point ann_file at the generated json'
+        assert noise_kwargs is None, 'pseudo-box synthesis lives in huicv (not vendored); point ann_file at the generated json'
         if data_root is not None and not os.path.isabs(ann_file):
             ann_file = os.path.join(data_root, ann_file)
+        if corner_kwargs is not None:          # cocofmt.py:77-81: train on the tile file, generating it when missing
+            from .tiles import corner_file_name, generate_corner_dataset
+            tile_file = corner_file_name(ann_file, corner_kwargs['max_tile_size'], corner_kwargs['tile_overlap'])
+            if not os.path.exists(tile_file):
+                generate_corner_dataset(ann_file, save_path=tile_file, **corner_kwargs)
+            ann_file = tile_file
         if data_root is not None and img_prefix and not os.path.isabs(img_prefix):
             img_prefix = os.path.join(data_root, img_prefix)
         self.ann_file, self.img_prefix, self.test_mode = ann_file, img_prefix, test_mode
@@ -144,11 +151,17 @@ class CocoFmtDataset:
         path = os.path.join(self.img_prefix, info['filename']) if self.img_prefix else info['filename']
         assert self.image_loader is not None, 'pass image_loader= (e.g. datasets.pipeline.pil_bgr_loader)'
         img = self.image_loader(path)
+        if 'corner' in info:                   # LoadImageFromFile, loading.py:63-68: a tile of the source image
+            l, u, r, b = info['corner']
+            img = np.ascontiguousarray(img[u:b, l:r])
+            assert img.shape[0] * img.shape[1] > 0
         s = dict(img=img, filename=path, ori_filename=info['filename'], ori_shape=tuple(img.shape),
                  gt_bboxes=ann['bboxes'].copy(), gt_labels=ann['labels'].copy(),
                  gt_bboxes_ignore=ann['bboxes_ignore'].copy(),
                  gt_true_bboxes=(ann['true_bboxes'] if 'true_bboxes' in ann else ann['bboxes']).copy())
         s['gt_anns_id'] = np.asarray(ann['anns_id'], dtype=np.int64).copy()      # loading.py:274-275
+        if 'corner' in info:
+            s['corner'] = info['corner']
         return s
 
     def load_batch(self, indices, rng=None):

@@ -144,3 +144,137 @@ def test_gpu_pipeline_output_feeds_forward_train():
         nchw = batch['img'][:, :3].contiguous()                     # the reference's input format
         b = m.forward_train(nchw, batch['img_metas'], batch['gt_bboxes'], batch['gt_labels'])
     assert {k: float(v) for k, v in a.items()} == {k: float(v) for k, v in b.items()}
+
+
+def test_group_sampler_matches_reference_class():
+    """DistributedGroupSampler: index streams of the reference class executed from its source (two aspect-ratio groups,
+    several (samples_per_gpu, world, seed, epoch) settings, every rank)."""
+    from pointtinybenchmark_amd.datasets import DistributedGroupSampler
+    g = GOLD['group_sampler']
+    ds = type('D', (), {})()
+    ds.flag = np.array(g['flags'], dtype=np.uint8)
+    for c in g['cases']:
+        s = DistributedGroupSampler(ds, c['samples_per_gpu'], c['num_replicas'], c['rank'], c['seed'])
+        s.set_epoch(c['epoch'])
+        assert len(s) == c['length']
+        assert [int(i) for i in s] == c['indices'], c
+    # the ranks of one setting partition ONE shared stream: same multiset of chunks, no chunk on two ranks
+    a = [c for c in g['cases'] if (c['samples_per_gpu'], c['num_replicas'], c['epoch']) == (2, 2, 0)]
+    assert len(a) == 2 and len(set(map(tuple, np.array(a[0]['indices']).reshape(-1, 2).tolist())) &
+                               set(map(tuple, np.array(a[1]['indices']).reshape(-1, 2).tolist()))) <= 1
+
+
+def test_load_sample_fields_match_reference_load_annotations(tmp_path):
+    """CocoFmtDataset.load_sample against LoadAnnotations._load_bboxes / _load_labels executed from the reference source
+    (which ann_info field feeds which pipeline key), plus the corner crop of LoadImageFromFile (loading.py:63-68)."""
+    from PIL import Image
+    from pointtinybenchmark_amd.datasets import CocoFmtDataset
+    from pointtinybenchmark_amd.datasets.pipeline import pil_bgr_loader
+    ds = DO.synthetic_dataset(0)
+    rng = np.random.RandomState(0)
+    for im in ds['images']:
+        Image.fromarray(rng.randint(0, 256, (im['height'], im['width'], 3)).astype(np.uint8)).save(
+            str(tmp_path / im['file_name'].replace('.jpg', '.png')))
+        im['file_name'] = im['file_name'].replace('.jpg', '.png')
+    d = CocoFmtDataset(ds, classes=['person', 'rider', 'other'], img_prefix=str(tmp_path), min_gt_size=2,
+                       image_loader=pil_bgr_loader)
+    for i, ref in enumerate(GOLD['load_annotations']):
+        s = d.load_sample(i)
+        for key in ('gt_bboxes', 'gt_bboxes_ignore', 'gt_true_bboxes', 'gt_labels', 'gt_anns_id'):
+            if isinstance(ref[key], list):      # anns_id stays a plain list without true_bbox; DefaultFormatBundle's to_tensor
+                want = np.array(ref[key], dtype=np.int64)       # (formating.py:210) turns it into the same int64 tensor
+            else:
+                want = np.array(ref[key]['data'], dtype=ref[key]['dtype']).reshape(ref[key]['shape'])
+            assert np.array_equal(np.asarray(s[key]), want) and np.asarray(s[key]).dtype == want.dtype, key
+        assert s['img'].dtype == np.uint8 and s['img'].shape == (640, 640, 3)
+    # a tile entry: the decoded image is cropped to its corner, annotations are already in tile coordinates
+    full = pil_bgr_loader(os.path.join(str(tmp_path), d.data_infos[0]['filename']))
+    d.data_infos[0] = dict(d.data_infos[0], corner=[100, 40, 420, 300])
+    s = d.load_sample(0)
+    assert np.array_equal(s['img'], full[40:300, 100:420]) and s['corner'] == [100, 40, 420, 300]
+
+
+def test_tile_generation_properties(tmp_path):
+    """640x640 tiles with 100 px overlap (TinyPersonV2.md:7-36; generator un-vendored -> restated, parity unpinned):
+    full coverage, full-size tiles, overlap >= 100 between neighbours, every annotation re-appears in tile coordinates in
+    every tile that holds its centre, and CocoFmtDataset(corner_kwargs=...) trains on the generated file."""
+    from pointtinybenchmark_amd.datasets import CocoFmtDataset, generate_corner_dataset, image_tiles
+    from pointtinybenchmark_amd.datasets.tiles import corner_file_name, tile_origins
+    for L in (300, 640, 641, 1180, 1181, 1920, 2000, 5000):
+        xs = tile_origins(L, 640, 100)
+        assert xs[0] == 0 and xs[-1] + min(640, L) == L and xs == sorted(set(xs))
+        assert all(b - a <= 540 for a, b in zip(xs, xs[1:])), (L, xs)          # neighbours overlap by >= 100
+    tiles = image_tiles(1920, 1080)
+    cover = np.zeros((1080, 1920), dtype=np.int32)
+    for l, u, r, b in tiles:
+        assert (r - l, b - u) == (640, 640)
+        cover[u:b, l:r] += 1
+    assert cover.min() >= 1
+    rng = np.random.RandomState(1)
+    anns = []
+    for i in range(200):
+        cx, cy = rng.uniform(0, 1920), rng.uniform(0, 1080)
+        anns.append(dict(id=i + 1, image_id=7, category_id=1, bbox=[cx - 8, cy - 8, 16.0, 16.0], area=256.0, iscrowd=0,
+                         true_bbox=[cx - 5, cy - 11, 10.0, 22.0]))
+    src = dict(images=[dict(id=7, width=1920, height=1080, file_name='a.jpg')], annotations=anns,
+               categories=[dict(id=1, name='person')])
+    path = tmp_path / 'rgb_train.json'
+    import json
+    json.dump(src, open(path, 'w'))
+    out = generate_corner_dataset(str(path))
+    assert len(out['images']) == 8 and len({a['id'] for a in out['annotations']}) == len(out['annotations'])
+    corner = {im['id']: im['corner'] for im in out['images']}
+    seen = {}
+    for a in out['annotations']:
+        l, u, r, b = corner[a['image_id']]
+        o = anns[a['ori_id'] - 1]
+        assert a['bbox'][0] + l == o['bbox'][0] and a['bbox'][1] + u == o['bbox'][1] and a['bbox'][2:] == o['bbox'][2:]
+        assert a['true_bbox'][0] + l == o['true_bbox'][0] and a['true_bbox'][1] + u == o['true_bbox'][1]
+        cx, cy = a['bbox'][0] + 8, a['bbox'][1] + 8
+        assert 0 <= cx < r - l and 0 <= cy < b - u                        # centre inside its tile
+        seen[a['ori_id']] = seen.get(a['ori_id'], 0) + 1
+    assert set(seen) == {a['id'] for a in anns}                           # nothing lost
+    want = {a['id']: sum(1 for (l, u, r, b) in tiles if l <= a['bbox'][0] + 8 < r and u <= a['bbox'][1] + 8 < b) for a in anns}
+    assert seen == want and max(seen.values()) > 1                        # points in an overlap strip live in several tiles
+    d = CocoFmtDataset(str(path), classes=['person'], corner_kwargs=dict(max_tile_size=(640, 640), tile_overlap=(100, 100)))
+    assert os.path.exists(corner_file_name(str(path), (640, 640), (100, 100))) and len(d) == 8
+    assert all('corner' in info for info in d.data_infos)
+
+
+@pytest.mark.gpu
+def test_batch_loader_feeds_forward_train(tmp_path):
+    """Source image + point annotations -> 640x640 tiles (100 px overlap) -> CocoFmtDataset -> DistributedGroupSampler ->
+    GpuImagePipeline -> BasicLocator.forward_train: the whole data side in front of the hot path, two 'ranks'."""
+    import json
+    from PIL import Image
+    from oracle.gen_golden import CPR_CASES
+    from pointtinybenchmark_amd.datasets import BatchLoader, CocoFmtDataset, GpuImagePipeline
+    from pointtinybenchmark_amd.datasets.pipeline import pil_bgr_loader
+    from tests.test_gpu_cpr_parity import build_hip_locator
+    rng = np.random.RandomState(2)
+    W, H = 1300, 700
+    Image.fromarray(rng.randint(0, 256, (H, W, 3)).astype(np.uint8)).save(str(tmp_path / 'a.png'))
+    anns = []
+    for i in range(60):
+        cx, cy = rng.uniform(8, W - 8), rng.uniform(8, H - 8)
+        anns.append(dict(id=i + 1, image_id=1, category_id=1 + i % 3, bbox=[cx - 8, cy - 8, 16.0, 16.0], area=256.0, iscrowd=0))
+    src = dict(images=[dict(id=1, width=W, height=H, file_name='a.png')], annotations=anns,
+               categories=[dict(id=1, name='person'), dict(id=2, name='rider'), dict(id=3, name='other')])
+    json.dump(src, open(tmp_path / 'ann.json', 'w'))
+    d = CocoFmtDataset(str(tmp_path / 'ann.json'), classes=['person', 'rider', 'other'], img_prefix=str(tmp_path),
+                       corner_kwargs=dict(max_tile_size=(640, 640), tile_overlap=(100, 100)), image_loader=pil_bgr_loader)
+    assert len(d) == 6                                         # 3 x 2 tiles
+    m, _ = build_hip_locator(CPR_CASES['cpr_r18_c3_128'])
+    pipe = GpuImagePipeline(flip_ratio=0.5)
+    seen = []
+    for rank in range(2):
+        loader = BatchLoader(d, pipe, samples_per_gpu=2, num_replicas=2, rank=rank, seed=0)
+        assert len(loader) == 2
+        for batch in loader:
+            assert tuple(batch['img'].shape) == (2, 4, 640, 640) and len(batch['gt_bboxes']) == 2
+            assert all(mt['img_shape'] == (640, 640, 3) for mt in batch['img_metas'])
+            with torch.no_grad():
+                losses = m.forward_train(batch['img'], batch['img_metas'], batch['gt_bboxes'], batch['gt_labels'])
+            assert all(bool(torch.isfinite(v)) for v in losses.values())
+            seen += [mt['ori_filename'] for mt in batch['img_metas']]
+    assert len(seen) == 8                                      # 6 tiles padded to 2 ranks x 2 batches x 2 images
