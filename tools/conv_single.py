@@ -18,6 +18,7 @@ ap.add_argument('--cout', type=int, default=256)
 ap.add_argument('--k', type=int, default=3)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--plain', action='store_true')
+ap.add_argument('--gn-stats', action='store_true', help='plain input, GroupNorm statistics in the epilogue (the forward\'s dominant launch)')
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--pipeline', type=int, default=1)
 args = ap.parse_args()
@@ -33,6 +34,8 @@ b = torch.randn((args.batch, args.cin), generator=g).cuda()
 for _ in range(args.iters):
     if args.plain:
         ops.conv2d(x, pc)
+    elif args.gn_stats:
+        ops.conv2d(x, pc, gn_part=True)
     else:
         ops.conv2d(x, pc, in_ab=(a, b), in_relu=True, gn_part=True)
 torch.cuda.synchronize()
@@ -41,6 +44,8 @@ s.record()
 for _ in range(args.iters):
     if args.plain:
         ops.conv2d(x, pc)
+    elif args.gn_stats:
+        ops.conv2d(x, pc, gn_part=True)
     else:
         ops.conv2d(x, pc, in_ab=(a, b), in_relu=True, gn_part=True)
 e.record()

@@ -23,7 +23,7 @@ for grp in ('sq', 'fetch', 'write'):
 simd_cycles = res['GRBM_GUI_ACTIVE'] / 8 * 1024
 out = {
     'kernel': kernel.replace('void ', '').replace('(ConvParams)', ''), 'batch': batch,
-    'shape': '3x3 256->256 on (B,160,160,256), fused GN input + GN stats epilogue (tools/conv_single.py)',
+    'shape': '3x3 256->256 on (B,160,160,256), GN stats epilogue (tools/conv_single.py %s)' % os.environ.get('CONV_ARGS', ''),
     'hbm_read_bytes_per_launch': res['FETCH_SIZE'] * 1024 * 2, 'hbm_write_bytes_per_launch': res['WRITE_SIZE'] * 1024,
     'hbm_bytes_per_launch': res['FETCH_SIZE'] * 1024 * 2 + res['WRITE_SIZE'] * 1024,
     'algorithmic_bytes_per_launch': batch * 160 * 160 * 256 * 4 * 2 + 256 * 2304 * 4,
