@@ -174,6 +174,13 @@ int cpr_lsa_topk(const float* costT, const int* m_of, const int* g_of, const lon
  * (ties: lower index first).  k <= 4096.  out_vals (k) float, out_idx (k) int64. */
 int cpr_topk_desc(const float* scores, int n, int k, float* out_vals, long long* out_idx, void* stream);
 
+/* Candidate list of multiclass_nms (T/mmdet/core/post_processing/bbox_nms.py:28-60): every (proposal, class) pair with
+ * scores[p][c] > score_thr (scores (n,C+1), last column = background), row-major order; boxes (n, box_stride) with
+ * box_stride = 4 (shared by the classes) or 4*C; factors (n) optional score_factors.  Outputs sized n*C:
+ * cand_boxes (.,4), cand_scores, cand_labels (int32), cand_inds (int64, p*C + c), count (1) int32. */
+int cpr_nms_candidates(const float* boxes, int box_stride, const float* scores, const float* factors, int n, int C,
+                       float score_thr, float* cand_boxes, float* cand_scores, int* cand_labels, long long* cand_inds,
+                       int* count, void* stream);
 /* mmcv.ops.nms.batched_nms as called by multiclass_nms (T/mmdet/core/post_processing/bbox_nms.py:85; mmcv-full
  * 1.3.x, third-party): class-offset trick, sort by score (descending, ties by index), greedy IoU > thr suppression.
  * boxes (n,4), scores (n), labels (n) int32, n <= 16384.  keep_idx (n) int64: indices of kept boxes in descending

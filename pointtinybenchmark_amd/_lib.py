@@ -39,6 +39,7 @@ SIGNATURES = {
     'cpr_hungarian_cost': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _p],
     'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i] + [_p] * 15,
     'cpr_topk_desc': [_p, _i, _i, _p, _p, _p],
+    'cpr_nms_candidates': [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p],
     'cpr_nms': [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
     'cpr_p2p_decode': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'cpr_rowmax_sigmoid': [_p, _p, ctypes.c_longlong, _i, _p],

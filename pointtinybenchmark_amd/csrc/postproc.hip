@@ -106,6 +106,64 @@ extern "C" int cpr_topk_desc(const float* scores, int n, int k, float* out_vals,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Candidate list of multiclass_nms (T/mmdet/core/post_processing/bbox_nms.py:28-60): every (proposal, class) pair whose
+// score exceeds score_thr, in row-major (proposal, class) order -- boxes shared by all classes (box_stride 4) or one box
+// per class (box_stride 4*C); the stored score is score * score_factor[proposal] (the filter uses the raw score, :44-49).
+// One workgroup, ordered compaction with wave ballots (the candidate count is a few thousand).
+__global__ void nms_candidates_kernel(const float* __restrict__ boxes, int box_stride, const float* __restrict__ scores,
+                                      const float* __restrict__ factors, int n, int C, float thr,
+                                      float* __restrict__ cboxes, float* __restrict__ cscores,
+                                      int* __restrict__ clabels, long long* __restrict__ cinds,
+                                      int* __restrict__ count) {
+    __shared__ int s_wcnt[16], s_base;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6;
+    const long long total = (long long)n * C;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (long long base = 0; base < total; base += nt) {
+        const long long j = base + tid;
+        const int row = j < total ? (int)(j / C) : 0, cls = j < total ? (int)(j - (long long)row * C) : 0;
+        const float sc = j < total ? scores[(size_t)row * (C + 1) + cls] : 0.f;
+        const bool a = j < total && sc > thr;
+        const unsigned long long bal = __ballot(a);
+        if (lane == 0) s_wcnt[w] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int q = 0; q < w; ++q) off += s_wcnt[q];
+        if (a) {
+            const int o = off + __popcll(bal & ((1ull << lane) - 1ull));
+            const float* bp = boxes + (size_t)row * box_stride + (box_stride > 4 ? cls * 4 : 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cboxes[(size_t)o * 4 + c] = bp[c];
+            cscores[o] = factors ? __fmul_rn(sc, factors[row]) : sc;
+            clabels[o] = cls;
+            cinds[o] = j;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int q = 0; q < (nt >> 6); ++q) tot += s_wcnt[q];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *count = s_base;
+}
+extern "C" int cpr_nms_candidates(const float* boxes, int box_stride, const float* scores, const float* factors, int n,
+                                  int C, float score_thr, float* cand_boxes, float* cand_scores, int* cand_labels,
+                                  long long* cand_inds, int* count, hipStream_t stream) {
+    CPR_CHECK_ARG(n >= 0 && C > 0 && (box_stride == 4 || box_stride == 4 * C) && count);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int), stream);
+        return e == hipSuccess ? CPR_OK : -(int)e;
+    }
+    CPR_CHECK_ARG(boxes && scores && cand_boxes && cand_scores && cand_labels && cand_inds);
+    hipLaunchKernelGGL(nms_candidates_kernel, dim3(1), dim3(1024), 0, stream, boxes, box_stride, scores, factors, n, C,
+                       score_thr, cand_boxes, cand_scores, cand_labels, cand_inds, count);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ void nms_prepare_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                    const int* __restrict__ labels, int n, int* __restrict__ order,
                                    float* __restrict__ sboxes, unsigned long long* __restrict__ ws) {

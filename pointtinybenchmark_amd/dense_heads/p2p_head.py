@@ -1,2 +1,265 @@
-"""P2PHead (T/mmdet/models/point/dense_heads/p2p_head.py:18-572)."""
-from .p2p_head_impl import P2PHead  # noqa: F401
+"""P2PHead -- P2PNet head with multi-class support (T/mmdet/models/point/dense_heads/p2p_head.py:18-572).
+
+  forward        two towers of 4 x [conv3x3 -> GN32 -> ReLU] + 3x3 cls_out / reg_out; GroupNorm statistics ride in the
+                 conv epilogues and every GN-apply+ReLU is folded into the consumer conv's load (nothing materialised)
+  loss           decode kernel -> fused FocalLossCost + DisCostV2 cost -> ONE batched device LSA launch for all images
+                 (topk_k rounds) -> fused sigmoid-focal + SmoothL1 loss straight from the assignment
+  get_bboxes     sigmoid row-max -> radix-select top-k -> 16x16 pseudo boxes -> bitmask NMS
+NHWC makes the reference's permute/reshape of the output maps (p2p_head.py:143-148) a free view."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..core.assigners import HungarianAssignerV2
+from ..core.point_generator import PointGenerator
+from ..core.post_processing import multiclass_nms
+from ..layers import ConvModule, _PackCache, conv_gn, packed_conv
+from ..registry import HEADS, build_assigner, build_sampler
+
+
+def _get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    return cfg.get(key, default) if isinstance(cfg, dict) else getattr(cfg, key, default)
+
+
+@HEADS.register_module()
+class P2PHead(nn.Module):
+    def __init__(self, num_classes, in_channels,
+                 point_anchor=[(-0.25, -0.25), (0.25, -0.25), (0.25, 0.25), (-0.25, 0.25)],
+                 assign_before_pred=False, pts_gamma=100. / 8, reg_norm=1. / 8,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_reg=dict(type='MSELoss', loss_weight=2e-4), init_cfg=None,
+                 feat_channels=256, stacked_convs=4, strides=(4, 8, 16, 32, 64), dcn_on_last_conv=False,
+                 conv_bias='auto', loss_bbox=None, conv_cfg=None, norm_cfg=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        assert loss_cls['type'] == 'FocalLoss' and loss_cls.get('use_sigmoid', False) and \
+            loss_reg['type'] == 'SmoothL1Loss', 'the fused loss kernel implements the shipped P2P config ' \
+            '(FocalLoss + SmoothL1Loss, T/configs2/TinyPersonV2/p2p/p2p_r50_fpns4_1x_fl_sl1_TinyPersonV2_640.py:40-47)'
+        assert norm_cfg is not None and norm_cfg['type'] == 'GN' and not dcn_on_last_conv
+        assert len(strides) == 1, 'single FPN level, as in the shipped config'
+        self.point_anchor = torch.FloatTensor(point_anchor)
+        self.num_points = len(point_anchor)
+        self.use_sigmoid_cls = True
+        self.num_classes = self.num_cls_out = self.cls_out_channels = num_classes
+        self.loss_cls_cfg, self.loss_reg_cfg = dict(loss_cls), dict(loss_reg)
+        self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
+        self.strides, self.conv_bias = list(strides), conv_bias
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.assign_before_pred, self.pts_gamma, self.reg_norm = assign_before_pred, pts_gamma, reg_norm
+        self.point_generators = [PointGenerator() for _ in self.strides]
+        if self.train_cfg:
+            self.assigner = build_assigner(_get(self.train_cfg, 'assigner'))
+            self.sampler = build_sampler(_get(self.train_cfg, 'sampler'))
+            assert isinstance(self.assigner, HungarianAssignerV2)
+        self.cls_convs, self.reg_convs = nn.ModuleList(), nn.ModuleList()
+        for i in range(stacked_convs):
+            chn = in_channels if i == 0 else feat_channels
+            self.cls_convs.append(ConvModule(chn, feat_channels, 3, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                                             bias=conv_bias))
+            self.reg_convs.append(ConvModule(chn, feat_channels, 3, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                                             bias=conv_bias))
+        self.cls_out = nn.Conv2d(feat_channels, self.num_cls_out * self.num_points, 3, padding=1)
+        self.reg_out = nn.Conv2d(feat_channels, self.num_points * 2, 3, padding=1)
+        self._cache = _PackCache()
+        self.init_weights()
+
+    def init_weights(self):  # p2p_head.py:46-57
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0, 0.01)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        nn.init.constant_(self.cls_out.bias, float(-math.log((1 - 0.01) / 0.01)))
+
+    # ------------------------------------------------------------------ forward (p2p_head.py:107-123)
+    def _tower(self, convs, out_conv, x, tape=None):
+        """tape (list): training mode -- one record per conv+GN layer and a final one for the output conv."""
+        ab = None
+        for m in convs:
+            rec = None
+            if tape is not None:
+                rec = dict(kind='tower')
+                tape.append(rec)
+            x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=True, materialize=False, save=rec)
+        pc = packed_conv(self._cache, out_conv)
+        H, W = x.shape[1:3]
+        if tape is not None:
+            tape.append(dict(kind='out', conv=out_conv, x=x, in_ab=ab))
+        if (H * W) % 128 == 0:
+            return ops.conv2d(x, pc, bias=out_conv.bias, in_ab=ab, in_relu=True)
+        return ops.conv2d(ops.gn_apply(x, ab[0], ab[1], relu=True), pc, bias=out_conv.bias)
+
+    def forward_single(self, feat):
+        x = ops.from_nchw(feat)
+        return (ops.as_nchw(self._tower(self.cls_convs, self.cls_out, x)),
+                ops.as_nchw(self._tower(self.reg_convs, self.reg_out, x)))
+
+    def forward(self, feats):
+        outs = [self.forward_single(f) for f in feats]
+        return [o[0] for o in outs], [o[1] for o in outs]
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kw):
+        outs = self(x)
+        return self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+
+    # ------------------------------------------------------------------ points (p2p_head.py:125-170, 425-465)
+    def get_pred_points(self, cls_outs, pts_outs, img_metas):
+        assert len(cls_outs) == 1
+        cls = ops.from_nchw(cls_outs[0])
+        reg = ops.from_nchw(pts_outs[0])
+        B, H, W, _ = cls.shape
+        stride = self.strides[0]
+        pa = self._cache.get('pa', [], lambda: self.point_anchor.to(cls.device).contiguous())
+        pred, anchor = ops.p2p_decode(reg, pa, stride, self.pts_gamma, want_anchor=True)
+        cls = cls.reshape(B, H * W * self.num_points, self.num_cls_out)
+        # valid_flags (p2p_head.py:451-463, PointGenerator.valid_flags): cells beyond ceil(pad_shape / stride) -- an image
+        # padded less than the batch maximum -- are invalid: not assigned, label weight 0
+        valid = None
+        for b, m in enumerate(img_metas):
+            ph, pw = m['pad_shape'][:2]
+            vh, vw = min(int(np.ceil(ph / stride)), H), min(int(np.ceil(pw / stride)), W)
+            if vh != H or vw != W:
+                if valid is None:
+                    valid = torch.ones((B, H, W, self.num_points), dtype=torch.bool)
+                valid[b, vh:] = False
+                valid[b, :, vw:] = False
+        if valid is None:
+            valid = torch.ones((B, H * W * self.num_points), dtype=torch.bool, device=cls.device)
+            valid.all_valid = True
+        else:
+            valid = valid.reshape(B, -1).to(cls.device)
+            valid.all_valid = False
+        return anchor, pred, valid, cls
+
+    @staticmethod
+    def pseudo_bbox_to_center(gt_bboxes):
+        return [ops.box_centers(b.float().contiguous()) for b in gt_bboxes]
+
+    # ------------------------------------------------------------------ loss (p2p_head.py:172-328)
+    def assign_batch(self, proposals, cls, gt_points, gt_labels, img_metas, valid=None):
+        """All images' Hungarian problems in one LSA launch.  Returns gt_inds (B, M) int64: j+1 = gt j, 0 = background,
+        -1 = invalid cell (``valid`` false: not offered to the assigner, label weight 0 -- p2p_head.py:288-305).
+        Degenerate images follow HungarianAssignerV2.assign (hungarian_assigner.py:207-219,251): no gts -> all background;
+        fewer proposals than gts with topk_k > 1 -> the loop never runs, all background."""
+        a = self.assigner
+        B, M = proposals.shape[:2]
+        all_valid = True if valid is None else getattr(valid, 'all_valid', None)
+        if all_valid is None:
+            all_valid = bool(valid.all())
+        masked = not all_valid
+        out = proposals.new_zeros((B, M), dtype=torch.long)
+        costs, where = [], []
+        for b in range(B):
+            idx = torch.nonzero(valid[b], as_tuple=False).squeeze(1) if masked else None
+            if masked:
+                out[b][~valid[b]] = -1
+            props, c = (proposals[b][idx], cls[b][idx]) if masked else (proposals[b], cls[b])
+            G, Mb = gt_points[b].shape[0], props.shape[0]
+            if G == 0 or Mb == 0:
+                continue
+            if Mb < G:
+                if a.topk_k == 1:
+                    raise NotImplementedError('fewer proposals than gts with topk_k == 1 (scipy solves the transposed '
+                                              'problem there; the device LSA needs M >= G)')
+                continue
+            costs.append(a.cost_t(props.contiguous(), c.contiguous(), gt_points[b], gt_labels[b], img_metas[b]))
+            where.append((b, idx))
+        if costs:
+            inds, _ = ops.lsa_topk(costs, a.topk_k)
+            for (b, idx), gi in zip(where, inds):
+                if idx is None:
+                    out[b] = gi
+                else:
+                    out[b][idx] = gi
+        return out
+
+    def loss(self, cls_outs, pts_outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None, save=None):
+        for gb in gt_bboxes:
+            assert len(gb) > 0, gt_bboxes
+        anchor, pred, valid, cls = self.get_pred_points(cls_outs, pts_outs, img_metas)
+        dev = cls.device
+        gt_points = self.pseudo_bbox_to_center([b.to(dev) for b in gt_bboxes])
+        gt_labels = [l.to(dev) for l in gt_labels]
+        proposals = anchor if self.assign_before_pred else pred
+        gt_inds = self.assign_batch(proposals, cls, gt_points, gt_labels, img_metas, valid)
+        counts = [len(l) for l in gt_labels]
+        start = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(dev)
+        lc, lr = self.loss_cls_cfg, self.loss_reg_cfg
+        out = ops.p2p_loss(cls.contiguous(), pred, gt_inds.contiguous(), torch.cat(gt_points).contiguous(),
+                           torch.cat(gt_labels).to(torch.int32).contiguous(), start, lc.get('alpha', 0.25),
+                           lc.get('gamma', 2.0), lr.get('beta', 1.0), _get(self.train_cfg, 'pos_weight', 1.0),
+                           _get(self.train_cfg, 'neg_weight', 1.0), self.reg_norm, lc.get('loss_weight', 1.0),
+                           lr.get('loss_weight', 1.0))
+        B = out.shape[0]
+        if save is not None:      # what the loss backward re-reads (training.P2PTrainer)
+            save.update(cls=cls.contiguous(), pred=pred, gt_inds=gt_inds.contiguous(), gt_pts=torch.cat(gt_points).contiguous(),
+                        gt_labels=torch.cat(gt_labels).to(torch.int32).contiguous(), gt_start=start)
+        return {'loss_cls': [out[b, 0] for b in range(B)], 'loss_pts': [out[b, 1] for b in range(B)]}
+
+    def get_targets(self, pred_pts, valid_flag_list, cls_outs_list, gt_points, gt_labels, img_metas,
+                    gt_points_ignore=None, unmap_outputs=True):
+        """Reference-format targets (p2p_head.py:250-328) derived from the device assignment."""
+        valid = valid_flag_list if torch.is_tensor(valid_flag_list) else torch.stack(list(valid_flag_list))
+        gt_inds = self.assign_batch(pred_pts, cls_outs_list, gt_points, gt_labels, img_metas, valid)
+        labels, lw, tgt, w = [], [], [], []
+        pos_w = _get(self.train_cfg, 'pos_weight', 1.0)
+        neg_w = _get(self.train_cfg, 'neg_weight', 1.0)
+        for b in range(gt_inds.shape[0]):
+            gi = gt_inds[b]
+            pos = gi > 0
+            lab = gi.new_full(gi.shape, self.num_classes)
+            lab[pos] = gt_labels[b][gi[pos] - 1]
+            t = pred_pts.new_zeros((gi.shape[0], 2))
+            t[pos] = gt_points[b][gi[pos] - 1]
+            ww = pred_pts.new_zeros((gi.shape[0], 2))
+            ww[pos] = 1.0
+            l_w = pred_pts.new_full(gi.shape, 1.0 if neg_w <= 0 else neg_w)
+            l_w[pos] = pos_w
+            inv = gi < 0                       # unmap(fill=0) of the reference: label 0, weight 0 on invalid cells
+            lab[inv] = 0
+            l_w[inv] = 0
+            labels.append(lab), lw.append(l_w), tgt.append(t), w.append(ww)
+        return labels, lw, tgt, w
+
+    # ------------------------------------------------------------------ inference (p2p_head.py:330-423)
+    def get_bboxes(self, cls_outs, pts_outs, img_metas, cfg=None, rescale=False, with_nms=True):
+        anchor, pred, valid, cls = self.get_pred_points(cls_outs, pts_outs, img_metas)
+        res = []
+        for b in range(len(img_metas)):
+            pts_scores, labels = self._get_bboxes_single(pred[b][..., :2], valid[b], cls[b], img_metas[b]['img_shape'],
+                                                         img_metas[b]['scale_factor'], cfg, rescale, with_nms)
+            res.append((self.center_to_pseudo_bbox([pts_scores])[0], labels))
+        return res
+
+    def _get_bboxes_single(self, pred_pts, valid_flag, cls_outs, img_shape, scale_factor, cfg, rescale=False,
+                           with_nms=True):
+        cfg = self.test_cfg if cfg is None else cfg
+        assert with_nms
+        nms_pre = _get(cfg, 'nms_pre', -1)
+        logits = cls_outs.contiguous()
+        if 0 < nms_pre < logits.shape[0]:
+            _, topk_inds = ops.topk_desc(ops.rowmax_sigmoid(logits), nms_pre)
+            logits, pred_pts = logits[topk_inds], pred_pts[topk_inds]
+        scores = ops.rowmax_sigmoid(logits)[:, None] if self.num_cls_out == 1 else ops.sigmoid_exact(logits)
+        x = pred_pts[:, 0].clamp(min=0, max=img_shape[1])
+        y = pred_pts[:, 1].clamp(min=0, max=img_shape[0])
+        pts = torch.stack([x, y], dim=-1)
+        if rescale:
+            pts = pts / pts.new_tensor(scale_factor[:2])
+        scores = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
+        wh = pts.new_tensor(_get(self.test_cfg, 'pseudo_wh', (16, 16)))
+        boxes = torch.cat([pts - wh / 2, pts + wh / 2], dim=-1)
+        dets, labels = multiclass_nms(boxes, scores, _get(cfg, 'score_thr'), _get(cfg, 'nms'), _get(cfg, 'max_per_img'))
+        ctr = torch.stack([(dets[:, 0] + dets[:, 2]) * 0.5, (dets[:, 1] + dets[:, 3]) * 0.5, dets[:, 4]], dim=-1)
+        return ctr, labels
+
+    def center_to_pseudo_bbox(self, center_scores):
+        wh = center_scores[0].new_tensor(_get(self.test_cfg, 'pseudo_wh', (16, 16)))
+        return [torch.cat([c[:, :2] - wh / 2, c[:, :2] + wh / 2, c[:, 2:]], dim=-1) for c in center_scores]
+
+    def simple_test(self, feats, img_metas, rescale=False, **kwargs):
+        return self.get_bboxes(*self(feats), img_metas, rescale=rescale)

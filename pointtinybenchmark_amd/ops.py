@@ -451,6 +451,24 @@ def topk_desc(scores, k):
     return vals, idx
 
 
+def nms_candidates(boxes, scores, score_thr, factors=None):
+    """(proposal, class) pairs above score_thr in row-major order.  boxes (n,4) or (n,4C), scores (n,C+1) (last column =
+    background).  -> cand_boxes (k,4), cand_scores (k), cand_labels (k) int32, cand_inds (k) int64.
+    One host read of k (the list is variable-length in the reference too)."""
+    n, C = scores.shape[0], scores.shape[1] - 1
+    dev = scores.device
+    cap = max(n * C, 1)
+    cb = torch.empty((cap, 4), device=dev, dtype=torch.float32)
+    cs = torch.empty((cap,), device=dev, dtype=torch.float32)
+    cl = torch.empty((cap,), device=dev, dtype=torch.int32)
+    ci = torch.empty((cap,), device=dev, dtype=torch.int64)
+    cnt = torch.zeros((1,), device=dev, dtype=torch.int32)
+    _lib.call('cpr_nms_candidates', _ptr(_check(boxes)), boxes.shape[1], _ptr(_check(scores)), _ptr(factors), n, C,
+              float(score_thr), _ptr(cb), _ptr(cs), _ptr(cl), _ptr(ci), _ptr(cnt), _stream())
+    k = int(cnt.item())
+    return cb[:k], cs[:k], cl[:k], ci[:k]
+
+
 def nms(boxes, scores, labels, iou_thr):
     """Class-aware greedy NMS (batched_nms semantics).  -> keep indices (int64, descending score).
     One host read of the keep count (the reference's NMS output is variable-length too)."""

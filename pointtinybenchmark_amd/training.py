@@ -462,7 +462,7 @@ class P2PTrainer(CprTrainer):
         return losses, save
 
     def _backward_head(self, head, s):
-        from .dense_heads.p2p_head_impl import _get
+        from .dense_heads.p2p_head import _get
         lc, lr = head.loss_cls_cfg, head.loss_reg_cfg
         B, M, C = s['cls'].shape
         H, W = s['hw']
