@@ -355,6 +355,37 @@ def measure_small_batch(model, b, size, num_gts, steps=30, graph_too=True):
     return res
 
 
+def dry_run(args, world, rank):
+    """The N-rank control flow of main() without any device work (CPU, gloo): process group, barrier on both sides of the
+    timed region, MAX over ranks of the elapsed time, exactly one JSON line from rank 0.  Used by tests/test_host_cpu.py to
+    cover the self-spawning ``python bench.py --gpus N`` entry point where no GPU exists."""
+    import torch.distributed as dist
+    if world > 1 or 'RANK' in os.environ:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    assert world == args.gpus, (world, args.gpus)
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (rank + 1))          # rank-dependent "step": the MAX over ranks must win
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run (no device work)', 'value': args.batch * world * args.steps / float(t),
+                          'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': float(t) / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'none', 'data': 'none', 'config': {'workload': 'dry run'}}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
 def spawn_ranks(n):
     import socket
     import subprocess
@@ -391,6 +422,8 @@ def main():
     ap.add_argument('--mode', default='fwd_loss', choices=['fwd_loss', 'train', 'infer'],
                     help="fwd_loss = BASELINE.json's metric; train = the full optimisation step (backward, bucketed RCCL "
                          "gradient all-reduce, clip + SGD) as the timed step")
+    ap.add_argument('--dry', action='store_true',
+                    help='plumbing check without a GPU: ranks rendezvous over gloo, barrier, max-over-ranks, one JSON line (tests)')
     ap.add_argument('--graph', action='store_true', help='replay backbone..projection as one hipGraph (forward + loss only)')
     ap.add_argument('--small-batch', type=int, default=2,
                     help="also report this per-GPU batch (the reference's samples_per_gpu) as 'small_batch' (0 = skip)")
@@ -407,6 +440,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if args.dry:
+        return dry_run(args, world, rank)
     torch.cuda.set_device(local)
     # launched by torch.distributed.run (RANK in the environment): take the distributed code path even with one rank, so the
     # N-GPU plumbing (process group, barriers, max-over-ranks, gradient collectives) can be exercised on a 1-GPU box

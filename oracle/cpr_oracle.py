@@ -5,12 +5,13 @@ algorithm, keyed on a state dict with the reference's parameter names.  It is th
 for the HIP path (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg) and is never
 imported by ``pointtinybenchmark_amd``.
 
-Parity pinning: every function below is compared against the reference's own classes
-(loaded read-only by ``oracle/ref_loader.py``) in ``tests/test_oracle_vs_reference.py``
-(runs only where /root/reference exists) and against the committed fixtures in
-``tests/golden/`` generated from the reference by ``oracle/gen_golden.py`` (runs everywhere).
-The reference's own known-answer vectors for this path (PointAssigner,
-T/tests/test_utils/test_assigner.py:155-194) are in ``tests/test_point_assigner_golden.py``.
+Parity pinning: every function below is compared against fixtures in ``tests/golden/`` that were generated from the
+reference's OWN classes (loaded read-only by ``oracle/ref_loader.py``) by ``oracle/gen_golden.py`` /
+``oracle/gen_golden_r2.py`` (build container only; the comparison, ``tests/test_oracle_golden.py``, runs everywhere):
+feature maps, bag points, validity, negative masks, assigner indices and the PointRefiner's chosen-point masks bit for bit,
+logits / losses to 2e-6, gradients through torch autograd to 1e-3.  The reference's own known-answer vectors for this path
+(PointAssigner, T/tests/test_utils/test_assigner.py:155-194) are asserted in ``tests/test_gpu_assigners.py``.
+One op is PARITY UNPINNED: ``batched_nms`` (mmcv-full, un-vendored) -- see its docstring.
 
 Citations: ``T/`` = /root/reference/TOV_mmdetection/.
 """

@@ -250,3 +250,19 @@ def test_step_lr_schedule_matches_the_published_policy():
     assert abs(s.lr(11000) - 0.0001) < 1e-15
     short = StepLrSchedule(0.02, iters_per_epoch=10, step=(8, 11))   # warm-up longer than 8 epochs: both factors apply
     assert abs(short.lr(85) - 0.002 * (1 - (1 - 85 / 500) * 0.999)) < 1e-15
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no RANK in the environment must start its two ranks itself (torch.distributed.run on
+    127.0.0.1) and print exactly ONE JSON line; --dry keeps the control flow (process group, barriers, max over ranks) and
+    skips the device work, so the entry point is covered where no GPU exists."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '0',
+                          '--dry', '--batch', '4'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3
+    assert d['ms_per_step'] >= 19.0, d          # rank 1 sleeps 20 ms per step: the MAX over ranks is reported

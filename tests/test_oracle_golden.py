@@ -163,3 +163,48 @@ def test_correctly_rounded_log_cost_vs_reference_cost_fixture(golden_dir):
         total_diff += int((ulp > 0).sum())
         assert np.array_equal(inds.numpy(), g['ha%d_gt_inds' % case])
     assert total_diff <= 8, total_diff
+
+
+def _option_names():
+    from oracle.gen_golden_r2 import OPTION_CASES
+    return list(OPTION_CASES)
+
+
+@pytest.mark.parametrize('name', _option_names())
+def test_option_oracle_matches_reference_fixture(golden_dir, name):
+    """oracle/cpr_options_oracle.py (num_refine > 1 bag policies, grid-circle bags, softmax / normed_sigmoid, binary_ins,
+    AllPosLoss) against what the reference's own classes computed (tests/golden/cpr_options.npz): bag points, validity,
+    negative masks and the refiner's chosen-point masks bit for bit, losses to 3e-6."""
+    from oracle import cpr_options_oracle as OO
+    from oracle.gen_golden_r2 import case_inputs, option_cfg
+    cfg = option_cfg(name)
+    g = _load(golden_dir, 'cpr_options')
+    p = name + ':'
+    sd, batch = case_inputs(cfg)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        feats = O.fpn_forward(sd, O.resnet_forward(sd, batch['img'], cfg['depth']), cfg['start_level'], 1)
+        cls_feat, _ = O.cpr_head_forward(sd, feats)
+        losses, per = OO.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg)
+    pts = torch.cat([q['pts'] for q in per]).numpy()
+    assert np.array_equal(pts, g[p + 'pos_pts'])
+    assert np.array_equal(torch.cat([q['valid'] for q in per]).numpy(), g[p + 'pos_valid'])
+    nv = torch.cat([q['neg_valid'] for q in per]).numpy()
+    gv = np.unpackbits(g[p + 'neg_valid'])[:nv.size].reshape(nv.shape).astype(bool)
+    assert np.array_equal(nv, gv) and int(nv.sum()) == int(g[p + 'neg_valid_count'])
+    np.testing.assert_allclose(torch.cat([q['cls_logit'] for q in per]).numpy(), g[p + 'pos_cls_logit'], atol=2e-5, rtol=1e-5)
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), float(g[p + 'loss_' + k]), rtol=3e-6, atol=1e-7)
+    assert set('loss_' + k for k in losses) == set(k[len(p):] for k in g.files if k.startswith(p + 'loss_'))
+    if (p + 'refine_asserts_in_reference') in g.files:
+        with pytest.raises(AssertionError):
+            OO.cpr_refine(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg)
+        return
+    with torch.no_grad():
+        ref = OO.cpr_refine(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg)
+    chosen = torch.cat([r['chosen'] for r in ref]).numpy()
+    want = np.unpackbits(g[p + 'chosen'])[:chosen.size].reshape(chosen.shape).astype(bool)
+    assert np.array_equal(chosen, want)
+    assert np.array_equal(torch.cat([r['not_refine'] for r in ref]).numpy(), g[p + 'not_refine'])
+    np.testing.assert_allclose(torch.cat([r['refine_pts'] for r in ref]).numpy(), g[p + 'refine_pts'], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(torch.cat([r['scores'] for r in ref]).numpy(), g[p + 'scores'], rtol=1e-6, atol=1e-7)

@@ -19,6 +19,7 @@ ap.add_argument('--k', type=int, default=3)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--plain', action='store_true')
 ap.add_argument('--gn-stats', action='store_true', help='plain input, GroupNorm statistics in the epilogue (the forward\'s dominant launch)')
+ap.add_argument('--bf16', action='store_true', help='bf16 compute mode kernel (plain input, GN stats epilogue)')
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--pipeline', type=int, default=1)
 args = ap.parse_args()
@@ -28,7 +29,10 @@ _lib.call('cpr_conv_set_pipeline', args.pipeline)
 g = torch.Generator().manual_seed(0)
 x = torch.randn((args.batch, args.hw, args.hw, args.cin), generator=g).cuda()
 w = (torch.randn((args.cout, args.cin, args.k, args.k), generator=g) * 0.02).cuda()
-pc = ops.PackedConv(w, 1, args.k // 2)
+pc = ops.PackedConv(w, 1, args.k // 2, torch.bfloat16 if args.bf16 else torch.float32)
+if args.bf16:
+    x = x.bfloat16()
+    args.gn_stats = True
 a = (torch.rand((args.batch, args.cin), generator=g) + 0.5).cuda()
 b = torch.randn((args.batch, args.cin), generator=g).cuda()
 for _ in range(args.iters):

@@ -7,13 +7,15 @@ import os
 import sys
 
 tag, batch = sys.argv[1], int(sys.argv[2])
+match = sys.argv[3] if len(sys.argv) > 3 else 'conv_mfma_kernel'      # kernel-name substring
+out_name = sys.argv[4] if len(sys.argv) > 4 else 'pmc_dominant_kernel.json'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 res, kernel = {}, None
 for grp in ('sq', 'fetch', 'write'):
     rows = list(csv.DictReader(open(os.path.join(root, 'gpurun_out', '%s_%s_counters.csv' % (tag, grp)))))
     agg, dur = collections.defaultdict(list), []
     for r in rows:
-        if 'conv_mfma_kernel' in r['Kernel_Name']:
+        if match in r['Kernel_Name']:
             kernel = r['Kernel_Name']
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
             dur.append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
@@ -22,7 +24,7 @@ for grp in ('sq', 'fetch', 'write'):
     res['duration_us_' + grp] = sum(dur) / len(dur) / 1e3
 simd_cycles = res['GRBM_GUI_ACTIVE'] / 8 * 1024
 out = {
-    'kernel': kernel.replace('void ', '').replace('(ConvParams)', ''), 'batch': batch,
+    'kernel': kernel.replace('void ', '').replace('(ConvParamsBf16)', '').replace('(ConvParams)', ''), 'batch': batch,
     'shape': '3x3 256->256 on (B,160,160,256), GN stats epilogue (tools/conv_single.py %s)' % os.environ.get('CONV_ARGS', ''),
     'hbm_read_bytes_per_launch': res['FETCH_SIZE'] * 1024 * 2, 'hbm_write_bytes_per_launch': res['WRITE_SIZE'] * 1024,
     'hbm_bytes_per_launch': res['FETCH_SIZE'] * 1024 * 2 + res['WRITE_SIZE'] * 1024,
@@ -37,5 +39,7 @@ out = {
 sys.path.insert(0, root)
 from bench import kernel_source_sha16  # noqa: E402
 out['source_sha16'] = kernel_source_sha16()      # bench.py only replays this figure for the same kernel source
-json.dump(out, open(os.path.join(root, 'profiles', 'pmc_dominant_kernel.json'), 'w'), indent=1)
+if 'bf16' in match:
+    out['algorithmic_bytes_per_launch'] = batch * 160 * 160 * 256 * 2 * 2 + 256 * 2304 * 2
+json.dump(out, open(os.path.join(root, 'profiles', out_name), 'w'), indent=1)
 print(json.dumps(out, indent=1))
