@@ -126,7 +126,7 @@ def test_cpr_path_vs_oracle_more_seeds(seed, hw, G, C):
                height=hw, width=hw + 32, num_gts=G, ragged=True)
     r = run_hip(cfg)
     sd, batch = r['sd'], r['batch']
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))     # 256 oversubscribed threads on the GPU box take 30 s here
     with torch.no_grad():
         losses, cls_feat, per = O.locator_forward_train(sd, batch, cfg['depth'], 0, 4, 5, C)
         ref = O.cpr_refine(sd, cls_feat, batch['gt_bboxes'], batch['gt_labels'], batch['gt_anns_id'],
