@@ -23,6 +23,7 @@
 // to a per-channel affine, the bottleneck shortcut add and the activation never touch HBM separately.
 // Optional fused GroupNorm statistics: per (image, group) sum / sum-of-squares partials of the raw conv
 // output (one slot per M-tile, reduced by gn_finalize -- deterministic, no float atomics).
+#include <type_traits>
 #include "common.h"
 
 struct ConvParams {
@@ -108,7 +109,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         woff[j] = wok[j] ? (c * p.Kpad + c4 * 4) * 4 : -1;
     }
 
-    f32x4 ra[AL], rb[BL], xa, xb;
+    // Global -> register staging.  The plain 64x64 instance keeps TWO register sets in flight: tile t+3 is requested as soon
+    // as tile t+1 has been written to LDS, so a load has one whole iteration plus two k-steps (~6 k-steps instead of ~2) to
+    // arrive.  Measured at B=64 (profiles/round2_two_register_sets.txt): +4 % on the long-K 3x3 layers that run this tile
+    // (40x40x256 0.860 -> 0.829 ms, 20x20x512 0.889 -> 0.851), nothing on the short-K 1x1 layers (bounded by per-tile fixed
+    // costs), and -3 % on the 128x128 instance (194 VGPRs, 16 MFMAs per k-step already cover its loads) -- hence 64x64 only.
+    constexpr int NSET = (!XF && BM == 64 && BN == 64) ? 2 : 1;
+    f32x4 ra[NSET][AL], rb[NSET][BL], xa, xb;
     unsigned okmask = 0;         // bit j: row j of the tile in flight is a real (not padded) pixel
     bool any_pad = true;         // wave-uniform: some lane of this wave has a padded row in the tile being stored
     int tapoff = 0;              // element offset of the current tap / channel chunk (wave-uniform)
@@ -146,13 +153,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         }
     };
     if (MODE == 0) refresh_rows();
-    auto load_a = [&](int kt, int j) {
+    auto load_a = [&](auto set_c, int kt, int j) {
+        constexpr int SET = decltype(set_c)::value;
         if (MODE == 0) {
             if (j == 0) {
                 okmask = okcur;
                 tapoff = c0 * 4;  // channel-chunk byte offset, wave-uniform (SALU)
             }
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voffA[j], tapoff, 0));
+            ra[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voffA[j], tapoff, 0));
         } else {
             if (j == 0) okmask = 0;
             const int tap = kt * 8 + c4;
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             const bool ok = (tap < p.KH * p.KW) & mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             okmask |= (ok ? 1u : 0u) << j;
             const int voff = ok ? ((nimg[j] * p.H + iy) * p.W + ix) * 16 : -1;
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0));
+            ra[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0));
         }
     };
     auto load_x_advance = [&]() {  // after the last A row of a tile: GN affine of this K-chunk, then next tap
@@ -179,11 +187,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         }
     };
     const int kt_last = p.Kpad / BK - 1;
-    auto load_b = [&](int kt, int j) {  // tile indices past the end are clamped (the pipeline prefetches 2 ahead)
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[j], min(kt, kt_last) * (BK * 4), 0));
+    auto load_b = [&](auto set_c, int kt, int j) {  // tile indices past the end are clamped (the pipeline prefetches ahead)
+        constexpr int SET = decltype(set_c)::value;
+        rb[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[j], min(kt, kt_last) * (BK * 4), 0));
     };
-    auto store_a = [&](int buf, int j) {
-        f32x4 v = ra[j];
+    auto store_a = [&](auto set_c, int buf, int j) {
+        constexpr int SET = decltype(set_c)::value;
+        f32x4 v = ra[SET][j];
         if (MODE == 0 && xform) {
             v = v * xa + xb;
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
@@ -197,22 +207,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         }
         *reinterpret_cast<f32x4*>(As + buf * BM * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) = v;
     };
-    auto store_b = [&](int buf, int j) {
-        *reinterpret_cast<f32x4*>(Bs + buf * BN * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) = rb[j];
+    auto store_b = [&](auto set_c, int buf, int j) {
+        constexpr int SET = decltype(set_c)::value;
+        *reinterpret_cast<f32x4*>(Bs + buf * BN * LDSW + (r0 + 32 * j) * LDSW + c4 * 4) = rb[SET][j];
     };
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](auto set_c, int kt) {
 #pragma unroll
-        for (int j = 0; j < AL; ++j) load_a(kt, j);
+        for (int j = 0; j < AL; ++j) load_a(set_c, kt, j);
         load_x_advance();
 #pragma unroll
-        for (int j = 0; j < BL; ++j) load_b(kt, j);
+        for (int j = 0; j < BL; ++j) load_b(set_c, kt, j);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto set_c, int buf) {
 #pragma unroll
-        for (int j = 0; j < AL; ++j) store_a(buf, j);
+        for (int j = 0; j < AL; ++j) store_a(set_c, buf, j);
 #pragma unroll
-        for (int j = 0; j < BL; ++j) store_b(buf, j);
+        for (int j = 0; j < BL; ++j) store_b(set_c, buf, j);
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, NSET - 1>;   // = Set0 when there is a single register set
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -250,19 +263,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 
     if (PIPE == 0) {
         // phase-separated schedule: [issue loads t+1] [MFMAs of t] [write t+1] barrier
-        load_tile(0);
-        store_tile(0);
+        load_tile(Set0{}, 0);
+        store_tile(Set0{}, 0);
         __syncthreads();
         for (int kt = 0; kt < KT; ++kt) {
             const int buf = kt & 1;
-            if (kt + 1 < KT) load_tile(kt + 1);
+            if (kt + 1 < KT) load_tile(Set0{}, kt + 1);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 f32x4 fa[MI], fb[NI];
                 read_frags(buf, kk, fa, fb);
                 mfma_group(fa, fb);
             }
-            if (kt + 1 < KT) store_tile(buf ^ 1);
+            if (kt + 1 < KT) store_tile(Set0{}, buf ^ 1);
             __syncthreads();
         }
     } else {
@@ -275,9 +288,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         //   barrier (all reads of this buffer are complete, all writes of the other are visible)
         //   kk3: MFMAs | prefetch frags kk0 of tile t+1
         f32x4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
-        load_tile(0);
-        store_tile(0);
-        load_tile(1);
+        // tile t lives in register set t & (NSET-1): with two sets, tiles 1 and 2 are both in flight when the loop starts
+        load_tile(Set0{}, 0);
+        store_tile(Set0{}, 0);
+        load_tile(Set1{}, 1);
+        if (NSET == 2) load_tile(Set0{}, 2);
         __syncthreads();
         read_frags(0, 0, fa0, fb0);
         constexpr int NM = 4 * MI * NI;  // MFMAs (= slots) per k-group
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             FB[(z) >= MI ? (z) - MI : 0] = *reinterpret_cast<const f32x4*>(                                   \
                 b_lds + (buf) * BN * LDSW + ((z) >= MI ? (z) - MI : 0) * 32 * LDSW + (kk) * 8);                \
     } while (0)
-        for (int kt = 0; kt < KT; ++kt) {
+        auto iteration = [&](auto nxt_c, int kt) {   // nxt_c: the register set of tile kt+1 (written to LDS here, then re-filled)
             const int buf = kt & 1;
             // ---- k-step 0: MFMAs on (fa0, fb0) | prefetch k-step 1 fragments
 #pragma unroll
@@ -320,11 +335,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                     if (z < NF) { if (!(ABL & 2)) FRAG_PIECE(fa0, fb0, buf, 2, z); }
                     else if (ABL & 1) {}
                     else if (ABL & 8) {  // keep the loaded registers alive, skip the LDS write
-                        if (z < NF + AL) asm volatile("" ::"v"(ra[z - NF < AL ? z - NF : 0]));
-                        else if (z < P1) asm volatile("" ::"v"(rb[z - NF - AL < BL ? z - NF - AL : 0]));
+                        if (z < NF + AL) asm volatile("" ::"v"(ra[decltype(nxt_c)::value][z - NF < AL ? z - NF : 0]));
+                        else if (z < P1) asm volatile("" ::"v"(rb[decltype(nxt_c)::value][z - NF - AL < BL ? z - NF - AL : 0]));
                     }
-                    else if (z < NF + AL) store_a(buf ^ 1, z - NF);
-                    else if (z < P1) store_b(buf ^ 1, z - NF - AL);
+                    else if (z < NF + AL) store_a(nxt_c, buf ^ 1, z - NF);
+                    else if (z < P1) store_b(nxt_c, buf ^ 1, z - NF - AL);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -336,9 +351,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 for (int z = q * PP2; z < (q + 1) * PP2; ++z) {
                     if (z < NF) { if (!(ABL & 2)) FRAG_PIECE(fa1, fb1, buf, 3, z); }
                     else if (ABL & (1 | 16)) {}
-                    else if (z < NF + AL) load_a(kt + 2, z - NF);
+                    else if (z < NF + AL) load_a(nxt_c, kt + 1 + NSET, z - NF);     // the set just written to LDS is free again
                     else if (z == NF + AL) load_x_advance();
-                    else if (z < P2) load_b(kt + 2, z - NF - AL - 1);
+                    else if (z < P2) load_b(nxt_c, kt + 1 + NSET, z - NF - AL - 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -356,6 +371,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                     if (z < NF && !(ABL & 2)) FRAG_PIECE(fa0, fb0, buf ^ 1, 0, z);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if constexpr (NSET == 2) {
+            for (int kt = 0; kt < KT; kt += 2) {   // unrolled by the number of register sets: set indices stay compile-time
+                iteration(Set1{}, kt);
+                if (kt + 1 < KT) iteration(Set0{}, kt + 1);
+            }
+        } else {   // one register set: the plain loop (unrolling it by two cost the 128x128 instance 2 %)
+            for (int kt = 0; kt < KT; ++kt) iteration(Set0{}, kt);
         }
 #undef MFMA_SLOT
 #undef FRAG_PIECE
