@@ -78,19 +78,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     int iy0[AL], ix0[AL], nimg[AL], rowoff[AL];
     bool mok[AL];
     const int ohw = p.OH * p.OW;
+    // 1x1 / stride 1 / unpadded launches are plain GEMMs: a row of A is pixel m itself, no (n, oy, ox) decomposition (two
+    // integer divisions per row -- a tenth of the instructions of a short-K tile, which is issue-bound, not MFMA-bound)
+    const bool gemm = (p.KH == 1) & (p.KW == 1) & (p.stride == 1) & (p.pad == 0) & (MODE == 0);
 #pragma unroll
     for (int j = 0; j < AL; ++j) {
         int m = m0 + r0 + 32 * j;
         mok[j] = m < p.M;
         int mm = mok[j] ? m : 0;
-        int n = mm / ohw;
-        int rem = mm - n * ohw;
-        int oy = rem / p.OW, ox = rem - oy * p.OW;
-        nimg[j] = n;
-        iy0[j] = oy * p.stride - p.pad;
-        ix0[j] = ox * p.stride - p.pad;
-        // 32-bit element offset of (n, iy0, ix0, c4*4); may be "negative" for padded rows/cols -- only used when in range
-        rowoff[j] = ((n * p.H + iy0[j]) * p.W + ix0[j]) * p.Cin + c4 * 4;
+        if (gemm) {       // wave-uniform branch
+            nimg[j] = 0; iy0[j] = 0; ix0[j] = 0;
+            rowoff[j] = mm * p.Cin + c4 * 4;
+        } else {
+            int n = mm / ohw;
+            int rem = mm - n * ohw;
+            int oy = rem / p.OW, ox = rem - oy * p.OW;
+            nimg[j] = n;
+            iy0[j] = oy * p.stride - p.pad;
+            ix0[j] = ox * p.stride - p.pad;
+            // 32-bit element offset of (n, iy0, ix0, c4*4); may be "negative" for padded rows/cols -- only used when in range
+            rowoff[j] = ((n * p.H + iy0[j]) * p.W + ix0[j]) * p.Cin + c4 * 4;
+        }
     }
     // Buffer descriptors: out-of-range offsets return 0, which IS the conv zero padding (no clamps, no selects)
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         } else {
             if (j == 0) okmask = 0;
             const int tap = kt * 8 + c4;
-            const int th = tap / p.KW, tw = tap - th * p.KW;
+            const int th = (p.KW == 7) ? tap / 7 : tap / p.KW;   // the stem is 7x7: a constant divisor is a multiply + shift
+            const int tw = tap - th * p.KW;
             const int iy = iy0[j] + th, ix = ix0[j] + tw;
             const bool ok = (tap < p.KH * p.KW) & mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             okmask |= (ok ? 1u : 0u) << j;
@@ -387,6 +396,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     // ---- epilogue.  D layout: col j = lane&31 (cout), row i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).
     // Branch-free: residual values are fetched in one batch from clamped addresses, stores are predicated.
     const int half = lane >> 5;
+    const unsigned row_bytes = (unsigned)p.Cout * 4u;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual : p.out), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int c = n0 + wn * WN + j * 32 + (lane & 31);
@@ -398,13 +412,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int rbase = m0 + wm * WM + i * 32 + 4 * half;
+            // 32-bit byte offsets through buffer descriptors whose range is the tensor: rows >= M and (offset 2^31)
+            // channels >= Cout fall outside num_records -- loads return 0, stores are dropped, no predicates, and one
+            // v_add per element instead of a 64-bit multiply-add
+            const unsigned off0 = cok ? (unsigned)(rbase * p.Cout + c) * 4u : 0x80000000u;
             float res[16];
             if (p.residual) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-                    res[r] = p.residual[(size_t)m * p.Cout + cc];
-                }
+                for (int r = 0; r < 16; ++r)
+                    res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rs_res, (int)(off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes), 0, 0));
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) res[r] = 0.f;
@@ -416,18 +433,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 if (p.res_mask) v = res[r] > 0.f ? v : 0.f;
                 else v += res[r];
                 if (p.relu) v = fmaxf(v, 0.f);
-                const bool ok = cok && m < p.M;
-                if (ok) {
-                    if (p.out_bf16) {  // bf16 compute mode: the fp32 stem hands a bf16 map to the bf16 layers
+                if (p.out_bf16) {  // bf16 compute mode: the fp32 stem hands a bf16 map to the bf16 layers
+                    if (cok && m < p.M) {
                         const __bf16 hv = (__bf16)v;
                         reinterpret_cast<unsigned short*>(p.out)[(size_t)m * p.Cout + c] = __builtin_bit_cast(unsigned short, hv);
-                    } else {
-                        p.out[(size_t)m * p.Cout + c] = v;
                     }
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out,
+                                                          (int)(off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes), 0, 0);
                 }
-                v = ok ? v : 0.f;
-                gsum += v;
-                gsq += v * v;
+                if (p.gn_part) {     // statistics only count real pixels / channels
+                    const float u = (cok && m < p.M) ? v : 0.f;
+                    gsum += u;
+                    gsq += u * u;
+                }
             }
         }
         if (p.gn_part) {
@@ -506,7 +525,8 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     CPR_CHECK_ARG(p.OH > 0 && p.OW > 0);
     long long M = (long long)N * p.OH * p.OW;
     // 32-bit byte offsets inside the buffer descriptors: < 2 GiB per tensor (B=64 at 160x160x256 is 1.7 GB)
-    if ((long long)N * H * W * Cin * 4 >= (1ll << 31) || (long long)Cout * Kpad * 4 >= (1ll << 31) || M >= (1ll << 31))
+    if ((long long)N * H * W * Cin * 4 >= (1ll << 31) || (long long)Cout * Kpad * 4 >= (1ll << 31) || M >= (1ll << 31) ||
+        M * Cout * 4 >= (1ll << 31))
         return CPR_ERR_UNSUPPORTED;
     p.M = (int)M;
     const bool mode1 = (Cin == 4);
