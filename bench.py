@@ -479,8 +479,11 @@ def main():
     model.use_graph = bool(args.graph)
     batch = synthetic.synthetic_batch(args.batch, args.size, args.size, args.num_gts, 1, seed=rank)   # per-rank shard
     img = batch['img'].cuda()
-    gtb = [b.cuda() for b in batch['gt_bboxes']]
-    gtl = [l.cuda() for l in batch['gt_labels']]
+    # per-image gt lists as the device pipeline hands them over (datasets.GpuImagePipeline: ONE device tensor, torch.split
+    # into per-image views) -- the head re-joins such views without a copy
+    counts = [len(l) for l in batch['gt_labels']]
+    gtb = list(torch.split(torch.cat(batch['gt_bboxes']).cuda(), counts))
+    gtl = list(torch.split(torch.cat(batch['gt_labels']).cuda(), counts))
     metas = batch['img_metas']
 
     trainer = None

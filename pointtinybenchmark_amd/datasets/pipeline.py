@@ -74,7 +74,10 @@ class GpuImagePipeline:
                 batch[key] = self._boxes([s[key] for s in samples], flips_d, img_hw)
         for key in ('gt_labels', 'gt_anns_id'):
             if key in self.keys and all(key in s for s in samples):
-                batch[key] = [torch.from_numpy(np.asarray(s[key], dtype=np.int64)).to(dev) for s in samples]
+                counts = [len(s[key]) for s in samples]          # one host->device copy, per-image views (cat_rows re-joins them)
+                flat = np.concatenate([np.asarray(s[key], dtype=np.int64).reshape(-1) for s in samples]) if sum(counts) else \
+                    np.zeros((0,), np.int64)
+                batch[key] = list(torch.split(torch.from_numpy(flat).to(dev), counts))
         return batch
 
     def _launch(self, img_u8, flips, out, n, H, W, Hp, Wp):

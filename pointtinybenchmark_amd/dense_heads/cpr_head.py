@@ -97,6 +97,23 @@ class _Extractor:
         return self._off[key]
 
 
+def cat_rows(tensors):
+    """torch.cat(tensors) along dim 0 -- without any copy when the list is what ``torch.split`` of ONE contiguous tensor
+    produced (GpuImagePipeline hands the per-image gt lists over like that): consecutive views of one storage are re-joined
+    as a view.  Otherwise a plain cat (one small copy per image)."""
+    t0 = tensors[0]
+    if len(tensors) > 1 and t0.is_contiguous():
+        end = t0.data_ptr() + t0.numel() * t0.element_size()
+        for t in tensors[1:]:
+            if not (t.is_contiguous() and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:] and t.data_ptr() == end and
+                    t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr()):
+                return torch.cat(list(tensors))
+            end += t.numel() * t.element_size()
+        rows = sum(t.shape[0] for t in tensors)
+        return torch.as_strided(t0, (rows,) + tuple(t0.shape[1:]), t0.stride())
+    return torch.cat(list(tensors)) if len(tensors) > 1 else t0
+
+
 class _Gts:
     """The annotated / refine points of a batch in the kernels' CSR form.  With num_refine = R > 1 an image brings
     (num_gts*R, 4) pseudo boxes (cpr_head.py:1240-1246): ``points`` holds all of them (gt-major), ``pt_*`` describe points,
@@ -312,8 +329,8 @@ class CPRHead(nn.Module):
             assert b.shape[0] == c * R and R >= 1, 'every image must bring num_gts * num_refine pseudo boxes'
         g = _Gts()
         g.R, g.counts, g.G = R, counts, sum(counts)
-        boxes = torch.cat([b.float() for b in gt_bboxes]).contiguous()
-        labels = torch.cat(list(gt_labels)).to(torch.int32).contiguous()
+        boxes = cat_rows([b if b.dtype == torch.float32 else b.float() for b in gt_bboxes]).contiguous()
+        labels = cat_rows(list(gt_labels)).to(torch.int32).contiguous()
         start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         gt_img = np.repeat(np.arange(len(counts), dtype=np.int32), counts)
         hw = np.array([[m[shape_key][0], m[shape_key][1]] for m in img_metas], dtype=np.int32).reshape(-1)

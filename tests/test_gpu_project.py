@@ -58,3 +58,16 @@ def test_hipgraph_forward_train_equals_eager():
             for k in eager:
                 assert float(eager[k]) == float(graphed[k]), (seed, k, float(eager[k]), float(graphed[k]))
     assert len(m._graphs) == 1
+
+
+def test_cat_rows_rejoins_split_views_without_a_copy():
+    from pointtinybenchmark_amd.dense_heads.cpr_head import cat_rows
+    t = torch.arange(40, dtype=torch.float32).reshape(10, 4).cuda()
+    parts = list(torch.split(t, [3, 1, 4, 2]))
+    j = cat_rows(parts)
+    assert j.data_ptr() == t.data_ptr() and torch.equal(j, t)             # a view of the original storage
+    mixed = [parts[0], parts[2]]                                           # not adjacent -> a real cat
+    assert torch.equal(cat_rows(mixed), torch.cat(mixed)) and cat_rows(mixed).data_ptr() != t.data_ptr()
+    lab = list(torch.split(torch.arange(9).cuda(), [2, 0, 7]))            # an empty image in the middle
+    assert torch.equal(cat_rows(lab), torch.arange(9).cuda())
+    assert torch.equal(cat_rows([t[:2].clone(), t[2:5].clone()]), t[:5])
