@@ -50,17 +50,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
     int iy0[AL], ix0[AL], rowoff[AL];
     bool mok[AL];
     const int ohw = p.OH * p.OW;
+    const bool gemm = (p.KH == 1) & (p.KW == 1) & (p.stride == 1) & (p.pad == 0);
 #pragma unroll
     for (int j = 0; j < AL; ++j) {
         int m = m0 + r0 + 32 * j;
         mok[j] = m < p.M;
         int mm = mok[j] ? m : 0;
-        int n = mm / ohw;
-        int rem = mm - n * ohw;
-        int oy = rem / p.OW, ox = rem - oy * p.OW;
-        iy0[j] = oy * p.stride - p.pad;
-        ix0[j] = ox * p.stride - p.pad;
-        rowoff[j] = ((n * p.H + iy0[j]) * p.W + ix0[j]) * p.Cin + c8 * 8;  // element offset
+        if (gemm) {   // 1x1 / stride 1 / unpadded: row m is pixel m (no integer divisions; see conv_mfma.hip)
+            iy0[j] = 0; ix0[j] = 0;
+            rowoff[j] = mm * p.Cin + c8 * 8;
+        } else {
+            int n = mm / ohw;
+            int rem = mm - n * ohw;
+            int oy = rem / p.OW, ox = rem - oy * p.OW;
+            iy0[j] = oy * p.stride - p.pad;
+            ix0[j] = ox * p.stride - p.pad;
+            rowoff[j] = ((n * p.H + iy0[j]) * p.W + ix0[j]) * p.Cin + c8 * 8;  // element offset
+        }
     }
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000);
@@ -213,7 +219,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
     // ---- epilogue: col j = lane&31 (cout), row i = (r&3) + 8*(r>>2) + 4*half (pixel)
     float* smf = reinterpret_cast<float*>(smem);
     unsigned short* out16 = reinterpret_cast<unsigned short*>(p.out);
-    float* out32 = reinterpret_cast<float*>(p.out);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)((size_t)p.M * p.Cout * (p.out_fp32 ? 4 : 2)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.residual ? p.residual : (const unsigned short*)p.out), 0,
+        (int)((size_t)p.M * p.Cout * 2), 0x00020000);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int c = n0 + wn * WN + j * 32 + (lane & 31);
@@ -225,13 +235,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int rbase = m0 + wm * WM + i * 32 + 4 * half;
+            // 32-bit byte offsets through buffer descriptors whose range is the tensor (rows >= M, and offset 2^31 for
+            // channels >= Cout, fall outside num_records: loads return 0, stores are dropped; see conv_mfma.hip)
+            const unsigned e0 = (unsigned)(rbase * p.Cout + c);            // element offset of (rbase, c)
             float res[16];
             if (p.residual) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-                    res[r] = bf16_to_f32(p.residual[(size_t)m * p.Cout + cc]);
-                }
+                for (int r = 0; r < 16; ++r)
+                    res[r] = bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(
+                        rs_res, (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0));
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) res[r] = 0.f;
@@ -242,30 +254,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
                 const int m = rbase + (r & 3) + 8 * (r >> 2);
                 float x = acc[i][j][r] * sc + bi + res[r];
                 if (p.relu) x = fmaxf(x, 0.f);
-                const bool ok = cok && m < p.M;
-                x = ok ? x : 0.f;
                 v[r] = x;
-                gsum += x;
-                gsq += x * x;
+                if (p.gn_part) {
+                    const float u = (cok && m < p.M) ? x : 0.f;
+                    gsum += u;
+                    gsq += u * u;
+                }
             }
             if (p.out_fp32) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = rbase + (r & 3) + 8 * (r >> 2);
-                    if (cok && m < p.M) out32[(size_t)m * p.Cout + c] = v[r];
-                }
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, v[r]), rs_out,
+                        (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 4u : 0x80000000u), 0, 0);
             } else if ((p.Cout & 1) == 0) {
                 // pack cout pairs: even lanes write the even rows of the register set, odd lanes the odd ones, each as one
                 // dword = (cout even, cout odd) -> 8 dword stores per lane instead of 16 two-byte stores
+                const unsigned ep = (unsigned)(rbase * p.Cout + (c & ~1));
+                const bool pok = (c & ~1) < p.Cout;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float nb = __shfl_xor(v[r], 1, 64);
-                    const bool mine = ((r & 1) == (lane & 1));
-                    const int m = rbase + (r & 3) + 8 * (r >> 2);
-                    if (mine && m < p.M && (c & ~1) < p.Cout) {
-                        const bf16x2 pk = (lane & 1) ? bf16x2{(__bf16)nb, (__bf16)v[r]} : bf16x2{(__bf16)v[r], (__bf16)nb};
-                        *reinterpret_cast<unsigned*>(out16 + (size_t)m * p.Cout + (c & ~1)) = __builtin_bit_cast(unsigned, pk);
-                    }
+                    const bool mine = ((r & 1) == (lane & 1)) && pok;
+                    const bf16x2 pk = (lane & 1) ? bf16x2{(__bf16)nb, (__bf16)v[r]} : bf16x2{(__bf16)v[r], (__bf16)nb};
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, pk), rs_out,
+                        (int)(mine ? (ep + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0);
                 }
             } else {
 #pragma unroll
@@ -315,7 +329,8 @@ extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, c
     p.OW = (W + 2 * pad - KW) / stride + 1;
     CPR_CHECK_ARG(p.OH > 0 && p.OW > 0);
     const long long M = (long long)N * p.OH * p.OW;
-    if ((long long)N * H * W * Cin * 2 >= (1ll << 31) || (long long)Cout * Kpad * 2 >= (1ll << 31) || M >= (1ll << 31))
+    if ((long long)N * H * W * Cin * 2 >= (1ll << 31) || (long long)Cout * Kpad * 2 >= (1ll << 31) || M >= (1ll << 31) ||
+        M * Cout * (out_fp32 ? 4 : 2) >= (1ll << 31))
         return CPR_ERR_UNSUPPORTED;
     p.M = (int)M;
     if (gn_part) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
