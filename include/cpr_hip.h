@@ -45,6 +45,20 @@ int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* s
                    int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int flags, int in_relu,
                    int* variant_out, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies than
+ * cpr_conv2d_fwd; same call sites: the CPR head towers cpr_head.py:1033-1043, the FPN output conv fpn.py:190-194, the 3x3 of
+ * every stride-1 bottleneck resnet.py:630-645).  The transforms only add/subtract, the result differs from the direct fp32
+ * sum by ~1e-6 of the map's max per layer (tests/test_gpu_wino.py states the bound).
+ *   cpr_wino_pack_weights: wgt = the cpr_conv2d_fwd layout [Cout][3][3][Cin] (row stride Kpad) -> u, 16*Cin*Cout floats
+ *                          (G g G^T per (cout, cin), stored as the kernel's LDS chunk images); Cin % 8 == 0, Cout % 64 == 0.
+ *   cpr_conv3x3_wino_fwd:  in (N,H,W,Cin) -> out (N,H,W,Cout) = conv * scale[c] + bias[c] (ReLU when flags & CPR_CONV_RELU);
+ *                          gn_part [N * ceil(H/16) * ceil(W/16)][Cout][2] (may be NULL): per-channel (sum, sumsq) of every 16x16
+ *                          output region (an image's regions are contiguous: cpr_gn_finalize with P = regions per image).
+ *                          Tensors < 2 GiB (CPR_ERR_UNSUPPORTED). */
+int cpr_wino_pack_weights(const float* wgt, float* u, int Cin, int Cout, int Kpad, void* stream);
+int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out, const float* scale, const float* bias,
+                         float* gn_part, int N, int H, int W, int Cin, int Cout, int flags, void* stream);
+
 /* bf16 compute mode (BASELINE.json configs[4]): bf16 activations / weights / residual, fp32 accumulate
  * (v_mfma_f32_32x32x16_bf16), K chunks of 64 (Cin % 64 == 0, Kpad == KH*KW*Cin), output bf16 or fp32 (out_fp32).
  * No fused producer-GroupNorm input; GroupNorm statistics come from the fp32 accumulators.
@@ -302,6 +316,7 @@ int cpr_conv_force_tile(int bm, int bn); /* force the conv output tile (0 = heur
 int cpr_conv_set_pipeline(int mode);     /* K-loop schedule: 1 = interleaved (product), 0 = phase-separated */
 int cpr_conv_set_ablation(int mode);     /* loop ablations: results are WRONG when non-zero */
 int cpr_wgrad_set_ablation(int mode);    /* same for the weight-gradient kernel */
+int cpr_wino_set_variant(int sched, int ablate); /* Winograd K-loop schedule (0 = product, 1 = late write) and ablations */
 #endif
 
 #ifdef __cplusplus

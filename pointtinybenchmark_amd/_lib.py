@@ -18,6 +18,8 @@ _l = ctypes.c_longlong
 SIGNATURES = {
     'cpr_version': [],
     'cpr_conv2d_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
+    'cpr_wino_pack_weights': [_p, _p, _i, _i, _i, _p],
+    'cpr_conv3x3_wino_fwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'cpr_conv2d_fwd_bf16': [_p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p, _p],
     'cpr_maxpool3x3s2_bf16': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_gn_stats_bf16': [_p, _p, _i, _i, _i, _i, _p],
@@ -73,6 +75,7 @@ BENCH_SIGNATURES = {
     'cpr_conv_set_pipeline': [_i],
     'cpr_conv_set_ablation': [_i],
     'cpr_wgrad_set_ablation': [_i],
+    'cpr_wino_set_variant': [_i, _i],
 }
 BENCH_LIB_PATH = os.path.join(_HERE, 'csrc', 'libcprhip_bench.so')
 

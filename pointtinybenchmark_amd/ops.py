@@ -6,6 +6,7 @@ Activations are NHWC fp32 (see csrc/conv_mfma.hip for why).  ``as_nchw`` / ``fro
 NCHW-shaped (channels_last-strided) tensors, which is what crosses the reference's module boundaries.
 """
 import ctypes
+import os
 
 import torch
 
@@ -65,6 +66,7 @@ def nhwc_to_nchw_dense(x_nhwc):
 class PackedConv:
     """Conv weight repacked for the implicit-GEMM kernel: [Cout][KH][KW][Cin'] fp32, rows padded to a
     multiple of 32 floats.  Cin' = 4 for the 3-channel stem (zero 4th channel)."""
+    wino = None     # transformed weights of the Winograd path, built on first use (conv3x3_wino)
 
     def __init__(self, weight, stride=1, padding=0, dtype=torch.float32):
         Cout, Cin, KH, KW = weight.shape
@@ -131,6 +133,40 @@ CONV_RELU, CONV_OUT_BF16, CONV_RES_MASK, CONV_COLSUM = 1, 2, 4, 8      # include
 # (kind, code).  Host-side, single-threaded bookkeeping of a value the C ABI returns through an out-parameter.
 TRACE_CONV_VARIANT = [False, None]
 
+# 3x3 / stride 1 / pad 1 fp32 layers run as fused Winograd F(2x2,3x3) (csrc/conv_wino.hip, 2.25x fewer multiplies) when the
+# map fills its 16x16 output regions well enough; CPR_WINOGRAD=0 keeps every layer on the direct implicit GEMM (A/B runs).
+WINOGRAD = [os.environ.get('CPR_WINOGRAD', '1') != '0']
+WINO_MIN_FILL = 0.6      # useful share of the 16x16 regions (40x40 -> 0.69 runs Winograd, 20x20 -> 0.39 stays direct)
+
+
+def wino_eligible(pc, H, W, dtype=torch.float32):
+    if not (WINOGRAD[0] and dtype == torch.float32 and pc.dtype == torch.float32 and pc.KH == 3 and pc.KW == 3 and
+            pc.stride == 1 and pc.padding == 1 and pc.Cin % 8 == 0 and pc.Cin >= 16 and pc.Cout % 64 == 0):
+        return False
+    fill = (H * W) / float(((H + 15) // 16 * 16) * ((W + 15) // 16 * 16))
+    return fill >= WINO_MIN_FILL
+
+
+def conv3x3_wino(x, pc, scale=None, bias=None, relu=False, gn_part=False, out=None):
+    """Winograd F(2x2,3x3) path of conv2d for 3x3 / stride 1 / pad 1 fp32 layers.  gn_part=True also returns one
+    (sum, sumsq) slot per 16x16 output region: (N * ceil(H/16) * ceil(W/16), Cout, 2)."""
+    _check(x, ACT)
+    N, H, W, Cin = x.shape
+    assert x.dtype == torch.float32 and Cin == pc.Cin and pc.KH == 3 and pc.stride == 1 and pc.padding == 1
+    if pc.wino is None:     # G g G^T of the packed weights, once per PackedConv (= once per weight update)
+        pc.wino = torch.empty((16 * pc.Cin * pc.Cout,), device=x.device, dtype=torch.float32)
+        _lib.call('cpr_wino_pack_weights', _ptr(pc.w), _ptr(pc.wino), pc.Cin, pc.Cout, pc.Kpad, _stream())
+    if out is None:
+        out = torch.empty((N, H, W, pc.Cout), device=x.device, dtype=torch.float32)
+    part = None
+    if gn_part:
+        part = torch.empty((N * ((H + 15) // 16) * ((W + 15) // 16), pc.Cout, 2), device=x.device, dtype=torch.float32)
+    _lib.call('cpr_conv3x3_wino_fwd', _ptr(x), _ptr(pc.wino), _ptr(out), _ptr(scale), _ptr(bias), _ptr(part), N, H, W,
+              Cin, pc.Cout, CONV_RELU if relu else 0, _stream())
+    if TRACE_CONV_VARIANT[0]:
+        TRACE_CONV_VARIANT[1] = ('wino', 16016064)
+    return (out, part) if gn_part else out
+
 
 def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, in_relu=False, gn_part=False,
            out=None, out_dtype=None, res_mask=False, colsum=False):
@@ -147,6 +183,9 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     assert x.dtype == pc.dtype, 'weights were packed for %s, input is %s' % (pc.dtype, x.dtype)
     OH, OW = pc.out_hw(H, W)
     odt = out_dtype or x.dtype
+    if residual is None and in_ab is None and not (res_mask or colsum) and odt == torch.float32 and \
+            wino_eligible(pc, H, W, x.dtype):
+        return conv3x3_wino(x, pc, scale, bias, relu, gn_part, out)
     if out is None:
         out = torch.empty((N, OH, OW, pc.Cout), device=x.device, dtype=odt)
     part = None

@@ -1,0 +1,87 @@
+"""Fused Winograd F(2x2,3x3) conv (csrc/conv_wino.hip) against an fp64 torch convolution of the same operands, next to the
+direct implicit-GEMM kernel on the same inputs.  Stated bound: |wino - fp64| <= 1e-5 * max|fp64| per layer and <= 3x the direct
+kernel's own error + 1e-6 (both are printed); the end-to-end 1e-4 logit bar is in test_gpu_fullsize.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # N, H, W, Cin, Cout, scale/bias, relu
+    (2, 32, 32, 64, 64, True, True),
+    (1, 48, 40, 256, 128, False, False),     # partial regions on the right edge (40 = 2.5 x 16)
+    (2, 16, 16, 32, 64, True, False),        # four chunks only
+    (1, 40, 40, 256, 256, True, True),       # layer3 3x3 shape
+    (3, 18, 34, 32, 64, False, True),        # one spare row / two spare columns
+    (1, 160, 160, 256, 256, False, False),   # head tower shape
+]
+
+
+def _ref(x, w, scale, bias, relu):
+    y = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=1)
+    if scale is not None:
+        y = y * scale.double().cpu()[None, :, None, None] + bias.double().cpu()[None, :, None, None]
+    if relu:
+        y = y.relu()
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_wino_matches_fp64_conv(case):
+    from pointtinybenchmark_amd import ops
+    N, H, W, Cin, Cout, affine, relu = case
+    g = torch.Generator().manual_seed(H * 1000 + Cin)
+    x = torch.randn((N, H, W, Cin), generator=g).cuda()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda() if affine else None
+    bias = torch.randn(Cout, generator=g).cuda() if affine else None
+    pc = ops.PackedConv(w, 1, 1)
+    assert ops.wino_eligible(pc, H, W) or H * W < 0.6 * ((H + 15) // 16 * 16) * ((W + 15) // 16 * 16)
+    y = ops.conv3x3_wino(x, pc, scale, bias, relu)
+    ops.WINOGRAD[0] = False
+    try:
+        yd = ops.conv2d(x, pc, scale, bias, relu=relu)
+    finally:
+        ops.WINOGRAD[0] = True
+    ref = _ref(x, w, scale, bias, relu)
+    m = ref.abs().max().item()
+    ew = (y.double().cpu() - ref).abs().max().item() / m
+    ed = (yd.double().cpu() - ref).abs().max().item() / m
+    print('wino %.2e direct %.2e of max' % (ew, ed))
+    assert ed <= 5e-6, ed
+    assert ew <= 1e-5 and ew <= 3 * ed + 1e-6, (ew, ed)
+
+
+def test_wino_gn_partials():
+    from pointtinybenchmark_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (N, H, W, C) in ((2, 32, 48, 64), (1, 40, 24, 128)):
+        x = torch.randn((N, H, W, C), generator=g).cuda()
+        w = (torch.randn((C, C, 3, 3), generator=g) * 0.05).cuda()
+        b = torch.randn(C, generator=g).cuda()
+        pc = ops.PackedConv(w, 1, 1)
+        y, part = ops.conv3x3_wino(x, pc, None, b, False, gn_part=True)
+        P = ((H + 15) // 16) * ((W + 15) // 16)
+        assert part.shape == (N * P, C, 2)
+        s = part.view(N, P, C, 2).double().sum(1)
+        yy = y.double()
+        torch.testing.assert_close(s[..., 0], yy.sum((1, 2)), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(s[..., 1], (yy * yy).sum((1, 2)), rtol=1e-5, atol=1e-3)
+        # through the dispatcher + gn_finalize == GroupNorm of the output
+        gam, bet = torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda()
+        y2, part2 = ops.conv2d(x, pc, bias=b, gn_part=True)
+        assert torch.equal(y2, y) and part2.shape == part.shape
+        a, bb = ops.gn_finalize(part2, gam, bet, N, H * W, 32, 1e-5)
+        out = ops.gn_apply(y2, a, bb, relu=False)
+        ref = F.group_norm(y.permute(0, 3, 1, 2), 32, gam, bet, 1e-5).permute(0, 2, 3, 1)
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_wino_dispatch_rules():
+    from pointtinybenchmark_amd import ops
+    w = torch.zeros((64, 64, 3, 3)).cuda()
+    assert ops.wino_eligible(ops.PackedConv(w, 1, 1), 160, 160)
+    assert ops.wino_eligible(ops.PackedConv(w, 1, 1), 40, 40)
+    assert not ops.wino_eligible(ops.PackedConv(w, 1, 1), 20, 20)          # 39 % of its regions
+    assert not ops.wino_eligible(ops.PackedConv(w, 2, 1), 160, 160)        # stride 2 stays direct
+    assert not ops.wino_eligible(ops.PackedConv(torch.zeros((32, 64, 3, 3)).cuda(), 1, 1), 160, 160)

@@ -20,12 +20,17 @@ ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--plain', action='store_true')
 ap.add_argument('--gn-stats', action='store_true', help='plain input, GroupNorm statistics in the epilogue (the forward\'s dominant launch)')
 ap.add_argument('--bf16', action='store_true', help='bf16 compute mode kernel (plain input, GN stats epilogue)')
+ap.add_argument('--no-wino', action='store_true', help='keep the 3x3 layer on the direct implicit GEMM')
+ap.add_argument('--wino-sched', type=int, default=0)
+ap.add_argument('--wino-ablate', type=int, default=0)
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--pipeline', type=int, default=1)
 args = ap.parse_args()
 from pointtinybenchmark_amd import _lib  # noqa: E402
+ops.WINOGRAD[0] = not args.no_wino
 _lib.call('cpr_conv_set_ablation', args.ablate)
 _lib.call('cpr_conv_set_pipeline', args.pipeline)
+_lib.call('cpr_wino_set_variant', args.wino_sched, args.wino_ablate)
 g = torch.Generator().manual_seed(0)
 x = torch.randn((args.batch, args.hw, args.hw, args.cin), generator=g).cuda()
 w = (torch.randn((args.cout, args.cin, args.k, args.k), generator=g) * 0.02).cuda()
