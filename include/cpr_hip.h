@@ -50,14 +50,25 @@ int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* s
  * every stride-1 bottleneck resnet.py:630-645).  The transforms only add/subtract, the result differs from the direct fp32
  * sum by ~1e-6 of the map's max per layer (tests/test_gpu_wino.py states the bound).
  *   cpr_wino_pack_weights: wgt = the cpr_conv2d_fwd layout [Cout][3][3][Cin] (row stride Kpad) -> u, 16*Cin*Cout floats
- *                          (G g G^T per (cout, cin), stored as the kernel's LDS chunk images); Cin % 8 == 0, Cout % 64 == 0.
+ *                          (G g G^T per (cout, cin), stored as the kernel's LDS chunk images); Cin % 8 == 0, Cout % 64 == 0
+ *                          (the conv itself needs Cin % 16 == 0, Cin >= 32).
  *   cpr_conv3x3_wino_fwd:  in (N,H,W,Cin) -> out (N,H,W,Cout) = conv * scale[c] + bias[c] (ReLU when flags & CPR_CONV_RELU);
+ *                          in_a/in_b (N,Cin) optional (Cin <= 512): the input is read as relu?(x*a+b), in_relu selects the ReLU
+ *                          (GroupNorm apply of the producing layer fused into the load, as in cpr_conv2d_fwd);
+ *                          layout: CPR_WINO_IN_B8 / CPR_WINO_OUT_B8 -- `in` / `out` are channel-blocked [N][C/8][H][W][8]
+ *                          instead of NHWC (whole cache lines per 8-channel K chunk: the fast form between chained layers);
  *                          gn_part [N * ceil(H/16) * ceil(W/16)][Cout][2] (may be NULL): per-channel (sum, sumsq) of every 16x16
  *                          output region (an image's regions are contiguous: cpr_gn_finalize with P = regions per image).
- *                          Tensors < 2 GiB (CPR_ERR_UNSUPPORTED). */
+ *                          Tensors < 2 GiB (CPR_ERR_UNSUPPORTED).
+ *   cpr_gn_apply_b8:       channel-blocked x -> NHWC y = relu?(x*a+b) (a, b NULL: layout conversion only). */
+#define CPR_WINO_IN_B8 1
+#define CPR_WINO_OUT_B8 2
 int cpr_wino_pack_weights(const float* wgt, float* u, int Cin, int Cout, int Kpad, void* stream);
 int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out, const float* scale, const float* bias,
-                         float* gn_part, int N, int H, int W, int Cin, int Cout, int flags, void* stream);
+                         const float* in_a, const float* in_b, float* gn_part, int N, int H, int W, int Cin, int Cout,
+                         int flags, int in_relu, int layout, void* stream);
+int cpr_gn_apply_b8(const float* x, const float* a, const float* b, float* y, int N, int H, int W, int C, int relu,
+                    void* stream);
 
 /* bf16 compute mode (BASELINE.json configs[4]): bf16 activations / weights / residual, fp32 accumulate
  * (v_mfma_f32_32x32x16_bf16), K chunks of 64 (Cin % 64 == 0, Kpad == KH*KW*Cin), output bf16 or fp32 (out_fp32).
@@ -316,7 +327,7 @@ int cpr_conv_force_tile(int bm, int bn); /* force the conv output tile (0 = heur
 int cpr_conv_set_pipeline(int mode);     /* K-loop schedule: 1 = interleaved (product), 0 = phase-separated */
 int cpr_conv_set_ablation(int mode);     /* loop ablations: results are WRONG when non-zero */
 int cpr_wgrad_set_ablation(int mode);    /* same for the weight-gradient kernel */
-int cpr_wino_set_variant(int sched, int ablate); /* Winograd K-loop schedule (0 = product, 1 = late write) and ablations */
+int cpr_wino_set_variant(int sched, int ablate); /* Winograd: sched 1 = one workgroup per tile (product: persistent); loop ablations */
 #endif
 
 #ifdef __cplusplus

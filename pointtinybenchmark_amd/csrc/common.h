@@ -13,6 +13,10 @@
 #define CPR_CONV_RES_MASK 4   // `residual` is a ReLU mask source: out = residual > 0 ? v : 0 (backward of a fused ReLU)
 #define CPR_CONV_COLSUM 8     // gn_part receives per-tile per-channel sums that are only reduced over the whole tensor
 
+// cpr_conv3x3_wino_fwd `layout`: channel-blocked [N][C/8][H][W][8] tensors (mirrors include/cpr_hip.h)
+#define CPR_WINO_IN_B8 1
+#define CPR_WINO_OUT_B8 2
+
 #define CPR_CHECK_ARG(cond) \
     do {                    \
         if (!(cond)) return CPR_ERR_ARG; \

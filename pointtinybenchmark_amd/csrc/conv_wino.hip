@@ -23,17 +23,21 @@
 //   transform and LDS access sits behind one of the wave's own 32 MFMAs per chunk, one barrier per chunk.
 //   Epilogue: R[i][b] = sum_j M[i][j] A[j][b] in registers, exchanged through LDS (the K-loop buffers, 128 KB),
 //   Y[a][b] = sum_i A[i][a] R[i][b], then scale/bias/ReLU and (optionally) the GroupNorm (sum, sumsq) partials.
+#include <type_traits>
 #include "common.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WinoParams {
-    const float* in;      // NHWC
+    const float* in;      // NHWC, or channel-blocked [N][Cin/8][H][W][8] (in_b8)
     const float* u;       // packed transformed weights, see wino_pack_kernel
-    float* out;           // NHWC
+    float* out;           // NHWC, or channel-blocked [N][Cout/8][H][W][8] (out_b8)
     const float* scale;   // [Cout] or null
     const float* bias;    // [Cout] or null
     float* gn_part;       // [regions][Cout][2] per-region per-channel (sum, sumsq) of the output, or null
+    const float* in_a;    // [N][Cin] or null: the input is read as relu?(x * a + b) (GroupNorm apply of the producer, fused)
+    const float* in_b;
+    int in_relu, out_b8;
     int N, H, W, Cin, Cout, relu, RY, RX, regions, tilesN, nch;
 };
 
@@ -69,103 +73,139 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-// SCHED 0: chunk c+1 is written to LDS behind the j = 1 MFMAs and chunk c+2 requested behind j = 2; SCHED 1: written behind
-// j = 2 (just before the barrier) and requested behind j = 3 (a load then has two and a half phases to land instead of two).
+// Staging history (profiles/round2_wino_ablation.txt, 160x160x256->256, B=64; pure MFMA time 5.46 ms, loop without any staging
+// 6.1): loading every tile's 4x4 patch straight into registers cost 8.0 ms -- 1.4 of it on the patch loads themselves, not on
+// the transform arithmetic (0.3) or the LDS writes (0); two register sets (deeper prefetch) did not help, spreading the SAME
+// loads over three phases instead of one did (7.05): the wave stalls AT a load instruction when the texture path is backed
+// up, in front of its own MFMAs.  Hence the patch is fetched once (648 x 16 B instead of 8192 x 4 B per chunk) into a raw LDS
+// buffer and the transform reads it from there.
+// INB8: the input is channel-blocked [N][Cin/8][H][W][8] -- a chunk's patch rows are 18 x 32 contiguous bytes (whole cache
+// lines) instead of 32 bytes out of every pixel's Cin*4-byte row (half the L2 requests).
+// XF: fused per-(image, channel) affine (+ReLU) on the input = GroupNorm apply of the producing layer.
 // ABL (benchmark-only, results are then WRONG): bit0 = no global loads / transform / LDS writes, bit1 = no fragment reads,
-// bit2 = no barrier, bit3 = no input loads, bit4 = no weight loads, bit5 = weight loads non-temporal.  ABL = 0 in every product launch.
-template <int SCHED, int ABL>
+// bit2 = no barrier, bit3 = no patch loads, bit4 = no output stores, bit5 = no epilogue at all.  ABL = 0 in every product launch.
+template <int ABL, bool INB8, bool XF>
 __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * WBUF];   // V0 V1 U0 U1
+    constexpr int XFMAX = 512;      // fused-affine launches keep the image's (a, b) table in LDS (Cin <= 512)
+    constexpr int RAWBUF = 2592;    // 18 x 18 pixels x 8 channels (floats)
+    __shared__ __attribute__((aligned(16))) float smem[4 * WBUF + 2 * RAWBUF + (XF ? 2 * XFMAX : 0)];   // V0 V1 U0 U1 raw0 raw1 [a | b]
     float* Vs = smem;
     float* Us = smem + 2 * WBUF;
 
     // XCD-aware order (block b runs on XCD b % 8): each XCD gets a contiguous run of tiles, cout tiles fastest, so the
     // Cout/64 workgroups that read the same input region share one L2
+    // Persistent workgroups (one per CU: the kernel is LDS-bound to one anyway): a 512-thread, 152 KB workgroup costs
+    // microseconds to launch against ~60 us of work; block b walks the virtual block ids b, b + gridDim.x, ... (gridDim.x is
+    // a multiple of 8, so a workgroup stays on its XCD's run of tiles).
     const int T = p.regions * p.tilesN;
     const int per = (T + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= T) return;
+    for (int vb = blockIdx.x; vb < per * 8; vb += gridDim.x) {
+    const int tile = (vb & 7) * per + (vb >> 3);
+    if (tile >= T) continue;
     const int rg = tile / p.tilesN, tn = tile - rg * p.tilesN;
     const int n = rg / (p.RY * p.RX);
     const int rrem = rg - n * p.RY * p.RX;
     const int ry = rrem / p.RX, rx = rrem - ry * p.RX;
     const int oy0 = ry * 16, ox0 = rx * 16, n0 = tn * 64;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool a_loader = __builtin_amdgcn_readfirstlane(tid) < 256;   // wave-uniform (scalar branch): waves 0-3 stage the input, waves 4-7 the weights
-    const int wi = wave & 3;           // frequency row of this wave's accumulators
-    const int nh = wave >> 2;          // cout half
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it stays in SGPRs
+    const int wi = wave & 3;           // MFMA role: frequency row of this wave's accumulators
+    const int nh = wave >> 2;          //            cout half
 
+    // ---- staging (all 8 waves alike), three steps per 8-channel chunk k, one barrier apart:
+    //   G  global -> registers: the 18 x 18 pixel patch ONCE (648 x 16 bytes over 512 threads: neighbouring tiles share
+    //      12 of their 16 pixels, loading per tile asks the texture path for 4x the bytes and the wave stalls AT the load
+    //      instructions in front of its own MFMAs) + 4 x 16 bytes of the 32 KB weight image per thread
+    //   R  registers -> LDS: patch raw[k % 2] (the fused GroupNorm affine + ReLU runs here, once per element), weights U[k % 2]
+    //   T  raw[k % 2] -> B^T d B -> V[k % 2]: thread = (Winograd tile, channel): 16 LDS reads, 32 adds, 16 LDS writes
+    // Zero padding: a patch pixel outside the image gets an out-of-range vector offset (the load returns 0).
+    const int pixbytes = INB8 ? 32 : p.Cin * 4;
+    const int chunk_bytes = INB8 ? p.H * p.W * 32 : 32;   // distance between the 8-channel chunks of one pixel
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.u), 0, (int)((size_t)p.tilesN * p.nch * WBUF * 4), 0x00020000);
-
-    // ---- loader state.  Input threads: (tile = tid >> 2, channel pair cp = tid & 3); the byte offsets of the 16 patch
-    // pixels never change over the K loop (-1 = outside the image -> the load returns 0 = the conv zero padding); the
-    // channel chunk is the instruction's scalar offset.
-    int voff[16];
-    const int ltile = (tid >> 2) & 63, cp = tid & 3;
-    {
-        const int ty = ltile >> 3, tx = ltile & 7;
+    float* Rw = smem + 4 * WBUF;                       // raw0 raw1: [324 pixels][8 channels]
+    float* ABs = smem + 4 * WBUF + 2 * RAWBUF;         // [a | b] of this image (XF)
+    int voffA[2];          // patch unit u = tid + 512 k: pixel u >> 1 (row-major 18 x 18), channels 4 (u & 1) .. +3
+    unsigned uok = 0;      // bit k: unit k is a pixel inside the image
+    const int img_base = INB8 ? (n * (p.Cin >> 3)) * p.H * p.W * 32 : n * p.H * p.W * p.Cin * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int iy = oy0 + 2 * ty - 1 + r, ix = ox0 + 2 * tx - 1 + s;
-                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                voff[r * 4 + s] = ok ? (((n * p.H + iy) * p.W + ix) * p.Cin + cp * 2) * 4 : -1;
-            }
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 512 * k, pix = u >> 1;
+        const int py = pix / 18, px = pix - py * 18;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool ok = (u < 648) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        uok |= (ok ? 1u : 0u) << k;
+        voffA[k] = ok ? img_base + (iy * p.W + ix) * pixbytes + (u & 1) * 16 : (int)0x80000000;
     }
-    const int uvoff = (tid & 255) * 16;                                            // weight threads: float4 #(tid-256) + 256 z
-    const int v_wr = ltile * 8 + 4 * ((cp >> 1) ^ ((ltile >> 3) & 1)) + (cp & 1) * 2;  // float offset of this thread's pair in a V row
-    const int u_wr = (tid & 255) * 4;
+    const bool second_unit = wave < 3;                 // scalar: units 512 .. 647 live in waves 0 - 2
+    const bool unit1_live = tid + 512 < 648;
+    const int lch = tid & 7, tx = (tid >> 3) & 7, ltile = tid >> 3;   // T role: tile row = wave
+    const float* t_rd = Rw + ((2 * wave) * 18 + 2 * tx) * 8 + lch;    // + (r * 18 + s) * 8
+    const int v_wr = ltile * 8 + 4 * ((lch >> 2) ^ ((ltile >> 3) & 1)) + (lch & 3);   // this thread's float in a V row
     const int last = p.nch - 1;
-
-    float stage[32];   // 16 x float2 (input threads) or 8 x float4 (weight threads)
-    if (ABL & 24) {
-#pragma unroll
-        for (int e = 0; e < 32; ++e) stage[e] = 1.f;
+    // XF: padding must be 0 AFTER the affine; interior regions skip the selects with one scalar branch
+    const bool any_pad = XF && __builtin_amdgcn_ballot_w64(uok != (unit1_live ? 3u : 1u)) != 0;
+    const float relu_floor = (XF && p.in_relu) ? 0.f : -INFINITY;
+    if (XF) {
+        for (int i = tid; i < p.Cin; i += 512) {
+            ABs[i] = p.in_a[n * p.Cin + i];
+            ABs[XFMAX + i] = p.in_b[n * p.Cin + i];
+        }
+        __syncthreads();
     }
-    auto load_piece = [&](int chunk, int z) {   // z = 0..7
-        const int ck = chunk < last ? chunk : last;
-        if (a_loader) {
-#pragma unroll
-            for (int e = 2 * z; e < 2 * z + 2; ++e) {
-                if (ABL & 8) continue;
-                const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, voff[e], ck * 32, 0));
-                stage[2 * e] = v.x;
-                stage[2 * e + 1] = v.y;
-            }
-        } else {
-            if (ABL & 16) return;
-            const f32x4 v = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uvoff + z * 4096, (tn * p.nch + ck) * (WBUF * 4), (ABL & 32) ? 2 : 0));
-            stage[4 * z] = v.x; stage[4 * z + 1] = v.y; stage[4 * z + 2] = v.z; stage[4 * z + 3] = v.w;
-        }
+
+    f32x4 sa[2];          // the thread's two patch units of the chunk in flight
+    f32x4 su[2][4];       // weight pieces: chunk k lives in set k % 2
+    float d[16];          // T: the 4 x 4 patch of (tile, channel)
+    if (ABL & 9) { sa[0] = f32x4{1.f, 1.f, 1.f, 1.f}; sa[1] = sa[0]; }
+    auto g_a = [&](int chunk, int k) {                 // G, patch unit k
+        if (ABL & 8) return;
+        const int ck = chunk < last ? chunk : last;    // the pipeline requests past the end: clamp (the data is never used)
+        if (k == 0 || second_unit)
+            sa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voffA[k], ck * chunk_bytes, 0));
     };
-    auto store_piece = [&](int buf, int z) {    // z = 0..7
-        if (a_loader) {
-            if (z < 4) {   // row z of B^T d, then the column pass: the four frequencies (z, 0..3) of both channels
-                f32x2 t[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const f32x2 d0 = {stage[2 * (0 + s)], stage[2 * (0 + s) + 1]};
-                    const f32x2 d1 = {stage[2 * (4 + s)], stage[2 * (4 + s) + 1]};
-                    const f32x2 d2 = {stage[2 * (8 + s)], stage[2 * (8 + s) + 1]};
-                    const f32x2 d3 = {stage[2 * (12 + s)], stage[2 * (12 + s) + 1]};
-                    t[s] = z == 0 ? d0 - d2 : z == 1 ? d1 + d2 : z == 2 ? d2 - d1 : d1 - d3;
-                }
-                float* dst = Vs + buf * WBUF + (z * 4) * 512 + v_wr;
-                *reinterpret_cast<f32x2*>(dst + 0 * 512) = t[0] - t[2];
-                *reinterpret_cast<f32x2*>(dst + 1 * 512) = t[1] + t[2];
-                *reinterpret_cast<f32x2*>(dst + 2 * 512) = t[2] - t[1];
-                *reinterpret_cast<f32x2*>(dst + 3 * 512) = t[1] - t[3];
-            }
-        } else {
-            *reinterpret_cast<f32x4*>(Us + buf * WBUF + u_wr + z * 1024) =
-                f32x4{stage[4 * z], stage[4 * z + 1], stage[4 * z + 2], stage[4 * z + 3]};
+    auto g_u = [&](auto set_c, int chunk, int z) {     // G, weight piece z = 0..3
+        constexpr int SET = decltype(set_c)::value;
+        const int ck = chunk < last ? chunk : last;
+        su[SET][z] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, tid * 16 + z * 8192, (tn * p.nch + ck) * (WBUF * 4), 0));
+    };
+    auto r_a = [&](int buf, int chunk, int k) {        // R, patch unit k (the affine + ReLU of the producer's GroupNorm)
+        if (k == 1 && !second_unit) return;
+        f32x4 v = sa[k];
+        if (XF) {
+            const int ck = chunk < last ? chunk : last;
+            const int c4 = ck * 8 + (tid & 1) * 4;
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ABs + c4), b4 = *reinterpret_cast<const f32x4*>(ABs + XFMAX + c4);
+            v = v * a4 + b4;
+            v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+            if (any_pad) { if (!((uok >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
+        if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + buf * RAWBUF + (tid + 512 * k) * 4) = v;
+    };
+    auto r_u = [&](auto set_c, int buf, int z) {       // R, weight piece z
+        constexpr int SET = decltype(set_c)::value;
+        *reinterpret_cast<f32x4*>(Us + buf * WBUF + tid * 4 + z * 2048) = su[SET][z];
+    };
+    auto t_read = [&](int buf, int r) {                // T, patch row r -> registers
+#pragma unroll
+        for (int s = 0; s < 4; ++s) d[r * 4 + s] = t_rd[buf * RAWBUF + (r * 18 + s) * 8];
+    };
+    auto t_row = [&](int buf, int i) {                 // T, row i of B^T d, then the column pass: frequencies (i, 0..3)
+        float t[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float d0 = d[s], d1 = d[4 + s], d2 = d[8 + s], d3 = d[12 + s];
+            t[s] = i == 0 ? d0 - d2 : i == 1 ? d1 + d2 : i == 2 ? d2 - d1 : d1 - d3;
+        }
+        float* dst = Vs + buf * WBUF + (i * 4) * 512 + v_wr;
+        dst[0 * 512] = t[0] - t[2];
+        dst[1 * 512] = t[1] + t[2];
+        dst[2 * 512] = t[2] - t[1];
+        dst[3 * 512] = t[1] - t[3];
     };
 
     f32x16 acc[4][2];   // [frequency column j][tile block]
@@ -188,43 +228,67 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     } while (0)
 #define WMFMA(FA, FB, j, q) \
     acc[j][(q) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[(q) & 1][(q) >> 1], FB[(q) >> 1], acc[j][(q) & 1], 0, 0, 0)
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
 
-    // prologue: chunk 0 into LDS buffer 0, chunk 1 in flight
+    // prologue: V[0], U[0] and raw[1] complete; patch of chunk 2 and weights of chunks 1 (set 1), 2 (set 0) in flight
+    g_a(0, 0); g_a(0, 1);
 #pragma unroll
-    for (int z = 0; z < 8; ++z) load_piece(0, z);
+    for (int z = 0; z < 4; ++z) g_u(Set0{}, 0, z);
+    r_a(0, 0, 0); r_a(0, 0, 1);
 #pragma unroll
-    for (int z = 0; z < 8; ++z) store_piece(0, z);
+    for (int z = 0; z < 4; ++z) r_u(Set0{}, 0, z);
+    g_a(1, 0); g_a(1, 1);
 #pragma unroll
-    for (int z = 0; z < 8; ++z) load_piece(1, z);
+    for (int z = 0; z < 4; ++z) g_u(Set1{}, 1, z);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t_read(0, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t_row(0, i);
+    r_a(1, 1, 0); r_a(1, 1, 1);
+    g_a(2, 0); g_a(2, 1);
+#pragma unroll
+    for (int z = 0; z < 4; ++z) g_u(Set0{}, 2, z);
     __syncthreads();
 #pragma unroll
     for (int z = 0; z < 3; ++z) WFRAG(fa0, fb0, 0, 0, z);
 
-    for (int c = 0; c < p.nch; ++c) {
+    // One chunk c (LDS buffers buf = c & 1): the direct kernel's interleaved schedule with the frequency column j in the role
+    // of the k-step; every staging instruction sits behind one of the wave's own MFMAs, spread so that the texture path sees
+    // a steady trickle (a burst of loads stalls the wave AT the load, in front of its next MFMAs).
+    //   j = 0: MFMAs | prefetch the j = 1 fragments | T reads of chunk c+1 (raw[buf^1], complete since the last barrier)
+    //   j = 1: MFMAs | prefetch j = 2 | T rows of chunk c+1 -> V[buf^1] | R weights of chunk c+1 (set nxt_c) -> U[buf^1]
+    //   j = 2: MFMAs | prefetch j = 3 | R patch of chunk c+2 -> raw[buf] | G weights of chunk c+3 (pieces 0-2) into set nxt_c
+    //   barrier (all reads of V/U[buf] and raw[buf^1] are complete, all writes to V/U[buf^1] and raw[buf] are visible)
+    //   j = 3: MFMAs | prefetch j = 0 of chunk c+1 | G patch of chunk c+3 | G weights piece 3
+    auto iteration = [&](auto nxt_c, int c) {
         const int buf = c & 1;
-        // ---- j = 0 | prefetch the j = 1 fragments
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             WMFMA(fa0, fb0, 0, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa1, fb1, buf, 1, q);
+            if (q >= 4 && !(ABL & 1)) t_read(buf ^ 1, q - 4);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- j = 1 | prefetch j = 2 | SCHED 0: transform / write chunk c+1 (requested one iteration ago) into the other buffer
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             WMFMA(fa1, fb1, 1, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa0, fb0, buf, 2, q);
-            if (SCHED == 0 && !(ABL & 1)) store_piece(buf ^ 1, q);
+            if (!(ABL & 1)) {
+                if (q & 1) r_u(nxt_c, buf ^ 1, q >> 1);
+                else t_row(buf ^ 1, q >> 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- j = 2 | prefetch j = 3 | SCHED 0: request chunk c+2, SCHED 1: write chunk c+1
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             WMFMA(fa0, fb0, 2, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa1, fb1, buf, 3, q);
             if (!(ABL & 1)) {
-                if (SCHED == 0) load_piece(c + 2, q);
-                else store_piece(buf ^ 1, q);
+                if (q == 3) r_a(buf, c + 2, 0);
+                if (q == 4) r_a(buf, c + 2, 1);
+                if (q == 5 || q == 6 || q == 7) g_u(nxt_c, c + 3, q - 5);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -233,18 +297,26 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // ---- j = 3 | prefetch j = 0 of chunk c+1 from the other (now complete) buffer | SCHED 1: request chunk c+2
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             WMFMA(fa1, fb1, 3, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa0, fb0, buf ^ 1, 0, q);
-            if (SCHED == 1 && !(ABL & 1)) load_piece(c + 2, q);
+            if (!(ABL & 1)) {
+                if (q == 3) g_a(c + 3, 0);
+                if (q == 5) g_a(c + 3, 1);
+                if (q == 7) g_u(nxt_c, c + 3, 3);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    for (int c = 0; c < p.nch; c += 2) {   // unrolled by the number of weight register sets: set indices stay compile-time
+        iteration(Set1{}, c);
+        iteration(Set0{}, c + 1);          // nch is even (Cin % 16 == 0)
     }
 #undef WFRAG
 #undef WMFMA
 
+    if (ABL & 32) { asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][1]), "v"(acc[2][0]), "v"(acc[3][1])); continue; }
     // ---- epilogue.  D layout of a 32x32 block: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (tile).
     __syncthreads();   // every wave is past its last fragment read: the K-loop buffers become R[4 i][2 b][64 tiles][64 couts]
     float* Rs = smem;
@@ -282,8 +354,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
                 f32x4 v = y[a] * sc + bi;
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 const bool ok = (oy + a < p.H) & (ox + b < p.W);   // partial regions at the right / bottom edge
-                const unsigned off = ok ? (unsigned)(((n * p.H + oy + a) * p.W + ox + b) * p.Cout + co) * 4u : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs_out, (int)off, 0, 0);
+                const unsigned off = !ok ? 0x80000000u
+                    : p.out_b8 ? (unsigned)((((n * (p.Cout >> 3) + (co >> 3)) * p.H + oy + a) * p.W + ox + b) * 8 + (co & 7)) * 4u
+                               : (unsigned)(((n * p.H + oy + a) * p.W + ox + b) * p.Cout + co) * 4u;
+                if (!(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs_out, (int)off, 0, 0);
                 if (p.gn_part && ok) { gs += v; gq += v * v; }
             }
         }
@@ -312,12 +386,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             dst[0] = s; dst[1] = q;
         }
     }
+    __syncthreads();   // the next tile's prologue overwrites the LDS this epilogue read
+    }   // persistent tile loop
 }
 
 // C-ABI ------------------------------------------------------------------------------------------
-#ifdef CPR_BENCH_HOOKS   // measurement build only (libcprhip_bench.so): K-loop schedule A/B and loop ablations, process-global
+#ifdef CPR_BENCH_HOOKS   // measurement build only (libcprhip_bench.so): register-set A/B and loop ablations, process-global
 static int wino_sched = 0, wino_ablate = 0;
-extern "C" int cpr_wino_set_variant(int sched, int ablate) {
+extern "C" int cpr_wino_set_variant(int sched, int ablate) {   // sched 1: one workgroup per tile instead of persistent ones
     CPR_CHECK_ARG((sched == 0 || sched == 1) && ablate >= 0 && ablate <= 32);
     wino_sched = sched;
     wino_ablate = ablate;
@@ -332,34 +408,48 @@ extern "C" int cpr_wino_pack_weights(const float* wgt, float* u, int Cin, int Co
     CPR_LAUNCH_STATUS();
 }
 extern "C" int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out, const float* scale, const float* bias,
-                                    float* gn_part, int N, int H, int W, int Cin, int Cout, int flags, hipStream_t stream) {
+                                    const float* in_a, const float* in_b, float* gn_part, int N, int H, int W, int Cin,
+                                    int Cout, int flags, int in_relu, int layout, hipStream_t stream) {
     CPR_CHECK_ARG(in && u && out && N > 0 && H > 0 && W > 0);
-    CPR_CHECK_ARG(Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 64 == 0 && Cin >= 16);
-    CPR_CHECK_ARG((flags & ~CPR_CONV_RELU) == 0);
+    CPR_CHECK_ARG(Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 64 == 0 && Cin >= 32);
+    CPR_CHECK_ARG((flags & ~CPR_CONV_RELU) == 0 && (layout & ~3) == 0);
+    if (in_a) CPR_CHECK_ARG(in_b && Cin <= 512);
     if ((long long)N * H * W * Cin * 4 >= (1ll << 31) || (long long)N * H * W * Cout * 4 >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
     WinoParams p;
     p.in = in; p.u = u; p.out = out; p.scale = scale; p.bias = bias; p.gn_part = gn_part;
+    p.in_a = in_a; p.in_b = in_b; p.in_relu = in_relu; p.out_b8 = (layout & CPR_WINO_OUT_B8) ? 1 : 0;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = flags & CPR_CONV_RELU;
     p.RY = (H + 15) / 16; p.RX = (W + 15) / 16;
     p.regions = N * p.RY * p.RX; p.tilesN = Cout / 64; p.nch = Cin / 8;
     const long long T = (long long)p.regions * p.tilesN;
     if (T >= (1ll << 30)) return CPR_ERR_UNSUPPORTED;
-    const int grid = (int)((T + 7) / 8 * 8);
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    ncu = (ncu + 7) / 8 * 8;
+    int grid = (int)((T + 7) / 8 * 8);
+    if (grid > ncu && !wino_sched) grid = ncu;   // persistent: one workgroup per CU (bench hook sched = 1: one per tile)
+    const bool b8 = (layout & CPR_WINO_IN_B8) != 0, xf = in_a != nullptr;
+#define WLAUNCH(A_)                                                                                                  \
+    do {                                                                                                             \
+        if (b8 && xf) hipLaunchKernelGGL((conv_wino_kernel<A_, true, true>), dim3(grid), dim3(512), 0, stream, p);    \
+        else if (b8) hipLaunchKernelGGL((conv_wino_kernel<A_, true, false>), dim3(grid), dim3(512), 0, stream, p);    \
+        else if (xf) hipLaunchKernelGGL((conv_wino_kernel<A_, false, true>), dim3(grid), dim3(512), 0, stream, p);    \
+        else hipLaunchKernelGGL((conv_wino_kernel<A_, false, false>), dim3(grid), dim3(512), 0, stream, p);           \
+    } while (0)
 #ifdef CPR_BENCH_HOOKS
-    if (wino_ablate || wino_sched) {
+    if (wino_ablate) {
         switch (wino_ablate) {
-            case 0: hipLaunchKernelGGL((conv_wino_kernel<1, 0>), dim3(grid), dim3(512), 0, stream, p); break;
-            case 1: hipLaunchKernelGGL((conv_wino_kernel<0, 1>), dim3(grid), dim3(512), 0, stream, p); break;
-            case 2: hipLaunchKernelGGL((conv_wino_kernel<0, 2>), dim3(grid), dim3(512), 0, stream, p); break;
-            case 3: hipLaunchKernelGGL((conv_wino_kernel<0, 3>), dim3(grid), dim3(512), 0, stream, p); break;
-            case 4: hipLaunchKernelGGL((conv_wino_kernel<0, 4>), dim3(grid), dim3(512), 0, stream, p); break;
-            case 8: hipLaunchKernelGGL((conv_wino_kernel<0, 8>), dim3(grid), dim3(512), 0, stream, p); break;
-            case 16: hipLaunchKernelGGL((conv_wino_kernel<0, 16>), dim3(grid), dim3(512), 0, stream, p); break;
-            case 32: hipLaunchKernelGGL((conv_wino_kernel<0, 32>), dim3(grid), dim3(512), 0, stream, p); break;
-            default: hipLaunchKernelGGL((conv_wino_kernel<0, 7>), dim3(grid), dim3(512), 0, stream, p); break;
+            case 1: WLAUNCH(1); break;
+            case 2: WLAUNCH(2); break;
+            case 4: WLAUNCH(4); break;
+            case 8: WLAUNCH(8); break;
+            case 16: WLAUNCH(16); break;
+            case 32: WLAUNCH(32); break;
+            default: WLAUNCH(7); break;
         }
     } else
 #endif
-    hipLaunchKernelGGL((conv_wino_kernel<0, 0>), dim3(grid), dim3(512), 0, stream, p);
+    WLAUNCH(0);
+#undef WLAUNCH
     CPR_LAUNCH_STATUS();
 }

@@ -228,6 +228,40 @@ extern "C" int cpr_gn_apply(const float* x, const float* a, const float* b, cons
     CPR_LAUNCH_STATUS();
 }
 
+// channel-blocked [N][C/8][H][W][8] (the Winograd conv's fast layout, conv_wino.hip) -> NHWC, optionally through the same
+// affine (+ReLU) as gn_apply: one 32 x 32-channel LDS tile per step so both sides move whole 128-byte runs.
+__global__ __launch_bounds__(256) void gn_apply_b8_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                          const float* __restrict__ b, float* __restrict__ y, int HW, int C,
+                                                          int relu) {
+    __shared__ float t[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    {   // read: 4 blocks of 8 channels x 32 pixels; a block row is 32 pixels x 32 bytes contiguous
+        const int k = tid & 7, px = (tid >> 3) & 31;
+        for (int blk = 0; blk < 4; ++blk) {
+            const int p = p0 + px, c = c0 + blk * 8 + k;
+            t[px][blk * 8 + k] = (p < HW && c < C) ? x[(((size_t)n * (C >> 3) + (c >> 3)) * HW + p) * 8 + k] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int cx = tid & 31;
+    for (int r = tid >> 5; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + cx;
+        if (p < HW && c < C) {
+            float v = t[r][cx];
+            if (a) v = v * a[(size_t)n * C + c] + b[(size_t)n * C + c];
+            if (relu) v = fmaxf(v, 0.f);
+            y[((size_t)n * HW + p) * C + c] = v;
+        }
+    }
+}
+extern "C" int cpr_gn_apply_b8(const float* x, const float* a, const float* b, float* y, int N, int H, int W, int C,
+                               int relu, hipStream_t stream) {
+    CPR_CHECK_ARG(x && y && x != y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && (a == nullptr) == (b == nullptr));
+    hipLaunchKernelGGL(gn_apply_b8_kernel, dim3(cdiv(H * W, 32), cdiv(C, 32), N), dim3(256), 0, stream, x, a, b, y, H * W, C, relu);
+    CPR_LAUNCH_STATUS();
+}
+
 // ================================================================================================
 // bf16 variants (bf16 compute mode, BASELINE.json configs[4]): same kernels with 4 bf16 (8 bytes) per lane, fp32 math.
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

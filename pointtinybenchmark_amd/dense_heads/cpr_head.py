@@ -123,6 +123,7 @@ class _Gts:
 
 @HEADS.register_module()
 class CPRHead(nn.Module):
+    accepts_b8 = True     # forward_train_lazy / _tower read a channel-blocked neck output (ops.is_b8) directly
     def __init__(self, num_classes, in_channels, num_cls_fcs=0, fc_out_channels=1024,
                  train_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=5),
                                           neg_generator=dict(type='OutCirclePtFeatGenerator', radius=3)),
@@ -217,13 +218,18 @@ class CPRHead(nn.Module):
     def _tower(self, x, ab=None, in_relu=True, tape=None, own_input=False):
         """4 x [conv3x3 -> GN -> ReLU]; returns the LAST layer un-normalised: (raw, (a, b)).
         own_input: nobody else reads ``x`` (its pending GroupNorm may be applied in place)."""
+        last = len(self.cls_convs) - 1
         for i, m in enumerate(self.cls_convs):
             rec = None
             if tape is not None:
                 rec = dict(kind='tower', level=i)
                 tape.append(rec)
+            # forward only: layers hand their raw output to the next one channel-blocked (the Winograd kernel's fast input
+            # form); the last layer stays NHWC for the logit projection.  conv_gn ignores the request when it cannot serve it
             x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=(in_relu if i == 0 else True), materialize=False,
-                            save=rec, consume_input=(own_input or i > 0))
+                            save=rec, consume_input=(own_input or i > 0), out_b8=(tape is None and i < last))
+        if ops.is_b8(x):       # (a one-layer tower cannot get here; kept for stacked_convs the configs do not use)
+            x = ops.gn_apply_b8(x)
         return x, ab
 
     def forward_single(self, x):

@@ -94,7 +94,8 @@ class BasicLocator(nn.Module):
         entry = self._graphs.get(key)
         if entry is None:
             def run(x):
-                raw, ab = head._tower(*self.neck.forward_lazy(self.backbone(x))[0], in_relu=False, own_input=True)
+                raw, ab = head._tower(*self.neck.forward_lazy(self.backbone(x), out_b8=getattr(head, 'accepts_b8', False))[0],
+                                      in_relu=False, own_input=True)
                 return raw, ab, head._logit_map(raw, ab)
             static_img = img.clone()
             side = torch.cuda.Stream()
@@ -129,7 +130,7 @@ class BasicLocator(nn.Module):
                                           else {}))
         if self.with_neck and hasattr(self.neck, 'forward_lazy') and hasattr(self.bbox_head, 'forward_train_lazy') \
                 and os.environ.get('CPR_LAZY_GN', '1') == '1':
-            lazy = self.neck.forward_lazy(self.backbone(img))
+            lazy = self.neck.forward_lazy(self.backbone(img), out_b8=getattr(self.bbox_head, 'accepts_b8', False))
             return self.bbox_head.forward_train_lazy(lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore,
                                                      gt_true_bboxes)
         x = self.extract_feat(img)

@@ -92,36 +92,49 @@ class ConvModule(nn.Module):
         return getattr(self, self.norm_name) if self.norm_name else None
 
 
-def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None, save=None, consume_input=False):
-    """Run a ConvModule(conv, GN[, ReLU]) on an NHWC tensor.
+def conv_gn(cache, m, x, in_ab=None, in_relu=False, materialize=True, up=None, save=None, consume_input=False,
+            out_b8=False):
+    """Run a ConvModule(conv, GN[, ReLU]) on an NHWC tensor (or a channel-blocked one, ops.is_b8: Winograd layers only).
 
-    The GroupNorm statistics come out of the conv epilogue when the map is tile-aligned (no extra pass);
-    with ``materialize=False`` the raw conv output and the per-(image, channel) affine (a, b) are returned so
-    the CONSUMER conv applies normalisation + ReLU while loading its input tile (no apply pass either).
+    The GroupNorm statistics come out of the conv epilogue (no extra pass: always for the Winograd layers, for the
+    direct kernel when the map is tile-aligned); with ``materialize=False`` the raw conv output and the per-(image,
+    channel) affine (a, b) are returned so the CONSUMER conv applies normalisation + ReLU while loading its input (no
+    apply pass either).
     ``save`` (dict): training mode -- records what the backward needs (conv input and its pending affine, raw output,
     GroupNorm affine and statistics) and keeps the raw output intact (the apply pass goes out of place).
     ``consume_input``: the caller owns ``x`` and nobody else reads it -- a pending producer-GroupNorm may be applied in place.
+    ``out_b8``: the consumer is a Winograd layer -- hand it the raw output channel-blocked (forward only, materialize=False).
 
-    Fused-on-load vs one streaming apply pass (forward only; the training step keeps the fused form because its backward
-    needs the raw map): a KxK consumer re-transforms every input element K*K x (cout tiles) times behind its MFMAs
-    (3x3 256->256 at 160x160, B=16: 3.52 ms fused vs 3.30 ms plain), while gn_apply touches it once at HBM speed
-    (0.14 ms) -- so 3x3 consumers take the materialised input, 1x1 consumers fuse (CPR_GN_FUSE_IN=1 forces the fused form).
+    Fused-on-load vs one streaming apply pass: the Winograd layers (3x3, stride 1) transform every input element once per
+    cout tile on its way into the 4x4 patch transform -- 2 packed FMA/max per 8 bytes, invisible behind the MFMAs -- so they
+    always fuse.  The direct kernel's KxK consumers re-transform every element K*K x (cout tiles) times (3x3 256->256 at
+    160x160, B=16: 3.52 ms fused vs 3.30 ms plain) while gn_apply touches it once at HBM speed (0.14 ms): those take the
+    materialised input in forward-only mode, 1x1 consumers fuse (CPR_GN_FUSE_IN=1 forces the fused form).
     """
     pc = packed_conv(cache, m.conv, x.dtype)
     gn = m.norm
-    N, H, W, _ = x.shape
+    blocked = ops.is_b8(x)
+    if blocked:
+        N, _, H, W, _ = x.shape
+    else:
+        N, H, W, _ = x.shape
+    wino = x.dtype == torch.float32 and ops.wino_eligible(pc, H, W, x.dtype) and pc.Cin <= 512
+    if blocked and not wino:       # a channel-blocked map reached a layer that cannot read it: back to NHWC (+ its pending affine)
+        x = ops.gn_apply_b8(x, *(in_ab if in_ab is not None else (None, None)), relu=in_relu and in_ab is not None)
+        in_ab, blocked = None, False
     OH, OW = pc.out_hw(H, W)
-    fused_stats = (OH * OW) % 128 == 0
-    fuse_in = in_ab is not None and (H * W) % 128 == 0 and pc.stride == 1 and (OH, OW) == (H, W) \
-        and x.dtype == torch.float32   # the bf16 kernel does not fuse the producer GN (see conv_mfma_bf16.hip)
-    if fuse_in and save is None and pc.KH * pc.KW > 1 and os.environ.get('CPR_GN_FUSE_IN', '0') != '1':
+    fused_stats = wino or (OH * OW) % 128 == 0
+    fuse_in = in_ab is not None and (wino or ((H * W) % 128 == 0 and pc.stride == 1 and (OH, OW) == (H, W)
+                                              and x.dtype == torch.float32))   # the bf16 kernel does not fuse the producer GN
+    if fuse_in and not wino and save is None and pc.KH * pc.KW > 1 and os.environ.get('CPR_GN_FUSE_IN', '0') != '1':
         fuse_in = False
     if in_ab is not None and not fuse_in:
         x = ops.gn_apply(x, in_ab[0], in_ab[1], relu=in_relu, out=x if (consume_input and save is None) else None)
         in_ab = None
+    out_b8 = bool(out_b8) and wino and save is None and not materialize
     bias = m.conv.bias
     if fused_stats:
-        raw, part = ops.conv2d(x, pc, bias=bias, in_ab=in_ab, in_relu=in_relu, gn_part=True)
+        raw, part = ops.conv2d(x, pc, bias=bias, in_ab=in_ab, in_relu=in_relu, gn_part=True, out_b8=out_b8)
     else:
         raw = ops.conv2d(x, pc, bias=bias, in_ab=in_ab, in_relu=in_relu)
         part = ops.gn_stats(raw)

@@ -44,7 +44,7 @@ class FPN(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def _run(self, inputs, lazy, tape=None):
+    def _run(self, inputs, lazy, tape=None, out_b8=False):
         assert len(inputs) == len(self.in_channels)
         c = self._cache
         xs = [ops.from_nchw(inputs[i + self.start_level]) for i in range(len(self.lateral_convs))]
@@ -64,13 +64,14 @@ class FPN(nn.Module):
             if tape is not None:
                 rec = dict(kind='out', level=i)
                 tape.append(rec)
-            outs.append(conv_gn(c, self.fpn_convs[i], lat[i], materialize=not lazy, save=rec))
+            outs.append(conv_gn(c, self.fpn_convs[i], lat[i], materialize=not lazy, save=rec, out_b8=out_b8 and lazy))
         return outs
 
     def forward(self, inputs):
         return tuple(ops.as_nchw(t) for t in self._run(inputs, lazy=False))
 
-    def forward_lazy(self, inputs, tape=None):
+    def forward_lazy(self, inputs, tape=None, out_b8=False):
         """Internal fast path: per level (raw conv output NHWC, (a, b)) -- the consumer conv applies the GroupNorm
-        affine while loading (no activation after the FPN convs: act_cfg=None).  tape: training records."""
-        return self._run(inputs, lazy=True, tape=tape)
+        affine while loading (no activation after the FPN convs: act_cfg=None).  tape: training records.
+        out_b8: the consumer is a Winograd 3x3 layer (CPRHead tower) -- raw outputs channel-blocked where the layer can."""
+        return self._run(inputs, lazy=True, tape=tape, out_b8=out_b8 and tape is None)

@@ -141,35 +141,63 @@ WINO_MIN_FILL = 0.6      # useful share of the 16x16 regions (40x40 -> 0.69 runs
 
 def wino_eligible(pc, H, W, dtype=torch.float32):
     if not (WINOGRAD[0] and dtype == torch.float32 and pc.dtype == torch.float32 and pc.KH == 3 and pc.KW == 3 and
-            pc.stride == 1 and pc.padding == 1 and pc.Cin % 8 == 0 and pc.Cin >= 16 and pc.Cout % 64 == 0):
+            pc.stride == 1 and pc.padding == 1 and pc.Cin % 16 == 0 and pc.Cin >= 32 and pc.Cout % 64 == 0):
         return False
     fill = (H * W) / float(((H + 15) // 16 * 16) * ((W + 15) // 16 * 16))
     return fill >= WINO_MIN_FILL
 
 
-def conv3x3_wino(x, pc, scale=None, bias=None, relu=False, gn_part=False, out=None):
-    """Winograd F(2x2,3x3) path of conv2d for 3x3 / stride 1 / pad 1 fp32 layers.  gn_part=True also returns one
-    (sum, sumsq) slot per 16x16 output region: (N * ceil(H/16) * ceil(W/16), Cout, 2)."""
+def is_b8(x):
+    """Channel-blocked activation (N, C/8, H, W, 8): the layout Winograd layers hand to each other (csrc/conv_wino.hip)."""
+    return x.dim() == 5 and x.shape[-1] == 8
+
+
+def conv3x3_wino(x, pc, scale=None, bias=None, relu=False, gn_part=False, out=None, in_ab=None, in_relu=False,
+                 out_b8=False):
+    """Winograd F(2x2,3x3) path of conv2d for 3x3 / stride 1 / pad 1 fp32 layers.  x: NHWC (N,H,W,Cin) or channel-blocked
+    (N,Cin/8,H,W,8); out_b8=True returns the blocked form (N,Cout/8,H,W,8).  in_ab=(a,b): input read as relu?(x*a+b).
+    gn_part=True also returns one (sum, sumsq) slot per 16x16 output region: (N * ceil(H/16) * ceil(W/16), Cout, 2)."""
     _check(x, ACT)
-    N, H, W, Cin = x.shape
+    in_b8 = is_b8(x)
+    if in_b8:
+        N, _, H, W, _ = x.shape
+        Cin = x.shape[1] * 8
+    else:
+        N, H, W, Cin = x.shape
     assert x.dtype == torch.float32 and Cin == pc.Cin and pc.KH == 3 and pc.stride == 1 and pc.padding == 1
     if pc.wino is None:     # G g G^T of the packed weights, once per PackedConv (= once per weight update)
         pc.wino = torch.empty((16 * pc.Cin * pc.Cout,), device=x.device, dtype=torch.float32)
         _lib.call('cpr_wino_pack_weights', _ptr(pc.w), _ptr(pc.wino), pc.Cin, pc.Cout, pc.Kpad, _stream())
+    shape = (N, pc.Cout // 8, H, W, 8) if out_b8 else (N, H, W, pc.Cout)
     if out is None:
-        out = torch.empty((N, H, W, pc.Cout), device=x.device, dtype=torch.float32)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    assert tuple(out.shape) == shape and out.is_contiguous()
     part = None
     if gn_part:
         part = torch.empty((N * ((H + 15) // 16) * ((W + 15) // 16), pc.Cout, 2), device=x.device, dtype=torch.float32)
-    _lib.call('cpr_conv3x3_wino_fwd', _ptr(x), _ptr(pc.wino), _ptr(out), _ptr(scale), _ptr(bias), _ptr(part), N, H, W,
-              Cin, pc.Cout, CONV_RELU if relu else 0, _stream())
+    a = b = None
+    if in_ab is not None:
+        a, b = in_ab
+        assert Cin <= 512
+    _lib.call('cpr_conv3x3_wino_fwd', _ptr(x), _ptr(pc.wino), _ptr(out), _ptr(scale), _ptr(bias), _ptr(a), _ptr(b),
+              _ptr(part), N, H, W, Cin, pc.Cout, CONV_RELU if relu else 0, int(in_relu), (1 if in_b8 else 0) | (2 if out_b8 else 0),
+              _stream())
     if TRACE_CONV_VARIANT[0]:
-        TRACE_CONV_VARIANT[1] = ('wino', 16016064)
+        TRACE_CONV_VARIANT[1] = ('wino', (1 if in_b8 else 0) | (2 if out_b8 else 0) | (4 if in_ab is not None else 0))
     return (out, part) if gn_part else out
 
 
+def gn_apply_b8(x, a=None, b=None, relu=False):
+    """Channel-blocked (N,C/8,H,W,8) -> NHWC (N,H,W,C), optionally through y = relu?(x*a+b)."""
+    assert is_b8(x)
+    N, C8, H, W, _ = _check(x, ACT).shape
+    y = torch.empty((N, H, W, C8 * 8), device=x.device, dtype=torch.float32)
+    _lib.call('cpr_gn_apply_b8', _ptr(x), _ptr(a), _ptr(b), _ptr(y), N, H, W, C8 * 8, int(relu), _stream())
+    return y
+
+
 def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, in_relu=False, gn_part=False,
-           out=None, out_dtype=None, res_mask=False, colsum=False):
+           out=None, out_dtype=None, res_mask=False, colsum=False, out_b8=False):
     """x (N,H,W,Cin) -> (N,OH,OW,Cout).  Epilogue: *scale[c] + bias[c] (+residual) (ReLU).
     in_ab=(a,b) applies x*a[n,c]+b[n,c] (+ReLU) to the input on load (fused GroupNorm of the producer; fp32 only).
     gn_part=True also returns per-128-pixel-tile per-channel (sum, sumsq) partials of the output.
@@ -178,14 +206,19 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     Backward helpers (fp32): res_mask=True turns ``residual`` into a ReLU mask source (out = residual > 0 ? v : 0);
     colsum=True also returns the per-channel sums of the output (C,), taken from the epilogue partials."""
     _check(x, ACT)
+    if is_b8(x):     # channel-blocked input: only the Winograd layers read it
+        assert residual is None and not (res_mask or colsum) and out_dtype in (None, torch.float32) and \
+            wino_eligible(pc, x.shape[2], x.shape[3], x.dtype), 'channel-blocked input needs a Winograd-eligible layer'
+        return conv3x3_wino(x, pc, scale, bias, relu, gn_part, out, in_ab, in_relu, out_b8)
     N, H, W, Cin = x.shape
     assert Cin == pc.Cin, (Cin, pc.Cin)
     assert x.dtype == pc.dtype, 'weights were packed for %s, input is %s' % (pc.dtype, x.dtype)
     OH, OW = pc.out_hw(H, W)
     odt = out_dtype or x.dtype
-    if residual is None and in_ab is None and not (res_mask or colsum) and odt == torch.float32 and \
-            wino_eligible(pc, H, W, x.dtype):
-        return conv3x3_wino(x, pc, scale, bias, relu, gn_part, out)
+    if residual is None and not (res_mask or colsum) and odt == torch.float32 and wino_eligible(pc, H, W, x.dtype) and \
+            (in_ab is None or Cin <= 512):
+        return conv3x3_wino(x, pc, scale, bias, relu, gn_part, out, in_ab, in_relu, out_b8)
+    assert not out_b8, 'channel-blocked output is produced by the Winograd layers only (check wino_eligible first)'
     if out is None:
         out = torch.empty((N, OH, OW, pc.Cout), device=x.device, dtype=odt)
     part = None

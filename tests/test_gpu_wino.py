@@ -85,3 +85,45 @@ def test_wino_dispatch_rules():
     assert not ops.wino_eligible(ops.PackedConv(w, 1, 1), 20, 20)          # 39 % of its regions
     assert not ops.wino_eligible(ops.PackedConv(w, 2, 1), 160, 160)        # stride 2 stays direct
     assert not ops.wino_eligible(ops.PackedConv(torch.zeros((32, 64, 3, 3)).cuda(), 1, 1), 160, 160)
+
+
+def _to_b8(x):
+    N, H, W, C = x.shape
+    return x.view(N, H, W, C // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
+
+
+def _from_b8(x):
+    N, C8, H, W, _ = x.shape
+    return x.permute(0, 2, 3, 1, 4).reshape(N, H, W, C8 * 8).contiguous()
+
+
+@pytest.mark.parametrize('case', [(2, 32, 48, 64, 128), (1, 40, 24, 256, 64), (2, 16, 16, 512, 64)])
+def test_wino_blocked_layout_and_fused_affine(case):
+    """Channel-blocked input / output and the fused producer-GroupNorm affine (+ReLU) give the SAME bits as the NHWC
+    kernel on the materialised input (the arithmetic is identical, only the addressing / where the affine runs differ)."""
+    from pointtinybenchmark_amd import ops
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(Cin + W)
+    x = torch.randn((N, H, W, Cin), generator=g).cuda()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * 0.05).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    a = (torch.rand((N, Cin), generator=g) + 0.5).cuda()
+    b = torch.randn((N, Cin), generator=g).cuda()
+    pc = ops.PackedConv(w, 1, 1)
+    ref = ops.conv3x3_wino(x, pc, None, bias, True)
+    y1 = ops.conv3x3_wino(_to_b8(x), pc, None, bias, True)
+    assert torch.equal(y1, ref)
+    y2, part2 = ops.conv3x3_wino(_to_b8(x), pc, None, bias, True, gn_part=True, out_b8=True)
+    assert ops.is_b8(y2) and torch.equal(_from_b8(y2), ref)
+    _, part = ops.conv3x3_wino(x, pc, None, bias, True, gn_part=True)
+    assert torch.equal(part, part2)
+    assert torch.equal(ops.gn_apply_b8(y2), ref)
+    torch.testing.assert_close(ops.gn_apply_b8(y2, a[:, :1].expand(N, Cout).contiguous(), b[:, :1].expand(N, Cout).contiguous(), relu=True),
+                               (ref * a[:, :1, None, None].permute(0, 2, 3, 1) + b[:, :1, None, None].permute(0, 2, 3, 1)).relu(),
+                               rtol=1e-6, atol=1e-6)
+    for relu in (False, True):
+        xm = ops.gn_apply(x, a, b, relu=relu)                       # the materialised input: same fma, same max
+        refx = ops.conv3x3_wino(xm, pc, None, bias, False)
+        for xin in (x, _to_b8(x)):
+            y = ops.conv3x3_wino(xin, pc, None, bias, False, in_ab=(a, b), in_relu=relu)
+            assert torch.equal(y, refx), (relu, ops.is_b8(xin), float((y - refx).abs().max()))

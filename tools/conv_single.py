@@ -21,6 +21,7 @@ ap.add_argument('--plain', action='store_true')
 ap.add_argument('--gn-stats', action='store_true', help='plain input, GroupNorm statistics in the epilogue (the forward\'s dominant launch)')
 ap.add_argument('--bf16', action='store_true', help='bf16 compute mode kernel (plain input, GN stats epilogue)')
 ap.add_argument('--no-wino', action='store_true', help='keep the 3x3 layer on the direct implicit GEMM')
+ap.add_argument('--b8', action='store_true', help='Winograd layer with channel-blocked input and output + fused input affine')
 ap.add_argument('--wino-sched', type=int, default=0)
 ap.add_argument('--wino-ablate', type=int, default=0)
 ap.add_argument('--ablate', type=int, default=0)
@@ -40,8 +41,13 @@ if args.bf16:
     args.gn_stats = True
 a = (torch.rand((args.batch, args.cin), generator=g) + 0.5).cuda()
 b = torch.randn((args.batch, args.cin), generator=g).cuda()
+if args.b8:
+    xb = x.view(args.batch, args.hw, args.hw, args.cin // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
+    run_b8 = lambda: ops.conv3x3_wino(xb, pc, gn_part=True, in_ab=(a, b), in_relu=True, out_b8=True)
 for _ in range(args.iters):
-    if args.plain:
+    if args.b8:
+        run_b8()
+    elif args.plain:
         ops.conv2d(x, pc)
     elif args.gn_stats:
         ops.conv2d(x, pc, gn_part=True)
@@ -51,7 +57,9 @@ torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(args.iters):
-    if args.plain:
+    if args.b8:
+        run_b8()
+    elif args.plain:
         ops.conv2d(x, pc)
     elif args.gn_stats:
         ops.conv2d(x, pc, gn_part=True)
