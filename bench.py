@@ -27,11 +27,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); only used with --dtype bf16
 
 
-def kernel_source_sha16():
-    """Content hash of the conv kernel source: profiles/pmc_dominant_kernel.json is stamped with it (tools/pmc_to_json.py),
-    so a PMC figure measured on an older kernel is never replayed into a newer bench line."""
+def kernel_source_sha16(kernel_name='conv_mfma_kernel'):
+    """Content hash of the source file of a conv kernel: profiles/pmc_dominant_kernel.json is stamped with it
+    (tools/pmc_to_json.py), so a PMC figure measured on an older kernel is never replayed into a newer bench line."""
     import hashlib
-    src = os.path.join(ROOT, 'pointtinybenchmark_amd', 'csrc', 'conv_mfma.hip')
+    fname = 'conv_wino.hip' if 'wino' in kernel_name else 'conv_mfma_bf16.hip' if 'bf16' in kernel_name else 'conv_mfma.hip'
+    src = os.path.join(ROOT, 'pointtinybenchmark_amd', 'csrc', fname)
     return hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
 
 
@@ -40,14 +41,14 @@ def pmc_traffic(kernel_name, batch):
     produced by tools/gpu_pmc.sh + tools/pmc_to_json.py: separate rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950
     note of MI355X_MICROARCH.md).  Counters cannot be read from inside the timed run, so this is the profile's figure,
     scaled linearly if the batch differs; null when no profile of this kernel INSTANCE and this kernel SOURCE is committed
-    (the JSON carries the template instance name and the sha of conv_mfma.hip it was measured on)."""
+    (the JSON carries the template instance name and the sha of the kernel's source file it was measured on)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
     if d.get('kernel', '').replace(' ', '') != kernel_name.replace(' ', ''):
         return None
-    if d.get('source_sha16') != kernel_source_sha16():
+    if d.get('source_sha16') != kernel_source_sha16(kernel_name):
         return None
     return d['hbm_bytes_per_launch'] * batch / d['batch']
 GN = dict(type='GN', num_groups=32, requires_grad=True)
@@ -106,8 +107,15 @@ class ConvProbe:
         self.only = only      # set of shape keys to bracket, or None = every launch
 
     @staticmethod
+    def nhwc_shape(x):
+        """(N, H, W, C) of an NHWC or channel-blocked (N, C/8, H, W, 8) activation."""
+        if x.dim() == 5:
+            return (x.shape[0], x.shape[2], x.shape[3], x.shape[1] * 8)
+        return tuple(x.shape)
+
+    @staticmethod
     def key(x, pc):
-        return (tuple(x.shape), pc.Cout, pc.KH, pc.stride)
+        return (ConvProbe.nhwc_shape(x), pc.Cout, pc.KH, pc.stride)
 
     def install(self):
         from pointtinybenchmark_amd import _lib, ops
@@ -123,10 +131,12 @@ class ConvProbe:
             s.record()
             out = probe._orig(x, pc, *a, **k)
             e.record()
-            N, H, W, _ = x.shape
+            N, H, W, _ = probe.nhwc_shape(x)
             OH, OW = pc.out_hw(H, W)
             kind, v = ops.TRACE_CONV_VARIANT[1]          # what the launcher returned through its out-parameter
-            if kind == 'bf16':
+            if kind == 'wino':       # template instance of csrc/conv_wino.hip: <ABL = 0, INB8, XF>
+                variant = 'conv_wino_kernel<0, %s, %s>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false')
+            elif kind == 'bf16':
                 variant = 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
             else:
                 variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
@@ -616,6 +626,12 @@ def main():
                                'per_instance_tflops': {k: round(v['tflops'], 2) for k, v in fsum.items()},
                                'per_instance_source': 'every conv launch of 2 untimed steps bracketed with HIP events; '
                                                       'achieved/avg_launch_ms: the dominant instance inside the timed region'}
+            if 'wino' in name:
+                # frac > 1 is possible and meant: `achieved` counts the ALGORITHMIC flops of the 3x3 conv (2 * M * Cout * 9 * Cin,
+                # SURVEY.md 8d); Winograd F(2x2,3x3) executes 16 multiplies per 2x2 outputs instead of 36, so the matrix pipe
+                # itself runs at achieved / 2.25 -- that figure is the one to hold against the MFMA peak as a kernel-quality number
+                out['roofline'].update({'algorithm': 'fused Winograd F(2x2,3x3): 2.25x fewer multiplies than the algorithmic count',
+                                        'mfma_executed_tflops': ach / 2.25, 'mfma_executed_frac': ach / 2.25 / peak})
             out['conv_time_frac'] = conv_s / (elapsed / args.steps)
             out['end_to_end_tflops'] = conv_f / (elapsed / args.steps) / 1e12   # conv FLOPs of a step / step time
         if world == 1 and not args.no_probe:

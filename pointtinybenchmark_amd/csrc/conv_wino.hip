@@ -88,25 +88,9 @@ template <int ABL, bool INB8, bool XF>
 __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     constexpr int XFMAX = 512;      // fused-affine launches keep the image's (a, b) table in LDS (Cin <= 512)
     constexpr int RAWBUF = 2592;    // 18 x 18 pixels x 8 channels (floats)
-    __shared__ __attribute__((aligned(16))) float smem[4 * WBUF + 2 * RAWBUF + (XF ? 2 * XFMAX : 0)];   // V0 V1 U0 U1 raw0 raw1 [a | b]
+    __shared__ __attribute__((aligned(16))) float smem[4 * WBUF + 2 * RAWBUF + (XF ? 4 * XFMAX : 0)];   // V0 V1 U0 U1 raw0 raw1 [a | b] x 2
     float* Vs = smem;
     float* Us = smem + 2 * WBUF;
-
-    // XCD-aware order (block b runs on XCD b % 8): each XCD gets a contiguous run of tiles, cout tiles fastest, so the
-    // Cout/64 workgroups that read the same input region share one L2
-    // Persistent workgroups (one per CU: the kernel is LDS-bound to one anyway): a 512-thread, 152 KB workgroup costs
-    // microseconds to launch against ~60 us of work; block b walks the virtual block ids b, b + gridDim.x, ... (gridDim.x is
-    // a multiple of 8, so a workgroup stays on its XCD's run of tiles).
-    const int T = p.regions * p.tilesN;
-    const int per = (T + 7) >> 3;
-    for (int vb = blockIdx.x; vb < per * 8; vb += gridDim.x) {
-    const int tile = (vb & 7) * per + (vb >> 3);
-    if (tile >= T) continue;
-    const int rg = tile / p.tilesN, tn = tile - rg * p.tilesN;
-    const int n = rg / (p.RY * p.RX);
-    const int rrem = rg - n * p.RY * p.RX;
-    const int ry = rrem / p.RX, rx = rrem - ry * p.RX;
-    const int oy0 = ry * 16, ox0 = rx * 16, n0 = tn * 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it stays in SGPRs
@@ -127,18 +111,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.u), 0, (int)((size_t)p.tilesN * p.nch * WBUF * 4), 0x00020000);
     float* Rw = smem + 4 * WBUF;                       // raw0 raw1: [324 pixels][8 channels]
-    float* ABs = smem + 4 * WBUF + 2 * RAWBUF;         // [a | b] of this image (XF)
-    int voffA[2];          // patch unit u = tid + 512 k: pixel u >> 1 (row-major 18 x 18), channels 4 (u & 1) .. +3
-    unsigned uok = 0;      // bit k: unit k is a pixel inside the image
-    const int img_base = INB8 ? (n * (p.Cin >> 3)) * p.H * p.W * 32 : n * p.H * p.W * p.Cin * 4;
+    float* ABs = smem + 4 * WBUF + 2 * RAWBUF;         // XF: [a | b] of the current tile's image, and of the next tile's
+    int par = 0;                                       //     table in use (flips per tile)
+    // patch unit u = tid + 512 k: pixel u >> 1 (row-major 18 x 18), channels 4 (u & 1) .. +3
+    int upy[2], upx[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int u = tid + 512 * k, pix = u >> 1;
-        const int py = pix / 18, px = pix - py * 18;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        const bool ok = (u < 648) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        uok |= (ok ? 1u : 0u) << k;
-        voffA[k] = ok ? img_base + (iy * p.W + ix) * pixbytes + (u & 1) * 16 : (int)0x80000000;
+        const int pix = (tid + 512 * k) >> 1;
+        upy[k] = pix / 18;
+        upx[k] = pix - upy[k] * 18;
     }
     const bool second_unit = wave < 3;                 // scalar: units 512 .. 647 live in waves 0 - 2
     const bool unit1_live = tid + 512 < 648;
@@ -146,45 +127,102 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     const float* t_rd = Rw + ((2 * wave) * 18 + 2 * tx) * 8 + lch;    // + (r * 18 + s) * 8
     const int v_wr = ltile * 8 + 4 * ((lch >> 2) ^ ((ltile >> 3) & 1)) + (lch & 3);   // this thread's float in a V row
     const int last = p.nch - 1;
-    // XF: padding must be 0 AFTER the affine; interior regions skip the selects with one scalar branch
-    const bool any_pad = XF && __builtin_amdgcn_ballot_w64(uok != (unit1_live ? 3u : 1u)) != 0;
     const float relu_floor = (XF && p.in_relu) ? 0.f : -INFINITY;
-    if (XF) {
-        for (int i = tid; i < p.Cin; i += 512) {
-            ABs[i] = p.in_a[n * p.Cin + i];
-            ABs[XFMAX + i] = p.in_b[n * p.Cin + i];
+
+    // Persistent workgroups, one per CU (the kernel is LDS-bound to one anyway).  XCD-aware order: block b runs on XCD
+    // b % 8 and walks the virtual ids b, b + gridDim.x, ... (gridDim.x % 8 == 0: it stays on its XCD); each XCD owns a
+    // contiguous run of tiles, cout tiles fastest, so the Cout/64 tiles that read one input region share one L2.
+    // A tile's first two chunks are requested BEFORE the previous tile's epilogue: the prologue then is LDS work only.
+    struct Tile {
+        int rg, tn, n, oy0, ox0, n0;   // scalars
+        int voffA[2];                  // byte offsets of the thread's two patch units, or out of range (zero padding)
+        unsigned uok;                  // bit k: unit k is a pixel inside the image
+        bool any_pad, valid;           // scalars
+    };
+    const int T = p.regions * p.tilesN;
+    const int per = (T + 7) >> 3;
+    auto setup = [&](int vb) {
+        Tile t;
+        const int tile = (vb & 7) * per + (vb >> 3);
+        t.valid = vb < per * 8 && tile < T;
+        const int tl = t.valid ? tile : 0;
+        t.rg = tl / p.tilesN; t.tn = tl - t.rg * p.tilesN;
+        t.n = t.rg / (p.RY * p.RX);
+        const int rrem = t.rg - t.n * p.RY * p.RX;
+        const int ry = rrem / p.RX, rx = rrem - ry * p.RX;
+        t.oy0 = ry * 16; t.ox0 = rx * 16; t.n0 = t.tn * 64;
+        const int img_base = INB8 ? (t.n * (p.Cin >> 3)) * p.H * p.W * 32 : t.n * p.H * p.W * p.Cin * 4;
+        t.uok = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int iy = t.oy0 - 1 + upy[k], ix = t.ox0 - 1 + upx[k];
+            const bool ok = (k == 0 || unit1_live) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            t.uok |= (ok ? 1u : 0u) << k;
+            t.voffA[k] = ok ? img_base + (iy * p.W + ix) * pixbytes + (tid & 1) * 16 : (int)0x80000000;
         }
-        __syncthreads();
-    }
+        // XF: padding must be 0 AFTER the affine; interior regions skip the selects with one scalar branch
+        t.any_pad = XF && __builtin_amdgcn_ballot_w64(t.uok != (unit1_live ? 3u : 1u)) != 0;
+        return t;
+    };
 
     f32x4 sa[2];          // the thread's two patch units of the chunk in flight
+    f32x4 pa[2];          // ... of chunk 1 of a tile being prefetched
     f32x4 su[2][4];       // weight pieces: chunk k lives in set k % 2
+    float tab_a = 0.f, tab_b = 0.f;   // XF: this thread's entry of the next image's (a, b) table
     float d[16];          // T: the 4 x 4 patch of (tile, channel)
-    if (ABL & 9) { sa[0] = f32x4{1.f, 1.f, 1.f, 1.f}; sa[1] = sa[0]; }
+    if (ABL & 9) { sa[0] = f32x4{1.f, 1.f, 1.f, 1.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0]; }
+    Tile cur = setup(blockIdx.x);
+    auto ld_a = [&](const Tile& t, int ck, int k) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, t.voffA[k], ck * chunk_bytes, 0));
+    };
+    auto ld_u = [&](const Tile& t, int ck, int z) {
+        return __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, tid * 16 + z * 8192, (t.tn * p.nch + ck) * (WBUF * 4), 0));
+    };
+    auto prefetch = [&](const Tile& t) {   // chunks 0 and 1 of tile t (Cin >= 32: both exist)
+        if (!(ABL & 8)) {
+            sa[0] = ld_a(t, 0, 0); pa[0] = ld_a(t, 1, 0);
+            if (second_unit) { sa[1] = ld_a(t, 0, 1); pa[1] = ld_a(t, 1, 1); }
+        }
+#pragma unroll
+        for (int z = 0; z < 4; ++z) { su[0][z] = ld_u(t, 0, z); su[1][z] = ld_u(t, 1, z); }
+        if (XF) {
+            if (tid < p.Cin) { tab_a = p.in_a[t.n * p.Cin + tid]; tab_b = p.in_b[t.n * p.Cin + tid]; }
+        }
+    };
     auto g_a = [&](int chunk, int k) {                 // G, patch unit k
         if (ABL & 8) return;
         const int ck = chunk < last ? chunk : last;    // the pipeline requests past the end: clamp (the data is never used)
-        if (k == 0 || second_unit)
-            sa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voffA[k], ck * chunk_bytes, 0));
+        if (k == 0 || second_unit) sa[k] = ld_a(cur, ck, k);
     };
     auto g_u = [&](auto set_c, int chunk, int z) {     // G, weight piece z = 0..3
         constexpr int SET = decltype(set_c)::value;
-        const int ck = chunk < last ? chunk : last;
-        su[SET][z] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, tid * 16 + z * 8192, (tn * p.nch + ck) * (WBUF * 4), 0));
+        su[SET][z] = ld_u(cur, chunk < last ? chunk : last, z);
     };
-    auto r_a = [&](int buf, int chunk, int k) {        // R, patch unit k (the affine + ReLU of the producer's GroupNorm)
+    auto affine = [&](f32x4 v, f32x4 a4, f32x4 b4, int k) {   // the producer's GroupNorm apply (+ReLU); padding stays 0
+        v = v * a4 + b4;
+        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+        if (cur.any_pad) { if (!((cur.uok >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        return v;
+    };
+    auto r_a = [&](int buf, int chunk, int k) {        // R, patch unit k
         if (k == 1 && !second_unit) return;
         f32x4 v = sa[k];
         if (XF) {
-            const int ck = chunk < last ? chunk : last;
-            const int c4 = ck * 8 + (tid & 1) * 4;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ABs + c4), b4 = *reinterpret_cast<const f32x4*>(ABs + XFMAX + c4);
-            v = v * a4 + b4;
-            v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-            if (any_pad) { if (!((uok >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            const int c4 = (chunk < last ? chunk : last) * 8 + (tid & 1) * 4;
+            const float* tab = ABs + par * 2 * XFMAX;
+            v = affine(v, *reinterpret_cast<const f32x4*>(tab + c4), *reinterpret_cast<const f32x4*>(tab + XFMAX + c4), k);
         }
         if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + buf * RAWBUF + (tid + 512 * k) * 4) = v;
+    };
+    auto r_a_pro = [&](int chunk01, int k) {           // R of the prefetched chunks 0 (sa) and 1 (pa) -> raw[chunk01]
+        if (k == 1 && !second_unit) return;
+        f32x4 v = chunk01 ? pa[k] : sa[k];
+        if (XF) {
+            const float* tab = ABs + par * 2 * XFMAX + chunk01 * 8 + (tid & 1) * 4;
+            v = affine(v, *reinterpret_cast<const f32x4*>(tab), *reinterpret_cast<const f32x4*>(tab + XFMAX), k);
+        }
+        if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + chunk01 * RAWBUF + (tid + 512 * k) * 4) = v;
     };
     auto r_u = [&](auto set_c, int buf, int z) {       // R, weight piece z
         constexpr int SET = decltype(set_c)::value;
@@ -207,6 +245,20 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         dst[2 * 512] = t[2] - t[1];
         dst[3 * 512] = t[1] - t[3];
     };
+    // ---- MFMA operand fragments: A[m = lane & 31][k = lane >> 5] = V row (tile), B = U row (cout)
+    const int l31 = lane & 31, half = lane >> 5;
+    const float* a_lds = Vs + (wi * 4 * 64 + l31) * 8 + 4 * (half ^ ((l31 >> 3) & 1));          // + tb * 256 (+32 rows keeps the swizzle bit)
+    const float* b_lds = Us + (wi * 4 * 64 + nh * 32 + l31) * 8 + 4 * (half ^ ((l31 >> 3) & 1));
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+
+    if (cur.valid) prefetch(cur);
+    if (XF) {   // the first tile's table (later ones are written at the end of the previous tile's epilogue)
+        if (tid < p.Cin) { ABs[tid] = tab_a; ABs[XFMAX + tid] = tab_b; }
+        __syncthreads();
+    }
+    for (int vb = blockIdx.x; cur.valid; vb += gridDim.x) {   // an invalid tile is the end of this block's run
+    const int rg = cur.rg, n = cur.n, oy0 = cur.oy0, ox0 = cur.ox0, n0 = cur.n0;
 
     f32x16 acc[4][2];   // [frequency column j][tile block]
 #pragma unroll
@@ -216,10 +268,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][tb][r] = 0.f;
 
-    // ---- MFMA operand fragments: A[m = lane & 31][k = lane >> 5] = V row (tile), B = U row (cout)
-    const int l31 = lane & 31, half = lane >> 5;
-    const float* a_lds = Vs + (wi * 4 * 64 + l31) * 8 + 4 * (half ^ ((l31 >> 3) & 1));          // + tb * 256 (+32 rows keeps the swizzle bit)
-    const float* b_lds = Us + (wi * 4 * 64 + nh * 32 + l31) * 8 + 4 * (half ^ ((l31 >> 3) & 1));
     f32x4 fa0[2], fb0, fa1[2], fb1;
 #define WFRAG(FA, FB, buf, j, z)                                                                                    \
     do {                                                                                                            \
@@ -228,28 +276,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     } while (0)
 #define WMFMA(FA, FB, j, q) \
     acc[j][(q) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[(q) & 1][(q) >> 1], FB[(q) >> 1], acc[j][(q) & 1], 0, 0, 0)
-    using Set0 = std::integral_constant<int, 0>;
-    using Set1 = std::integral_constant<int, 1>;
-
-    // prologue: V[0], U[0] and raw[1] complete; patch of chunk 2 and weights of chunks 1 (set 1), 2 (set 0) in flight
-    g_a(0, 0); g_a(0, 1);
-#pragma unroll
-    for (int z = 0; z < 4; ++z) g_u(Set0{}, 0, z);
-    r_a(0, 0, 0); r_a(0, 0, 1);
+    // prologue, from the prefetched registers (chunks 0, 1): raw[0], raw[1], U[0], then V[0]; chunk 2 requested
+    r_a_pro(0, 0); r_a_pro(0, 1);
+    r_a_pro(1, 0); r_a_pro(1, 1);
 #pragma unroll
     for (int z = 0; z < 4; ++z) r_u(Set0{}, 0, z);
-    g_a(1, 0); g_a(1, 1);
+    g_a(2, 0); g_a(2, 1);
 #pragma unroll
-    for (int z = 0; z < 4; ++z) g_u(Set1{}, 1, z);
+    for (int z = 0; z < 4; ++z) g_u(Set0{}, 2, z);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) t_read(0, r);
 #pragma unroll
     for (int i = 0; i < 4; ++i) t_row(0, i);
-    r_a(1, 1, 0); r_a(1, 1, 1);
-    g_a(2, 0); g_a(2, 1);
-#pragma unroll
-    for (int z = 0; z < 4; ++z) g_u(Set0{}, 2, z);
     __syncthreads();
 #pragma unroll
     for (int z = 0; z < 3; ++z) WFRAG(fa0, fb0, 0, 0, z);
@@ -316,7 +355,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
 #undef WFRAG
 #undef WMFMA
 
-    if (ABL & 32) { asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][1]), "v"(acc[2][0]), "v"(acc[3][1])); continue; }
+    if (ABL & 32) {
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+        asm volatile("" ::"v"(acc[2][0]), "v"(acc[2][1]), "v"(acc[3][0]), "v"(acc[3][1]));
+        cur = setup(vb + gridDim.x);
+        if (cur.valid) prefetch(cur);
+        if (XF && tid < p.Cin) { ABs[(par ^ 1) * 2 * XFMAX + tid] = tab_a; ABs[(par ^ 1) * 2 * XFMAX + XFMAX + tid] = tab_b; }
+        par ^= 1;
+        __syncthreads();
+        continue;
+    }
+    // the next tile's first two chunks start their way in now (every staging register is free again)
+    const Tile nxt = setup(vb + gridDim.x);
+    if (nxt.valid) prefetch(nxt);
     // ---- epilogue.  D layout of a 32x32 block: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (tile).
     __syncthreads();   // every wave is past its last fragment read: the K-loop buffers become R[4 i][2 b][64 tiles][64 couts]
     float* Rs = smem;
@@ -386,7 +437,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             dst[0] = s; dst[1] = q;
         }
     }
+    if (XF && tid < p.Cin) {   // the next tile's (a, b) table (requested before the epilogue) into the idle half
+        ABs[(par ^ 1) * 2 * XFMAX + tid] = tab_a;
+        ABs[(par ^ 1) * 2 * XFMAX + XFMAX + tid] = tab_b;
+    }
+    par ^= 1;
     __syncthreads();   // the next tile's prologue overwrites the LDS this epilogue read
+    cur = nxt;
     }   // persistent tile loop
 }
 

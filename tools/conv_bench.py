@@ -45,7 +45,10 @@ def main():
     torch.cuda.synchronize()
     uniq = {}
     for x, pc, a, k in calls:
-        N, H, W, Cin = x.shape
+        if ops.is_b8(x):      # channel-blocked (N, C/8, H, W, 8)
+            N, H, W, Cin = x.shape[0], x.shape[2], x.shape[3], x.shape[1] * 8
+        else:
+            N, H, W, Cin = x.shape
         key = (N, H, W, Cin, pc.Cout, pc.KH, pc.stride, k.get('residual') is not None, k.get('in_ab') is not None,
                bool(k.get('gn_part')))
         uniq.setdefault(key, [0, x, pc, a, k])[0] += 1

@@ -24,7 +24,7 @@ for grp in ('sq', 'fetch', 'write'):
     res['duration_us_' + grp] = sum(dur) / len(dur) / 1e3
 simd_cycles = res['GRBM_GUI_ACTIVE'] / 8 * 1024
 out = {
-    'kernel': kernel.replace('void ', '').replace('(ConvParamsBf16)', '').replace('(ConvParams)', ''), 'batch': batch,
+    'kernel': kernel.replace('void ', '').replace('(ConvParamsBf16)', '').replace('(ConvParams)', '').replace('(WinoParams)', ''), 'batch': batch,
     'shape': '3x3 256->256 on (B,160,160,256), GN stats epilogue (tools/conv_single.py %s)' % os.environ.get('CONV_ARGS', ''),
     'hbm_read_bytes_per_launch': res['FETCH_SIZE'] * 1024 * 2, 'hbm_write_bytes_per_launch': res['WRITE_SIZE'] * 1024,
     'hbm_bytes_per_launch': res['FETCH_SIZE'] * 1024 * 2 + res['WRITE_SIZE'] * 1024,
@@ -38,7 +38,7 @@ out = {
 }
 sys.path.insert(0, root)
 from bench import kernel_source_sha16  # noqa: E402
-out['source_sha16'] = kernel_source_sha16()      # bench.py only replays this figure for the same kernel source
+out['source_sha16'] = kernel_source_sha16(match)      # bench.py only replays this figure for the same kernel source
 if 'bf16' in match:
     out['algorithmic_bytes_per_launch'] = batch * 160 * 160 * 256 * 2 * 2 + 256 * 2304 * 2
 json.dump(out, open(os.path.join(root, 'profiles', out_name), 'w'), indent=1)
