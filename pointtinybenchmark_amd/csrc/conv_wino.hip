@@ -205,14 +205,16 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         if (cur.any_pad) { if (!((cur.uok >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
         return v;
     };
-    auto r_a = [&](int buf, int chunk, int k) {        // R, patch unit k
+    f32x4 xa4, xb4;       // XF: the affine of the chunk about to be written (both units of a thread share the channel half)
+    auto xf_fetch = [&](int chunk) {                   // read one phase before r_a needs it: no LDS latency in front of an MFMA
+        const float* tab = ABs + par * 2 * XFMAX + (chunk < last ? chunk : last) * 8 + (tid & 1) * 4;
+        xa4 = *reinterpret_cast<const f32x4*>(tab);
+        xb4 = *reinterpret_cast<const f32x4*>(tab + XFMAX);
+    };
+    auto r_a = [&](int buf, int k) {                   // R, patch unit k
         if (k == 1 && !second_unit) return;
         f32x4 v = sa[k];
-        if (XF) {
-            const int c4 = (chunk < last ? chunk : last) * 8 + (tid & 1) * 4;
-            const float* tab = ABs + par * 2 * XFMAX;
-            v = affine(v, *reinterpret_cast<const f32x4*>(tab + c4), *reinterpret_cast<const f32x4*>(tab + XFMAX + c4), k);
-        }
+        if (XF) v = affine(v, xa4, xb4, k);
         if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + buf * RAWBUF + (tid + 512 * k) * 4) = v;
     };
     auto r_a_pro = [&](int chunk01, int k) {           // R of the prefetched chunks 0 (sa) and 1 (pa) -> raw[chunk01]
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             if (!(ABL & 1)) {
                 if (q & 1) r_u(nxt_c, buf ^ 1, q >> 1);
                 else t_row(buf ^ 1, q >> 1);
+                if (XF && q == 7) xf_fetch(c + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -325,8 +328,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             WMFMA(fa0, fb0, 2, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa1, fb1, buf, 3, q);
             if (!(ABL & 1)) {
-                if (q == 3) r_a(buf, c + 2, 0);
-                if (q == 4) r_a(buf, c + 2, 1);
+                if (q == 3) r_a(buf, 0);
+                if (q == 4) r_a(buf, 1);
                 if (q == 5 || q == 6 || q == 7) g_u(nxt_c, c + 3, q - 5);
             }
             __builtin_amdgcn_sched_barrier(0);
