@@ -11,7 +11,7 @@
 // ~2x the direct sum's (measured 7e-7 vs 3e-7 of max per layer, 2.8e-6 on the head logits against a 1e-4 bar).
 //
 // One workgroup = 512 threads = 8 waves, ONE per CU (128 KB of LDS, 2 waves per SIMD):
-//   output region 16x16 pixels of one image = 8x8 Winograd tiles (GEMM M = 64), 64 output channels (GEMM N = 64)
+//   output region 16x16 pixels of one image = 8x8 Winograd tiles (GEMM M = 64, row = 8 * tile column + tile row), 64 output channels (GEMM N = 64)
 //   wave (i, h): frequency row i (f = 4i..4i+3), cout half h: 4 x [64 tiles x 32 couts] accumulators = 128 registers
 //   K loop over chunks of 8 input channels, double-buffered LDS:
 //     V[16][64 tiles][8]  transformed input  (waves 0-3 load the 4x4 patches -- 16 x 8-byte loads per thread, zero padding
@@ -87,7 +87,8 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 template <int ABL, bool INB8, bool XF>
 __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     constexpr int XFMAX = 512;      // fused-affine launches keep the image's (a, b) table in LDS (Cin <= 512)
-    constexpr int RAWBUF = 2592;    // 18 x 18 pixels x 8 channels (floats)
+    constexpr int RAWROW = 148;     // a patch row: 18 pixels x 8 channels + 4 floats, so that 8 lanes two rows apart hit 8 distinct bank groups
+    constexpr int RAWBUF = 18 * RAWROW;
     __shared__ __attribute__((aligned(16))) float smem[4 * WBUF + 2 * RAWBUF + (XF ? 4 * XFMAX : 0)];   // V0 V1 U0 U1 raw0 raw1 [a | b] x 2
     float* Vs = smem;
     float* Us = smem + 2 * WBUF;
@@ -110,21 +111,24 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.u), 0, (int)((size_t)p.tilesN * p.nch * WBUF * 4), 0x00020000);
-    float* Rw = smem + 4 * WBUF;                       // raw0 raw1: [324 pixels][8 channels]
+    float* Rw = smem + 4 * WBUF;                       // raw0 raw1: [18 rows][18 pixels][8 channels], rows padded to RAWROW
     float* ABs = smem + 4 * WBUF + 2 * RAWBUF;         // XF: [a | b] of the current tile's image, and of the next tile's
     int par = 0;                                       //     table in use (flips per tile)
     // patch unit u = tid + 512 k: pixel u >> 1 (row-major 18 x 18), channels 4 (u & 1) .. +3
-    int upy[2], upx[2];
+    int upyx[2], raw_wr[2];   // patch (row << 8 | column) of the unit's pixel; its float offset in a raw buffer
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int pix = (tid + 512 * k) >> 1;
-        upy[k] = pix / 18;
-        upx[k] = pix - upy[k] * 18;
+        const int py = pix / 18, px = pix - py * 18;
+        upyx[k] = py << 8 | px;
+        raw_wr[k] = py * RAWROW + px * 8 + (tid & 1) * 4;
     }
     const bool second_unit = wave < 3;                 // scalar: units 512 .. 647 live in waves 0 - 2
     const bool unit1_live = tid + 512 < 648;
-    const int lch = tid & 7, tx = (tid >> 3) & 7, ltile = tid >> 3;   // T role: tile row = wave
-    const float* t_rd = Rw + ((2 * wave) * 18 + 2 * tx) * 8 + lch;    // + (r * 18 + s) * 8
+    // T role: tile COLUMN = wave, tile row = lane >> 3 (with RAWROW = 148 the 8 rows of a wave's tiles are 8 distinct bank
+    // groups: conflict-free reads); GEMM row m = 8 * column + row, so a wave writes 8 consecutive V rows
+    const int lch = tid & 7, tyl = (tid >> 3) & 7, ltile = wave * 8 + tyl;
+    const float* t_rd = Rw + (2 * tyl) * RAWROW + (2 * wave) * 8 + lch;    // + r * RAWROW + s * 8
     const int v_wr = ltile * 8 + 4 * ((lch >> 2) ^ ((ltile >> 3) & 1)) + (lch & 3);   // this thread's float in a V row
     const int last = p.nch - 1;
     const float relu_floor = (XF && p.in_relu) ? 0.f : -INFINITY;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         t.uok = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int iy = t.oy0 - 1 + upy[k], ix = t.ox0 - 1 + upx[k];
+            const int iy = t.oy0 - 1 + (upyx[k] >> 8), ix = t.ox0 - 1 + (upyx[k] & 255);
             const bool ok = (k == 0 || unit1_live) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             t.uok |= (ok ? 1u : 0u) << k;
             t.voffA[k] = ok ? img_base + (iy * p.W + ix) * pixbytes + (tid & 1) * 16 : (int)0x80000000;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         if (k == 1 && !second_unit) return;
         f32x4 v = sa[k];
         if (XF) v = affine(v, xa4, xb4, k);
-        if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + buf * RAWBUF + (tid + 512 * k) * 4) = v;
+        if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + buf * RAWBUF + raw_wr[k]) = v;
     };
     auto r_a_pro = [&](int chunk01, int k) {           // R of the prefetched chunks 0 (sa) and 1 (pa) -> raw[chunk01]
         if (k == 1 && !second_unit) return;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             const float* tab = ABs + par * 2 * XFMAX + chunk01 * 8 + (tid & 1) * 4;
             v = affine(v, *reinterpret_cast<const f32x4*>(tab), *reinterpret_cast<const f32x4*>(tab + XFMAX), k);
         }
-        if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + chunk01 * RAWBUF + (tid + 512 * k) * 4) = v;
+        if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + chunk01 * RAWBUF + raw_wr[k]) = v;
     };
     auto r_u = [&](auto set_c, int buf, int z) {       // R, weight piece z
         constexpr int SET = decltype(set_c)::value;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     };
     auto t_read = [&](int buf, int r) {                // T, patch row r -> registers
 #pragma unroll
-        for (int s = 0; s < 4; ++s) d[r * 4 + s] = t_rd[buf * RAWBUF + (r * 18 + s) * 8];
+        for (int s = 0; s < 4; ++s) d[r * 4 + s] = t_rd[buf * RAWBUF + r * RAWROW + s * 8];
     };
     auto t_row = [&](int buf, int i) {                 // T, row i of B^T d, then the column pass: frequencies (i, 0..3)
         float t[4];
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int t = (tid >> 4) + 32 * k;
-        const int oy = oy0 + 2 * (t >> 3), ox = ox0 + 2 * (t & 7);
+        const int oy = oy0 + 2 * (t & 7), ox = ox0 + 2 * (t >> 3);   // GEMM row t = 8 * tile column + tile row
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const f32x4 r0 = *reinterpret_cast<const f32x4*>(Rs + ((0 * 2 + b) * 64 + t) * 64 + c4 * 4);
@@ -483,8 +487,17 @@ extern "C" int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out,
     p.regions = N * p.RY * p.RX; p.tilesN = Cout / 64; p.nch = Cin / 8;
     const long long T = (long long)p.regions * p.tilesN;
     if (T >= (1ll << 30)) return CPR_ERR_UNSUPPORTED;
+    // CU count of the current device: an immutable hardware property, looked up once per device (a racing first call
+    // stores the same value twice)
+    static int cu_of_device[64] = {};
     int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cu_of_device[dev] == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu_of_device[dev] = v;
+        }
+        if (cu_of_device[dev] > 0) ncu = cu_of_device[dev];
+    }
     ncu = (ncu + 7) / 8 * 8;
     int grid = (int)((T + 7) / 8 * 8);
     if (grid > ncu && !wino_sched) grid = ncu;   // persistent: one workgroup per CU (bench hook sched = 1: one per tile)
