@@ -84,7 +84,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 // XF: fused per-(image, channel) affine (+ReLU) on the input = GroupNorm apply of the producing layer.
 // ABL (benchmark-only, results are then WRONG): bit0 = no global loads / transform / LDS writes, bit1 = no fragment reads,
 // bit2 = no barrier, bit3 = no patch loads, bit4 = no output stores, bit5 = no epilogue at all.  ABL = 0 in every product launch.
-template <int ABL, bool INB8, bool XF>
+template <int ABL, bool INB8, bool XF, int TSPREAD = 1>
 __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     constexpr int XFMAX = 512;      // fused-affine launches keep the image's (a, b) table in LDS (Cin <= 512)
     constexpr int RAWROW = 148;     // a patch row: 18 pixels x 8 channels + 4 floats, so that 8 lanes two rows apart hit 8 distinct bank groups
@@ -295,6 +295,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     for (int r = 0; r < 4; ++r) t_read(0, r);
 #pragma unroll
     for (int i = 0; i < 4; ++i) t_row(0, i);
+    if (TSPREAD == 1) {   // the loop finishes T of chunk 1 behind its first two phases
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t_read(1, r);
+    }
     __syncthreads();
 #pragma unroll
     for (int z = 0; z < 3; ++z) WFRAG(fa0, fb0, 0, 0, z);
@@ -302,18 +306,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     // One chunk c (LDS buffers buf = c & 1): the direct kernel's interleaved schedule with the frequency column j in the role
     // of the k-step; every staging instruction sits behind one of the wave's own MFMAs, spread so that the texture path sees
     // a steady trickle (a burst of loads stalls the wave AT the load, in front of its next MFMAs).
-    //   j = 0: MFMAs | prefetch the j = 1 fragments | T reads of chunk c+1 (raw[buf^1], complete since the last barrier)
-    //   j = 1: MFMAs | prefetch j = 2 | T rows of chunk c+1 -> V[buf^1] | R weights of chunk c+1 (set nxt_c) -> U[buf^1]
+    //   j = 0: MFMAs | prefetch the j = 1 fragments | T rows 0, 1 of chunk c+1 -> V[buf^1] (its patch sits in registers)
+    //   j = 1: MFMAs | prefetch j = 2 | T rows 2, 3 of chunk c+1 | R weights of chunk c+1 (set nxt_c) -> U[buf^1]
     //   j = 2: MFMAs | prefetch j = 3 | R patch of chunk c+2 -> raw[buf] | G weights of chunk c+3 (pieces 0-2) into set nxt_c
-    //   barrier (all reads of V/U[buf] and raw[buf^1] are complete, all writes to V/U[buf^1] and raw[buf] are visible)
-    //   j = 3: MFMAs | prefetch j = 0 of chunk c+1 | G patch of chunk c+3 | G weights piece 3
+    //   barrier (all reads of V/U[buf] are complete, all writes to V/U[buf^1] and raw[buf] are visible)
+    //   j = 3: MFMAs | prefetch j = 0 of chunk c+1 | T reads of chunk c+2 (raw[buf]) | G patch of chunk c+3 | G weights piece 3
+    // (TSPREAD = 0: T reads behind j = 0 and all four T rows behind j = 1.  Which one wins depends on what else the phases carry:
+    // the fused-affine instances run 2 % faster with TSPREAD = 0, the plain ones 0.7 % faster with 1 -- see the launcher)
     auto iteration = [&](auto nxt_c, int c) {
         const int buf = c & 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             WMFMA(fa0, fb0, 0, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa1, fb1, buf, 1, q);
-            if (q >= 4 && !(ABL & 1)) t_read(buf ^ 1, q - 4);
+            if (!(ABL & 1)) {
+                if (TSPREAD == 0) { if (q >= 4) t_read(buf ^ 1, q - 4); }
+                else { if (q == 3) t_row(buf ^ 1, 0); if (q == 6) t_row(buf ^ 1, 1); }   // patch read behind the last j = 3
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -322,7 +331,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             if (q < 3 && !(ABL & 2)) WFRAG(fa0, fb0, buf, 2, q);
             if (!(ABL & 1)) {
                 if (q & 1) r_u(nxt_c, buf ^ 1, q >> 1);
-                else t_row(buf ^ 1, q >> 1);
+                else if (TSPREAD == 0) t_row(buf ^ 1, q >> 1);
+                else if (q == 2) t_row(buf ^ 1, 2);
+                else if (q == 6) t_row(buf ^ 1, 3);
                 if (XF && q == 7) xf_fetch(c + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
                 if (q == 3) g_a(c + 3, 0);
                 if (q == 5) g_a(c + 3, 1);
                 if (q == 7) g_u(nxt_c, c + 3, 3);
+                if (TSPREAD == 1 && q >= 4) t_read(buf, q - 4);   // chunk c+2's patch (raw[buf], written behind j = 2)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
 // C-ABI ------------------------------------------------------------------------------------------
 #ifdef CPR_BENCH_HOOKS   // measurement build only (libcprhip_bench.so): register-set A/B and loop ablations, process-global
 static int wino_sched = 0, wino_ablate = 0;
-extern "C" int cpr_wino_set_variant(int sched, int ablate) {   // sched 1: one workgroup per tile instead of persistent ones
+extern "C" int cpr_wino_set_variant(int sched, int ablate) {   // sched 1: the other placement of the patch transform (TSPREAD flipped)
     CPR_CHECK_ARG((sched == 0 || sched == 1) && ablate >= 0 && ablate <= 32);
     wino_sched = sched;
     wino_ablate = ablate;
@@ -500,29 +512,31 @@ extern "C" int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out,
     }
     ncu = (ncu + 7) / 8 * 8;
     int grid = (int)((T + 7) / 8 * 8);
-    if (grid > ncu && !wino_sched) grid = ncu;   // persistent: one workgroup per CU (bench hook sched = 1: one per tile)
+    if (grid > ncu) grid = ncu;   // persistent: one workgroup per CU
     const bool b8 = (layout & CPR_WINO_IN_B8) != 0, xf = in_a != nullptr;
-#define WLAUNCH(A_)                                                                                                  \
-    do {                                                                                                             \
-        if (b8 && xf) hipLaunchKernelGGL((conv_wino_kernel<A_, true, true>), dim3(grid), dim3(512), 0, stream, p);    \
-        else if (b8) hipLaunchKernelGGL((conv_wino_kernel<A_, true, false>), dim3(grid), dim3(512), 0, stream, p);    \
-        else if (xf) hipLaunchKernelGGL((conv_wino_kernel<A_, false, true>), dim3(grid), dim3(512), 0, stream, p);    \
-        else hipLaunchKernelGGL((conv_wino_kernel<A_, false, false>), dim3(grid), dim3(512), 0, stream, p);           \
+    // TSPREAD: measured per instance (same box, B=64): fused-affine input 6.87 ms single-phase vs 7.02 spread; plain input 6.74 vs 6.69
+#define WLAUNCH(A_, F_)                                                                                                       \
+    do {                                                                                                                     \
+        if (b8 && xf) hipLaunchKernelGGL((conv_wino_kernel<A_, true, true, 0 ^ F_>), dim3(grid), dim3(512), 0, stream, p);    \
+        else if (b8) hipLaunchKernelGGL((conv_wino_kernel<A_, true, false, 1 ^ F_>), dim3(grid), dim3(512), 0, stream, p);    \
+        else if (xf) hipLaunchKernelGGL((conv_wino_kernel<A_, false, true, 0 ^ F_>), dim3(grid), dim3(512), 0, stream, p);    \
+        else hipLaunchKernelGGL((conv_wino_kernel<A_, false, false, 1 ^ F_>), dim3(grid), dim3(512), 0, stream, p);           \
     } while (0)
 #ifdef CPR_BENCH_HOOKS
-    if (wino_ablate) {
+    if (wino_ablate || wino_sched) {
         switch (wino_ablate) {
-            case 1: WLAUNCH(1); break;
-            case 2: WLAUNCH(2); break;
-            case 4: WLAUNCH(4); break;
-            case 8: WLAUNCH(8); break;
-            case 16: WLAUNCH(16); break;
-            case 32: WLAUNCH(32); break;
-            default: WLAUNCH(7); break;
+            case 0: WLAUNCH(0, 1); break;
+            case 1: WLAUNCH(1, 0); break;
+            case 2: WLAUNCH(2, 0); break;
+            case 4: WLAUNCH(4, 0); break;
+            case 8: WLAUNCH(8, 0); break;
+            case 16: WLAUNCH(16, 0); break;
+            case 32: WLAUNCH(32, 0); break;
+            default: WLAUNCH(7, 0); break;
         }
     } else
 #endif
-    WLAUNCH(0);
+    WLAUNCH(0, 0);
 #undef WLAUNCH
     CPR_LAUNCH_STATUS();
 }
