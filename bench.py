@@ -135,7 +135,9 @@ class ConvProbe:
             OH, OW = pc.out_hw(H, W)
             kind, v = ops.TRACE_CONV_VARIANT[1]          # what the launcher returned through its out-parameter
             if kind == 'wino':       # template instance of csrc/conv_wino.hip: <ABL = 0, INB8, XF>
-                variant = 'conv_wino_kernel<0, %s, %s>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false')
+                # <ABL = 0, INB8, XF, TSPREAD>; the launcher picks TSPREAD = 0 for the fused-affine instances, 1 for the plain ones
+                variant = 'conv_wino_kernel<0, %s, %s, %d>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false',
+                                                               0 if v & 4 else 1)
             elif kind == 'bf16':
                 variant = 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
             else:
