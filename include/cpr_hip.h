@@ -327,6 +327,7 @@ int cpr_conv_force_tile(int bm, int bn); /* force the conv output tile (0 = heur
 int cpr_conv_set_pipeline(int mode);     /* K-loop schedule: 1 = interleaved (product), 0 = phase-separated */
 int cpr_conv_set_ablation(int mode);     /* loop ablations: results are WRONG when non-zero */
 int cpr_wgrad_set_ablation(int mode);    /* same for the weight-gradient kernel */
+int cpr_conv_set_extra_lds(int bytes);   /* occupancy probe: dynamic LDS added to every direct-conv launch */
 int cpr_wino_set_variant(int sched, int ablate); /* Winograd: sched 1 = the other placement of the patch transform (see conv_wino.hip); loop ablations */
 #endif
 

@@ -484,6 +484,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 static int force_tile_bm = 0, force_tile_bn = 0;  // cpr_conv_force_tile, 0 = heuristic
 static int conv_pipeline = 1;                      // 1 = interleaved K loop (default), 0 = phase-separated (A/B reference)
 static int conv_ablate = 0;                        // cpr_conv_set_ablation
+static int conv_extra_lds = 0;                     // cpr_conv_set_extra_lds: dynamic LDS bytes added to every launch (occupancy probe)
+extern "C" int cpr_conv_set_extra_lds(int bytes) {
+    CPR_CHECK_ARG(bytes >= 0 && bytes <= 65536);
+    conv_extra_lds = bytes;
+    return CPR_OK;
+}
 extern "C" int cpr_conv_set_ablation(int mode) {
     CPR_CHECK_ARG(mode >= 0 && mode <= 16);
     conv_ablate = mode;
@@ -501,7 +507,7 @@ extern "C" int cpr_conv_force_tile(int bm, int bn) {
     return CPR_OK;
 }
 #else
-constexpr int force_tile_bm = 0, force_tile_bn = 0, conv_pipeline = 1, conv_ablate = 0;
+constexpr int force_tile_bm = 0, force_tile_bn = 0, conv_pipeline = 1, conv_ablate = 0, conv_extra_lds = 0;
 #endif
 
 extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
@@ -558,9 +564,9 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
 #define LAUNCH(BM_, BN_, MODE_, XF_)                                                                               \
     do {                                                                                                           \
         if (conv_pipeline == 0)                                                                                    \
-            hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 0>), dim3(grid), dim3(256), 0, stream, p); \
+            hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 0>), dim3(grid), dim3(256), conv_extra_lds, stream, p); \
         else                                                                                                       \
-            hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 1>), dim3(grid), dim3(256), 0, stream, p); \
+            hipLaunchKernelGGL((conv_mfma_kernel<BM_, BN_, MODE_, XF_, 1>), dim3(grid), dim3(256), conv_extra_lds, stream, p); \
     } while (0)
 #else
 #define LAUNCH(BM_, BN_, MODE_, XF_) \

@@ -22,10 +22,12 @@ def main():
     ap.add_argument('--out', default=None)
     ap.add_argument('--pipeline', type=int, default=1)
     ap.add_argument('--tile', default='0,0')
+    ap.add_argument('--extra-lds', type=int, default=0, help='occupancy probe: dynamic LDS bytes added to every direct-conv launch')
     args = ap.parse_args()
     from pointtinybenchmark_amd import _lib
     _lib.call('cpr_conv_set_pipeline', args.pipeline)
     _lib.call('cpr_conv_force_tile', *[int(v) for v in args.tile.split(',')])
+    _lib.call('cpr_conv_set_extra_lds', args.extra_lds)
     model = P.build_detector(bench.model_cfg()).cuda()
     model.load_state_dict(synthetic.locator_state_dict(50, 1, 0, 'cpr', 0), strict=True)
     batch = synthetic.synthetic_batch(args.batch, 640, 640, 32, 1, 0)
