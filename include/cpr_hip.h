@@ -243,6 +243,12 @@ int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH,
 int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w, float* ws,
                      int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int in_relu,
                      int accumulate, void* stream);
+/* The same weight gradient for 3x3 / stride 1 / pad 1 layers as fused Winograd F(2x2,3x3) (the adjoint of
+ * cpr_conv3x3_wino_fwd with respect to the weights: 2.25x fewer multiplies; csrc/conv_wino_wgrad.hip).  Cin % 64 == 0,
+ * Cout % 64 == 0; ws: cpr_conv3x3_wino_wgrad_workspace(...) floats (split-K partials, reduced inside the call). */
+int cpr_conv3x3_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
+int cpr_conv3x3_wino_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w, float* ws,
+                           int N, int H, int W, int Cin, int Cout, int in_relu, int accumulate, void* stream);
 /* nn.GroupNorm (+ReLU) backward from the raw conv output x, the forward affine a,b (N,C), mean/rstd (N,G):
  * dx (N,HW,C), dgamma/dbeta (C).  ws_part N*P*C*2 floats, ws_k 2*N*G + 2*N*C floats. */
 int cpr_gn_bwd(const float* x, const float* dz, const float* a, const float* b, const float* mean, const float* rstd,

@@ -127,3 +127,39 @@ def test_wino_blocked_layout_and_fused_affine(case):
         for xin in (x, _to_b8(x)):
             y = ops.conv3x3_wino(xin, pc, None, bias, False, in_ab=(a, b), in_relu=relu)
             assert torch.equal(y, refx), (relu, ops.is_b8(xin), float((y - refx).abs().max()))
+
+
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, False), (1, 20, 40, 128, 64, True), (3, 18, 34, 64, 128, True),
+                                  (2, 32, 32, 256, 256, False)])
+def test_wino_wgrad_matches_autograd(case):
+    """Winograd weight gradient (csrc/conv_wino_wgrad.hip) against fp64 autograd of the same conv, next to the direct kernel.
+    Stated bound: 2e-5 of the gradient's largest entry (sums of N*H*W products per entry; measured values are printed)."""
+    from pointtinybenchmark_amd import ops
+    N, H, W, Cin, Cout, xf = case
+    g = torch.Generator().manual_seed(N * 100 + W)
+    x = torch.randn((N, H, W, Cin), generator=g).cuda()
+    dy = torch.randn((N, H, W, Cout), generator=g).cuda()
+    ab = ((torch.rand((N, Cin), generator=g) + 0.5).cuda(), torch.randn((N, Cin), generator=g).cuda()) if xf else None
+    shape = (Cout, Cin, 3, 3)
+    gw = ops.conv2d_wgrad(dy, x, shape, 1, 1, in_ab=ab, in_relu=True)
+    ops.WINOGRAD[0] = False
+    try:
+        gd = ops.conv2d_wgrad(dy, x, shape, 1, 1, in_ab=ab, in_relu=True)
+    finally:
+        ops.WINOGRAD[0] = True
+    xin = x.double().cpu()
+    if xf:
+        xin = (xin * ab[0].double().cpu()[:, None, None, :] + ab[1].double().cpu()[:, None, None, :]).relu()
+    w = torch.zeros(shape, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xin.permute(0, 3, 1, 2), w, padding=1)
+    (y * dy.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    m = w.grad.abs().max().item()
+    ew = (gw.double().cpu() - w.grad).abs().max().item() / m
+    ed = (gd.double().cpu() - w.grad).abs().max().item() / m
+    print('wino wgrad %.2e direct %.2e of max' % (ew, ed))
+    assert ed <= 2e-5 and ew <= 2e-5, (ew, ed)
+    # accumulate=True adds into an existing gradient
+    base = torch.randn(shape, generator=g).cuda()
+    acc = base.clone()
+    ops.conv2d_wgrad(dy, x, shape, 1, 1, in_ab=ab, in_relu=True, grad=acc)
+    torch.testing.assert_close(acc - base, gw, rtol=1e-4, atol=1e-4 * m)

@@ -18,10 +18,12 @@ ap.add_argument('--cout', type=int, default=256)
 ap.add_argument('--k', type=int, default=3)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--xf', action='store_true')
+ap.add_argument('--no-wino', action='store_true', help='keep the 3x3 layer on the direct weight-gradient kernel')
 ap.add_argument('--ablate', type=int, default=0)
 args = ap.parse_args()
 from pointtinybenchmark_amd import _lib  # noqa: E402
 _lib.call('cpr_wgrad_set_ablation', args.ablate)
+ops.WINOGRAD[0] = not args.no_wino
 g = torch.Generator().manual_seed(0)
 x = torch.randn((args.batch, args.hw, args.hw, args.cin), generator=g).cuda()
 dy = torch.randn((args.batch, args.hw, args.hw, args.cout), generator=g).cuda()
