@@ -688,7 +688,8 @@ def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False
     KH, KW = weight_shape[2], weight_shape[3]
     assert weight_shape[0] == Cout and weight_shape[1] == Cin, (weight_shape, Cout, Cin)
     if WINOGRAD[0] and KH == 3 and KW == 3 and stride == 1 and padding == 1 and Cin % 64 == 0 and Cout % 64 == 0 and \
-            x.dtype == torch.float32 and W / float((W + 15) // 16 * 16) >= WINO_MIN_FILL and (in_ab is None or Cin <= 512):
+            x.dtype == torch.float32 and W / float((W + 15) // 16 * 16) >= WINO_MIN_FILL and H * W >= 1024 and \
+            (in_ab is None or Cin <= 512):     # (20x20 maps: too few tiles per K slice against 16 frequencies of partials)
         # fused Winograd F(2x2,3x3) weight gradient (csrc/conv_wino_wgrad.hip): 16 GEMMs over the tiles, 2.25x fewer multiplies
         n = _lib.call('cpr_conv3x3_wino_wgrad_workspace', N, H, W, Cin, Cout, positive=True)
         ws = torch.empty((n,), device=x.device, dtype=torch.float32)

@@ -1,8 +1,2 @@
 cd /root/repo
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests -q -m gpu --tb=short -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|Error" | head -10
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 600 python bench.py > gpurun_out/r2final3_bench.json 2> gpurun_out/r2final3_bench.err; cut -c1-200 gpurun_out/r2final3_bench.json
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o t -- python /root/repo/bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline --no-probe > /tmp/prof_t.log 2>&1 )
-find /tmp/prof_t -name "*kernel_stats*" -exec cp {} gpurun_out/r2final3_train_kernel_stats.csv \; 2>/dev/null
-head -8 gpurun_out/r2final3_train_kernel_stats.csv | cut -c1-150
+for shp in "--hw 40 --cin 256 --cout 256" "--hw 80 --cin 128 --cout 128" "--hw 20 --cin 512 --cout 512" "--hw 160 --cin 64 --cout 64" "--hw 160 --cin 256 --cout 256 --batch 2"; do for a in "" "--no-wino"; do b="--batch 64"; case "$shp" in *batch*) b="";; esac; timeout 120 python tools/wgrad_single.py $b --iters 5 $shp $a 2>&1 | grep -v amdgpu; done; done
