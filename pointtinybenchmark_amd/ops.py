@@ -680,6 +680,24 @@ def conv2d_dgrad(dy, pc_t, in_hw, stride=1, mask=None, add=None, colsum=False):
     return out
 
 
+def conv3x3_wino_wgrad(dy, x, weight_shape, in_ab=None, in_relu=False, grad=None, out=None):
+    """Weight gradient of a 3x3 / stride 1 / pad 1 conv as fused Winograd F(2x2,3x3) (csrc/conv_wino_wgrad.hip: 16 GEMMs over
+    the tiles, 2.25x fewer multiplies).  Same arguments as conv2d_wgrad; Cin % 64 == 0, Cout % 64 == 0."""
+    N, H, W, Cin = _check(x).shape
+    Cout = _check(dy).shape[-1]
+    assert tuple(weight_shape) == (Cout, Cin, 3, 3) and tuple(dy.shape[:3]) == (N, H, W)
+    n = _lib.call('cpr_conv3x3_wino_wgrad_workspace', N, H, W, Cin, Cout, positive=True)
+    ws = torch.empty((n,), device=x.device, dtype=torch.float32)
+    acc = grad is not None
+    if grad is None:
+        grad = out if out is not None else torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
+    assert tuple(grad.shape) == tuple(weight_shape) and grad.is_contiguous()
+    a, b = in_ab if in_ab is not None else (None, None)
+    _lib.call('cpr_conv3x3_wino_wgrad', _ptr(dy), _ptr(x), _ptr(a), _ptr(b), _ptr(grad), _ptr(ws), N, H, W, Cin, Cout,
+              int(in_relu), int(acc), _stream())
+    return grad
+
+
 def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False, grad=None, out=None):
     """grad_w [Cout][Cin][KH][KW]: accumulated into ``grad`` when given, written into ``out`` when given, else a new
     tensor.  in_ab: fused GroupNorm affine (+ReLU) of the input."""
@@ -690,17 +708,7 @@ def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False
     if WINOGRAD[0] and KH == 3 and KW == 3 and stride == 1 and padding == 1 and Cin % 64 == 0 and Cout % 64 == 0 and \
             x.dtype == torch.float32 and W / float((W + 15) // 16 * 16) >= WINO_MIN_FILL and H * W >= 1024 and \
             (in_ab is None or Cin <= 512):     # (20x20 maps: too few tiles per K slice against 16 frequencies of partials)
-        # fused Winograd F(2x2,3x3) weight gradient (csrc/conv_wino_wgrad.hip): 16 GEMMs over the tiles, 2.25x fewer multiplies
-        n = _lib.call('cpr_conv3x3_wino_wgrad_workspace', N, H, W, Cin, Cout, positive=True)
-        ws = torch.empty((n,), device=x.device, dtype=torch.float32)
-        acc = grad is not None
-        if grad is None:
-            grad = out if out is not None else torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
-        assert tuple(grad.shape) == tuple(weight_shape) and grad.is_contiguous()
-        a, b = in_ab if in_ab is not None else (None, None)
-        _lib.call('cpr_conv3x3_wino_wgrad', _ptr(dy), _ptr(x), _ptr(a), _ptr(b), _ptr(grad), _ptr(ws), N, H, W, Cin, Cout,
-                  int(in_relu), int(acc), _stream())
-        return grad
+        return conv3x3_wino_wgrad(dy, x, weight_shape, in_ab, in_relu, grad, out)
     n = _lib.call('cpr_conv2d_wgrad_workspace', N, OH, OW, Cin, Cout, KH, KW, positive=True)
     ws = torch.empty((n,), device=x.device, dtype=torch.float32)
     acc = grad is not None

@@ -141,7 +141,7 @@ def test_wino_wgrad_matches_autograd(case):
     dy = torch.randn((N, H, W, Cout), generator=g).cuda()
     ab = ((torch.rand((N, Cin), generator=g) + 0.5).cuda(), torch.randn((N, Cin), generator=g).cuda()) if xf else None
     shape = (Cout, Cin, 3, 3)
-    gw = ops.conv2d_wgrad(dy, x, shape, 1, 1, in_ab=ab, in_relu=True)
+    gw = ops.conv3x3_wino_wgrad(dy, x, shape, in_ab=ab, in_relu=True)
     ops.WINOGRAD[0] = False
     try:
         gd = ops.conv2d_wgrad(dy, x, shape, 1, 1, in_ab=ab, in_relu=True)
@@ -161,5 +161,5 @@ def test_wino_wgrad_matches_autograd(case):
     # accumulate=True adds into an existing gradient
     base = torch.randn(shape, generator=g).cuda()
     acc = base.clone()
-    ops.conv2d_wgrad(dy, x, shape, 1, 1, in_ab=ab, in_relu=True, grad=acc)
+    ops.conv3x3_wino_wgrad(dy, x, shape, in_ab=ab, in_relu=True, grad=acc)
     torch.testing.assert_close(acc - base, gw, rtol=1e-4, atol=1e-4 * m)
