@@ -266,3 +266,25 @@ def test_bench_gpus_n_spawns_its_own_ranks():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3
     assert d['ms_per_step'] >= 19.0, d          # rank 1 sleeps 20 ms per step: the MAX over ranks is reported
+
+
+def test_winograd_dispatch_rules_host_side():
+    """Which layers run the fused Winograd kernels is host logic (ops.wino_eligible): 3x3 / stride 1 / pad 1, fp32,
+    Cin % 16 == 0 (>= 32), Cout % 64 == 0 and at least 60 % of the 16x16 output regions filled."""
+    import torch
+    from pointtinybenchmark_amd import ops
+    pc = ops.PackedConv(torch.zeros(64, 64, 3, 3), 1, 1)
+    assert ops.wino_eligible(pc, 160, 160) and ops.wino_eligible(pc, 40, 40) and ops.wino_eligible(pc, 200, 336)
+    assert not ops.wino_eligible(pc, 20, 20)                                             # 39 % of its regions
+    assert not ops.wino_eligible(ops.PackedConv(torch.zeros(64, 64, 3, 3), 2, 1), 160, 160)      # stride 2
+    assert not ops.wino_eligible(ops.PackedConv(torch.zeros(64, 64, 1, 1), 1, 0), 160, 160)      # 1x1
+    assert not ops.wino_eligible(ops.PackedConv(torch.zeros(32, 64, 3, 3), 1, 1), 160, 160)      # Cout % 64
+    assert not ops.wino_eligible(pc, 160, 160, torch.bfloat16)                                   # bf16 mode stays direct
+    saved = ops.WINOGRAD[0]
+    try:
+        ops.WINOGRAD[0] = False
+        assert not ops.wino_eligible(pc, 160, 160)                                               # CPR_WINOGRAD=0
+    finally:
+        ops.WINOGRAD[0] = saved
+    x5 = torch.zeros(2, 8, 16, 16, 8)
+    assert ops.is_b8(x5) and not ops.is_b8(torch.zeros(2, 16, 16, 64))
