@@ -33,7 +33,19 @@ def kernel_source_sha16(kernel_name='conv_mfma_kernel'):
     import hashlib
     fname = 'conv_wino.hip' if 'wino' in kernel_name else 'conv_mfma_bf16.hip' if 'bf16' in kernel_name else 'conv_mfma.hip'
     src = os.path.join(ROOT, 'pointtinybenchmark_amd', 'csrc', fname)
-    return hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
+    return source_code_sha16(open(src).read())
+
+
+def source_code_sha16(text):
+    """sha256 of the CODE of a source file: `//` comments and blank lines do not count, so a reworded comment does not
+    invalidate a PMC measurement (neither kernel source has `//` inside a string literal)."""
+    import hashlib
+    lines = []
+    for ln in text.splitlines():
+        code = ln.split('//', 1)[0].rstrip()
+        if code.strip():
+            lines.append(code)
+    return hashlib.sha256('\n'.join(lines).encode()).hexdigest()[:16]
 
 
 def pmc_traffic(kernel_name, batch):

@@ -7,20 +7,21 @@
 // Why: the direct implicit GEMM sits at 0.93 of the fp32 MFMA peak -- the only way past it at fp32 is fewer multiplies.
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 4x4 input patch d -> 2x2 outputs, 16 multiplies instead of 36 (2.25x)
 // turns the conv into 16 independent GEMMs  M_f[tile][cout] = sum_cin V_f[tile][cin] * U_f[cin][cout]  (f = 4i+j the
-// "frequency").  The transforms only add/subtract (B, A) or are done once per weight update (G), so the fp32 error is
-// ~2x the direct sum's (measured 7e-7 vs 3e-7 of max per layer, 2.8e-6 on the head logits against a 1e-4 bar).
+// "frequency").  The transforms only add/subtract (B, A) or are done once per weight update (G) and the K chain per output
+// is 9x shorter than the direct sum's: against an fp64 convolution the result is 2e-7 .. 7e-7 of the map's max (direct kernel:
+// 6e-7 .. 2e-6; tests/test_gpu_wino.py), ~3e-6 on the head logits against the 1e-4 bar.
 //
-// One workgroup = 512 threads = 8 waves, ONE per CU (128 KB of LDS, 2 waves per SIMD):
+// One workgroup = 512 threads = 8 waves, ONE per CU (up to 160 KB of LDS, 2 waves per SIMD), persistent over its run of tiles:
 //   output region 16x16 pixels of one image = 8x8 Winograd tiles (GEMM M = 64, row = 8 * tile column + tile row), 64 output channels (GEMM N = 64)
 //   wave (i, h): frequency row i (f = 4i..4i+3), cout half h: 4 x [64 tiles x 32 couts] accumulators = 128 registers
 //   K loop over chunks of 8 input channels, double-buffered LDS:
-//     V[16][64 tiles][8]  transformed input  (waves 0-3 load the 4x4 patches -- 16 x 8-byte loads per thread, zero padding
-//                         through the buffer descriptor's range check -- transform them in registers and write 16 x 8 bytes)
-//     U[16][64 couts][8]  transformed weights (waves 4-7 copy the pre-packed 32 KB chunk image, 8 x 16 bytes per thread)
+//     V[16][64 tiles][8]  transformed input      U[16][64 couts][8]  transformed weights (pre-packed 32 KB chunk images)
 //   rows are 32 bytes = two 16-byte halves (k0-3 for lanes < 32, k4-7 for lanes >= 32 of the MFMA operand); the halves of
 //   rows 8-15 of every 16 are swapped so a ds_read_b128 of 16 consecutive rows covers all 64 banks.
-//   The loop is the direct kernel's interleaved schedule with the frequency j in the role of the k-step: every global load,
-//   transform and LDS access sits behind one of the wave's own 32 MFMAs per chunk, one barrier per chunk.
+//   Staging (all waves alike, see the kernel): the 18x18 pixel patch of a chunk is fetched ONCE into a raw LDS buffer (with
+//   the producer's GroupNorm affine + ReLU applied), the transform B^T d B reads it from there; the loop is the direct
+//   kernel's interleaved schedule with the frequency j in the role of the k-step: every load, transform step and LDS access
+//   sits behind one of the wave's own 32 MFMAs per chunk, one barrier per chunk.
 //   Epilogue: R[i][b] = sum_j M[i][j] A[j][b] in registers, exchanged through LDS (the K-loop buffers, 128 KB),
 //   Y[a][b] = sum_i A[i][a] R[i][b], then scale/bias/ReLU and (optionally) the GroupNorm (sum, sumsq) partials.
 #include <type_traits>
