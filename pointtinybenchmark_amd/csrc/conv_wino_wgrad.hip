@@ -98,24 +98,25 @@ __global__ __launch_bounds__(512, 1) void conv_wino_wgrad_kernel(WinoWgradParams
 
     f32x4 sx[3], sd;            // staging registers of the chunk in flight
     unsigned okbits = 0;        // bit k: x unit k of that chunk is inside the image (XF: padding stays 0 after the affine)
-    auto g_all = [&](int k_chunk) {          // G: request chunk k_chunk (clamped: the pipeline runs two chunks past the end)
+    auto g_x = [&](int k_chunk, int k) {      // G: request x unit k of chunk k_chunk (clamped: the pipeline runs two chunks past the end)
+        if (k == 2 && !unit2_wave) return;
         const int kc = k_chunk < nk ? k_chunk : nk - 1;
         const int tyr = row0 + kc / p.SX, sxi = kc - (kc / p.SX) * p.SX;
         const int iy0 = 2 * tyr - 1, ix0 = 16 * sxi - 1;
         const int xbase = (((n * p.H + iy0) * p.W + ix0) * p.Cin + ci0) * 4;        // may be "negative": only used when in range
-        okbits = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k == 2 && !unit2_wave) break;
-            const bool ok = (k < 2 || unit2) & ((unsigned)(iy0 + xr[k]) < (unsigned)p.H) & ((unsigned)(ix0 + xc[k]) < (unsigned)p.W);
-            okbits |= (ok ? 1u : 0u) << k;
-            sx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? xbase + xrel[k] : (int)0x80000000, 0, 0));
-        }
-        const int oy = 2 * tyr + da, ox = 16 * sxi + dc;
-        const bool okd = (oy < p.H) & (ox < p.W);
+        const bool ok = (k < 2 || unit2) & ((unsigned)(iy0 + xr[k]) < (unsigned)p.H) & ((unsigned)(ix0 + xc[k]) < (unsigned)p.W);
+        if (k == 0) okbits = 0;
+        okbits |= (ok ? 1u : 0u) << k;
+        sx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? xbase + xrel[k] : (int)0x80000000, 0, 0));
+    };
+    auto g_d = [&](int k_chunk) {             // G: request the dy unit
+        const int kc = k_chunk < nk ? k_chunk : nk - 1;
+        const int tyr = row0 + kc / p.SX, sxi = kc - (kc / p.SX) * p.SX;
+        const bool okd = (2 * tyr + da < p.H) & (16 * sxi + dc < p.W);
         const int dbase = (((n * p.H + 2 * tyr) * p.W + 16 * sxi) * p.Cout + co0) * 4;
         sd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, okd ? dbase + drel : (int)0x80000000, 0, 0));
     };
+    auto g_all = [&](int k_chunk) { g_x(k_chunk, 0); g_x(k_chunk, 1); g_x(k_chunk, 2); g_d(k_chunk); };
     auto r_x = [&](int k) {                  // R: x unit k -> raw (affine + ReLU of the producer's GroupNorm; padding stays 0)
         if (k == 2 && !unit2_wave) return;
         f32x4 v = sx[k];
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_wgrad_kernel(WinoWgradParams
         for (int q = 0; q < 8; ++q) {
             WMFMA(fa1, fb1, 3, q);
             if (q < 3) WFRAG(fa0, fb0, buf ^ 1, 0, q);
-            if (q == 4) g_all(c + 3);
+            if (q == 1) g_x(c + 3, 0);          // one request every other MFMA: a burst stalls the wave AT the loads
+            if (q == 3) g_x(c + 3, 1);
+            if (q == 5) g_x(c + 3, 2);
+            if (q == 7) g_d(c + 3);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("" ::: "memory");
