@@ -13,6 +13,7 @@ CASES = [  # N, H, W, Cin, Cout, scale/bias, relu
     (2, 16, 16, 32, 64, True, False),        # four chunks only
     (1, 40, 40, 256, 256, True, True),       # layer3 3x3 shape
     (3, 18, 34, 32, 64, False, True),        # one spare row / two spare columns
+    (1, 19, 21, 64, 64, True, True),         # odd height and width
     (1, 160, 160, 256, 256, False, False),   # head tower shape
 ]
 
@@ -129,7 +130,7 @@ def test_wino_blocked_layout_and_fused_affine(case):
             assert torch.equal(y, refx), (relu, ops.is_b8(xin), float((y - refx).abs().max()))
 
 
-@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, False), (1, 20, 40, 128, 64, True), (3, 18, 34, 64, 128, True),
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, False), (1, 20, 40, 128, 64, True), (3, 18, 34, 64, 128, True), (1, 19, 21, 64, 64, True),
                                   (2, 32, 32, 256, 256, False)])
 def test_wino_wgrad_matches_autograd(case):
     """Winograd weight gradient (csrc/conv_wino_wgrad.hip) against fp64 autograd of the same conv, next to the direct kernel.
