@@ -4,7 +4,7 @@ first ``num_outs`` 3x3 output convs exist.  GroupNorm-apply and the top-down add
 import torch.nn as nn
 
 from .. import ops
-from ..layers import ConvModule, _PackCache, conv_gn, packed_conv
+from ..layers import ConvModule, _PackCache, conv_gn
 from ..registry import NECKS
 
 
