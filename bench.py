@@ -31,7 +31,8 @@ def kernel_source_sha16(kernel_name='conv_mfma_kernel'):
     """Content hash of the source file of a conv kernel: profiles/pmc_dominant_kernel.json is stamped with it
     (tools/pmc_to_json.py), so a PMC figure measured on an older kernel is never replayed into a newer bench line."""
     import hashlib
-    fname = 'conv_wino.hip' if 'wino' in kernel_name else 'conv_mfma_bf16.hip' if 'bf16' in kernel_name else 'conv_mfma.hip'
+    fname = 'conv_wino_wgrad.hip' if 'wino_wgrad' in kernel_name else 'conv_wino.hip' if 'wino' in kernel_name else \
+        'conv_mfma_bf16.hip' if 'bf16' in kernel_name else 'conv_mfma.hip'
     src = os.path.join(ROOT, 'pointtinybenchmark_amd', 'csrc', fname)
     return source_code_sha16(open(src).read())
 
