@@ -121,11 +121,18 @@ def test_oracle_autograd_matches_reference_autograd(golden_dir, name):
         assert np.abs(smp - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6 * gmax), k
 
 
-@pytest.mark.parametrize('name', list(CPR_CASES))
+def _refine_names():
+    from oracle.gen_golden_r2 import REFINE_CASES
+    return list(REFINE_CASES)
+
+
+@pytest.mark.parametrize('name', _refine_names())
 def test_oracle_refine_internals_match_reference(golden_dir, name):
     """PointRefiner internals of the restatement (chosen-point masks, not_refine, refined points, scores) against what the
-    reference's own refine_single returned (tests/golden/refine.npz, oracle/gen_golden_r2.py): masks bit-exact."""
-    cfg = CPR_CASES[name]
+    reference's own refine_single returned (tests/golden/refine.npz, oracle/gen_golden_r2.py): masks bit-exact.
+    ``cpr_r50_c80_s8_r8_live`` is the C = 80 / K = 289 case whose merge branch is not empty (576 chosen points)."""
+    from oracle.gen_golden_r2 import REFINE_CASES
+    cfg = REFINE_CASES[name]
     g = _load(golden_dir, 'refine')
     p = name + ':'
     sd = synthetic.locator_state_dict(cfg['depth'], cfg['num_classes'], cfg['start_level'], 'cpr', cfg['seed'],
