@@ -6,8 +6,11 @@ A "step" is one pass of the hot path (BasicLocator.forward_train: backbone -> ne
 extraction / scoring / MIL + gfocal losses) over one batch of synthetic 640x640 tiles already resident in HBM.
 Images shard data-parallel with a fixed per-GPU batch (weak scaling); forward + loss has no data-path collective.
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel (conv_mfma_kernel<128,0>, the fp32-MFMA implicit-GEMM conv): algorithmic FLOPs
-                of its launches in the timed region / their summed HIP-event durations, vs the 157.3 TF fp32 MFMA peak
+  roofline      the dominant kernel (since round 2 a fused Winograd 3x3 conv on the fp32 matrix cores, csrc/conv_wino*.hip;
+                named in ``roofline.kernel``): the FLOPs its launches EXECUTE on the matrix pipe in the timed region / their
+                summed HIP-event durations, vs the 157.3 TF fp32 MFMA peak -> ``achieved`` / ``frac`` (<= 1).  The
+                algorithmic count of the same launches (2 * M * Cout * 9 * Cin, SURVEY.md 8d) is ``effective_tflops``;
+                ``algorithmic_speedup`` (2.25 for F(2x2,3x3), 4 for F(4x4,3x3)) is the ratio of the two
   cpu_baseline  the CPU oracle (torch-CPU restatement that executes the reference's op sequence bit for bit) timed on
                 this box's host cores on a bounded sample (rank 0, N=1 only)
 """
@@ -25,6 +28,16 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); only used with --dtype bf16
+
+
+def mult_reduction(kernel_name):
+    """Algorithmic multiplies / executed multiplies of a conv template instance: Winograd F(2x2,3x3) computes a 2x2 output
+    tile with 16 multiplies instead of 36, F(4x4,3x3) a 4x4 tile with 36 instead of 144; the direct kernels execute them all."""
+    if 'conv_wino4_kernel' in kernel_name:
+        return 4.0
+    if 'conv_wino_kernel' in kernel_name:
+        return 2.25
+    return 1.0
 
 
 def kernel_source_sha16(kernel_name='conv_mfma_kernel'):
@@ -628,27 +641,39 @@ def main():
             summ = probe.summary()
             name = dom_name if dom_name in summ else max(summ, key=lambda k: summ[k]['seconds'])
             dom = summ[name]                                   # dominant template instance, launches of the TIMED region
-            ach = dom['tflops']
+            red = mult_reduction(name)
+            eff = dom['tflops']                                # algorithmic FLOPs / time
+            ach = eff / red                                    # what the matrix pipe executes: the roofline figure (<= peak)
             conv_s = sum(v['seconds'] for v in fsum.values()) / 2   # per step, from the untimed full-probe pass
             conv_f = sum(v['flops'] for v in fsum.values()) / 2
+            conv_x = sum(v['flops'] / mult_reduction(k) for k, v in fsum.items()) / 2      # executed on the matrix pipe
             peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in name else PEAK_FP32_MFMA_TFLOPS
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                                'frac': ach / peak, 'traffic': pmc_traffic(name, args.batch), 'kernel': name,
-                               'launches': dom['launches'], 'flops_per_launch': dom['flops'] / dom['launches'],
+                               'what': 'achieved = FLOPs the kernel EXECUTES on the matrix pipe per launch / HIP-event launch '
+                                       'time (timed region); effective_tflops = the algorithmic 3x3-conv count '
+                                       '(2*M*Cout*9*Cin) of the same launches / the same time',
+                               'effective_tflops': eff, 'algorithmic_speedup': red,
+                               'launches': dom['launches'],
+                               'algorithmic_flops_per_launch': dom['flops'] / dom['launches'],
+                               'executed_flops_per_launch': dom['flops'] / dom['launches'] / red,
                                'avg_launch_ms': dom['seconds'] / dom['launches'] * 1e3,
                                'share_of_step_time': dom['seconds'] / elapsed,
-                               'all_conv_instances_tflops': conv_f / conv_s / 1e12,
-                               'per_instance_tflops': {k: round(v['tflops'], 2) for k, v in fsum.items()},
+                               'all_conv_instances_effective_tflops': conv_f / conv_s / 1e12,
+                               'all_conv_instances_executed_tflops': conv_x / conv_s / 1e12,
+                               'per_instance_effective_tflops': {k: round(v['tflops'], 2) for k, v in fsum.items()},
+                               'per_instance_executed_frac': {k: round(v['tflops'] / mult_reduction(k) / peak, 3)
+                                                              for k, v in fsum.items()},
+                               'per_instance_share_of_conv_time': {k: round(v['seconds'] / 2 / conv_s, 3) for k, v in fsum.items()},
                                'per_instance_source': 'every conv launch of 2 untimed steps bracketed with HIP events; '
                                                       'achieved/avg_launch_ms: the dominant instance inside the timed region'}
-            if 'wino' in name:
-                # frac > 1 is possible and meant: `achieved` counts the ALGORITHMIC flops of the 3x3 conv (2 * M * Cout * 9 * Cin,
-                # SURVEY.md 8d); Winograd F(2x2,3x3) executes 16 multiplies per 2x2 outputs instead of 36, so the matrix pipe
-                # itself runs at achieved / 2.25 -- that figure is the one to hold against the MFMA peak as a kernel-quality number
-                out['roofline'].update({'algorithm': 'fused Winograd F(2x2,3x3): 2.25x fewer multiplies than the algorithmic count',
-                                        'mfma_executed_tflops': ach / 2.25, 'mfma_executed_frac': ach / 2.25 / peak})
+            if red > 1:
+                out['roofline']['algorithm'] = 'fused Winograd %s: %.2fx fewer multiplies than the algorithmic count' % (
+                    'F(4x4,3x3)' if red == 4.0 else 'F(2x2,3x3)', red)
+            out['end_to_end_executed_tflops'] = conv_x / (elapsed / args.steps) / 1e12
+            out['end_to_end_executed_frac'] = conv_x / (elapsed / args.steps) / 1e12 / peak
             out['conv_time_frac'] = conv_s / (elapsed / args.steps)
-            out['end_to_end_tflops'] = conv_f / (elapsed / args.steps) / 1e12   # conv FLOPs of a step / step time
+            out['end_to_end_effective_tflops'] = conv_f / (elapsed / args.steps) / 1e12   # algorithmic conv FLOPs of a step / step time
         if world == 1 and not args.no_probe:
             try:
                 out['hbm_kernels'] = hbm_probe(args.batch, args.size)

@@ -93,4 +93,21 @@ __device__ __forceinline__ float d2_chain(float px, float py, float pn, float cx
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// The conv kernels address activations through buffer descriptors with 32-bit byte offsets (out-of-range offsets ARE the zero
+// padding), so one launch takes tensors below 2 GiB; the launchers walk a larger batch in balanced chunks of whole images
+// (every per-image quantity -- tile, region and GroupNorm-slot indexing -- is unchanged, so the results are bit-identical to an
+// unsplit launch).  Returns the images per launch (a multiple of `align` unless everything fits in one), or 0 when a single
+// image (or `align` of them) already exceeds the range.
+static inline int cpr_images_per_launch(int N, long long bytes_per_image, int align = 1) {
+    const long long lim = (1ll << 31) - 1;
+    if (bytes_per_image <= 0 || bytes_per_image > lim) return 0;
+    const long long fit = lim / bytes_per_image;
+    if (fit >= N) return N;
+    const long long launches = (N + fit - 1) / fit;
+    long long n = (N + launches - 1) / launches;          // balanced
+    n = (n + align - 1) / align * align;
+    if (n > fit) n = fit / align * align;
+    return (int)n;
+}
+static inline long long cpr_max2(long long a, long long b) { return a > b ? a : b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

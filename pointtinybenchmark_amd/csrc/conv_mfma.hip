@@ -510,10 +510,11 @@ extern "C" int cpr_conv_force_tile(int bm, int bn) {
 constexpr int force_tile_bm = 0, force_tile_bn = 0, conv_pipeline = 1, conv_ablate = 0, conv_extra_lds = 0;
 #endif
 
-extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
-                              const float* residual, const float* in_a, const float* in_b, float* gn_part, int N,
-                              int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad,
-                              int flags, int in_relu, int* variant_out, hipStream_t stream) {
+// one launch: every tensor below 2 GiB.  bm_fix > 0: the M tile of an earlier chunk of the same call (column-sum slots must line up)
+static int conv2d_fwd_launch(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
+                             const float* residual, const float* in_a, const float* in_b, float* gn_part, int N,
+                             int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad,
+                             int flags, int in_relu, int bm_fix, int* variant_out, hipStream_t stream) {
     CPR_CHECK_ARG(in && wgt && out);
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     CPR_CHECK_ARG(Kpad % BK == 0);
@@ -554,6 +555,7 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
         if (!(kt >= 16 && t128 >= 4096 && Cout > 64)) { bm = 64; bn = 64; }
     }
     if (force_tile_bm > 0 && (!gn_part || colsum_mode) && !in_a && !mode1) { bm = force_tile_bm; }
+    if (bm_fix > 0) bm = bm_fix;      // later chunk of a split batch: same M tile as the first one
     if (force_tile_bn > 0 && Cout > 64 && !mode1) { bn = force_tile_bn; }
     if (variant_out) *variant_out = bm * 1000000 + bn * 1000 + (mode1 ? 100 : 0) + (in_a ? 10 : 0) + conv_pipeline;
     p.tilesM = (p.M + bm - 1) / bm;
@@ -596,4 +598,38 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
     }
 #undef LAUNCH
     CPR_LAUNCH_STATUS();
+}
+
+extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
+                              const float* residual, const float* in_a, const float* in_b, float* gn_part, int N,
+                              int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad,
+                              int flags, int in_relu, int* variant_out, hipStream_t stream) {
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    CPR_CHECK_ARG(OH > 0 && OW > 0);
+    const long long in_img = (long long)H * W * Cin * 4, out_img = (long long)OH * OW * Cout * ((flags & CPR_CONV_OUT_BF16) ? 2 : 4);
+    const long long res_img = (long long)OH * OW * Cout * 4;
+    // column-sum partials are indexed by M tile across images: chunks must start on a 128-row boundary
+    int align = 1;
+    if (flags & CPR_CONV_COLSUM) { const long long r = (long long)OH * OW; align = 1; while ((r * align) % 128 != 0) align *= 2; }
+    const int per = cpr_images_per_launch(N, cpr_max2(cpr_max2(in_img, out_img), residual ? res_img : 0), align);
+    if (per <= 0) return CPR_ERR_UNSUPPORTED;
+    if (per >= N) return conv2d_fwd_launch(in, wgt, out, scale, bias, residual, in_a, in_b, gn_part, N, H, W, Cin, Cout, KH, KW,
+                                           stride, pad, Kpad, flags, in_relu, 0, variant_out, stream);
+    int bm_fix = 0, variant = 0;
+    const size_t oe = (flags & CPR_CONV_OUT_BF16) ? 2 : 4;
+    for (int n0 = 0; n0 < N; n0 += per) {
+        const int n = N - n0 < per ? N - n0 : per;
+        const size_t rows = (size_t)n0 * OH * OW;
+        // partial slots: one per 128-pixel tile of an image (GroupNorm statistics) or one per bm-row tile (column sums)
+        float* part = nullptr;
+        if (gn_part) part = gn_part + ((flags & CPR_CONV_COLSUM) ? (bm_fix ? rows / bm_fix : 0) : rows / 128) * Cout * 2;
+        const int rc = conv2d_fwd_launch(in + (size_t)n0 * H * W * Cin, wgt, (float*)((char*)out + rows * Cout * oe), scale, bias,
+                                         residual ? residual + rows * Cout : nullptr, in_a ? in_a + (size_t)n0 * Cin : nullptr,
+                                         in_b ? in_b + (size_t)n0 * Cin : nullptr, part, n, H, W, Cin, Cout, KH, KW, stride, pad,
+                                         Kpad, flags, in_relu, bm_fix, &variant, stream);
+        if (rc != CPR_OK) return rc;
+        if (n0 == 0) { bm_fix = variant / 1000000; if (variant_out) *variant_out = variant; }
+    }
+    return CPR_OK;
 }

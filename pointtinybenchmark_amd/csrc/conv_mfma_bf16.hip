@@ -314,9 +314,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
     }
 }
 
-extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
-                                   const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
-                                   int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream) {
+static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+                                  const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
+                                  int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream) {
     CPR_CHECK_ARG(in && wgt && out);
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     CPR_CHECK_ARG(Cin % BKH == 0 && Kpad == KH * KW * Cin);
@@ -345,4 +345,26 @@ extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, c
     if (big) hipLaunchKernelGGL((conv_mfma_bf16_kernel<128, 128>), dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_mfma_bf16_kernel<64, 64>), dim3(grid), dim3(256), 0, stream, p);
     CPR_LAUNCH_STATUS();
+}
+
+// >= 2 GiB maps: balanced chunks of whole images (see cpr_images_per_launch)
+extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+                                   const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
+                                   int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream) {
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    CPR_CHECK_ARG(OH > 0 && OW > 0);
+    const size_t oe = out_fp32 ? 4 : 2;
+    const int per = cpr_images_per_launch(N, cpr_max2((long long)H * W * Cin * 2, (long long)OH * OW * Cout * (long long)oe));
+    if (per <= 0) return CPR_ERR_UNSUPPORTED;
+    for (int n0 = 0; n0 < N; n0 += per) {
+        const int n = N - n0 < per ? N - n0 : per;
+        const size_t rows = (size_t)n0 * OH * OW;
+        const int rc = conv2d_fwd_bf16_launch((const char*)in + (size_t)n0 * H * W * Cin * 2, wgt, (char*)out + rows * Cout * oe,
+                                              scale, bias, residual ? (const char*)residual + rows * Cout * 2 : nullptr,
+                                              gn_part ? gn_part + rows / 128 * Cout * 2 : nullptr, n, H, W, Cin, Cout, KH, KW,
+                                              stride, pad, Kpad, relu, out_fp32, n0 == 0 ? variant_out : nullptr, stream);
+        if (rc != CPR_OK) return rc;
+    }
+    return CPR_OK;
 }

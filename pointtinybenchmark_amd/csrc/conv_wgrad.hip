@@ -376,6 +376,7 @@ extern "C" int cpr_wgrad_set_ablation(int mode) {
     return CPR_OK;
 }
 #endif
+// (the slab count never grows when M shrinks, so the workspace of the whole batch also serves every chunk of a split batch)
 extern "C" int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Cout, int KH, int KW) {
     CPR_CHECK_ARG(N > 0 && OH > 0 && OW > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0);
     const int S = wgrad_split((long long)N * OH * OW, Cout, Cin, KH * KW);
@@ -383,9 +384,9 @@ extern "C" int cpr_conv2d_wgrad_workspace(int N, int OH, int OW, int Cin, int Co
     return n < (1ll << 31) ? (int)n : CPR_ERR_UNSUPPORTED;
 }
 
-extern "C" int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
-                                float* ws, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                int in_relu, int accumulate, hipStream_t stream) {
+static int conv2d_wgrad_launch(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
+                               float* ws, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                               int in_relu, int accumulate, hipStream_t stream) {
     CPR_CHECK_ARG(dy && x && grad_w && ws);
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     CPR_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0);
@@ -437,4 +438,25 @@ extern "C" int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, ws, grad_w, p.S, Cout,
                        KK, Cin, accumulate);
     CPR_LAUNCH_STATUS();
+}
+
+// >= 2 GiB maps: balanced chunks of whole images, every chunk after the first accumulates into grad_w (deterministic; the
+// summation is grouped per chunk, so the result equals the unsplit one up to fp32 rounding, not bit for bit).
+extern "C" int cpr_conv2d_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
+                                float* ws, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                int in_relu, int accumulate, hipStream_t stream) {
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    CPR_CHECK_ARG(OH > 0 && OW > 0);
+    const int per = cpr_images_per_launch(N, cpr_max2((long long)OH * OW * Cout * 4, (long long)H * W * Cin * 4));
+    if (per <= 0) return CPR_ERR_UNSUPPORTED;
+    for (int n0 = 0; n0 < N; n0 += per) {
+        const int n = N - n0 < per ? N - n0 : per;
+        const int rc = conv2d_wgrad_launch(dy + (size_t)n0 * OH * OW * Cout, x + (size_t)n0 * H * W * Cin,
+                                           in_a ? in_a + (size_t)n0 * Cin : nullptr, in_b ? in_b + (size_t)n0 * Cin : nullptr,
+                                           grad_w, ws, n, H, W, Cin, Cout, KH, KW, stride, pad, in_relu,
+                                           n0 == 0 ? accumulate : 1, stream);
+        if (rc != CPR_OK) return rc;
+    }
+    return CPR_OK;
 }

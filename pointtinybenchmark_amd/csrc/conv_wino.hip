@@ -484,9 +484,9 @@ extern "C" int cpr_wino_pack_weights(const float* wgt, float* u, int Cin, int Co
     hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, stream, wgt, u, Cin, Cout, Kpad);
     CPR_LAUNCH_STATUS();
 }
-extern "C" int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out, const float* scale, const float* bias,
-                                    const float* in_a, const float* in_b, float* gn_part, int N, int H, int W, int Cin,
-                                    int Cout, int flags, int in_relu, int layout, hipStream_t stream) {
+static int wino_fwd_launch(const float* in, const float* u, float* out, const float* scale, const float* bias,
+                           const float* in_a, const float* in_b, float* gn_part, int N, int H, int W, int Cin,
+                           int Cout, int flags, int in_relu, int layout, hipStream_t stream) {
     CPR_CHECK_ARG(in && u && out && N > 0 && H > 0 && W > 0);
     CPR_CHECK_ARG(Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 64 == 0 && Cin >= 32);
     CPR_CHECK_ARG((flags & ~CPR_CONV_RELU) == 0 && (layout & ~3) == 0);
@@ -540,4 +540,24 @@ extern "C" int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out,
     WLAUNCH(0, 0);
 #undef WLAUNCH
     CPR_LAUNCH_STATUS();
+}
+
+// A batch whose maps reach 2 GiB runs as balanced chunks of whole images (regions, GroupNorm slots and the affine table are
+// per image: bit-identical to an unsplit launch).
+extern "C" int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out, const float* scale, const float* bias,
+                                    const float* in_a, const float* in_b, float* gn_part, int N, int H, int W, int Cin,
+                                    int Cout, int flags, int in_relu, int layout, hipStream_t stream) {
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+    const int per = cpr_images_per_launch(N, (long long)H * W * cpr_max2(Cin, Cout) * 4);
+    if (per <= 0) return CPR_ERR_UNSUPPORTED;
+    const size_t slots = (size_t)((H + 15) / 16) * ((W + 15) / 16);
+    for (int n0 = 0; n0 < N; n0 += per) {
+        const int n = N - n0 < per ? N - n0 : per;
+        const int rc = wino_fwd_launch(in + (size_t)n0 * H * W * Cin, u, out + (size_t)n0 * H * W * Cout, scale, bias,
+                                       in_a ? in_a + (size_t)n0 * Cin : nullptr, in_b ? in_b + (size_t)n0 * Cin : nullptr,
+                                       gn_part ? gn_part + (size_t)n0 * slots * Cout * 2 : nullptr, n, H, W, Cin, Cout, flags,
+                                       in_relu, layout, stream);
+        if (rc != CPR_OK) return rc;
+    }
+    return CPR_OK;
 }

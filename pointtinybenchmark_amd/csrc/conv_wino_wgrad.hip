@@ -341,9 +341,9 @@ extern "C" int cpr_conv3x3_wino_wgrad_workspace(int N, int H, int W, int Cin, in
     const long long n = (long long)N * parts * 16 * Cin * Cout;
     return n < (1ll << 31) ? (int)n : CPR_ERR_UNSUPPORTED;
 }
-extern "C" int cpr_conv3x3_wino_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
-                                      float* ws, int N, int H, int W, int Cin, int Cout, int in_relu, int accumulate,
-                                      hipStream_t stream) {
+static int wino_wgrad_launch(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
+                             float* ws, int N, int H, int W, int Cin, int Cout, int in_relu, int accumulate,
+                             hipStream_t stream) {
     CPR_CHECK_ARG(dy && x && grad_w && ws && N > 0 && H > 0 && W > 0);
     CPR_CHECK_ARG(Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0);
     if (in_a) CPR_CHECK_ARG(in_b != nullptr);
@@ -363,4 +363,28 @@ extern "C" int cpr_conv3x3_wino_wgrad(const float* dy, const float* x, const flo
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, stream, ws, grad_w, N * p.parts,
                        Cin, Cout, accumulate);
     CPR_LAUNCH_STATUS();
+}
+
+// >= 2 GiB maps: balanced chunks of whole images; chunks after the first accumulate into grad_w.  The workspace of the whole
+// batch serves every chunk: a chunk's N * parts never exceeds the whole batch's (parts only grows when blocks * N < 512, i.e.
+// for batches far below the 2 GiB range) -- checked per launch.
+extern "C" int cpr_conv3x3_wino_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
+                                      float* ws, int N, int H, int W, int Cin, int Cout, int in_relu, int accumulate,
+                                      hipStream_t stream) {
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0);
+    const int per = cpr_images_per_launch(N, (long long)H * W * cpr_max2(Cin, Cout) * 4);
+    if (per <= 0) return CPR_ERR_UNSUPPORTED;
+    int parts_all, rpp;
+    wino_wgrad_split(N, H, Cin, Cout, &parts_all, &rpp);
+    for (int n0 = 0; n0 < N; n0 += per) {
+        const int n = N - n0 < per ? N - n0 : per;
+        int parts;
+        wino_wgrad_split(n, H, Cin, Cout, &parts, &rpp);
+        if ((long long)n * parts > (long long)N * parts_all) return CPR_ERR_UNSUPPORTED;   // workspace was sized for the whole batch
+        const int rc = wino_wgrad_launch(dy + (size_t)n0 * H * W * Cout, x + (size_t)n0 * H * W * Cin,
+                                         in_a ? in_a + (size_t)n0 * Cin : nullptr, in_b ? in_b + (size_t)n0 * Cin : nullptr,
+                                         grad_w, ws, n, H, W, Cin, Cout, in_relu, n0 == 0 ? accumulate : 1, stream);
+        if (rc != CPR_OK) return rc;
+    }
+    return CPR_OK;
 }

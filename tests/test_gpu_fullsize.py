@@ -99,6 +99,146 @@ def test_full_size_batch_order_equivariance(full):
     assert torch.equal(d1[0][0], d2[1][0]) and torch.equal(d1[1][0], d2[0][0])
 
 
+def _logit_map_vs_oracle(m, sd, cls_feat, ref_feat, C):
+    """head._logit_map over the WHOLE map against F.linear of the oracle's features (cpr_head.py:1045-1099: cls_out / ins_out
+    on every location): max abs error of the [cls ++ ins] logits."""
+    import torch.nn.functional as F
+    from pointtinybenchmark_amd import ops
+    lmap = m.bbox_head._logit_map(ops.from_nchw(cls_feat)).cpu()                        # (N, H, W, 2C)
+    f = ref_feat.permute(0, 2, 3, 1)
+    ref = torch.cat([F.linear(f, sd['bbox_head.cls_out.weight'], sd['bbox_head.cls_out.bias']),
+                     F.linear(f, sd['bbox_head.ins_out.weight'], sd['bbox_head.ins_out.bias'])], dim=-1)
+    assert lmap.shape == ref.shape and lmap.shape[-1] == 2 * C
+    return float((lmap - ref).abs().max()), float(ref.abs().max())
+
+
+def test_full_size_logit_map_vs_oracle(full):
+    """north star: 'within 1e-4 on the head logits' -- asserted directly on the full 160x160x2 logit map of the 640x640
+    configuration (R50, B=2), not only on the sampled bag logits."""
+    m, sd, batch, cb = full
+    cls_feat, _, _ = _run(m, cb)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        _, ref_feat, per = O.locator_forward_train(sd, batch, 50, 0, 4, 5, 1)
+        err, mag = _logit_map_vs_oracle(m, sd, cls_feat, ref_feat, 1)
+    assert err <= 1e-4, 'logit map max abs err %.3e (|logit| max %.2f, bar 1e-4)' % (err, mag)
+    # the oracle's own per-location classification logits are the same numbers (neg_logit = F.linear over the grid)
+    assert torch.equal(per[0]['neg_logit'].reshape(160, 160),
+                       torch.nn.functional.linear(ref_feat[0].permute(1, 2, 0), sd['bbox_head.cls_out.weight'],
+                                                  sd['bbox_head.cls_out.bias'])[..., 0])
+
+
+def test_headline_batch_64_bit_equal_to_single_image_runs():
+    """The configuration bench.py quotes (R50, 640x640, B=64: 1.68 GB maps, 78 % of the kernels' 32-bit byte-offset range).
+    Images 0, 31 and 63 of the 64-batch must come out BIT-equal to the same images run alone (tile / region / GroupNorm-slot
+    indexing is per image and no kernel's arithmetic depends on the batch size), then the oracle pins the last two images:
+    features 2e-4 * scale, the full logit map 1e-4, and the losses of that 2-image sub-batch."""
+    from pointtinybenchmark_amd import ops
+    m, sd = build_hip_locator(CFG)
+    B = 64
+    batch = synthetic.synthetic_batch(B, 640, 640, 32, 1, 0)
+    cb = to_cuda(batch)
+    head = m.bbox_head
+    with torch.no_grad():
+        cls64, ins64 = head(m.neck(m.backbone(cb['img'])))
+        lmap64 = head._logit_map(ops.from_nchw(cls64[0]))
+        losses64 = head.loss(cls64, ins64, cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'])
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(v).all()) for v in losses64.values())
+        for i in (0, 31, 63):
+            one, _ = head(m.neck(m.backbone(cb['img'][i:i + 1].contiguous())))
+            assert torch.equal(one[0][0], cls64[0][i]), 'image %d of the 64-batch differs from its single-image run' % i
+            assert torch.equal(head._logit_map(ops.from_nchw(one[0]))[0], lmap64[i])
+        sub = {k: v[62:64] for k, v in batch.items()}
+        sc = to_cuda(sub)
+        l2 = head.loss([cls64[0][62:64]], [ins64[0][62:64]], sc['gt_bboxes'], sc['gt_labels'], sc['img_metas'])
+        torch.cuda.synchronize()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref_losses, ref_feat, _ = O.locator_forward_train(sd, sub, 50, 0, 4, 5, 1)
+        err_l, mag = _logit_map_vs_oracle(m, sd, cls64[0][62:64], ref_feat, 1)
+    scale = max(1.0, float(ref_feat.abs().max()))
+    err = float((cls64[0][62:64].cpu() - ref_feat).abs().max())
+    assert err <= 2e-4 * scale, 'images 62-63 of the 64-batch: cls_feat max abs err %.3e (scale %.2e)' % (err, scale)
+    assert err_l <= 1e-4, 'images 62-63 of the 64-batch: logit map max abs err %.3e (bar 1e-4)' % err_l
+    for k in ('gt_loss', 'pos_loss', 'neg_loss', 'bag_acc'):
+        a, b = float(l2[k]), float(ref_losses[k])
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1e-6), (k, a, b)
+    del cls64, ins64, lmap64
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('depth,size,B', [(50, 640, 96), (101, 1024, 32)])
+def test_batches_past_2gib_run_in_chunks_bit_identically(depth, size, B):
+    """B=96 at 640x640 (2.5 GB per 160x160x256 map) and B=32 at R101 1024x1024 (2.1 GB): the conv launchers walk such a batch
+    in chunks of whole images below the 2 GiB range of their 32-bit buffer offsets (csrc/common.h cpr_images_per_launch).
+    Every image of the big batch must equal its single-image run bit for bit -- first / last image and both sides of the
+    chunk boundary -- and the loss of the big batch must be finite."""
+    cfg = dict(CFG, depth=depth, height=size, width=size, seed=70 + depth)
+    m, sd = build_hip_locator(cfg)
+    batch = synthetic.synthetic_batch(B, size, size, 8, 1, cfg['seed'])
+    cb = to_cuda(batch)
+    head = m.bbox_head
+    with torch.no_grad():
+        big, ins = head(m.neck(m.backbone(cb['img'])))
+        losses = m.forward_train(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(v).all()) for v in losses.values())
+        for i in (0, B // 2 - 1, B // 2, B - 1):
+            one, _ = head(m.neck(m.backbone(cb['img'][i:i + 1].contiguous())))
+            assert torch.equal(one[0][0], big[0][i]), 'image %d of the %d-batch differs from its single-image run' % (i, B)
+    del big, ins
+    torch.cuda.empty_cache()
+
+
+def test_split_batch_conv_entry_points_match_unsplit_halves():
+    """The C-ABI conv entry points on tensors past 2 GiB against the same call on each half (below the range): direct kernel
+    with residual + GroupNorm partials, Winograd kernel with fused affine input + partials (bit-equal), weight gradients
+    (direct and Winograd: the halves accumulate, equal up to fp32 summation order)."""
+    from pointtinybenchmark_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C = 84, 160, 160, 256                                    # 84 * 160 * 160 * 256 * 4 = 2.2 GB
+    x = torch.randn((N, H, W, C), generator=g).cuda()
+    h = N // 2
+    # direct 1x1 conv 256 -> 256 with residual, ReLU and GroupNorm partials
+    w1 = (torch.randn((C, C, 1, 1), generator=g) * 0.05).cuda()
+    pc1 = ops.PackedConv(w1, 1, 0)
+    res = torch.randn((N, H, W, C), generator=g).cuda()
+    y, part = ops.conv2d(x, pc1, residual=res, relu=True, gn_part=True)
+    for sl in (slice(0, h), slice(h, N)):
+        yy, pp = ops.conv2d(x[sl], pc1, residual=res[sl], relu=True, gn_part=True)
+        assert torch.equal(yy, y[sl])
+        per = part.shape[0] // N
+        assert torch.equal(pp, part[sl.start * per:sl.stop * per])
+    del res, y, part, yy, pp
+    # Winograd 3x3 with the fused producer affine
+    w3 = (torch.randn((C, C, 3, 3), generator=g) * 0.02).cuda()
+    pc3 = ops.PackedConv(w3, 1, 1)
+    a = (torch.rand((N, C), generator=g) + 0.5).cuda()
+    b = torch.randn((N, C), generator=g).cuda()
+    y, part = ops.conv2d(x, pc3, in_ab=(a, b), in_relu=True, gn_part=True)
+    for sl in (slice(0, h), slice(h, N)):
+        yy, pp = ops.conv2d(x[sl], pc3, in_ab=(a[sl].contiguous(), b[sl].contiguous()), in_relu=True, gn_part=True)
+        assert torch.equal(yy, y[sl])
+        per = part.shape[0] // N
+        assert torch.equal(pp, part[sl.start * per:sl.stop * per])
+    # weight gradients: whole batch in one call vs the two halves accumulated
+    dy = y
+
+    def three(fn):
+        whole, g0, g1 = fn(dy, x), fn(dy[:h], x[:h]), fn(dy[h:], x[h:])
+        ref = g0 + g1
+        return float((whole - ref).abs().max()) / float(ref.abs().max())
+    err = three(lambda d, v: ops.conv3x3_wino_wgrad(d, v, w3.shape))
+    assert err <= 2e-5, ('winograd weight gradient', err)
+    ops.WINOGRAD[0] = False
+    try:
+        err = three(lambda d, v: ops.conv2d_wgrad(d, v, w3.shape, 1, 1))
+    finally:
+        ops.WINOGRAD[0] = True
+    assert err <= 2e-5, ('direct weight gradient', err)
+
+
 def test_full_size_conv_linearity():
     """conv(a*x + y) == a*conv(x) + conv(y) on the head's 3x3 256->256 layer at 160x160 (fp32 rounding only)."""
     from pointtinybenchmark_amd import ops
@@ -147,6 +287,10 @@ def test_other_baseline_configs_parity_with_oracle(name, cfg):
         assert abs(a - b) <= 5e-4 * max(abs(b), 1e-6), (name, k, a, b)
     np.testing.assert_allclose(torch.cat([d for d, _ in dets]).cpu().numpy(),
                                torch.cat([r['dets'] for r in ref]).numpy(), rtol=1e-4, atol=5e-3)
+    # the full [cls ++ ins] logit map (2C channels: 160 for the COCO-style case) against the oracle, 1e-4 abs
+    with torch.no_grad():
+        err_l, mag = _logit_map_vs_oracle(m, sd, cls_feat, ref_feat, cfg['num_classes'])
+    assert err_l <= 1e-4 * max(1.0, mag / 16.0), '%s: logit map max abs err %.3e (|logit| max %.2f)' % (name, err_l, mag)
 
 
 def test_p2p_r50_640_full_network_vs_oracle():
