@@ -11,7 +11,10 @@ class BatchLoader:
     def __init__(self, dataset, pipeline, samples_per_gpu=2, num_replicas=None, rank=None, seed=0, flip_seed=None):
         self.dataset, self.pipeline, self.samples_per_gpu = dataset, pipeline, samples_per_gpu
         self.sampler = DistributedGroupSampler(dataset, samples_per_gpu, num_replicas, rank, seed)
-        self.rng = np.random.RandomState(seed if flip_seed is None else flip_seed)    # RandomFlip draws (per process)
+        # RandomFlip draws: the reference seeds every loader worker with num_workers * rank + worker_id + seed
+        # (T/mmdet/datasets/builder.py worker_init_fn), i.e. the ranks draw DIFFERENT flip sequences; one in-process
+        # "worker" per rank here -> seed + rank.  An explicit flip_seed is taken as given (tests).
+        self.rng = np.random.RandomState(seed + self.sampler.rank if flip_seed is None else flip_seed)
 
     def set_epoch(self, epoch):
         self.sampler.set_epoch(epoch)

@@ -18,6 +18,9 @@ in tile coordinates.  Restated from that contract and the documented parameters:
 import copy
 import json
 import os
+import warnings
+
+MIN_LAST_TILE_SHIFT = 8     # px: a flush last tile closer than this to its predecessor replaces it
 
 
 def tile_origins(length, tile, overlap):
@@ -26,7 +29,14 @@ def tile_origins(length, tile, overlap):
         return [0]
     stride = tile - overlap
     xs = list(range(0, length - tile, stride))
-    xs.append(length - tile)
+    last = length - tile
+    # a flush last tile a few pixels past the previous origin (L = 1181: 0, 540, 541) would emit every object of that band
+    # twice: the flush tile REPLACES that predecessor (0, 541: still every pixel covered; the overlap with the tile before
+    # shrinks by less than MIN_LAST_TILE_SHIFT pixels).  A single predecessor at 0 cannot be replaced (L = 641: 0, 1).
+    if len(xs) > 1 and last - xs[-1] < MIN_LAST_TILE_SHIFT:
+        xs[-1] = last
+    else:
+        xs.append(last)
     return xs
 
 
@@ -40,6 +50,10 @@ def image_tiles(width, height, max_tile_size=(640, 640), tile_overlap=(100, 100)
 
 def generate_corner_dataset(ann, save_path=None, max_tile_size=(640, 640), tile_overlap=(100, 100), **unused):
     """COCO-format dict (or json path) -> tile-level COCO-format dict; written to ``save_path`` when given."""
+    if save_path:
+        warnings.warn('generating the tile annotation file %s with pointtinybenchmark_amd.datasets.tiles -- a restatement of '
+                      "huicv's generator (not vendored, parity unpinned); AP parity with the reference needs the "
+                      'huicv-generated file (the reference itself generates the file and exits)' % save_path, stacklevel=2)
     ds = json.load(open(ann)) if isinstance(ann, str) else ann
     by_img = {}
     for a in ds.get('annotations', []):

@@ -82,9 +82,20 @@ class BasicLocator(nn.Module):
     # Small per-GPU batches (the reference trains with samples_per_gpu = 2) are launch-bound: ~150 kernel launches of a few
     # microseconds each.  ``model.use_graph = True`` (or CPR_GRAPH=1) captures backbone -> neck -> head towers -> logit
     # projection into ONE hipGraph per input shape and replays it; only the ragged, gt-dependent tail (bag sampling, masks,
-    # losses: 5 launches) stays eager.  Forward + loss only: weights must not change between replays (the training step
-    # re-packs them every iteration and does not use the graph).
+    # losses: 5 launches) stays eager.  Forward + loss only.  A captured graph bakes in the device pointers of the packed
+    # weights / folded norms of the moment of capture: the entry carries the signature of every parameter and buffer (storage
+    # pointer, version counter, the native optimizer's weight epoch) and is re-captured when it no longer matches (optimizer
+    # step, load_state_dict, .to()); it also holds the pack caches' tensors so they cannot be freed while the graph lives.
     use_graph = False
+
+    def _weights_signature(self):
+        from ..layers import _WEIGHT_EPOCH
+        sig = [_WEIGHT_EPOCH[0]]
+        for t in self.parameters():
+            sig.append((t.data_ptr(), t._version))
+        for t in self.buffers():
+            sig.append((t.data_ptr(), t._version))
+        return tuple(sig)
 
     def _graphed_logit_map(self, img):
         head = self.bbox_head
@@ -92,6 +103,10 @@ class BasicLocator(nn.Module):
         if not hasattr(self, '_graphs'):
             self._graphs = {}
         entry = self._graphs.get(key)
+        sig = self._weights_signature()
+        if entry is not None and entry[3] != sig:      # weights changed since the capture: the graph reads stale packs
+            del self._graphs[key]
+            entry = None
         if entry is None:
             def run(x):
                 raw, ab = head._tower(*self.neck.forward_lazy(self.backbone(x), out_b8=getattr(head, 'accepts_b8', False))[0],
@@ -104,11 +119,13 @@ class BasicLocator(nn.Module):
                 for _ in range(2):
                     run(static_img)
             torch.cuda.current_stream().wait_stream(side)
+            side.synchronize()                  # every weight pack of the warm-up is complete before the capture starts
             graph = torch.cuda.CUDAGraph()      # a hipGraph on ROCm
             with torch.cuda.graph(graph):
                 outs = run(static_img)
-            entry = self._graphs[key] = (graph, static_img, outs)
-        graph, static_img, outs = entry
+            packs = [dict(m._cache._d) for m in self.modules() if hasattr(m, '_cache') and hasattr(m._cache, '_d')]
+            entry = self._graphs[key] = (graph, static_img, outs, sig, packs)
+        graph, static_img, outs = entry[:3]
         static_img.copy_(img)
         graph.replay()
         return outs

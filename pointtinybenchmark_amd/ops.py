@@ -67,6 +67,14 @@ class PackedConv:
     """Conv weight repacked for the implicit-GEMM kernel: [Cout][KH][KW][Cin'] fp32, rows padded to a
     multiple of 32 floats.  Cin' = 4 for the 3-channel stem (zero 4th channel)."""
     wino = None     # transformed weights of the Winograd path, built on first use (conv3x3_wino)
+    ready = None    # event recorded behind the last pack kernel (weights / Winograd image); see pack_ready()
+
+    def _packed(self):
+        """A pack kernel was just enqueued on the current stream: consumers on OTHER streams (CPR_STREAMS > 1 sub-batches)
+        must order themselves behind it."""
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            self.ready = torch.cuda.Event()
+            self.ready.record()
 
     def __init__(self, weight, stride=1, padding=0, dtype=torch.float32):
         Cout, Cin, KH, KW = weight.shape
@@ -94,6 +102,7 @@ class PackedConv:
                 src = src.float().contiguous()
             self.w = torch.empty((Cout, Kpad), device=weight.device, dtype=torch.float32)
             _lib.call('cpr_pack_weights', _ptr(src), None, _ptr(self.w), Cout, Cin, KH, KW, cin_p, Kpad, 0, _stream())
+            self._packed()
             return
         wp = torch.zeros((Cout, KH, KW, cin_p), device=weight.device, dtype=torch.float32)
         wp[..., :Cin] = w
@@ -121,6 +130,7 @@ class PackedConv:
             src = src.float().contiguous()
         self.w = torch.empty((Cin, Kpad), device=weight.device, dtype=torch.float32)
         _lib.call('cpr_pack_weights', _ptr(src), _ptr(scale), _ptr(self.w), Cout, Cin, KH, KW, cols_p, Kpad, 1, _stream())
+        self._packed()
         return self
 
     def out_hw(self, H, W):
@@ -137,6 +147,18 @@ TRACE_CONV_VARIANT = [False, None]
 # map fills its 16x16 output regions well enough; CPR_WINOGRAD=0 keeps every layer on the direct implicit GEMM (A/B runs).
 WINOGRAD = [os.environ.get('CPR_WINOGRAD', '1') != '0']
 WINO_MIN_FILL = 0.6      # useful share of the 16x16 regions (40x40 -> 0.69 runs Winograd, 20x20 -> 0.39 stays direct)
+
+
+def pack_ready(pc):
+    """Order the current stream behind the kernels that packed ``pc`` (they may have run on another stream: the first
+    sub-batch of a multi-stream forward packs, the others only read).  The event is dropped once it has completed."""
+    ev = pc.ready
+    if ev is None or torch.cuda.is_current_stream_capturing():      # (a capture starts after a synchronised warm-up)
+        return
+    if ev.query():
+        pc.ready = None
+    else:
+        torch.cuda.current_stream().wait_event(ev)
 
 
 def wino_eligible(pc, H, W, dtype=torch.float32):
@@ -166,8 +188,12 @@ def conv3x3_wino(x, pc, scale=None, bias=None, relu=False, gn_part=False, out=No
         N, H, W, Cin = x.shape
     assert x.dtype == torch.float32 and Cin == pc.Cin and pc.KH == 3 and pc.stride == 1 and pc.padding == 1
     if pc.wino is None:     # G g G^T of the packed weights, once per PackedConv (= once per weight update)
-        pc.wino = torch.empty((16 * pc.Cin * pc.Cout,), device=x.device, dtype=torch.float32)
-        _lib.call('cpr_wino_pack_weights', _ptr(pc.w), _ptr(pc.wino), pc.Cin, pc.Cout, pc.Kpad, _stream())
+        pack_ready(pc)
+        wino = torch.empty((16 * pc.Cin * pc.Cout,), device=x.device, dtype=torch.float32)
+        _lib.call('cpr_wino_pack_weights', _ptr(pc.w), _ptr(wino), pc.Cin, pc.Cout, pc.Kpad, _stream())
+        pc.wino = wino
+        pc._packed()
+    pack_ready(pc)
     shape = (N, pc.Cout // 8, H, W, 8) if out_b8 else (N, H, W, pc.Cout)
     if out is None:
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
@@ -206,6 +232,7 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     Backward helpers (fp32): res_mask=True turns ``residual`` into a ReLU mask source (out = residual > 0 ? v : 0);
     colsum=True also returns the per-channel sums of the output (C,), taken from the epilogue partials."""
     _check(x, ACT)
+    pack_ready(pc)
     if is_b8(x):     # channel-blocked input: only the Winograd layers read it
         assert residual is None and not (res_mask or colsum) and out_dtype in (None, torch.float32) and \
             wino_eligible(pc, x.shape[2], x.shape[3], x.dtype), 'channel-blocked input needs a Winograd-eligible layer'

@@ -203,7 +203,12 @@ def test_tile_generation_properties(tmp_path):
     for L in (300, 640, 641, 1180, 1181, 1920, 2000, 5000):
         xs = tile_origins(L, 640, 100)
         assert xs[0] == 0 and xs[-1] + min(640, L) == L and xs == sorted(set(xs))
-        assert all(b - a <= 540 for a, b in zip(xs, xs[1:])), (L, xs)          # neighbours overlap by >= 100
+        # neighbours overlap by >= 100 px, less at most MIN_LAST_TILE_SHIFT - 1 px where a flush last tile replaced a
+        # predecessor a few pixels away (L = 1181: [0, 541] instead of [0, 540, 541], which duplicated a whole band)
+        from pointtinybenchmark_amd.datasets.tiles import MIN_LAST_TILE_SHIFT
+        assert all(b - a <= 540 for a, b in zip(xs[:-1], xs[1:-1])), (L, xs)
+        assert len(xs) < 2 or xs[-1] - xs[-2] <= 540 + MIN_LAST_TILE_SHIFT - 1, (L, xs)
+        assert len(xs) < 3 or xs[-1] - xs[-2] >= MIN_LAST_TILE_SHIFT, (L, xs)   # no near-duplicate last tile
     tiles = image_tiles(1920, 1080)
     cover = np.zeros((1080, 1920), dtype=np.int32)
     for l, u, r, b in tiles:
