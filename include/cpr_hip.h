@@ -335,6 +335,7 @@ int cpr_conv_set_ablation(int mode);     /* loop ablations: results are WRONG wh
 int cpr_wgrad_set_ablation(int mode);    /* same for the weight-gradient kernel */
 int cpr_conv_set_extra_lds(int bytes);   /* occupancy probe: dynamic LDS added to every direct-conv launch */
 int cpr_wino_set_variant(int sched, int ablate); /* Winograd: sched 1 = the other placement of the patch transform (see conv_wino.hip); loop ablations */
+int cpr_wino_set_staging(int var, int tpx);      /* Winograd: staging variant (kernel template VAR) and cout tiles per XCD; -1 = the product's choice */
 #endif
 
 #ifdef __cplusplus

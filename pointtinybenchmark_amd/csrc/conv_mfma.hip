@@ -39,6 +39,14 @@ struct ConvParams {
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, in_relu, out_bf16;
     int res_mask;           // residual is a ReLU mask source: out = residual > 0 ? v : 0 (backward of a fused ReLU)
     int tilesM, tilesN;
+    // DUAL instances: a second 1x1 / unpadded GEMM source accumulated beside the first one, out = epi1(acc) + epi2(acc2):
+    // the bottleneck's projection shortcut (T/mmdet/models/backbones/resnet.py:262-302: out = bn3(conv3(o2)) + bn_d(conv_d(x)))
+    // in the launch of conv3 -- the 4x-wide identity map is never written to or read back from HBM.
+    const float* in2;       // (N, H2, W2, Cin2); the output pixel (n, oy, ox) reads (n, oy * stride2, ox * stride2)
+    const float* wgt2;      // [Cout][Kpad2]
+    const float* scale2;    // [Cout] or null
+    const float* bias2;     // [Cout] or null
+    int H2, W2, Cin2, stride2, Kpad2;
 };
 
 constexpr int BK = 32;
@@ -48,8 +56,9 @@ constexpr int LDSW = 36;  // padded row (floats)
 // XF: fused per-(image, channel) affine (+ReLU) on the input = GroupNorm-apply of the producing layer.
 // ABL (benchmark-only ablations of the pipelined loop, results are then WRONG): bit0 = no global loads / LDS writes,
 // bit1 = no fragment reads, bit2 = no barrier.  ABL = 0 in every product launch.
-template <int BM, int BN, int MODE, bool XF, int PIPE, int ABL = 0>
+template <int BM, int BN, int MODE, bool XF, int PIPE, int ABL = 0, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
+    static_assert(!DUAL || (MODE == 0 && !XF && PIPE == 1 && ABL == 0), "the dual-source form exists for the plain pipelined instances");
     constexpr int WM = BM / 2;
     constexpr int WN = BN / 2;
     constexpr int MI = WM / 32;
@@ -101,10 +110,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         }
     }
     // Buffer descriptors: out-of-range offsets return 0, which IS the conv zero padding (no clamps, no selects)
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wgt), 0, (int)((size_t)p.Cout * p.Kpad * 4), 0x00020000);
+    int cin_cur = p.Cin;         // channels per tap of the source being read (DUAL: Cin2 in the second pass)
+    bool second = false;         // DUAL: the second source is being read (one tap: its row offsets never change)
     // ---- B row pointers
     const float* wrow[BL];
     int woff[BL];  // byte offset of this thread's float4 in weight row j (-1 = row beyond Cout -> reads 0)
@@ -188,14 +199,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
                 xb = *reinterpret_cast<const f32x4*>(ABs + XFMAX + c0 + c4 * 4);
             }
             c0 += BK;
-            if (c0 == p.Cin) {  // wave-uniform, once per Cin/32 chunks: next tap -> refresh the row offsets
+            if (c0 == cin_cur) {  // wave-uniform, once per Cin/32 chunks: next tap -> refresh the row offsets
                 c0 = 0;
-                if (++kw == p.KW) { kw = 0; ++kh; }
-                refresh_rows();
+                if (!(DUAL && second)) {
+                    if (++kw == p.KW) { kw = 0; ++kh; }
+                    refresh_rows();
+                }
             }
         }
     };
-    const int kt_last = p.Kpad / BK - 1;
+    int kt_last = p.Kpad / BK - 1;
     auto load_b = [&](auto set_c, int kt, int j) {  // tile indices past the end are clamped (the pipeline prefetches ahead)
         constexpr int SET = decltype(set_c)::value;
         rb[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[j], min(kt, kt_last) * (BK * 4), 0));
@@ -244,12 +257,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    f32x16 acc2[DUAL ? MI : 1][DUAL ? NI : 1];   // DUAL: the second source's sums
+    if (DUAL) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[DUAL ? i : 0][DUAL ? j : 0][r] = 0.f;
+    }
+
     const int wm = wave & 1, wn = wave >> 1;
     const int arow = wm * WM + (lane & 31);
     const int brow = wn * WN + (lane & 31);
     const int koff = 4 * (lane >> 5);
 
-    const int KT = p.Kpad / BK;
+    int KT = p.Kpad / BK;
     const float* a_lds = As + arow * LDSW + koff;
     const float* b_lds = Bs + brow * LDSW + koff;
     auto read_frags = [&](int buf, int kk, f32x4 (&fa)[MI], f32x4 (&fb)[NI]) {
@@ -288,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             __syncthreads();
         }
     } else {
+      auto kloop = [&](f32x16 (&accX)[MI][NI]) {
         // interleaved schedule: the two workgroups sharing a CU start together and run in lockstep, so a phase without
         // MFMAs idles the matrix pipe for BOTH (PMC: MFMA busy 70 % with the phase-separated loop).  Here every
         // non-MFMA instruction of an iteration sits in the shadow of that wave's own MFMAs:
@@ -312,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         constexpr int PPF = (NF + NM - 1) / NM, PP1 = (P1 + NM - 1) / NM, PP2 = (P2 + NM - 1) / NM;
         // one MFMA of a k-group: slot q -> (t, i, j)
 #define MFMA_SLOT(FA, FB, q)                                                                                  \
-    acc[((q) / NI) % MI][(q) % NI] = __builtin_amdgcn_mfma_f32_32x32x2f32(                                  \
-        FA[((q) / NI) % MI][(q) / (MI * NI)], FB[(q) % NI][(q) / (MI * NI)], acc[((q) / NI) % MI][(q) % NI], 0, 0, 0)
+    accX[((q) / NI) % MI][(q) % NI] = __builtin_amdgcn_mfma_f32_32x32x2f32(                                 \
+        FA[((q) / NI) % MI][(q) / (MI * NI)], FB[(q) % NI][(q) / (MI * NI)], accX[((q) / NI) % MI][(q) % NI], 0, 0, 0)
         // fragment-read piece z (0..NF-1) of k-step kk from LDS buffer `buf` into (FA, FB)
 #define FRAG_PIECE(FA, FB, buf, kk, z)                                                                        \
     do {                                                                                                      \
@@ -391,6 +415,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         }
 #undef MFMA_SLOT
 #undef FRAG_PIECE
+      };
+      kloop(acc);
+      if constexpr (DUAL) {
+        // ---- second source: 1x1, unpadded, stride2 over (N, H2, W2, Cin2); same M rows, same cout columns, its own accumulator
+        // (acc * scale + bias is formed per source in the epilogue, exactly as the two separate launches would).  After the
+        // first loop's last barrier no wave reads LDS data it still needs: the prologue below may overwrite both buffers.
+        rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2), 0,
+                                                  (int)((size_t)p.N * p.H2 * p.W2 * p.Cin2 * 4), 0x00020000);
+        rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt2), 0, (int)((size_t)p.Cout * p.Kpad2 * 4), 0x00020000);
+        okcur = 0;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            const int mm = mok[j] ? m0 + r0 + 32 * j : 0;
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            okcur |= (mok[j] ? 1u : 0u) << j;
+            voffA[j] = mok[j] ? (((n * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.Cin2 + c4 * 4) * 4 : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) woff[j] = wok[j] ? ((n0 + r0 + 32 * j) * p.Kpad2 + c4 * 4) * 4 : -1;
+        cin_cur = p.Cin2; second = true;
+        kh = 0; kw = 0; c0 = 0;
+        KT = p.Kpad2 / BK; kt_last = KT - 1;
+        kloop(acc2);
+      }
     }
 
     // ---- epilogue.  D layout: col j = lane&31 (cout), row i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).
@@ -408,6 +458,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         const int cc = cok ? c : p.Cout - 1;
         const float sc = p.scale ? p.scale[cc] : 1.f;
         const float bi = p.bias ? p.bias[cc] : 0.f;
+        const float sc2 = (DUAL && p.scale2) ? p.scale2[cc] : 1.f;
+        const float bi2 = (DUAL && p.bias2) ? p.bias2[cc] : 0.f;
         float gsum = 0.f, gsq = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -430,7 +482,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = rbase + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] * sc + bi;
-                if (p.res_mask) v = res[r] > 0.f ? v : 0.f;
+                if (DUAL) {   // the shortcut branch's value, rounded to fp32 before the add as the separate launch stores it
+                    const float idv = acc2[DUAL ? i : 0][DUAL ? j : 0][r] * sc2 + bi2;
+                    v += idv;
+                } else if (p.res_mask) v = res[r] > 0.f ? v : 0.f;
                 else v += res[r];
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.out_bf16) {  // bf16 compute mode: the fp32 stem hands a bf16 map to the bf16 layers
@@ -630,6 +685,67 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
                                          Kpad, flags, in_relu, bm_fix, &variant, stream);
         if (rc != CPR_OK) return rc;
         if (n0 == 0) { bm_fix = variant / 1000000; if (variant_out) *variant_out = variant; }
+    }
+    return CPR_OK;
+}
+
+// ---- dual-source launch: out = relu?((conv(in, wgt) * scale + bias) + (conv1x1_stride2(in2, wgt2) * scale2 + bias2)) -----------
+// The first block of every ResNet stage (T/mmdet/models/backbones/resnet.py:262-302, 564-610): conv3 + bn3 and the projection
+// shortcut (downsample conv + bn) share their output pixels and channels, so both GEMMs run in one launch with two
+// accumulators and the shortcut map (4x the bottleneck width: 1.68 GB at 160x160x256, B=64) never exists in HBM.  The result
+// is bit-identical to the two-launch form (same K order per source, same epilogue roundings).
+static int conv2d_dual_launch(const float* in, const float* wgt, const float* in2, const float* wgt2, float* out,
+                              const float* scale, const float* bias, const float* scale2, const float* bias2, int N, int H,
+                              int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int H2, int W2,
+                              int Cin2, int stride2, int Kpad2, int flags, int* variant_out, hipStream_t stream) {
+    ConvParams p;
+    p.in = in; p.wgt = wgt; p.out = out; p.scale = scale; p.bias = bias; p.residual = nullptr;
+    p.in_a = nullptr; p.in_b = nullptr; p.gn_part = nullptr;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Kpad = Kpad; p.relu = flags & CPR_CONV_RELU; p.in_relu = 0; p.out_bf16 = 0; p.res_mask = 0;
+    p.OH = (H + 2 * pad - KH) / stride + 1;
+    p.OW = (W + 2 * pad - KW) / stride + 1;
+    p.in2 = in2; p.wgt2 = wgt2; p.scale2 = scale2; p.bias2 = bias2;
+    p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2; p.Kpad2 = Kpad2;
+    const long long M = (long long)N * p.OH * p.OW;
+    if ((long long)N * H * W * Cin * 4 >= (1ll << 31) || (long long)N * H2 * W2 * Cin2 * 4 >= (1ll << 31) ||
+        (long long)Cout * Kpad * 4 >= (1ll << 31) || (long long)Cout * Kpad2 * 4 >= (1ll << 31) || M * Cout * 4 >= (1ll << 31))
+        return CPR_ERR_UNSUPPORTED;
+    p.M = (int)M;
+    // same tile rule as the single-source launcher, on the summed K
+    int bm = 64, bn = 64;
+    const long long t128 = (long long)((p.M + 127) / 128) * ((Cout + 127) / 128);
+    if ((Kpad + Kpad2) / BK >= 16 && t128 >= 4096 && Cout > 64) { bm = 128; bn = 128; }
+    if (force_tile_bm > 0) { bm = bn = force_tile_bm; }
+    if (variant_out) *variant_out = bm * 1000000 + bn * 1000 + 2;
+    p.tilesM = (p.M + bm - 1) / bm;
+    p.tilesN = (Cout + bn - 1) / bn;
+    const int grid = ((p.tilesM * p.tilesN + 7) / 8) * 8;
+    if (bm == 64) hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 0, false, 1, 0, true>), dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 0, false, 1, 0, true>), dim3(grid), dim3(256), 0, stream, p);
+    CPR_LAUNCH_STATUS();
+}
+
+extern "C" int cpr_conv2d_dual_fwd(const float* in, const float* wgt, const float* in2, const float* wgt2, float* out,
+                                   const float* scale, const float* bias, const float* scale2, const float* bias2, int N,
+                                   int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int H2,
+                                   int W2, int Cin2, int stride2, int Kpad2, int flags, int* variant_out, hipStream_t stream) {
+    CPR_CHECK_ARG(in && wgt && in2 && wgt2 && out);
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    CPR_CHECK_ARG(H2 > 0 && W2 > 0 && Cin2 > 0 && stride2 > 0 && (flags & ~CPR_CONV_RELU) == 0);
+    CPR_CHECK_ARG(Cin % BK == 0 && Kpad == KH * KW * Cin && Cin2 % BK == 0 && Kpad2 == Cin2);
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    CPR_CHECK_ARG(OH > 0 && OW > 0 && OH == (H2 - 1) / stride2 + 1 && OW == (W2 - 1) / stride2 + 1);
+    const long long img = cpr_max2(cpr_max2((long long)H * W * Cin, (long long)H2 * W2 * Cin2), (long long)OH * OW * Cout) * 4;
+    const int per = cpr_images_per_launch(N, img);
+    if (per <= 0) return CPR_ERR_UNSUPPORTED;
+    for (int n0 = 0; n0 < N; n0 += per) {
+        const int n = N - n0 < per ? N - n0 : per;
+        const int rc = conv2d_dual_launch(in + (size_t)n0 * H * W * Cin, wgt, in2 + (size_t)n0 * H2 * W2 * Cin2, wgt2,
+                                          out + (size_t)n0 * OH * OW * Cout, scale, bias, scale2, bias2, n, H, W, Cin, Cout,
+                                          KH, KW, stride, pad, Kpad, H2, W2, Cin2, stride2, Kpad2, flags,
+                                          n0 == 0 ? variant_out : nullptr, stream);
+        if (rc != CPR_OK) return rc;
     }
     return CPR_OK;
 }

@@ -28,6 +28,7 @@
 #include "common.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct WinoParams {
     const float* in;      // NHWC, or channel-blocked [N][Cin/8][H][W][8] (in_b8)
@@ -40,6 +41,7 @@ struct WinoParams {
     const float* in_b;
     int in_relu, out_b8;
     int N, H, W, Cin, Cout, relu, RY, RX, regions, tilesN, nch;
+    int tpx;              // cout tiles per XCD: 0 = every XCD walks (region, cout tile) runs; 1 / 2 = an XCD owns 1 / 2 cout tiles
 };
 
 constexpr int WBUF = 16 * 64 * 8;   // floats in one V or U chunk image (32 KB)
@@ -85,8 +87,12 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 // XF: fused per-(image, channel) affine (+ReLU) on the input = GroupNorm apply of the producing layer.
 // ABL (benchmark-only, results are then WRONG): bit0 = no global loads / transform / LDS writes, bit1 = no fragment reads,
 // bit2 = no barrier, bit3 = no patch loads, bit4 = no output stores, bit5 = no epilogue at all.  ABL = 0 in every product launch.
-template <int ABL, bool INB8, bool XF, int TSPREAD = 1>
+// VAR (staging depth, results identical): bit0 = the patch of chunk c+4 (not c+3) is requested during chunk c (two register
+// sets, 1.75 chunk periods for a request to land instead of 0.75); bit1 = ONE weight register set (chunk c+2 requested during
+// chunk c); bit2 = the weight image goes global -> LDS by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write).
+template <int ABL, bool INB8, bool XF, int TSPREAD = 1, int VAR = 0>
 __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
+    constexpr bool DEEP = (VAR & 1) != 0, UDMA = (VAR & 4) != 0, USINGLE = (VAR & 2) != 0 && !UDMA;
     constexpr int XFMAX = 512;      // fused-affine launches keep the image's (a, b) table in LDS (Cin <= 512)
     constexpr int RAWROW = 148;     // a patch row: 18 pixels x 8 channels + 4 floats, so that 8 lanes two rows apart hit 8 distinct bank groups
     constexpr int RAWBUF = 18 * RAWROW;
@@ -144,14 +150,27 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         unsigned uok;                  // bit k: unit k is a pixel inside the image
         bool any_pad, valid;           // scalars
     };
+    // p.tpx > 0: an XCD owns tpx of the cout tiles (its weight working set is tpx MB of the 4 MB L2 instead of all of it) and a
+    // 1 / (8 tpx / tilesN) share of the regions; the XCDs that share a region range walk it in the same order.
     const int T = p.regions * p.tilesN;
     const int per = (T + 7) >> 3;
+    const int ngrp = p.tpx > 0 ? p.tilesN / p.tpx : 1;            // cout-tile groups (divides 8)
+    const int per_r = p.tpx > 0 ? (p.regions * ngrp + 7) / 8 : 0;  // regions per XCD
     auto setup = [&](int vb) {
         Tile t;
-        const int tile = (vb & 7) * per + (vb >> 3);
-        t.valid = vb < per * 8 && tile < T;
-        const int tl = t.valid ? tile : 0;
-        t.rg = tl / p.tilesN; t.tn = tl - t.rg * p.tilesN;
+        if (p.tpx > 0) {
+            const int x = vb & 7, s = vb >> 3;
+            const int sr = s / p.tpx;
+            t.rg = (x / ngrp) * per_r + sr;
+            t.tn = (x % ngrp) * p.tpx + (s - sr * p.tpx);
+            t.valid = sr < per_r && t.rg < p.regions;
+            if (!t.valid) { t.rg = 0; t.tn = 0; }
+        } else {
+            const int tile = (vb & 7) * per + (vb >> 3);
+            t.valid = vb < per * 8 && tile < T;
+            const int tl = t.valid ? tile : 0;
+            t.rg = tl / p.tilesN; t.tn = tl - t.rg * p.tilesN;
+        }
         t.n = t.rg / (p.RY * p.RX);
         const int rrem = t.rg - t.n * p.RY * p.RX;
         const int ry = rrem / p.RX, rx = rrem - ry * p.RX;
@@ -170,12 +189,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         return t;
     };
 
-    f32x4 sa[2];          // the thread's two patch units of the chunk in flight
-    f32x4 pa[2];          // ... of chunk 1 of a tile being prefetched
-    f32x4 su[2][4];       // weight pieces: chunk k lives in set k % 2
+    f32x4 sp[2][2];       // [set][unit] the thread's two patch units: set 0 = the chunk in flight, set 1 = chunk 1 of a tile being
+                          // prefetched (DEEP: chunk k lives in set k % 2, two chunks in flight)
+    f32x4 su[(USINGLE || UDMA) ? 1 : 2][4];   // weight pieces: chunk k lives in set k % 2 (USINGLE: one set; UDMA: unused)
     float tab_a = 0.f, tab_b = 0.f;   // XF: this thread's entry of the next image's (a, b) table
     float d[16];          // T: the 4 x 4 patch of (tile, channel)
-    if (ABL & 9) { sa[0] = f32x4{1.f, 1.f, 1.f, 1.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0]; }
+    if (ABL & 9) { sp[0][0] = f32x4{1.f, 1.f, 1.f, 1.f}; sp[0][1] = sp[0][0]; sp[1][0] = sp[0][0]; sp[1][1] = sp[0][0]; }
     Tile cur = setup(blockIdx.x);
     auto ld_a = [&](const Tile& t, int ck, int k) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, t.voffA[k], ck * chunk_bytes, 0));
@@ -186,23 +205,45 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     };
     auto prefetch = [&](const Tile& t) {   // chunks 0 and 1 of tile t (Cin >= 32: both exist)
         if (!(ABL & 8)) {
-            sa[0] = ld_a(t, 0, 0); pa[0] = ld_a(t, 1, 0);
-            if (second_unit) { sa[1] = ld_a(t, 0, 1); pa[1] = ld_a(t, 1, 1); }
+            sp[0][0] = ld_a(t, 0, 0); sp[1][0] = ld_a(t, 1, 0);
+            if (second_unit) { sp[0][1] = ld_a(t, 0, 1); sp[1][1] = ld_a(t, 1, 1); }
         }
+        if (!UDMA) {
 #pragma unroll
-        for (int z = 0; z < 4; ++z) { su[0][z] = ld_u(t, 0, z); su[1][z] = ld_u(t, 1, z); }
+            for (int z = 0; z < 4; ++z) { su[0][z] = ld_u(t, 0, z); if (!USINGLE) su[USINGLE ? 0 : 1][z] = ld_u(t, 1, z); }
+        }
         if (XF) {
             if (tid < p.Cin) { tab_a = p.in_a[t.n * p.Cin + tid]; tab_b = p.in_b[t.n * p.Cin + tid]; }
         }
     };
-    auto g_a = [&](int chunk, int k) {                 // G, patch unit k
+    auto g_a = [&](auto set_c, int chunk, int k) {     // G, patch unit k into register set set_c
+        constexpr int SET = decltype(set_c)::value;
         if (ABL & 8) return;
         const int ck = chunk < last ? chunk : last;    // the pipeline requests past the end: clamp (the data is never used)
-        if (k == 0 || second_unit) sa[k] = ld_a(cur, ck, k);
+        if (k == 0 || second_unit) sp[SET][k] = ld_a(cur, ck, k);
     };
     auto g_u = [&](auto set_c, int chunk, int z) {     // G, weight piece z = 0..3
-        constexpr int SET = decltype(set_c)::value;
-        su[SET][z] = ld_u(cur, chunk < last ? chunk : last, z);
+        constexpr int SET = (USINGLE || UDMA) ? 0 : decltype(set_c)::value;
+        if (!UDMA) su[SET][z] = ld_u(cur, chunk < last ? chunk : last, z);
+    };
+    // UDMA: piece z of the chunk's 32 KB weight image straight into U[buf] (each wave 1 KB: lane * 16 bytes from the wave's base
+    // in M0).  Inline asm: the compiler neither counts it in its vmcnt bookkeeping nor waits for it -- the K loop counts by hand
+    // (dma_wait), and every request is older than the patch requests it shares the counter with when those are waited for.
+    const int lds_u0 = (int)(unsigned)(size_t)(smem + 2 * WBUF);    // LDS byte address of U[0]
+    const size_t u_addr = (size_t)p.u;                                // the same descriptor as rs_u, as four SGPR words
+    const i32x4 rs_u_raw = {(int)(unsigned)u_addr, (int)(unsigned)(u_addr >> 32) & 0xffff,
+                            (int)((size_t)p.tilesN * p.nch * WBUF * 4), 0x00020000};
+    auto dma_u = [&](int chunk, int buf, int z) {
+        const int soff = (cur.tn * p.nch + chunk) * (WBUF * 4);
+        const int m0v = lds_u0 + buf * (WBUF * 4) + z * 8192 + wave * 1024;
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:0 lds"
+                     :: "s"(m0v), "v"(tid * 16 + z * 8192), "s"(rs_u_raw), "s"(soff) : "memory");
+    };
+    auto dma_wait = [&](auto npatch_c) {               // all LDS-DMA pieces landed; NP patch requests per unit stay in flight
+        constexpr int NP = decltype(npatch_c)::value;
+        if (NP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (second_unit) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
     };
     auto affine = [&](f32x4 v, f32x4 a4, f32x4 b4, int k) {   // the producer's GroupNorm apply (+ReLU); padding stays 0
         v = v * a4 + b4;
@@ -216,15 +257,16 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         xa4 = *reinterpret_cast<const f32x4*>(tab);
         xb4 = *reinterpret_cast<const f32x4*>(tab + XFMAX);
     };
-    auto r_a = [&](int buf, int k) {                   // R, patch unit k
+    auto r_a = [&](auto set_c, int buf, int k) {       // R, patch unit k
+        constexpr int SET = decltype(set_c)::value;
         if (k == 1 && !second_unit) return;
-        f32x4 v = sa[k];
+        f32x4 v = sp[SET][k];
         if (XF) v = affine(v, xa4, xb4, k);
         if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + buf * RAWBUF + raw_wr[k]) = v;
     };
     auto r_a_pro = [&](int chunk01, int k) {           // R of the prefetched chunks 0 (sa) and 1 (pa) -> raw[chunk01]
         if (k == 1 && !second_unit) return;
-        f32x4 v = chunk01 ? pa[k] : sa[k];
+        f32x4 v = chunk01 ? sp[1][k] : sp[0][k];
         if (XF) {
             const float* tab = ABs + par * 2 * XFMAX + chunk01 * 8 + (tid & 1) * 4;
             v = affine(v, *reinterpret_cast<const f32x4*>(tab), *reinterpret_cast<const f32x4*>(tab + XFMAX), k);
@@ -232,8 +274,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         if (k == 0 || unit1_live) *reinterpret_cast<f32x4*>(Rw + chunk01 * RAWBUF + raw_wr[k]) = v;
     };
     auto r_u = [&](auto set_c, int buf, int z) {       // R, weight piece z
-        constexpr int SET = decltype(set_c)::value;
-        *reinterpret_cast<f32x4*>(Us + buf * WBUF + tid * 4 + z * 2048) = su[SET][z];
+        constexpr int SET = (USINGLE || UDMA) ? 0 : decltype(set_c)::value;
+        if (!UDMA) *reinterpret_cast<f32x4*>(Us + buf * WBUF + tid * 4 + z * 2048) = su[SET][z];
     };
     auto t_read = [&](int buf, int r) {                // T, patch row r -> registers
 #pragma unroll
@@ -286,11 +328,18 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     // prologue, from the prefetched registers (chunks 0, 1): raw[0], raw[1], U[0], then V[0]; chunk 2 requested
     r_a_pro(0, 0); r_a_pro(0, 1);
     r_a_pro(1, 0); r_a_pro(1, 1);
+    if (UDMA) {   // after the waits on the prefetched patch (the compiler's counts do not know these requests)
+#pragma unroll
+        for (int z = 0; z < 4; ++z) dma_u(0, 0, z);
+#pragma unroll
+        for (int z = 0; z < 4; ++z) dma_u(1, 1, z);
+    }
 #pragma unroll
     for (int z = 0; z < 4; ++z) r_u(Set0{}, 0, z);
-    g_a(2, 0); g_a(2, 1);
+    g_a(Set0{}, 2, 0); g_a(Set0{}, 2, 1);
+    if (DEEP) { g_a(Set1{}, 3, 0); g_a(Set1{}, 3, 1); }
 #pragma unroll
-    for (int z = 0; z < 4; ++z) g_u(Set0{}, 2, z);
+    for (int z = 0; z < 4; ++z) g_u(Set0{}, USINGLE ? 1 : 2, z);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) t_read(0, r);
@@ -300,6 +349,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) t_read(1, r);
     }
+    if (UDMA) dma_wait(std::integral_constant<int, DEEP ? 2 : 1>{});   // U[0], U[1] are in LDS; the patch requests stay in flight
     __syncthreads();
 #pragma unroll
     for (int z = 0; z < 3; ++z) WFRAG(fa0, fb0, 0, 0, z);
@@ -316,6 +366,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     // the fused-affine instances run 2 % faster with TSPREAD = 0, the plain ones 0.7 % faster with 1 -- see the launcher)
     auto iteration = [&](auto nxt_c, int c) {
         const int buf = c & 1;
+        // patch register set of this iteration: chunk c+2 (written to raw[buf] here) lives in set c % 2 when two are in flight
+        const std::integral_constant<int, DEEP ? 1 - decltype(nxt_c)::value : 0> pset_c{};
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             WMFMA(fa0, fb0, 0, q);
@@ -344,13 +396,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             WMFMA(fa0, fb0, 2, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa1, fb1, buf, 3, q);
             if (!(ABL & 1)) {
-                if (q == 3) r_a(buf, 0);
-                if (q == 4) r_a(buf, 1);
-                if (q == 5 || q == 6 || q == 7) g_u(nxt_c, c + 3, q - 5);
+                if (q == 3) r_a(pset_c, buf, 0);
+                if (q == 4) r_a(pset_c, buf, 1);
+                if (q == 5 || q == 6 || q == 7) g_u(nxt_c, c + (USINGLE ? 2 : 3), q - 5);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("" ::: "memory");
+        if (UDMA) dma_wait(std::integral_constant<int, DEEP ? 1 : 0>{});   // U[buf ^ 1] (requested behind the last j = 3) is in LDS
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS traffic is done; global loads stay in flight
         if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -360,9 +413,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             WMFMA(fa1, fb1, 3, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa0, fb0, buf ^ 1, 0, q);
             if (!(ABL & 1)) {
-                if (q == 3) g_a(c + 3, 0);
-                if (q == 5) g_a(c + 3, 1);
-                if (q == 7) g_u(nxt_c, c + 3, 3);
+                if (UDMA) {   // U[buf] is free since the barrier: chunk c+2's image, requested BEFORE this phase's patch requests
+                    if (q < 4 && c + 2 < p.nch) dma_u(c + 2, buf, q);
+                    if (q == 4) g_a(pset_c, c + (DEEP ? 4 : 3), 0);
+                    if (q == 6) g_a(pset_c, c + (DEEP ? 4 : 3), 1);
+                } else {
+                    if (q == 3) g_a(pset_c, c + (DEEP ? 4 : 3), 0);
+                    if (q == 5) g_a(pset_c, c + (DEEP ? 4 : 3), 1);
+                    if (q == 7) g_u(nxt_c, c + (USINGLE ? 2 : 3), 3);
+                }
                 if (TSPREAD == 1 && q >= 4) t_read(buf, q - 4);   // chunk c+2's patch (raw[buf], written behind j = 2)
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -469,16 +528,23 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
 
 // C-ABI ------------------------------------------------------------------------------------------
 #ifdef CPR_BENCH_HOOKS   // measurement build only (libcprhip_bench.so): register-set A/B and loop ablations, process-global
-static int wino_sched = 0, wino_ablate = 0;
+static int wino_sched = 0, wino_ablate = 0, wino_var = -1, wino_tpx = -1;
 extern "C" int cpr_wino_set_variant(int sched, int ablate) {   // sched 1: the other placement of the patch transform (TSPREAD flipped)
     CPR_CHECK_ARG((sched == 0 || sched == 1) && ablate >= 0 && ablate <= 32);
     wino_sched = sched;
     wino_ablate = ablate;
     return CPR_OK;
 }
+extern "C" int cpr_wino_set_staging(int var, int tpx) {   // staging depth (VAR of the kernel) and cout tiles per XCD; -1 = the product's choice
+    CPR_CHECK_ARG(var >= -1 && var <= 5 && tpx >= -1 && tpx <= 2);
+    wino_var = var;
+    wino_tpx = tpx;
+    return CPR_OK;
+}
 #else
-constexpr int wino_sched = 0, wino_ablate = 0;
+constexpr int wino_sched = 0, wino_ablate = 0, wino_var = -1, wino_tpx = -1;
 #endif
+constexpr int WINO_VAR_DEFAULT = 0, WINO_TPX_DEFAULT = 0;   // the product's staging variant / tile mapping (measured)
 extern "C" int cpr_wino_pack_weights(const float* wgt, float* u, int Cin, int Cout, int Kpad, hipStream_t stream) {
     CPR_CHECK_ARG(wgt && u && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 64 == 0 && Kpad >= 9 * Cin);
     hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, stream, wgt, u, Cin, Cout, Kpad);
@@ -515,16 +581,39 @@ static int wino_fwd_launch(const float* in, const float* u, float* out, const fl
     int grid = (int)((T + 7) / 8 * 8);
     if (grid > ncu) grid = ncu;   // persistent: one workgroup per CU
     const bool b8 = (layout & CPR_WINO_IN_B8) != 0, xf = in_a != nullptr;
+    p.tpx = wino_tpx >= 0 ? wino_tpx : WINO_TPX_DEFAULT;
+    if (p.tpx > 0 && !(p.tilesN % p.tpx == 0 && 8 % (p.tilesN / p.tpx) == 0)) p.tpx = 0;   // cout-tile groups must divide the 8 XCDs
+    if (p.tpx > 0) {   // virtual block ids: 8 XCDs x (regions per XCD x tpx)
+        const long long per_r = ((long long)p.regions * (p.tilesN / p.tpx) + 7) / 8;
+        const long long vbs = 8 * per_r * p.tpx;
+        if (vbs < grid) grid = (int)vbs;
+    }
+    const int var = wino_var >= 0 ? wino_var : WINO_VAR_DEFAULT;
     // TSPREAD: measured per instance (same box, B=64): fused-affine input 6.87 ms single-phase vs 7.02 spread; plain input 6.74 vs 6.69
-#define WLAUNCH(A_, F_)                                                                                                       \
-    do {                                                                                                                     \
-        if (b8 && xf) hipLaunchKernelGGL((conv_wino_kernel<A_, true, true, 0 ^ F_>), dim3(grid), dim3(512), 0, stream, p);    \
-        else if (b8) hipLaunchKernelGGL((conv_wino_kernel<A_, true, false, 1 ^ F_>), dim3(grid), dim3(512), 0, stream, p);    \
-        else if (xf) hipLaunchKernelGGL((conv_wino_kernel<A_, false, true, 0 ^ F_>), dim3(grid), dim3(512), 0, stream, p);    \
-        else hipLaunchKernelGGL((conv_wino_kernel<A_, false, false, 1 ^ F_>), dim3(grid), dim3(512), 0, stream, p);           \
+#define WLAUNCHV(A_, F_, V_)                                                                                                      \
+    do {                                                                                                                         \
+        if (b8 && xf) hipLaunchKernelGGL((conv_wino_kernel<A_, true, true, 0 ^ F_, V_>), dim3(grid), dim3(512), 0, stream, p);    \
+        else if (b8) hipLaunchKernelGGL((conv_wino_kernel<A_, true, false, 1 ^ F_, V_>), dim3(grid), dim3(512), 0, stream, p);    \
+        else if (xf) hipLaunchKernelGGL((conv_wino_kernel<A_, false, true, 0 ^ F_, V_>), dim3(grid), dim3(512), 0, stream, p);    \
+        else hipLaunchKernelGGL((conv_wino_kernel<A_, false, false, 1 ^ F_, V_>), dim3(grid), dim3(512), 0, stream, p);           \
     } while (0)
+#define WLAUNCH(A_, F_) WLAUNCHV(A_, F_, WINO_VAR_DEFAULT)
 #ifdef CPR_BENCH_HOOKS
-    if (wino_ablate || wino_sched) {
+    if (var != WINO_VAR_DEFAULT && !wino_ablate) {   // staging variants, measurement build only
+        switch (var * 2 + wino_sched) {
+            case 0: WLAUNCHV(0, 0, 0); break;
+            case 1: WLAUNCHV(0, 1, 0); break;
+            case 2: WLAUNCHV(0, 0, 1); break;
+            case 3: WLAUNCHV(0, 1, 1); break;
+            case 4: WLAUNCHV(0, 0, 2); break;
+            case 6: WLAUNCHV(0, 0, 3); break;
+            case 8: WLAUNCHV(0, 0, 4); break;
+            case 9: WLAUNCHV(0, 1, 4); break;
+            case 10: WLAUNCHV(0, 0, 5); break;
+            case 11: WLAUNCHV(0, 1, 5); break;
+            default: return CPR_ERR_UNSUPPORTED;
+        }
+    } else if (wino_ablate || wino_sched) {
         switch (wino_ablate) {
             case 0: WLAUNCH(0, 1); break;
             case 1: WLAUNCH(1, 0); break;
@@ -539,6 +628,7 @@ static int wino_fwd_launch(const float* in, const float* u, float* out, const fl
 #endif
     WLAUNCH(0, 0);
 #undef WLAUNCH
+#undef WLAUNCHV
     CPR_LAUNCH_STATUS();
 }
 

@@ -45,14 +45,14 @@ __global__ __launch_bounds__(256 * WPS, 1) void shadow_kernel(float* out, const 
                 asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(q * NV + k) & 7]) : "v"(c1), "v"(c2));
 #pragma unroll
             for (int k = 0; k < NR; ++k)
-                asm volatile("ds_read_b32 %0, %1 offset:4096" : "=v"(rr[(q * NR + k) & 3]) : "v"(laddr));
+                asm volatile("ds_read_b32 %0, %1 offset:4096" : "+v"(rr[(q * NR + k) & 3]) : "v"(laddr));
 #pragma unroll
             for (int k = 0; k < NW; ++k)
                 asm volatile("ds_write_b32 %0, %1 offset:32768" ::"v"(laddr), "v"(v[k & 7]));
-            if (NB > 0 && q < NB) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(b4[q & 1]) : "v"(laddr4));
+            if (NB > 0 && q < NB) asm volatile("ds_read_b128 %0, %1 offset:0" : "+v"(b4[q & 1]) : "v"(laddr4));
             if (NG > 0 && q < NG) {
                 const f32x4* gq = gp + ((it * 8 + q) & 63) * 4096;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g4[q & 3]) : "v"(gq));
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(g4[q & 3]) : "v"(gq));
             }
         }
     }
