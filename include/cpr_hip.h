@@ -45,6 +45,16 @@ int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, const float* s
                    int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int flags, int in_relu,
                    int* variant_out, void* stream);
 
+/* First block of a ResNet stage (Bottleneck.forward, T/mmdet/models/backbones/resnet.py:262-302 with the projection shortcut
+ * built by ResLayer, T/mmdet/models/utils/res_layer.py / resnet.py:564-610): out = relu?((conv(in, wgt) * scale + bias)
+ * + (conv1x1(in2, wgt2; stride2, unpadded) * scale2 + bias2)) in ONE launch -- the shortcut map is never stored.  Both
+ * convolutions produce the same (N, OH, OW, Cout) grid; in2 is (N, H2, W2, Cin2), wgt2 [Cout][Kpad2 = Cin2]; Cin, Cin2
+ * multiples of 32.  Bit-identical to cpr_conv2d_fwd(in2, wgt2) followed by cpr_conv2d_fwd(in, wgt, residual = that). */
+int cpr_conv2d_dual_fwd(const float* in, const float* wgt, const float* in2, const float* wgt2, float* out,
+                        const float* scale, const float* bias, const float* scale2, const float* bias2, int N, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int H2, int W2, int Cin2,
+                        int stride2, int Kpad2, int flags, int* variant_out, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies than
  * cpr_conv2d_fwd; same call sites: the CPR head towers cpr_head.py:1033-1043, the FPN output conv fpn.py:190-194, the 3x3 of
  * every stride-1 bottleneck resnet.py:630-645).  The transforms only add/subtract, the result differs from the direct fp32

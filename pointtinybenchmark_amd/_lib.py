@@ -18,6 +18,7 @@ _l = ctypes.c_longlong
 SIGNATURES = {
     'cpr_version': [],
     'cpr_conv2d_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
+    'cpr_conv2d_dual_fwd': [_p] * 9 + [_i] * 16 + [_p, _p],
     'cpr_wino_pack_weights': [_p, _p, _i, _i, _i, _p],
     'cpr_conv3x3_wino_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_conv3x3_wino_wgrad_workspace': [_i, _i, _i, _i, _i],

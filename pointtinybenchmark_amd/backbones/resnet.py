@@ -5,12 +5,17 @@ Interface of T/mmdet/models/backbones/resnet.py:305-657 (ctor kwargs, ``forward(
 BatchNorm is always evaluated with running statistics on this path (norm_eval=True in every CPR/P2P config)
 and is folded into the conv epilogue; the bottleneck shortcut add + ReLU are fused into conv3's epilogue.
 The backward of the trainable stages is driven by training.CprTrainer from the per-block records of ``forward(tape=)``."""
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import ops
 from ..layers import _PackCache, folded_bn, packed_conv
 from ..registry import BACKBONES
+
+
+FUSE_SHORTCUT = [os.environ.get('CPR_FUSE_SHORTCUT', '1') == '1']   # A/B switch (tests, tools)
 
 
 class _Block(nn.Module):
@@ -34,17 +39,26 @@ class _Block(nn.Module):
     def run(self, cache, x, save=None):
         """save (dict): training mode -- keeps the block's activations for the backward pass."""
         identity = x
-        if self.downsample is not None:
+        dt = x.dtype
+        # forward-only fp32 bottleneck with a projection shortcut: the shortcut GEMM rides in conv3's launch (bit-identical,
+        # ops.conv2d_dual); the training step keeps the two launches (its backward walks the recorded maps)
+        fuse_shortcut = FUSE_SHORTCUT[0] and self.downsample is not None and save is None and self.kind == 'bottleneck' and \
+            dt == torch.float32
+        if self.downsample is not None and not fuse_shortcut:
             s, b = folded_bn(cache, self.downsample[1])
             identity = ops.conv2d(x, packed_conv(cache, self.downsample[0], x.dtype), scale=s, bias=b)
-        dt = x.dtype
         s1, b1 = folded_bn(cache, self.bn1)
         o1 = ops.conv2d(x, packed_conv(cache, self.conv1, dt), scale=s1, bias=b1, relu=True)
         s2, b2 = folded_bn(cache, self.bn2)
         if self.kind == 'bottleneck':
             o2 = ops.conv2d(o1, packed_conv(cache, self.conv2, dt), scale=s2, bias=b2, relu=True)
             s3, b3 = folded_bn(cache, self.bn3)
-            out = ops.conv2d(o2, packed_conv(cache, self.conv3, dt), scale=s3, bias=b3, residual=identity, relu=True)
+            if fuse_shortcut:
+                sd, bd = folded_bn(cache, self.downsample[1])
+                out = ops.conv2d_dual(o2, packed_conv(cache, self.conv3, dt), x, packed_conv(cache, self.downsample[0], dt),
+                                      scale=s3, bias=b3, scale2=sd, bias2=bd, relu=True)
+            else:
+                out = ops.conv2d(o2, packed_conv(cache, self.conv3, dt), scale=s3, bias=b3, residual=identity, relu=True)
         else:
             o2 = None
             out = ops.conv2d(o1, packed_conv(cache, self.conv2, dt), scale=s2, bias=b2, residual=identity, relu=True)

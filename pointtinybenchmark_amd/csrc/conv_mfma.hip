@@ -451,6 +451,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         p.out, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.residual ? p.residual : p.out), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+    // (A 16-byte form of this epilogue -- affine in the accumulator layout, tile through LDS, buffer_*_dwordx4 residual loads
+    // and stores, 4x fewer memory instructions -- was built and measured per layer at B=64: +-0 over the step, -7 % on the
+    // HBM-bound 160x160 64->256 + residual layer; profiles/round3_wide_epilogue_ab.txt.  Not kept.)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int c = n0 + wn * WN + j * 32 + (lane & 31);
@@ -540,6 +543,7 @@ static int force_tile_bm = 0, force_tile_bn = 0;  // cpr_conv_force_tile, 0 = he
 static int conv_pipeline = 1;                      // 1 = interleaved K loop (default), 0 = phase-separated (A/B reference)
 static int conv_ablate = 0;                        // cpr_conv_set_ablation
 static int conv_extra_lds = 0;                     // cpr_conv_set_extra_lds: dynamic LDS bytes added to every launch (occupancy probe)
+
 extern "C" int cpr_conv_set_extra_lds(int bytes) {
     CPR_CHECK_ARG(bytes >= 0 && bytes <= 65536);
     conv_extra_lds = bytes;
@@ -580,6 +584,7 @@ static int conv2d_fwd_launch(const float* in, const float* wgt, float* out, cons
     CPR_CHECK_ARG((flags & ~15) == 0);
     p.Kpad = Kpad; p.relu = flags & CPR_CONV_RELU; p.in_relu = in_relu; p.out_bf16 = (flags & CPR_CONV_OUT_BF16) ? 1 : 0;
     p.res_mask = (flags & CPR_CONV_RES_MASK) ? 1 : 0;
+    p.in2 = nullptr; p.wgt2 = nullptr; p.scale2 = nullptr; p.bias2 = nullptr; p.H2 = p.W2 = p.Cin2 = p.stride2 = p.Kpad2 = 0;
     const bool colsum_mode = (flags & CPR_CONV_COLSUM) != 0;   // gn_part partials are only summed over the whole tensor (any tile)
     if (p.res_mask) CPR_CHECK_ARG(residual != nullptr);
     p.OH = (H + 2 * pad - KH) / stride + 1;
@@ -707,6 +712,7 @@ static int conv2d_dual_launch(const float* in, const float* wgt, const float* in
     p.OW = (W + 2 * pad - KW) / stride + 1;
     p.in2 = in2; p.wgt2 = wgt2; p.scale2 = scale2; p.bias2 = bias2;
     p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2; p.Kpad2 = Kpad2;
+    p.tilesM = p.tilesN = 0;
     const long long M = (long long)N * p.OH * p.OW;
     if ((long long)N * H * W * Cin * 4 >= (1ll << 31) || (long long)N * H2 * W2 * Cin2 * 4 >= (1ll << 31) ||
         (long long)Cout * Kpad * 4 >= (1ll << 31) || (long long)Cout * Kpad2 * 4 >= (1ll << 31) || M * Cout * 4 >= (1ll << 31))

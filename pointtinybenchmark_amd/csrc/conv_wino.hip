@@ -248,7 +248,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     auto affine = [&](f32x4 v, f32x4 a4, f32x4 b4, int k) {   // the producer's GroupNorm apply (+ReLU); padding stays 0
         v = v * a4 + b4;
         v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-        if (cur.any_pad) { if (!((cur.uok >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (cur.any_pad) {   // interior regions skip the selects with one scalar branch (the empty asm keeps it a branch)
+            asm volatile("");
+            if (!((cur.uok >> k) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         return v;
     };
     f32x4 xa4, xb4;       // XF: the affine of the chunk about to be written (both units of a thread share the channel half)
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             WMFMA(fa0, fb0, 0, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa1, fb1, buf, 1, q);
             if (!(ABL & 1)) {
-                if (TSPREAD == 0) { if (q >= 4) t_read(buf ^ 1, q - 4); }
+                if (TSPREAD == 0 || TSPREAD == 2) { if (q >= 4) t_read(buf ^ 1, q - 4); }
                 else { if (q == 3) t_row(buf ^ 1, 0); if (q == 6) t_row(buf ^ 1, 1); }   // patch read behind the last j = 3
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -385,6 +388,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             if (!(ABL & 1)) {
                 if (q & 1) r_u(nxt_c, buf ^ 1, q >> 1);
                 else if (TSPREAD == 0) t_row(buf ^ 1, q >> 1);
+                else if (TSPREAD == 2) {   // the whole transform behind ONE MFMA: every MFMA pair with vector-ALU work between
+                    if (q == 0) {          // them pays a fixed price (tools/diag/mfma_shadow), so fewer, fuller gaps
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t_row(buf ^ 1, i);
+                    }
+                }
                 else if (q == 2) t_row(buf ^ 1, 2);
                 else if (q == 6) t_row(buf ^ 1, 3);
                 if (XF && q == 7) xf_fetch(c + 2);
@@ -396,8 +405,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
             WMFMA(fa0, fb0, 2, q);
             if (q < 3 && !(ABL & 2)) WFRAG(fa1, fb1, buf, 3, q);
             if (!(ABL & 1)) {
-                if (q == 3) r_a(pset_c, buf, 0);
-                if (q == 4) r_a(pset_c, buf, 1);
+                if (q == 3) { r_a(pset_c, buf, 0); if (TSPREAD == 2) r_a(pset_c, buf, 1); }
+                if (q == 4 && TSPREAD != 2) r_a(pset_c, buf, 1);
                 if (q == 5 || q == 6 || q == 7) g_u(nxt_c, c + (USINGLE ? 2 : 3), q - 5);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
 #ifdef CPR_BENCH_HOOKS   // measurement build only (libcprhip_bench.so): register-set A/B and loop ablations, process-global
 static int wino_sched = 0, wino_ablate = 0, wino_var = -1, wino_tpx = -1;
 extern "C" int cpr_wino_set_variant(int sched, int ablate) {   // sched 1: the other placement of the patch transform (TSPREAD flipped)
-    CPR_CHECK_ARG((sched == 0 || sched == 1) && ablate >= 0 && ablate <= 32);
+    CPR_CHECK_ARG(sched >= 0 && sched <= 2 && ablate >= 0 && ablate <= 32);
     wino_sched = sched;
     wino_ablate = ablate;
     return CPR_OK;
@@ -544,7 +553,7 @@ extern "C" int cpr_wino_set_staging(int var, int tpx) {   // staging depth (VAR 
 #else
 constexpr int wino_sched = 0, wino_ablate = 0, wino_var = -1, wino_tpx = -1;
 #endif
-constexpr int WINO_VAR_DEFAULT = 0, WINO_TPX_DEFAULT = 0;   // the product's staging variant / tile mapping (measured)
+constexpr int WINO_VAR_DEFAULT = 4, WINO_TPX_DEFAULT = 0;   // the product's staging variant / tile mapping (measured)
 extern "C" int cpr_wino_pack_weights(const float* wgt, float* u, int Cin, int Cout, int Kpad, hipStream_t stream) {
     CPR_CHECK_ARG(wgt && u && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 64 == 0 && Kpad >= 9 * Cin);
     hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, stream, wgt, u, Cin, Cout, Kpad);
@@ -592,25 +601,28 @@ static int wino_fwd_launch(const float* in, const float* u, float* out, const fl
     // TSPREAD: measured per instance (same box, B=64): fused-affine input 6.87 ms single-phase vs 7.02 spread; plain input 6.74 vs 6.69
 #define WLAUNCHV(A_, F_, V_)                                                                                                      \
     do {                                                                                                                         \
-        if (b8 && xf) hipLaunchKernelGGL((conv_wino_kernel<A_, true, true, 0 ^ F_, V_>), dim3(grid), dim3(512), 0, stream, p);    \
-        else if (b8) hipLaunchKernelGGL((conv_wino_kernel<A_, true, false, 1 ^ F_, V_>), dim3(grid), dim3(512), 0, stream, p);    \
-        else if (xf) hipLaunchKernelGGL((conv_wino_kernel<A_, false, true, 0 ^ F_, V_>), dim3(grid), dim3(512), 0, stream, p);    \
-        else hipLaunchKernelGGL((conv_wino_kernel<A_, false, false, 1 ^ F_, V_>), dim3(grid), dim3(512), 0, stream, p);           \
+        constexpr int TX_ = F_ == 2 ? 2 : 0 ^ F_, TP_ = F_ == 2 ? 2 : 1 ^ F_;                                                     \
+        if (b8 && xf) hipLaunchKernelGGL((conv_wino_kernel<A_, true, true, TX_, V_>), dim3(grid), dim3(512), 0, stream, p);       \
+        else if (b8) hipLaunchKernelGGL((conv_wino_kernel<A_, true, false, TP_, V_>), dim3(grid), dim3(512), 0, stream, p);       \
+        else if (xf) hipLaunchKernelGGL((conv_wino_kernel<A_, false, true, TX_, V_>), dim3(grid), dim3(512), 0, stream, p);       \
+        else hipLaunchKernelGGL((conv_wino_kernel<A_, false, false, TP_, V_>), dim3(grid), dim3(512), 0, stream, p);              \
     } while (0)
 #define WLAUNCH(A_, F_) WLAUNCHV(A_, F_, WINO_VAR_DEFAULT)
 #ifdef CPR_BENCH_HOOKS
-    if (var != WINO_VAR_DEFAULT && !wino_ablate) {   // staging variants, measurement build only
-        switch (var * 2 + wino_sched) {
+    if ((var != WINO_VAR_DEFAULT || wino_sched == 2) && !wino_ablate) {   // staging variants, measurement build only
+        switch (var * 3 + wino_sched) {
             case 0: WLAUNCHV(0, 0, 0); break;
             case 1: WLAUNCHV(0, 1, 0); break;
-            case 2: WLAUNCHV(0, 0, 1); break;
-            case 3: WLAUNCHV(0, 1, 1); break;
-            case 4: WLAUNCHV(0, 0, 2); break;
-            case 6: WLAUNCHV(0, 0, 3); break;
-            case 8: WLAUNCHV(0, 0, 4); break;
-            case 9: WLAUNCHV(0, 1, 4); break;
-            case 10: WLAUNCHV(0, 0, 5); break;
-            case 11: WLAUNCHV(0, 1, 5); break;
+            case 2: WLAUNCHV(0, 2, 0); break;
+            case 6: WLAUNCHV(0, 0, 2); break;
+            case 7: WLAUNCHV(0, 1, 2); break;
+            case 8: WLAUNCHV(0, 2, 2); break;
+            case 9: WLAUNCHV(0, 0, 3); break;
+            case 10: WLAUNCHV(0, 1, 3); break;
+            case 11: WLAUNCHV(0, 2, 3); break;
+            case 12: WLAUNCHV(0, 0, 4); break;
+            case 13: WLAUNCHV(0, 1, 4); break;
+            case 14: WLAUNCHV(0, 2, 4); break;
             default: return CPR_ERR_UNSUPPORTED;
         }
     } else if (wino_ablate || wino_sched) {

@@ -281,6 +281,31 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     return (out, part) if gn_part else out
 
 
+def conv2d_dual(x, pc, x2, pc2, scale=None, bias=None, scale2=None, bias2=None, relu=False, out=None):
+    """relu?((conv(x, pc) * scale + bias) + (conv1x1(x2, pc2) * scale2 + bias2)) in one launch: conv3 + bn3 of a stage's first
+    bottleneck together with its projection shortcut (resnet.py:262-302) -- the shortcut map never reaches HBM.  Bit-identical
+    to ``conv2d(x, pc, scale, bias, residual=conv2d(x2, pc2, scale2, bias2), relu=relu)``.  fp32 NHWC; pc2 is 1x1, unpadded."""
+    _check(x, ACT)
+    _check(x2, ACT)
+    pack_ready(pc)
+    pack_ready(pc2)
+    N, H, W, Cin = x.shape
+    N2, H2, W2, Cin2 = x2.shape
+    assert x.dtype == torch.float32 and x2.dtype == torch.float32 and pc.dtype == torch.float32 and pc2.dtype == torch.float32
+    assert N == N2 and Cin == pc.Cin and Cin2 == pc2.Cin and pc.Cout == pc2.Cout and pc2.KH == 1 and pc2.KW == 1 and pc2.padding == 0
+    OH, OW = pc.out_hw(H, W)
+    assert (OH, OW) == pc2.out_hw(H2, W2), 'the two sources must produce the same output grid'
+    if out is None:
+        out = torch.empty((N, OH, OW, pc.Cout), device=x.device, dtype=torch.float32)
+    variant = ctypes.c_int(0) if TRACE_CONV_VARIANT[0] else None
+    _lib.call('cpr_conv2d_dual_fwd', _ptr(x), _ptr(pc.w), _ptr(x2), _ptr(pc2.w), _ptr(out), _ptr(scale), _ptr(bias),
+              _ptr(scale2), _ptr(bias2), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding, pc.Kpad, H2, W2, Cin2,
+              pc2.stride, pc2.Kpad, CONV_RELU if relu else 0, ctypes.byref(variant) if variant is not None else None, _stream())
+    if variant is not None:
+        TRACE_CONV_VARIANT[1] = ('fp32', variant.value)
+    return out
+
+
 class TilePartials:
     """Per-tile per-channel sums left by a conv epilogue; ``reduce()`` -> (C,) column sums on the CURRENT stream (the
     training step does it on its side stream, next to the only consumer, so the main chain never waits for it)."""

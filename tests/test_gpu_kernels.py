@@ -68,6 +68,41 @@ def test_conv2d_vs_torch(case):
     _cmp('conv', out.permute(0, 3, 1, 2), ref, atol=2e-5, rtol=2e-5)
 
 
+DUAL_CASES = [
+    # N, H2, W2, Cin2 (shortcut input), stride2, Cin (main 1x1 input), Cout
+    (2, 40, 40, 64, 1, 64, 256),        # layer1 block 0
+    (2, 40, 36, 256, 2, 128, 512),      # layer2 block 0 (stride-2 shortcut)
+    (3, 21, 19, 64, 2, 32, 96),         # ragged M, Cout not a tile multiple, odd map
+    (1, 64, 64, 512, 2, 256, 1024),     # long K
+    (64, 32, 32, 512, 1, 256, 1024),    # enough tiles for the 128x128 instance
+]
+
+
+@pytest.mark.parametrize('case', DUAL_CASES, ids=lambda c: 'n%d_%dx%d_c%d_s%d_c%d_o%d' % c)
+def test_conv2d_dual_bit_equal_to_two_launches(case):
+    """conv3 + bn3 + projection shortcut + ReLU in one launch (ops.conv2d_dual) == the two-launch form BIT for bit, and both
+    agree with torch (the first block of every ResNet stage, resnet.py:262-302)."""
+    ops = _ops()
+    N, H2, W2, Cin2, s2, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    OH, OW = (H2 - 1) // s2 + 1, (W2 - 1) // s2 + 1
+    x2 = torch.randn((N, Cin2, H2, W2), generator=g)
+    x = torch.randn((N, Cin, OH, OW), generator=g)
+    w = torch.randn((Cout, Cin, 1, 1), generator=g) / Cin ** 0.5
+    w2 = torch.randn((Cout, Cin2, 1, 1), generator=g) / Cin2 ** 0.5
+    sc, bi, sc2, bi2 = [(torch.rand(Cout, generator=g) + 0.5) if i % 2 == 0 else torch.randn(Cout, generator=g) for i in range(4)]
+    pc, pc2 = ops.PackedConv(w.cuda(), 1, 0), ops.PackedConv(w2.cuda(), s2, 0)
+    xc, x2c = _nhwc(x), _nhwc(x2)
+    ident = ops.conv2d(x2c, pc2, scale=sc2.cuda(), bias=bi2.cuda())
+    two = ops.conv2d(xc, pc, scale=sc.cuda(), bias=bi.cuda(), residual=ident, relu=True)
+    one = ops.conv2d_dual(xc, pc, x2c, pc2, scale=sc.cuda(), bias=bi.cuda(), scale2=sc2.cuda(), bias2=bi2.cuda(), relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), 'fused shortcut differs from the two-launch form: max %.3e' % float((one - two).abs().max())
+    ref = F.relu(F.conv2d(x, w) * sc[None, :, None, None] + bi[None, :, None, None] +
+                 F.conv2d(x2, w2, None, s2) * sc2[None, :, None, None] + bi2[None, :, None, None])
+    _cmp('dual conv', one.permute(0, 3, 1, 2), ref, atol=3e-5, rtol=3e-5)
+
+
 def test_conv_fused_groupnorm_chain():
     """conv -> GN stats in the epilogue -> finalize -> next conv applies GN+ReLU on load, vs the unfused torch ops."""
     ops = _ops()

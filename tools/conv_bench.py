@@ -41,9 +41,17 @@ def main():
         calls.append((x, pc, a, dict(k)))
         return orig(x, pc, *a, **k)
     ops.conv2d = rec
+    duals = []
+    orig_dual = ops.conv2d_dual
+
+    def rec_dual(x, pc, x2, pc2, *a, **k):
+        duals.append((x, pc, x2, pc2, a, dict(k)))
+        return orig_dual(x, pc, x2, pc2, *a, **k)
+    ops.conv2d_dual = rec_dual
     with torch.no_grad():
         model.forward_train(img, batch['img_metas'], gtb, gtl)
     ops.conv2d = orig
+    ops.conv2d_dual = orig_dual
     torch.cuda.synchronize()
     uniq = {}
     for x, pc, a, k in calls:
@@ -76,6 +84,25 @@ def main():
                          roof_frac=roof / t, gflop=flops / 1e9, mb=byts / 1e6))
         tot_t += cnt * t
         tot_f += cnt * flops
+    for x, pc, x2, pc2, a, k in duals:      # conv3 + projection shortcut in one launch (ops.conv2d_dual)
+        N, H, W, Cin = x.shape
+        flops = 2.0 * N * H * W * pc.Cout * (Cin + x2.shape[3])
+        byts = 4.0 * (x.numel() + N * H * W * x2.shape[3] + N * H * W * pc.Cout + pc.Cout * (Cin + x2.shape[3]))
+        for _ in range(3):
+            orig_dual(x, pc, x2, pc2, *a, **k)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.iters):
+            orig_dual(x, pc, x2, pc2, *a, **k)
+        e.record()
+        torch.cuda.synchronize()
+        t = s.elapsed_time(e) / args.iters * 1e-3
+        roof = max(flops / 157.3e12, byts / 6.3e12)
+        key = 'dual ' + str((N, H, W, Cin, '+', x2.shape[1], x2.shape[3], 's%d' % pc2.stride, pc.Cout))
+        rows.append(dict(key=key, count=1, ms=t * 1e3, tflops=flops / t / 1e12, gbs=byts / t / 1e9, roof_frac=roof / t,
+                         gflop=flops / 1e9, mb=byts / 1e6))
+        tot_t += t
+        tot_f += flops
     rows.sort(key=lambda r: -r['ms'] * r['count'])
     print('%-62s %3s %8s %8s %8s %6s %7s' % ('N,H,W,Cin,Cout,K,s,res,xf,gn', 'cnt', 'ms', 'TF/s', 'GB/s', 'roof', 'tot ms'))
     for r in rows:

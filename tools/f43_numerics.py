@@ -1,0 +1,53 @@
+import torch, math
+torch.manual_seed(0)
+torch.set_num_threads(16)
+BT = torch.tensor([[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]],dtype=torch.float64)
+G = torch.tensor([[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]],dtype=torch.float64)
+AT = torch.tensor([[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]],dtype=torch.float64)
+BT2 = torch.tensor([[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]],dtype=torch.float64)
+G2 = torch.tensor([[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]],dtype=torch.float64)
+AT2 = torch.tensor([[1,1,1,0],[0,1,-1,-1]],dtype=torch.float64)
+
+def wino(x, w, BT, G, AT, m):
+    """x (C,H,W) fp32, w (O,C,3,3) fp32 -> (O,H,W) fp32, all arithmetic fp32 (U from fp64 rounded)."""
+    C,H,W = x.shape; O = w.shape[0]
+    a = m+2
+    xp = torch.nn.functional.pad(x,(1,1,1,1))
+    # tiles
+    ty, tx = H//m, W//m
+    d = xp.unfold(1,a,m).unfold(2,a,m)            # C,ty,tx,a,a
+    BTf = BT.float(); ATf = AT.float()
+    V = torch.einsum('ij,ctujk,lk->ctuil', BTf, d, BTf)   # fp32
+    U = torch.einsum('ij,ocjk,lk->ocil', G, w.double(), G).float()
+    M = torch.einsum('ocil,ctuil->otuil', U, V)     # fp32 accumulate over c
+    Y = torch.einsum('ij,otujk,lk->otuil', ATf, M, ATf)   # O,ty,tx,m,m
+    return Y.permute(0,1,3,2,4).reshape(O,H,W)
+
+def gn(x, groups=32, eps=1e-5):
+    return torch.nn.functional.group_norm(x[None], groups, eps=eps)[0]
+
+C=256; H=W=48
+x0 = torch.relu(torch.randn(C,H,W))
+for wstd in (0.01, 0.05):
+    ws = [torch.randn(C,C,3,3)*wstd for _ in range(5)]
+    wl = torch.randn(2, C)*0.01
+    res = {}
+    for name,(BTm,Gm,ATm,m) in {'F2':(BT2,G2,AT2,2),'F4':(BT,G,AT,4)}.items():
+        x = x0.clone(); xd = x0.double()
+        errs=[]
+        for l,wt in enumerate(ws):
+            y = wino(x, wt, BTm, Gm, ATm, m)
+            yd = torch.nn.functional.conv2d(xd[None], wt.double(), padding=1)[0]
+            # single-layer error on the SAME input
+            y_same = torch.nn.functional.conv2d(x.double()[None], wt.double(), padding=1)[0]
+            errs.append(float((y.double()-y_same).abs().max()/y_same.abs().max()))
+            x = torch.relu(gn(y)); xd = torch.relu(gn(yd))
+        logit = torch.einsum('jc,chw->jhw', wl, x); logitd = torch.einsum('jc,chw->jhw', wl.double(), xd)
+        print(name, 'wstd', wstd, 'per-layer rel err (of max):', ['%.1e'%e for e in errs], 'chained feature abs err %.2e (max %.1f)'%(float((x.double()-xd).abs().max()), float(xd.abs().max())), 'logit abs err %.2e (|logit| max %.2f)'%(float((logit.double()-logitd).abs().max()), float(logitd.abs().max())))
+    # direct fp32 conv for comparison
+    x = x0.clone(); xd = x0.double()
+    for wt in ws:
+        y = torch.nn.functional.conv2d(x[None], wt, padding=1)[0]; yd = torch.nn.functional.conv2d(xd[None], wt.double(), padding=1)[0]
+        x = torch.relu(gn(y)); xd = torch.relu(gn(yd))
+    logit = torch.einsum('jc,chw->jhw', wl, x); logitd = torch.einsum('jc,chw->jhw', wl.double(), xd)
+    print('direct fp32 wstd', wstd, 'chained feature abs err %.2e'%float((x.double()-xd).abs().max()), 'logit abs err %.2e'%float((logit.double()-logitd).abs().max()))
