@@ -133,11 +133,13 @@ int cpr_logit_project(const float* x, const float* w, const float* bias, const f
  * gt_start (N+1)) -- with num_refine > 1 every refine point is a row, carrying its gt's label;
  * pad_hw (N,2) int32.  mask (N*H*W, C) uint8 = the reference's neg `valid`; partial[] (double, N*ceil(H*W*C/256))
  * = block partial sums of gfocal(prob(logit), 0, valid).  d2_thr = smallest fp32 whose torch-CPU sqrt is
- * >= stride*radius (the reference thresholds cdist, i.e. a sqrt).  n_partial [host, may be NULL] receives the count. */
+ * >= stride*radius (the reference thresholds cdist, i.e. a sqrt).  n_partial [host, may be NULL] receives the count.
+ * mask_classes = C, or 1 with C = 2 (normal_cfg.out_bg_cls, cpr_head.py:953: the one-class validity broadcasts over
+ * [class, background] outputs). */
 int cpr_neg_mask_loss(const float* logit, int J, const float* centers, const int* labels, const int* gt_start,
                       const int* pad_hw, unsigned char* mask, double* partial, int N, int H, int W, int C,
                       float stride, float d2_thr, float eps, int class_wise, int prob_type, float norm_p,
-                      int* n_partial, void* stream);
+                      int mask_classes, int* n_partial, void* stream);
 
 /* CirclePtFeatGenerator.generate (cpr_head.py:453-497,172-199): bag points (rings + the point itself last), validity
  * and bilinear samples of a J-channel NHWC map, one bag per annotated / refine point.  offsets (K-1,2) from the host.
@@ -172,12 +174,13 @@ int cpr_mil_loss(const float* logits, int J, int ins_off, const unsigned char* v
 
 /* PointRefiner.refine_single (cpr_head.py:711-850).  A gt owns Kt = Rv*Kv bag entries (Rv sub-bags of Kv; entry Kv-1 is
  * the annotated point); centers holds ctr_stride points per gt of which the first Rv take part in the nearest filter.
- * refine_pts (G,2), scores (G), not_refine (G) u8, chosen (G,Kt) u8 */
+ * refine_pts (G,2), scores (G), not_refine (G) u8, chosen (G,Kt) u8.  score_max: return_score_type 'max'
+ * (cpr_head.py:840-842) instead of the mean of the kept probabilities. */
 int cpr_refine(const float* logits, int J, const float* pts, const unsigned char* valid, const float* centers, int Rv,
                int ctr_stride, const int* labels, const int* gt_img, const int* gt_start, const int* img_hw,
                const unsigned char* not_refine_in, float* refine_pts, float* scores, unsigned char* not_refine,
                unsigned char* chosen, int G, int Kt, int Kv, int C, int prob_type, float norm_p, float gt_alpha,
-               float merge_th, float refine_th, int use_nearest, int use_classify, void* stream);
+               float merge_th, float refine_th, int use_nearest, int use_classify, int score_max, void* stream);
 
 /* ---- assigners -------------------------------------------------------------------------------------------------
  * PointAssigner.assign (T/mmdet/core/bbox/assigners/point_assigner.py:23-133): points (n,3)=(x,y,stride),

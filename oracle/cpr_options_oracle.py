@@ -6,7 +6,11 @@ A functional torch-CPU restatement of CPRHead.loss / loss0 / get_bboxes + PointR
   * GridCirclesPtFeatGenerator bags                            cpr_head.py:296-352,405-438
   * ``softmax`` / ``normed_sigmoid`` class probabilities        cpr_head.py:1080-1099
   * MILLoss(binary_ins=True), AllPosLoss                       T/mmdet/models/losses/multi_instance_learning_loss.py:153-243
-pinned by tests/golden/cpr_options.npz (the reference's own classes, oracle/gen_golden_r2.py) in
+  * (round 3) ins_share_head_feat=False: a second tower ``ins_convs`` / ``ins_fcs`` feeds the instance classifier
+                                                               cpr_head.py:992-1008,1030-1043,1055-1072
+  * (round 3) out_bg_cls=True for one class (a background output beside the class, never a label)   cpr_head.py:953
+  * (round 3) PointRefiner(return_score_type='max')            cpr_head.py:840-842
+pinned by tests/golden/cpr_options.npz / cpr_options_r3.npz (the reference's own classes, oracle/gen_golden_r2.py) in
 tests/test_oracle_golden.py.  ``cfg`` is an oracle.gen_golden_r2 case dict."""
 import torch
 import torch.nn.functional as F
@@ -50,12 +54,33 @@ def grid_circle_bag(feat, centers, radius, stride, max_pos_num):
     return out_pts, valid, out_feat
 
 
-def extract(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, prefix='bbox_head.'):
+def ins_tower_forward(sd, feats, stacked_convs=4, prefix='bbox_head.'):
+    """forward_single's second tower (ins_share_head_feat=False, cpr_head.py:1037-1040)."""
+    out = []
+    for x in feats:
+        for i in range(stacked_convs):
+            x = O._conv_gn(x, sd, '%sins_convs.%d' % (prefix, i), 1, True)
+        out.append(x)
+    return out
+
+
+def _fc_stack(sd, x, name, prefix='bbox_head.'):
+    """get_pts_outs.forward_with_fc (cpr_head.py:1055-1059) with the layers ``name``.{i} found in the state dict."""
+    i = 0
+    while prefix + '%s.%d.weight' % (name, i) in sd:
+        x = F.relu(F.linear(x, sd[prefix + '%s.%d.weight' % (name, i)], sd[prefix + '%s.%d.bias' % (name, i)]))
+        i += 1
+    return x
+
+
+def extract(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, prefix='bbox_head.', ins_feat=None):
     """PointExtractor + get_pts_outs for every image.  Returns per-image dicts with pts (G,Rv,Kv,2), valid (G,Rv,Kv),
-    cls_logit / ins_logit (G,Rv,Kv,.), the negative mask and grid logits, centers (G,R,2)."""
+    cls_logit / ins_logit (G,Rv,Kv,.), the negative mask and grid logits, centers (G,R,2).
+    ins_feat: the instance tower's map when cfg['ins_tower'] (the same points are sampled from it)."""
     stride, radius, C = cfg['stride'], cfg['radius'], cfg['num_classes']
     Wc, bc = sd[prefix + 'cls_out.weight'], sd[prefix + 'cls_out.bias']
     Wi, bi = sd[prefix + 'ins_out.weight'], sd[prefix + 'ins_out.bias']
+    assert (ins_feat is not None) == bool(cfg.get('ins_tower', False))
     out = []
     for b in range(len(gt_bboxes)):
         G = len(gt_labels[b])
@@ -70,19 +95,29 @@ def extract(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, prefix='bbox_hea
             pts = O.bag_points(ctr.reshape(-1, 2), radius, stride).reshape(G, R, -1, 2)
             valid = O.inside(pts, ph, pw)
             bag_feat = O.sample_bilinear(feat, pts.reshape(G * R, -1, 2) / stride).reshape(G, R, pts.shape[2], -1)
+        ins_bag = bag_feat
+        if ins_feat is not None:
+            assert cfg.get('pos', 'CirclePtFeatGenerator') == 'CirclePtFeatGenerator'
+            ins_bag = O.sample_bilinear(ins_feat[b:b + 1], pts.reshape(G * R, -1, 2) / stride).reshape(bag_feat.shape)
+            ins_bag = _fc_stack(sd, ins_bag, 'ins_fcs', prefix)
         h, w = feat.shape[2:]
         # negative mask: every refine point counts, carrying its gt's label (cpr_head.py:271-275: centers.flatten(0, 1))
         npts, nvalid = O.neg_valid_mask(h, w, stride, radius, ctr.reshape(-1, 2), gt_labels[b].repeat_interleave(R), C, ph, pw)
-        nfeat = feat.permute(0, 2, 3, 1)[0].flatten(0, 1)
+        nfeat = _fc_stack(sd, feat.permute(0, 2, 3, 1)[0].flatten(0, 1), 'cls_fcs', prefix)
+        bag_feat = _fc_stack(sd, bag_feat, 'cls_fcs', prefix)
+        if ins_feat is None:
+            ins_bag = bag_feat                      # ins_share_head_feat: the classifier inputs are shared (:1066)
         out.append(dict(centers=ctr, pts=pts, valid=valid, cls_logit=F.linear(bag_feat, Wc, bc),
-                        ins_logit=F.linear(bag_feat, Wi, bi), neg_valid=nvalid, neg_logit=F.linear(nfeat, Wc, bc)))
+                        ins_logit=F.linear(ins_bag, Wi, bi), neg_valid=nvalid, neg_logit=F.linear(nfeat, Wc, bc)))
     return out
 
 
-def cpr_loss(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, mil_weight=0.25, neg_weight=0.75, gt_weight=0.25):
+def cpr_loss(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, mil_weight=0.25, neg_weight=0.75, gt_weight=0.25,
+             ins_feat=None):
     """CPRHead.loss -> loss0 (cpr_head.py:1101-1229) with the options of ``cfg``."""
-    C = cfg['num_classes']
-    per = extract(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg)
+    # out_bg_cls: num_cls_out = C + 1 outputs; labels stay < C, the (.., C) validity masks broadcast over them (C = 1 only)
+    C = cfg['num_classes'] + (1 if cfg.get('out_bg_cls', False) else 0)
+    per = extract(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, ins_feat=ins_feat)
     labels = torch.cat(gt_labels)
     cls = torch.cat([p['cls_logit'] for p in per])                                       # (G,R,K,C)
     ins = torch.cat([p['ins_logit'] for p in per])
@@ -143,10 +178,10 @@ def cpr_loss(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, mil_weight=0.25
 
 
 def cpr_refine(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, gt_alpha=0.5, merge_th=0.1, refine_th=0.1,
-               classify_filter=True, nearest_filter=True, not_refine=None):
+               classify_filter=True, nearest_filter=True, not_refine=None, ins_feat=None):
     """PointRefiner.refine_single (cpr_head.py:780-850) on the bags of ``extract``.  Returns per image
     dict(refine_pts, scores, not_refine, chosen (G, Rv*Kv) bool, bag_pts)."""
-    per = extract(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg)
+    per = extract(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, ins_feat=ins_feat)
     res = []
     for b, p in enumerate(per):
         labels = gt_labels[b]
@@ -185,5 +220,8 @@ def cpr_refine(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, gt_alpha=0.5,
         if not_refine is not None:
             nr = not_refine[b] | nr
         rp[nr] = p['centers'][:, 0][nr]
+        if cfg.get('score_type', 'mean') == 'max':                                       # cpr_head.py:840-842
+            sc = pm.max(dim=-1)[0]
+            sc[sc == 0] = refine_th / 2
         res.append(dict(refine_pts=rp, scores=sc, not_refine=nr, chosen=wgt > 0, bag_pts=flat))
     return res

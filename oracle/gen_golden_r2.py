@@ -1,6 +1,6 @@
 """Round-2 fixtures from the REFERENCE's own classes (build container only).  TEST INFRASTRUCTURE ONLY.
 
-  python -m oracle.gen_golden_r2 [refine] [options] [costs] [p2p_edge]
+  python -m oracle.gen_golden_r2 [refine] [options] [costs] [p2p_edge] [options_r3] [ha_transposed]
 
   refine   tests/golden/refine.npz        PointRefiner internals (refine points, scores, not_refine, the chosen-point
                                           masks) of every CPR case + the out_geo / cascade_out_fmt / not_refine-input /
@@ -12,6 +12,11 @@
                                           (FocalLossCost + DisCostV2 evaluated by the reference classes on THIS host)
   p2p_edge tests/golden/p2p_edge.npz      P2PHead targets / losses on a batch with invalid feature-map cells (an image padded
                                           less than the batch maximum) and with a gt-less image (p2p_head.py:275-328,451-463)
+  options_r3    tests/golden/cpr_options_r3.npz  (round 3) return_score_type='max', AnchorPtFeatGenerator(scale_factor) as the
+                                          refine-time grid generator, ins_share_head_feat=False (with and without FC layers),
+                                          out_bg_cls=True for one class (cpr_head.py:206-232,840-842,953,992-1008,1037,1068)
+  ha_transposed tests/golden/assigner_transposed.npz  HungarianAssignerV2, topk_k = 1, fewer proposals than gts
+                                          (hungarian_assigner.py:229-240)
 Inputs and weights come from ``pointtinybenchmark_amd.synthetic`` (seeded, regenerated at test time)."""
 import os
 import sys
@@ -55,9 +60,19 @@ OPTION_CASES = {
 }
 
 
+# Round 3 (tests/golden/cpr_options_r3.npz): the options the round-2 head still asserted out
+OPTION_CASES_R3 = {
+    'score_max': dict(score_type='max', seed=52),                                   # cpr_head.py:840-842
+    'anchor_scale': dict(refine_neg='AnchorPtFeatGenerator', anchor_scale=0.5, seed=53),   # cpr_head.py:206-232
+    'ins_tower': dict(ins_tower=True, seed=54),                                     # ins_share_head_feat=False, :992-1008,1037,1068
+    'ins_tower_fc': dict(ins_tower=True, num_cls_fcs=1, fc_out_channels=64, seed=55),
+    'bg_cls': dict(num_classes=1, out_bg_cls=True, seed=56),                        # cpr_head.py:953
+}
+
+
 def option_cfg(name):
     cfg = dict(BASE)
-    cfg.update(OPTION_CASES[name])
+    cfg.update(OPTION_CASES[name] if name in OPTION_CASES else OPTION_CASES_R3[name])
     return cfg
 
 
@@ -68,7 +83,7 @@ def cpr_head_kwargs(cfg):
     pos = dict(type=cfg.get('pos', 'CirclePtFeatGenerator'), radius=r)
     if 'max_pos_num' in cfg:
         pos['max_pos_num'] = cfg['max_pos_num']
-    normal = dict(prob_cls_type=cfg.get('prob', 'sigmoid'), out_bg_cls=False)
+    normal = dict(prob_cls_type=cfg.get('prob', 'sigmoid'), out_bg_cls=cfg.get('out_bg_cls', False))
     if 'norm_p' in cfg:
         normal['normed_sigmoid_p'] = cfg['norm_p']
     loss_cfg = dict(with_neg=True, neg_loss_weight=1 - alpha, refine_bag_policy=cfg.get('policy', 'independent_with_gt_bag'),
@@ -76,24 +91,30 @@ def cpr_head_kwargs(cfg):
                     with_mil_loss=cfg.get('with_mil_loss', True))
     if 'gt_loss_type' in cfg:
         loss_cfg['gt_loss_type'] = cfg['gt_loss_type']
+    refine_neg = dict(type='OutCirclePtFeatGenerator', radius=r, keep_wh=True, class_wise=True)
+    if cfg.get('refine_neg') == 'AnchorPtFeatGenerator':
+        refine_neg = dict(type='AnchorPtFeatGenerator', scale_factor=cfg.get('anchor_scale', 1.0))
+    refiner = dict(merge_th=0.1, refine_th=0.1, classify_filter=True)
+    if 'score_type' in cfg:
+        refiner['return_score_type'] = cfg['score_type']
     return dict(
+        ins_share_head_feat=not cfg.get('ins_tower', False),
         norm_cfg=GN, num_classes=cfg['num_classes'], in_channels=256, feat_channels=256, stacked_convs=4,
         num_cls_fcs=cfg.get('num_cls_fcs', 0), fc_out_channels=cfg.get('fc_out_channels', 1024), strides=[cfg['stride']],
         loss_mil=dict(type=cfg.get('loss', 'MILLoss'), binary_ins=cfg.get('binary_ins', False), loss_weight=alpha),
         loss_type=0, loss_cfg=loss_cfg, normal_cfg=normal,
         train_pts_extractor=dict(pos_generator=dict(pos),
                                  neg_generator=dict(type='OutCirclePtFeatGenerator', radius=r, class_wise=True)),
-        refine_pts_extractor=dict(pos_generator=dict(pos),
-                                  neg_generator=dict(type='OutCirclePtFeatGenerator', radius=r, keep_wh=True,
-                                                     class_wise=True)),
-        point_refiner=dict(merge_th=0.1, refine_th=0.1, classify_filter=True))
+        refine_pts_extractor=dict(pos_generator=dict(pos), neg_generator=refine_neg),
+        point_refiner=refiner)
 
 
 def case_inputs(cfg):
     sd = synthetic.locator_state_dict(cfg['depth'], cfg['num_classes'], cfg['start_level'], 'cpr', cfg['seed'],
                                       cfg['head_std'], num_cls_fcs=cfg.get('num_cls_fcs', 0),
                                       fc_out_channels=cfg.get('fc_out_channels', 1024),
-                                      binary_ins=cfg.get('binary_ins', False))
+                                      binary_ins=cfg.get('binary_ins', False), ins_tower=cfg.get('ins_tower', False),
+                                      out_bg_cls=cfg.get('out_bg_cls', False))
     batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
                                       cfg['seed'], cfg.get('ragged', False))
     batch = synthetic.with_refine_points(batch, cfg.get('num_refine', 1), cfg['seed'])
@@ -207,18 +228,33 @@ def gen_refine(R):
     np.savez_compressed(os.path.join(GOLDEN, 'refine.npz'), **out)
 
 
-def gen_options(R):
+def gen_options(R, cases=None, fname='cpr_options.npz'):
+    cases = OPTION_CASES if cases is None else cases
     out = {}
-    for name in OPTION_CASES:
+    for name in cases:
         cfg = option_cfg(name)
         torch.manual_seed(0)
         backbone, neck, head, batch = build_reference(R, cfg)
+        if cfg.get('refine_neg') == 'AnchorPtFeatGenerator' and cfg.get('anchor_scale', 1.0) != 1.0:
+            # AnchorPtFeatGenerator hands scale_factor to F.interpolate as its SECOND POSITIONAL argument, which is `size`
+            # (cpr_head.py:229-231): the reference cannot run a scale_factor other than None / 1.0 -- record what it raises
+            try:
+                with torch.no_grad():
+                    cls_feat, ins_feat = head(neck(backbone(batch['img'])))
+                    head.get_bboxes(cls_feat, ins_feat, batch['img_metas'], gt_bboxes=batch['gt_bboxes'],
+                                    gt_labels=batch['gt_labels'], gt_anns_id=batch['gt_anns_id'])
+                out[name + ':reference_error'] = np.array('none')
+            except Exception as e:  # noqa: BLE001
+                out[name + ':reference_error'] = np.array('%s: %s' % (type(e).__name__, str(e)[:160]))
+            print('options', name, 'reference ->', out[name + ':reference_error'])
+            continue
         with torch.no_grad():
             cls_feat, ins_feat = head(neck(backbone(batch['img'])))
             losses = head.loss(cls_feat, ins_feat, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'])
             gt_points = head.pseudo_bbox_to_center(batch['gt_bboxes'])
             gt_r = [p.reshape(len(l), -1, 2) for p, l in zip(gt_points, batch['gt_labels'])]
-            pos, neg = head.train_pts_extractor(cls_feat, ins_feat, gt_r, batch['gt_labels'], batch['img_metas'], None, True)
+            pos, neg = head.train_pts_extractor(cls_feat, ins_feat, gt_r, batch['gt_labels'], batch['img_metas'], None,
+                                                head.ins_share_head_feat)
             pos.cls_outs, pos.ins_outs = head.get_pts_outs(pos.cls_feats, pos.ins_feats)
             p = name + ':'
             for k, v in losses.items():
@@ -242,6 +278,9 @@ def gen_options(R):
                 out[p + 'refine_asserts_in_reference'] = np.array(True)
         print('options', name, {k[len(p):]: float(v) for k, v in out.items() if k.startswith(p + 'loss_')},
               'pos', out[p + 'pos_pts'].shape, 'chosen', int(np.unpackbits(out[p + 'chosen']).sum()) if p + 'chosen' in out else 'n/a')
+    if cases is not OPTION_CASES:
+        np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+        return
     # the one generator that cannot run in the reference (documented in pointtinybenchmark_amd/dense_heads/cpr_head.py)
     try:
         cfg = dict(BASE, pos='GridEllipsePtFeatGenerator', num_refine=2)
@@ -325,11 +364,30 @@ def gen_p2p_edge(R):
           'positives', int((out['labels'] < C).sum()), 'no-gt image positives', int((out['nogt_labels'][1] < C).sum()))
 
 
+HA_T_CASES = [(3, 11, 1), (4, 30, 3), (2, 5, 2)]     # (n_side, G, C): n_side^2 proposals < G gts, topk_k = 1
+
+
+def gen_assigner_transposed(R):
+    """HungarianAssignerV2 with topk_k = 1 and FEWER proposals than gts (hungarian_assigner.py:229-240): scipy then solves the
+    problem with the proposals as rows and every proposal gets a distinct gt."""
+    out = {}
+    for case, (n_side, G, C) in enumerate(HA_T_CASES):
+        pred, logits, gt, labels, shp = assigner_inputs(300 + case, n_side, 4, G, C)
+        ha = R.HungarianAssignerV2(cls_costs=dict(type='FocalLossCost', weight=2.0),
+                                   reg_costs=dict(type='DisCostV2', weight=0.1, norm_with_img_wh=False), topk_k=1)
+        res = ha.assign(pred, logits, gt, labels, dict(img_shape=shp))
+        out['hat%d_gt_inds' % case] = res.gt_inds.numpy().astype(np.int32)
+        out['hat%d_labels' % case] = res.labels.numpy().astype(np.int32)
+        assert int((res.gt_inds > 0).sum()) == n_side * n_side
+    np.savez_compressed(os.path.join(GOLDEN, 'assigner_transposed.npz'), **out)
+    print('assigner transposed', {k: v.tolist() for k, v in out.items() if 'inds' in k})
+
+
 def main():
     assert ref_loader.available(), 'needs /root/reference'
     torch.set_num_threads(8)
     R = ref_loader.load()
-    which = sys.argv[1:] or ['refine', 'options', 'costs', 'p2p_edge']
+    which = sys.argv[1:] or ['refine', 'options', 'costs', 'p2p_edge', 'options_r3', 'ha_transposed']
     if 'refine' in which:
         gen_refine(R)
     if 'options' in which:
@@ -338,6 +396,10 @@ def main():
         gen_assigner_costs(R)
     if 'p2p_edge' in which:
         gen_p2p_edge(R)
+    if 'options_r3' in which:
+        gen_options(R, OPTION_CASES_R3, 'cpr_options_r3.npz')
+    if 'ha_transposed' in which:
+        gen_assigner_transposed(R)
 
 
 if __name__ == '__main__':

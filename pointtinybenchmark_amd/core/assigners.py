@@ -108,6 +108,20 @@ class HungarianAssignerV2:
                                   gt_bboxes.float().contiguous(), gt_labels.to(torch.int32).contiguous(), cc.weight,
                                   cc.alpha, float(cc.gamma), cc.eps, rc.weight, fx, fy, rc.p)
 
+    @staticmethod
+    def transposed_inds(costT_list):
+        """gt_inds of problems with FEWER proposals than gts (topk_k == 1).  costT (G, M), M < G: the device solver wants
+        rows <= columns, so it gets the (M, G) matrix -- the proposals in the role of its rows, exactly scipy's orientation
+        for this shape -- and answers per gt; the answer is inverted into per-proposal indices (j + 1 = gt j)."""
+        per_gt, _ = ops.lsa_topk([c.t().contiguous() for c in costT_list], 1)      # (G,): 1 + proposal, 0 = none
+        out = []
+        for c, pg in zip(costT_list, per_gt):
+            inds = pg.new_zeros((c.shape[1],))
+            g_of = torch.nonzero(pg > 0, as_tuple=False).squeeze(1)
+            inds[pg[g_of] - 1] = g_of + 1
+            out.append(inds)
+        return out
+
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None, eps=1e-7):
         assert gt_bboxes_ignore is None, 'Only case when gt_bboxes_ignore is None is supported.'
         num_gts, num_bboxes = gt_bboxes.size(0), bbox_pred.size(0)
@@ -117,13 +131,17 @@ class HungarianAssignerV2:
             if num_gts == 0:
                 inds[:] = 0
             return AssignResult(num_gts, inds, None, labels=labels)
+        costT = None
         if num_bboxes < num_gts:
-            if self.topk_k == 1:
-                raise NotImplementedError('fewer proposals than gts with topk_k == 1')
-            inds[:] = 0  # the reference's loop condition fails immediately (hungarian_assigner.py:251)
-            return AssignResult(num_gts, inds, None, labels=labels)
-        costT = self.cost_t(bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta)
-        (inds,), status = ops.lsa_topk([costT], self.topk_k)
+            if self.topk_k != 1:
+                inds[:] = 0  # the reference's loop condition fails immediately (hungarian_assigner.py:251)
+                return AssignResult(num_gts, inds, None, labels=labels)
+            # topk_k == 1 (hungarian_assigner.py:229-240): scipy keeps the FEWER proposals as rows, each gets a distinct gt
+            costT = self.cost_t(bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta)
+            inds = self.transposed_inds([costT])[0]
+        else:
+            costT = self.cost_t(bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta)
+            (inds,), status = ops.lsa_topk([costT], self.topk_k)
         pos = inds > 0
         labels[pos] = gt_labels[inds[pos] - 1]
         return AssignResult(num_gts, inds, None, labels=labels)

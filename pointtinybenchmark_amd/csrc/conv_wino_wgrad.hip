@@ -12,8 +12,10 @@
 // One workgroup = 512 threads = 8 waves (one per CU), a (64 ci) x (64 co) block of all 16 frequencies = the forward kernel's
 // accumulator layout (wave (i, h): frequency row i, co half h: 4 x [64 ci x 32 co] = 128 registers) and its MFMA loop,
 // fragment layout and swizzle verbatim, with "tile" -> ci rows and "cout" -> co rows; K chunk = 8 tiles = one strip of
-// 2 x 16 output pixels (patch 4 x 18 pixels of x, 2 x 16 pixels of dy), a workgroup walks the strips of its K slice
-// (a band of tile rows of ONE image, so the fused GroupNorm affine of x is one 64-entry table).
+// 2 x 16 output pixels (patch 4 x 18 pixels of x, 2 x 16 pixels of dy), a workgroup walks the strips of its K slice: a
+// contiguous run of the strips in (image, tile row, strip) order -- one pipeline across image boundaries, where only the fused
+// GroupNorm affine of x (4 channels per thread) is re-fetched.  ceil(CUs / blocks) slices: one workgroup per CU and a
+// partial buffer of 16 x [16][Cin][Cout] instead of one slice per image (round 2: 64 slices, 268 MB per head-layer launch).
 // Staging per chunk, all waves alike: G global -> registers (x patch 72 pixels x 64 channels = 3 x 16 B per thread, dy 32 x 64 =
 // 1 x 16 B), R registers -> raw LDS (affine + ReLU of x here, once per element; pixel stride 68 floats so that the
 // transform's reads are conflict free), T raw -> V / Z (thread = (tile of the strip, channel): x 16 reads + 32 adds + 16 writes,
@@ -30,7 +32,8 @@ struct WinoWgradParams {
     float* part;          // [slices][16][Cin][Cout]
     int N, H, W, Cin, Cout, in_relu;
     int TY, SX;           // tile rows (ceil(H/2)), strips per tile row (ceil(W/16))
-    int parts, rows_per_part, tilesCi, tilesCo;
+    int tilesCi, tilesCo;
+    int slices, spp, total;   // K split: slices of spp strips out of N * TY * SX
 };
 
 constexpr int WWBUF = 16 * 64 * 8;    // floats in one V or Z chunk image (32 KB)
@@ -50,16 +53,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_wgrad_kernel(WinoWgradParams
     // block -> (slice, ci tile, co tile): the tilesCi * tilesCo blocks of one slice are consecutive (they re-read the same
     // strips of x and dy: one L2), XCD-aware as in the forward kernel
     const int nblk = p.tilesCi * p.tilesCo;
-    const int T = p.N * p.parts * nblk;
+    const int T = p.slices * nblk;
     const int per = (T + 7) >> 3;
     const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (tile >= T) return;
     const int slice = tile / nblk, blk = tile - slice * nblk;
     const int tci = blk / p.tilesCo, tco = blk - tci * p.tilesCo;
-    const int n = slice / p.parts, part = slice - n * p.parts;
-    const int row0 = part * p.rows_per_part;
-    const int row1 = min(row0 + p.rows_per_part, p.TY);
-    const int nk = (row1 - row0) * p.SX;      // chunks (strips) of this slice
+    const int g0 = slice * p.spp;                          // first strip of this slice
+    const int nk = min(p.spp, p.total - g0);               // chunks (strips) of this slice, >= 1
+    const int spi = p.TY * p.SX;                           // strips per image
     const int ci0 = tci * 64, co0 = tco * 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -88,20 +90,20 @@ __global__ __launch_bounds__(512, 1) void conv_wino_wgrad_kernel(WinoWgradParams
     const int drel = ((da * p.W + dc) * p.Cout + (tid & 15) * 4) * 4;
     const int dwr = (tid >> 4) * WPS + (tid & 15) * 4;
     const float relu_floor = (XF && p.in_relu) ? 0.f : -INFINITY;
+    // XF: the affine of the image whose chunk sits in the staging registers -- the same 4 channels for all of a thread's
+    // units; re-fetched (two 16-byte loads, L2) when the slice crosses into the next image
     f32x4 xa4 = {1.f, 1.f, 1.f, 1.f}, xb4 = {0.f, 0.f, 0.f, 0.f};
-    if (XF) {   // this image's affine for the 64 channels of the ci tile
-        if (tid < 64) { ABs[tid] = p.in_a[n * p.Cin + ci0 + tid]; ABs[64 + tid] = p.in_b[n * p.Cin + ci0 + tid]; }
-        __syncthreads();
-        xa4 = *reinterpret_cast<const f32x4*>(ABs + (tid & 15) * 4);      // the same 4 channels for all of a thread's units
-        xb4 = *reinterpret_cast<const f32x4*>(ABs + 64 + (tid & 15) * 4);
-    }
+    int img_tab = -1, img_regs = 0;   // scalars: image of (xa4, xb4) / of the chunk in the staging registers
+    (void)ABs;
 
     f32x4 sx[3], sd;            // staging registers of the chunk in flight
     unsigned okbits = 0;        // bit k: x unit k of that chunk is inside the image (XF: padding stays 0 after the affine)
     auto g_x = [&](int k_chunk, int k) {      // G: request x unit k of chunk k_chunk (clamped: the pipeline runs two chunks past the end)
         if (k == 2 && !unit2_wave) return;
-        const int kc = k_chunk < nk ? k_chunk : nk - 1;
-        const int tyr = row0 + kc / p.SX, sxi = kc - (kc / p.SX) * p.SX;
+        const int g = g0 + (k_chunk < nk ? k_chunk : nk - 1);
+        const int n = g / spi, rs = g - n * spi;
+        const int tyr = rs / p.SX, sxi = rs - tyr * p.SX;
+        if (k == 0) img_regs = n;
         const int iy0 = 2 * tyr - 1, ix0 = 16 * sxi - 1;
         const int xbase = (((n * p.H + iy0) * p.W + ix0) * p.Cin + ci0) * 4;        // may be "negative": only used when in range
         const bool ok = (k < 2 || unit2) & ((unsigned)(iy0 + xr[k]) < (unsigned)p.H) & ((unsigned)(ix0 + xc[k]) < (unsigned)p.W);
@@ -110,8 +112,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_wgrad_kernel(WinoWgradParams
         sx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? xbase + xrel[k] : (int)0x80000000, 0, 0));
     };
     auto g_d = [&](int k_chunk) {             // G: request the dy unit
-        const int kc = k_chunk < nk ? k_chunk : nk - 1;
-        const int tyr = row0 + kc / p.SX, sxi = kc - (kc / p.SX) * p.SX;
+        const int g = g0 + (k_chunk < nk ? k_chunk : nk - 1);
+        const int n = g / spi, rs = g - n * spi;
+        const int tyr = rs / p.SX, sxi = rs - tyr * p.SX;
         const bool okd = (2 * tyr + da < p.H) & (16 * sxi + dc < p.W);
         const int dbase = (((n * p.H + 2 * tyr) * p.W + 16 * sxi) * p.Cout + co0) * 4;
         sd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, okd ? dbase + drel : (int)0x80000000, 0, 0));
@@ -119,6 +122,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino_wgrad_kernel(WinoWgradParams
     auto g_all = [&](int k_chunk) { g_x(k_chunk, 0); g_x(k_chunk, 1); g_x(k_chunk, 2); g_d(k_chunk); };
     auto r_x = [&](int k) {                  // R: x unit k -> raw (affine + ReLU of the producer's GroupNorm; padding stays 0)
         if (k == 2 && !unit2_wave) return;
+        if (XF && k == 0 && img_regs != img_tab) {   // wave-uniform, once per image of the slice
+            img_tab = img_regs;
+            xa4 = *reinterpret_cast<const f32x4*>(p.in_a + (size_t)img_tab * p.Cin + ci0 + (tid & 15) * 4);
+            xb4 = *reinterpret_cast<const f32x4*>(p.in_b + (size_t)img_tab * p.Cin + ci0 + (tid & 15) * 4);
+        }
         f32x4 v = sx[k];
         if (XF) {
             v = v * xa4 + xb4;
@@ -129,8 +137,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_wgrad_kernel(WinoWgradParams
     };
     auto r_d = [&]() { *reinterpret_cast<f32x4*>(Rd + dwr) = sd; };
 
-    // ---- T role: thread = (tile t of the strip, channel): lanes = (t, 8 channels), wave = channel block of 8
-    const int tt = tid & 7, chl = wave * 8 + ((tid >> 3) & 7);
+    // ---- T role: thread = (tile t of the strip, channel), wave = channel block of 8.  ds_read_b32 serves lanes 0-31 and 32-63
+    // in one cycle each over 32 banks: tiles are 2 pixels = 136 floats = 8 banks apart, so a 32-lane half holds FOUR tiles
+    // (banks 0, 8, 16, 24) x EIGHT channels (8 consecutive banks each) -- all 32 banks once.  (Round 2 had eight tiles x four
+    // channels per half: tiles t and t + 4 on the same banks, every transform read 2-way conflicted -- 262 M conflict cycles
+    // per head-layer launch, profiles/round2_pmc_wino_wgrad_kernel.json.)
+    const int tt = (tid & 3) | (((tid >> 5) & 1) << 2), chl = wave * 8 + ((tid >> 2) & 7);
     const float* tx_rd = Rx + (2 * tt) * WPS + chl;        // + (r * 18 + s) * WPS
     const float* td_rd = Rd + (2 * tt) * WPS + chl;        // + (a * 16 + b) * WPS
     const int vz_wr = chl * 8 + 4 * ((tt >> 2) ^ ((chl >> 3) & 1)) + (tt & 3);   // this thread's float in a V / Z row (row = channel, k = tile)
@@ -322,23 +334,23 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* 
     }
 }
 
-// K split: one slice = a band of tile rows of one image; enough slices for >= 2 workgroups per CU
-static void wino_wgrad_split(int N, int H, int Cin, int Cout, int* parts, int* rows_per_part) {
-    const int TY = (H + 1) / 2, blocks = (Cin / 64) * (Cout / 64);
-    int want = (512 + blocks * N - 1) / (blocks * N);
-    if (want < 1) want = 1;
-    if (want > TY) want = TY;
-    const int rpp = (TY + want - 1) / want;
-    *rows_per_part = rpp;
-    *parts = (TY + rpp - 1) / rpp;
+// K split: slices of consecutive strips, (CUs of an MI355X) / blocks of them: one resident workgroup per CU and slice
+static void wino_wgrad_split(int N, int H, int W, int Cin, int Cout, int* slices, int* spp) {
+    const long long total = (long long)N * ((H + 1) / 2) * ((W + 15) / 16);
+    const int blocks = (Cin / 64) * (Cout / 64);
+    long long want = (256 + blocks - 1) / blocks;
+    if (want > total) want = total;
+    const long long per = (total + want - 1) / want;
+    *spp = (int)per;
+    *slices = (int)((total + per - 1) / per);
 }
 
 // C-ABI ------------------------------------------------------------------------------------------
 extern "C" int cpr_conv3x3_wino_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0);
-    int parts, rpp;
-    wino_wgrad_split(N, H, Cin, Cout, &parts, &rpp);
-    const long long n = (long long)N * parts * 16 * Cin * Cout;
+    int slices, spp;
+    wino_wgrad_split(N, H, W, Cin, Cout, &slices, &spp);
+    const long long n = (long long)slices * 16 * Cin * Cout;
     return n < (1ll << 31) ? (int)n : CPR_ERR_UNSUPPORTED;
 }
 static int wino_wgrad_launch(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
@@ -352,35 +364,35 @@ static int wino_wgrad_launch(const float* dy, const float* x, const float* in_a,
     p.dy = dy; p.x = x; p.in_a = in_a; p.in_b = in_b; p.part = ws;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.in_relu = in_relu;
     p.TY = (H + 1) / 2; p.SX = (W + 15) / 16;
-    wino_wgrad_split(N, H, Cin, Cout, &p.parts, &p.rows_per_part);
+    wino_wgrad_split(N, H, W, Cin, Cout, &p.slices, &p.spp);
+    p.total = N * p.TY * p.SX;
     p.tilesCi = Cin / 64; p.tilesCo = Cout / 64;
-    const long long nfl = (long long)N * p.parts * 16 * Cin * Cout;
+    const long long nfl = (long long)p.slices * 16 * Cin * Cout;
     if (nfl >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
-    const long long T = (long long)N * p.parts * p.tilesCi * p.tilesCo;
+    const long long T = (long long)p.slices * p.tilesCi * p.tilesCo;
     const int grid = (int)((T + 7) / 8 * 8);
     if (in_a) hipLaunchKernelGGL((conv_wino_wgrad_kernel<true>), dim3(grid), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((conv_wino_wgrad_kernel<false>), dim3(grid), dim3(512), 0, stream, p);
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, stream, ws, grad_w, N * p.parts,
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, stream, ws, grad_w, p.slices,
                        Cin, Cout, accumulate);
     CPR_LAUNCH_STATUS();
 }
 
 // >= 2 GiB maps: balanced chunks of whole images; chunks after the first accumulate into grad_w.  The workspace of the whole
-// batch serves every chunk: a chunk's N * parts never exceeds the whole batch's (parts only grows when blocks * N < 512, i.e.
-// for batches far below the 2 GiB range) -- checked per launch.
+// batch serves every chunk (a sub-batch never needs more slices than the whole batch) -- checked per launch.
 extern "C" int cpr_conv3x3_wino_wgrad(const float* dy, const float* x, const float* in_a, const float* in_b, float* grad_w,
                                       float* ws, int N, int H, int W, int Cin, int Cout, int in_relu, int accumulate,
                                       hipStream_t stream) {
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0);
     const int per = cpr_images_per_launch(N, (long long)H * W * cpr_max2(Cin, Cout) * 4);
     if (per <= 0) return CPR_ERR_UNSUPPORTED;
-    int parts_all, rpp;
-    wino_wgrad_split(N, H, Cin, Cout, &parts_all, &rpp);
+    int slices_all, spp;
+    wino_wgrad_split(N, H, W, Cin, Cout, &slices_all, &spp);
     for (int n0 = 0; n0 < N; n0 += per) {
         const int n = N - n0 < per ? N - n0 : per;
-        int parts;
-        wino_wgrad_split(n, H, Cin, Cout, &parts, &rpp);
-        if ((long long)n * parts > (long long)N * parts_all) return CPR_ERR_UNSUPPORTED;   // workspace was sized for the whole batch
+        int slices;
+        wino_wgrad_split(n, H, W, Cin, Cout, &slices, &spp);
+        if (slices > slices_all) return CPR_ERR_UNSUPPORTED;   // workspace was sized for the whole batch
         const int rc = wino_wgrad_launch(dy + (size_t)n0 * H * W * Cout, x + (size_t)n0 * H * W * Cin,
                                          in_a ? in_a + (size_t)n0 * Cin : nullptr, in_b ? in_b + (size_t)n0 * Cin : nullptr,
                                          grad_w, ws, n, H, W, Cin, Cout, in_relu, n0 == 0 ? accumulate : 1, stream);

@@ -70,7 +70,7 @@ __global__ void neg_mask_loss_kernel(const float* __restrict__ logit, int J, con
                                      const int* __restrict__ labels, const int* __restrict__ gt_start,
                                      const int* __restrict__ pad_hw, unsigned char* __restrict__ mask,
                                      double* __restrict__ partial, int H, int W, int C, float stride,
-                                     float d2_thr, float eps, int class_wise, int ptype, float norm_p) {
+                                     float d2_thr, float eps, int class_wise, int ptype, float norm_p, int Cm) {
     __shared__ float sx[MAX_GT_LDS], sy[MAX_GT_LDS], sn[MAX_GT_LDS];
     __shared__ int sl[MAX_GT_LDS];
     __shared__ double red[4];
@@ -93,7 +93,8 @@ __global__ void neg_mask_loss_kernel(const float* __restrict__ logit, int J, con
         }
         __syncthreads();
         for (int i = 0; i < cnt; ++i) {
-            if (!class_wise || sl[i] == cls) {
+            // Cm < C (normal_cfg.out_bg_cls, cpr_head.py:953): the generator's (.., Cm) validity broadcasts over the C outputs
+            if (!class_wise || sl[i] == (cls < Cm ? cls : Cm - 1)) {
                 float d2 = d2_chain(px, py, pn, sx[i], sy[i], sn[i]);
                 d2 = fmaxf(d2, 0.f);  // clamp_min_(0) before the sqrt
                 dmin = fminf(dmin, d2);
@@ -125,13 +126,15 @@ __global__ void neg_mask_loss_kernel(const float* __restrict__ logit, int J, con
 extern "C" int cpr_neg_mask_loss(const float* logit, int J, const float* centers, const int* labels,
                                  const int* gt_start, const int* pad_hw, unsigned char* mask, double* partial,
                                  int N, int H, int W, int C, float stride, float d2_thr, float eps, int class_wise,
-                                 int prob_type, float norm_p, int* n_partial, hipStream_t stream) {
+                                 int prob_type, float norm_p, int mask_classes, int* n_partial, hipStream_t stream) {
     CPR_CHECK_ARG(logit && gt_start && pad_hw && mask && partial && N > 0 && H > 0 && W > 0 && C > 0 && J >= C);
+    CPR_CHECK_ARG(mask_classes == C || (mask_classes == 1 && C == 2));   // the reference's broadcast only exists for one class
     CPR_CHECK_ARG(prob_type >= 0 && prob_type <= 2 && norm_p > 0.f);
     const int blocks = cdiv(H * W * C, 256);
     if (n_partial) *n_partial = blocks * N;
     hipLaunchKernelGGL(neg_mask_loss_kernel, dim3(blocks, N), dim3(256), 0, stream, logit, J, centers, labels,
-                       gt_start, pad_hw, mask, partial, H, W, C, stride, d2_thr, eps, class_wise, prob_type, norm_p);
+                       gt_start, pad_hw, mask, partial, H, W, C, stride, d2_thr, eps, class_wise, prob_type, norm_p,
+                       mask_classes);
     CPR_LAUNCH_STATUS();
 }
 
@@ -481,7 +484,7 @@ __global__ void refine_kernel(const float* __restrict__ logits, int J, const flo
                               float* __restrict__ scores, unsigned char* __restrict__ not_refine,
                               unsigned char* __restrict__ chosen, int G, int Kt, int Kv, int C, int ptype,
                               float norm_p, float gt_alpha, float merge_th, float refine_th, int use_nearest,
-                              int use_classify) {
+                              int use_classify, int score_max) {
     const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (g >= G) return;
@@ -493,7 +496,7 @@ __global__ void refine_kernel(const float* __restrict__ logits, int J, const flo
     const float ih = (float)img_hw[n * 2], iw = (float)img_hw[n * 2 + 1];
     int same = 0;
     for (int o = g0; o < g1; ++o) same += (labels[o] == label) ? 1 : 0;
-    float sw = 0.f, sx = 0.f, sy = 0.f, cnt = 0.f;
+    float sw = 0.f, sx = 0.f, sy = 0.f, cnt = 0.f, pmax = 0.f;
     // pass 1: decide membership, accumulate sum of probabilities
     for (int k = lane; k < Kt; k += 64) {
         const float px = pts[((size_t)g * Kt + k) * 2], py = pts[((size_t)g * Kt + k) * 2 + 1];
@@ -528,9 +531,11 @@ __global__ void refine_kernel(const float* __restrict__ logits, int J, const flo
         const float pm = ok ? p : 0.f;
         chosen[(size_t)g * Kt + k] = (pm > 0.f) ? 1 : 0;
         sw += pm;
+        pmax = fmaxf(pmax, pm);
         cnt += (pm > 0.f) ? 1.f : 0.f;
     }
     sw = wave_sum(sw);
+    pmax = wave_max(pmax);
     cnt = wave_sum(cnt);
     const float denom = sw + 1e-8f;
     for (int k = lane; k < Kt; k += 64) {
@@ -549,7 +554,9 @@ __global__ void refine_kernel(const float* __restrict__ logits, int J, const flo
         if (not_refine_in) nr = nr || (not_refine_in[g] != 0);
         refine_pts[g * 2] = nr ? ctr[(size_t)g * ctr_stride * 2] : sx;
         refine_pts[g * 2 + 1] = nr ? ctr[(size_t)g * ctr_stride * 2 + 1] : sy;
-        scores[g] = score;
+        // return_score_type 'max' (cpr_head.py:840-842): the largest kept probability, refine_th / 2 when nothing was kept;
+        // the not_refine decision above always uses the mean
+        scores[g] = score_max ? (pmax == 0.f ? refine_th * 0.5f : pmax) : score;
         not_refine[g] = nr ? 1 : 0;
     }
 }
@@ -559,13 +566,14 @@ extern "C" int cpr_refine(const float* logits, int J, const float* pts, const un
                           const int* gt_start, const int* img_hw, const unsigned char* not_refine_in,
                           float* refine_pts, float* scores, unsigned char* not_refine, unsigned char* chosen, int G,
                           int Kt, int Kv, int C, int prob_type, float norm_p, float gt_alpha, float merge_th,
-                          float refine_th, int use_nearest, int use_classify, hipStream_t stream) {
+                          float refine_th, int use_nearest, int use_classify, int score_max, hipStream_t stream) {
     CPR_CHECK_ARG(G > 0 && Kt > 0 && Kv > 0 && Rv > 0 && Kt == Rv * Kv && ctr_stride >= Rv && C > 0 && J >= C);
     CPR_CHECK_ARG(prob_type >= 0 && prob_type <= 2 && norm_p > 0.f);
     CPR_CHECK_ARG(logits && pts && valid && centers && labels && gt_img && gt_start && img_hw && refine_pts &&
                   scores && not_refine && chosen);
     hipLaunchKernelGGL(refine_kernel, dim3(cdiv(G, 4)), dim3(256), 0, stream, logits, J, pts, valid, centers, Rv,
                        ctr_stride, labels, gt_img, gt_start, img_hw, not_refine_in, refine_pts, scores, not_refine,
-                       chosen, G, Kt, Kv, C, prob_type, norm_p, gt_alpha, merge_th, refine_th, use_nearest, use_classify);
+                       chosen, G, Kt, Kv, C, prob_type, norm_p, gt_alpha, merge_th, refine_th, use_nearest, use_classify,
+                       score_max);
     CPR_LAUNCH_STATUS();
 }

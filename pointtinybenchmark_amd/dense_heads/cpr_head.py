@@ -11,7 +11,10 @@ Same registry name, constructor keys and method signatures as the reference; the
 Single FPN level like every shipped config (the reference asserts the single level itself: cpr_head.py:799,1152).
 Options beyond the shipped configs, all on the same kernels: num_refine > 1 inputs with the three
 ``refine_bag_policy`` values and both ``gt_loss_type`` values, ``GridCirclesPtFeatGenerator`` bags, ``softmax`` /
-``normed_sigmoid`` class probabilities, ``binary_ins``, ``AllPosLoss``, ``num_cls_fcs > 0``."""
+``normed_sigmoid`` class probabilities, ``binary_ins``, ``AllPosLoss``, ``num_cls_fcs > 0``; round 3:
+``ins_share_head_feat=False`` (a second tower ``ins_convs`` / ``ins_fcs`` for the instance classifier, cpr_head.py:992-1008,
+1037,1068), ``out_bg_cls=True`` for one class (:953), ``PointRefiner(return_score_type='max')`` (:840-842).
+``AnchorPtFeatGenerator(scale_factor != 1)`` and ``GridEllipsePtFeatGenerator`` raise in the reference itself and are refused."""
 import math
 
 import numpy as np
@@ -85,6 +88,11 @@ class _Extractor:
                                same_num_all_radius=pg.pop('same_num_all_radius', False))
             assert pg.pop('append_center', True) and not pg, pg
         self.neg_is_anchor = ntype == 'AnchorPtFeatGenerator'
+        if self.neg_is_anchor and ng.get('scale_factor', None) not in (None, 1, 1.0):
+            # generate() hands scale_factor to F.interpolate as its second POSITIONAL argument, i.e. as `size`
+            # (cpr_head.py:229-231): the reference raises a TypeError on the first call (tests/golden/cpr_options_r3.npz)
+            raise NotImplementedError('AnchorPtFeatGenerator(scale_factor=%r) raises inside the reference itself '
+                                      '(cpr_head.py:229-231)' % (ng['scale_factor'],))
         self.neg_radius = ng.get('radius', 0)
         self.neg_class_wise = ng.get('class_wise', False)
         self.strides, self.num_classes = strides, num_classes
@@ -140,20 +148,21 @@ class CPRHead(nn.Module):
                  conv_bias='auto', loss_cls=None, loss_bbox=None, conv_cfg=None, norm_cfg=None, train_cfg=None,
                  test_cfg=None):
         super().__init__()
-        # ins_share_head_feat=False (a second, instance-only tower) and loss_type != 0 exist in no config of the reference
-        assert num_cls_fcs >= 0 and ins_share_head_feat and loss_type == 0, \
-            'ins_share_head_feat=False / loss_type != 0 are not built'
+        # loss_type != 0 has no loss{n} method in the reference either (cpr_head.py:1116: getattr(self, 'loss%d'))
+        assert num_cls_fcs >= 0 and loss_type == 0, 'loss_type != 0 does not exist'
         assert num_cls_fcs == 0 or fc_out_channels % 32 == 0, 'fc_out_channels must be a multiple of 32'
         self.num_cls_fcs, self.fc_out_channels = num_cls_fcs, fc_out_channels
         self.prob_type = normal_cfg.get('prob_cls_type', 'sigmoid')
         self.norm_p = float(normal_cfg.get('normed_sigmoid_p', 1))
         if self.prob_type not in ('sigmoid', 'softmax', 'normed_sigmoid'):
             raise ValueError(self.prob_type)                     # as get_cls_prob does (cpr_head.py:1097)
-        # out_bg_cls=True cannot run in the reference for C > 1 (the (.., C) validity mask meets (.., C+1) probabilities in
-        # gfocal_loss, cpr_head.py:1226) and no config sets it
-        assert not normal_cfg.get('out_bg_cls', False), 'out_bg_cls=True is not built'
+        # out_bg_cls=True (one more classifier output, never a label): runs in the reference for ONE class only -- for C > 1
+        # the (.., C) validity mask meets (.., C+1) probabilities in gfocal_loss (cpr_head.py:1226) and broadcasting fails
+        self.out_bg_cls = bool(normal_cfg.get('out_bg_cls', False))
+        assert not self.out_bg_cls or num_classes == 1, 'out_bg_cls=True cannot run in the reference for num_classes > 1'
         assert norm_cfg is not None and norm_cfg['type'] == 'GN' and not dcn_on_last_conv and not debug
-        self.num_classes = self.cls_out_channels = self.num_cls_out = num_classes
+        self.num_classes = self.cls_out_channels = num_classes
+        self.num_cls_out = num_classes + 1 if self.out_bg_cls else num_classes          # cpr_head.py:953
         self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
         self.strides = list(strides)
         self.ins_share_head_feat, self.ins_share_head_classifier = ins_share_head_feat, ins_share_head_classifier
@@ -170,15 +179,21 @@ class CPRHead(nn.Module):
         chn = in_channels
         for _ in range(stacked_convs):
             self.cls_convs.append(ConvModule(chn, feat_channels, 3, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg))
+            if not ins_share_head_feat:                                               # cpr_head.py:992-996
+                self.ins_convs.append(ConvModule(chn, feat_channels, 3, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg))
             chn = feat_channels
-        self.cls_fcs = nn.ModuleList()     # shared by the cls and ins classifiers (ins_share_head_feat, cpr_head.py:999-1005)
+        self.cls_fcs = nn.ModuleList()     # ins_share_head_feat: shared by the cls and ins classifiers (cpr_head.py:999-1005)
         self.ins_fcs = nn.ModuleList()
         for _ in range(num_cls_fcs):
             self.cls_fcs.append(nn.Linear(chn, fc_out_channels))
+            if not ins_share_head_feat:
+                self.ins_fcs.append(nn.Linear(chn, fc_out_channels))
             chn = fc_out_channels
-        self.cls_out = nn.Linear(chn, num_classes)
+        self.cls_out = nn.Linear(chn, self.num_cls_out)
         self.ins_out = self.cls_out if ins_share_head_classifier else \
-            nn.Linear(chn, num_classes * 2 if self.binary_ins else num_classes)      # cpr_head.py:1009-1011
+            nn.Linear(chn, self.num_cls_out * 2 if self.binary_ins else self.num_cls_out)      # cpr_head.py:1009-1011
+        # one projection serves both classifiers only when features AND classifier are shared (cpr_head.py:1068-1070)
+        self.ins_same_logits = ins_share_head_feat and ins_share_head_classifier
         self.loss_mil = build_loss(loss_mil)
         self.loss_cls = self.loss_mil
         self.train_pts_extractor = _Extractor(**train_pts_extractor, strides=self.strides, num_classes=num_classes)
@@ -186,7 +201,8 @@ class CPRHead(nn.Module):
         pr = dict(gt_alpha=0.5, merge_th=0.05, refine_th=0.05, classify_filter=False, return_score_type='mean',
                   nearest_filter=True)
         pr.update(point_refiner)
-        assert pr['return_score_type'] == 'mean', "return_score_type='max' is not built"
+        if pr['return_score_type'] not in ('mean', 'max'):
+            raise ValueError(pr['return_score_type'])                              # cpr_head.py:845
         self.point_refiner = pr
         self._cache = _PackCache()
         self._thr = {}
@@ -195,7 +211,8 @@ class CPRHead(nn.Module):
     def train_step_supported(self):
         """The hand-written backward (training.CprTrainer) covers the shipped configs' options."""
         return (self.prob_type == 'sigmoid' and not self.binary_ins and not self.loss_mil.allpos and
-                self.num_cls_fcs == 0 and not self.train_pts_extractor.pos_is_grid)
+                self.num_cls_fcs == 0 and not self.train_pts_extractor.pos_is_grid and self.ins_share_head_feat and
+                not self.out_bg_cls)
 
     # ------------------------------------------------------------------ init (cpr_head.py:939-948)
     def init_weights(self):
@@ -215,11 +232,13 @@ class CPRHead(nn.Module):
             ins.append(f[1])
         return cls, ins
 
-    def _tower(self, x, ab=None, in_relu=True, tape=None, own_input=False):
+    def _tower(self, x, ab=None, in_relu=True, tape=None, own_input=False, convs=None):
         """4 x [conv3x3 -> GN -> ReLU]; returns the LAST layer un-normalised: (raw, (a, b)).
-        own_input: nobody else reads ``x`` (its pending GroupNorm may be applied in place)."""
-        last = len(self.cls_convs) - 1
-        for i, m in enumerate(self.cls_convs):
+        own_input: nobody else reads ``x`` (its pending GroupNorm may be applied in place).
+        convs: the tower's layers (cls_convs; ins_convs for the instance tower of ins_share_head_feat=False)."""
+        convs = self.cls_convs if convs is None else convs
+        last = len(convs) - 1
+        for i, m in enumerate(convs):
             rec = None
             if tape is not None:
                 rec = dict(kind='tower', level=i)
@@ -233,9 +252,13 @@ class CPRHead(nn.Module):
         return x, ab
 
     def forward_single(self, x):
-        raw, ab = self._tower(ops.from_nchw(x))
+        xin = ops.from_nchw(x)
+        raw, ab = self._tower(xin)
         out = ops.as_nchw(ops.gn_apply(raw, ab[0], ab[1], relu=True, out=raw))
-        return out, out
+        if self.ins_share_head_feat:
+            return out, out
+        raw2, ab2 = self._tower(xin, convs=self.ins_convs)                           # cpr_head.py:1037-1040
+        return out, ops.as_nchw(ops.gn_apply(raw2, ab2[0], ab2[1], relu=True, out=raw2))
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, gt_true_bboxes=None,
                       proposal_cfg=None, **kwargs):
@@ -252,42 +275,50 @@ class CPRHead(nn.Module):
         the last tower layer is ever materialised in normalised form -- the consumer convs (tower layer 0, the logit
         projection) apply the GroupNorm affine (+ReLU) on load.  Same arithmetic as forward() + loss()."""
         assert len(lazy_feats) == 1
-        raw, ab = lazy_feats[0]
-        raw, ab = self._tower(raw, ab, in_relu=False, tape=tape, own_input=True)
-        return self.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
+        raw0, ab0 = lazy_feats[0]
+        ins = None
+        if not self.ins_share_head_feat:        # the instance tower reads the neck output first (the cls tower may consume it)
+            assert tape is None, 'the training step is built for ins_share_head_feat=True'
+            ins = [self._tower(raw0, ab0, in_relu=False, convs=self.ins_convs)]
+        raw, ab = self._tower(raw0, ab0, in_relu=False, tape=tape, own_input=True)
+        return self.loss([(raw, ab)], ins, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
                          gt_true_bboxes=gt_true_bboxes, save=save)
 
     # ------------------------------------------------------------------ shared extraction
-    def _fc_stack(self, rows_nhwc):
-        """get_pts_outs.forward_with_fc (cpr_head.py:1055-1059): relu(fc_i(.)) as 1x1 convs over an NHWC block of rows."""
+    def _fc_stack(self, rows_nhwc, ins=False):
+        """get_pts_outs.forward_with_fc (cpr_head.py:1055-1059): relu(fc_i(.)) as 1x1 convs over an NHWC block of rows
+        (ins: the instance tower's ``ins_fcs``)."""
         x = rows_nhwc
-        for i, fc in enumerate(self.cls_fcs):
-            pc, bias = self._cache.get(('fc', i, x.dtype), [fc.weight, fc.bias], lambda fc=fc, x=x: (
+        for i, fc in enumerate(self.ins_fcs if ins else self.cls_fcs):
+            pc, bias = self._cache.get(('fc', ins, i, x.dtype), [fc.weight, fc.bias], lambda fc=fc, x=x: (
                 ops.PackedConv(fc.weight.detach()[:, :, None, None], 1, 0, x.dtype), fc.bias.detach().float().contiguous()))
             x = ops.conv2d(x, pc, bias=bias, relu=True)
         return x
 
-    def _proj(self, dt):
-        """The classifiers as ONE packed 1x1 conv: rows [cls_out ++ ins_out] (cls_out alone when the classifier is shared)."""
+    def _proj(self, dt, part=None):
+        """The classifiers as ONE packed 1x1 conv: rows [cls_out ++ ins_out] (cls_out alone when features and classifier are
+        shared); part='cls' / 'ins': one classifier alone (ins_share_head_feat=False: each reads its own tower)."""
         def make():
-            w = [self.cls_out.weight] + ([] if self.ins_share_head_classifier else [self.ins_out.weight])
-            b = [self.cls_out.bias] + ([] if self.ins_share_head_classifier else [self.ins_out.bias])
-            wt = torch.cat(w, 0).detach()[:, :, None, None]
-            return (ops.PackedConv(wt, 1, 0, dt), torch.cat(b, 0).detach().float().contiguous(),
+            mods = {None: [self.cls_out] + ([] if self.ins_same_logits else [self.ins_out]),
+                    'cls': [self.cls_out], 'ins': [self.ins_out]}[part]
+            wt = torch.cat([m.weight for m in mods], 0).detach()[:, :, None, None]
+            return (ops.PackedConv(wt, 1, 0, dt), torch.cat([m.bias for m in mods], 0).detach().float().contiguous(),
                     wt[:, :, 0, 0].float().contiguous())
         srcs = [self.cls_out.weight, self.cls_out.bias, self.ins_out.weight, self.ins_out.bias]
-        return self._cache.get(('proj', dt), srcs, make)
+        return self._cache.get(('proj', dt, part), srcs, make)
 
-    def _logit_map(self, feat_nhwc, in_ab=None):
-        """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C, or 2C with binary_ins)] (or C when the classifier is shared).
+    def _logit_map(self, feat_nhwc, in_ab=None, part=None):
+        """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C, or 2C with binary_ins)] (or C when features and classifier are
+        shared; part='cls' / 'ins': that classifier's logits alone, through its own FC stack).
         in_ab: the input is the raw last-layer conv output and (a, b) its GroupNorm affine (+ReLU), applied on load.
-        With num_cls_fcs > 0 the (materialised) input first runs through the shared FC stack."""
+        With num_cls_fcs > 0 the (materialised) input first runs through the FC stack."""
+        assert part is not None or self.ins_share_head_feat, 'two towers: project each with its own part'
         dt = feat_nhwc.dtype
         if self.num_cls_fcs > 0:
             assert in_ab is None
-            feat_nhwc = self._fc_stack(feat_nhwc)
+            feat_nhwc = self._fc_stack(feat_nhwc, ins=(part == 'ins' and not self.ins_share_head_feat))
 
-        pc, bias, w_rows = self._proj(dt)
+        pc, bias, w_rows = self._proj(dt, part)
         if in_ab is not None and ((feat_nhwc.shape[1] * feat_nhwc.shape[2]) % 128 != 0 or dt != torch.float32):
             feat_nhwc, in_ab = ops.gn_apply(feat_nhwc, in_ab[0], in_ab[1], relu=True), None
         # the logit map is always fp32 (the loss / sampling kernels are shared by both compute modes)
@@ -298,17 +329,18 @@ class CPRHead(nn.Module):
                 return out
         return ops.conv2d(feat_nhwc, pc, bias=bias, in_ab=in_ab, in_relu=True, out_dtype=torch.float32)
 
-    def _bags(self, ex, feat, lmap, gts, stride):
-        """Bag points (E,2), validity (E) and bag logits (E,J) of the positive generator, E = G * entries-per-gt, plus
-        the bag view (sub_bags per gt, entries per sub-bag).  num_cls_fcs == 0: Linear commutes with bilinear sampling, so
-        the logits are sampled from the projected map.  Otherwise the 256-channel features are sampled and run through the
-        FC stack + classifiers (the ReLUs in between do not commute with the interpolation)."""
-        src = lmap if self.num_cls_fcs == 0 else feat
+    def _lmap_all(self, feat, ab=None, ifeat=None, iab=None):
+        """The logit map the loss reads: [cls ++ ins] channels.  Two towers (ins_share_head_feat=False): the class logits
+        come from the class tower's map, the instance logits from the instance tower's (cpr_head.py:1061-1070)."""
+        if self.ins_share_head_feat:
+            return self._logit_map(feat, ab)
+        return torch.cat([self._logit_map(feat, ab, 'cls'), self._logit_map(ifeat, iab, 'ins')], dim=-1).contiguous()
+
+    def _sample(self, ex, src, gts, stride, pad):
+        """The positive generator on one map: bag points, validity, samples and the bag view."""
         if ex.pos_is_grid:
             # the reference pads to max_pos_num + num_refine grid slots and THEN appends the num_refine points (cpr_head.py:325-349)
             kmax = ex.max_pos_num + gts.R
-            # padding slots hold zero features in the reference (:323-324): on the projected map that is the projection's bias
-            pad = self._proj(src.dtype)[1] if self.num_cls_fcs == 0 else None
             pts, valid, out, count = ops.grid_bag(src, gts.points, gts.gt_img, gts.R, kmax, ex.pos_radius * stride, stride,
                                                   pad_value=pad)
             # the reference fails inside generate() when a bag overflows (cpr_head.py:331-333: shape mismatch on assignment)
@@ -316,13 +348,34 @@ class CPRHead(nn.Module):
             if worst > kmax:
                 raise RuntimeError('GridCirclesPtFeatGenerator: %d grid points in one bag > max_pos_num + num_refine = %d'
                                    % (worst, kmax))
-            view = (1, kmax + gts.R)
+            return pts, valid, out, (1, kmax + gts.R)
+        pts, valid, out = ops.bag_sample(src, gts.points, gts.pt_img, gts.pad_hw, ex.offsets(stride, src.device), stride)
+        return pts, valid, out, (gts.R, pts.shape[1])
+
+    def _bags(self, ex, feat, lmap, gts, stride, ifeat=None, part=None):
+        """Bag points (E,2), validity (E) and bag logits (E,J) of the positive generator, E = G * entries-per-gt, plus
+        the bag view (sub_bags per gt, entries per sub-bag).  num_cls_fcs == 0: Linear commutes with bilinear sampling, so
+        the logits are sampled from the projected map ``lmap``.  Otherwise the 256-channel features are sampled and run
+        through the FC stack + classifiers (the ReLUs in between do not commute with the interpolation): ``feat`` for the
+        class logits and, with two towers, ``ifeat`` for the instance logits (part='cls': class logits only)."""
+        if self.num_cls_fcs == 0:
+            # padding slots hold zero features in the reference (:323-324): on the projected map that is the projection's bias
+            pad = None
+            if ex.pos_is_grid:
+                pad = self._proj(lmap.dtype, part)[1] if (self.ins_share_head_feat or part is not None) else \
+                    torch.cat([self._proj(lmap.dtype, 'cls')[1], self._proj(lmap.dtype, 'ins')[1]])
+            pts, valid, out, view = self._sample(ex, lmap, gts, stride, pad)
         else:
-            pts, valid, out = ops.bag_sample(src, gts.points, gts.pt_img, gts.pad_hw, ex.offsets(stride, src.device), stride)
-            view = (gts.R, pts.shape[1])
-        if self.num_cls_fcs > 0:
+            pts, valid, out, view = self._sample(ex, feat, gts, stride, None)
             E, K, Cf = out.shape
-            out = self._logit_map(out.view(1, E * K, 1, Cf)).view(E, K, -1)
+            if self.ins_share_head_feat:
+                out = self._logit_map(out.view(1, E * K, 1, Cf), part=part).view(E, K, -1)
+            else:
+                parts = [self._logit_map(out.view(1, E * K, 1, Cf), part='cls').view(E, K, -1)]
+                if part is None:
+                    _, _, iout, _ = self._sample(ex, ifeat, gts, stride, None)
+                    parts.append(self._logit_map(iout.view(1, E * K, 1, Cf), part='ins').view(E, K, -1))
+                out = torch.cat(parts, dim=-1).contiguous()
         G = gts.G
         return pts.view(G, -1, 2), valid.view(G, -1), out.view(G, -1, out.shape[-1]), view
 
@@ -384,19 +437,26 @@ class CPRHead(nn.Module):
              gt_weights=None, save=None, lmap=None):
         assert len(gt_labels) > 0
         assert len(cls_feat) == 1, 'single FPN level (the reference asserts the same: cpr_head.py:1152)'
-        ex, C, stride = self.train_pts_extractor, self.num_classes, self.strides[0]
-        if isinstance(cls_feat[0], tuple):          # (raw, (a, b)) from forward_train_lazy
-            feat, ab = cls_feat[0]
-        else:
-            feat, ab = ops.from_nchw(cls_feat[0]), None
+        # C = classifier outputs (num_classes, + 1 with out_bg_cls: the labels never name the extra output)
+        ex, C, stride = self.train_pts_extractor, self.num_cls_out, self.strides[0]
+
+        def unpack(f):
+            return f if isinstance(f, tuple) else (ops.from_nchw(f), None)      # (raw, (a, b)) from forward_train_lazy
+        feat, ab = unpack(cls_feat[0])
+        ifeat = iab = None
+        if not self.ins_share_head_feat:
+            ifeat, iab = unpack(ins_feat[0])
         dev = feat.device
-        if self.num_cls_fcs > 0 and ab is not None:       # the FC path samples the normalised, activated features
+        if self.num_cls_fcs > 0:                          # the FC path samples the normalised, activated features
             assert save is None, 'the training step is built for num_cls_fcs == 0'
-            feat, ab = ops.gn_apply(feat, ab[0], ab[1], relu=True), None
+            if ab is not None:
+                feat, ab = ops.gn_apply(feat, ab[0], ab[1], relu=True), None
+            if iab is not None:
+                ifeat, iab = ops.gn_apply(ifeat, iab[0], iab[1], relu=True), None
         if lmap is None:                            # (a caller that replays a hipGraph hands the projected map over)
-            lmap = self._logit_map(feat, ab)
+            lmap = self._lmap_all(feat, ab, ifeat, iab)
         gts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev)
-        _, valid, bag_logits, view = self._bags(ex, feat, lmap, gts, stride)
+        _, valid, bag_logits, view = self._bags(ex, feat, lmap, gts, stride, ifeat=ifeat)
         cfg = self.loss_cfg
         with_mil, with_gt, with_neg = cfg.get('with_mil_loss', True), cfg.get('with_gt_loss', False), cfg.get('with_neg', True)
         assert with_mil or with_gt, 'loss0 needs num_pos from the MIL or the gt loss (cpr_head.py:1180,1213,1227)'
@@ -406,9 +466,10 @@ class CPRHead(nn.Module):
             assert not ex.neg_is_anchor, 'AnchorPtFeatGenerator is a refine-time generator only'
             neg_mask, partial = ops.neg_mask_loss(lmap, gts.points, gts.pt_labels, gts.pt_start, gts.pad_hw, C, stride,
                                                   self._d2_threshold(stride, ex.neg_radius), self.loss_mil.eps,
-                                                  ex.neg_class_wise, self.prob_type, self.norm_p)
+                                                  ex.neg_class_wise, self.prob_type, self.norm_p,
+                                                  mask_classes=self.num_classes)
         bags, centres, labels, w = self._loss_geometry(gts, view, gt_weights, dev)
-        ins_off = 0 if self.ins_share_head_classifier else C
+        ins_off = 0 if self.ins_same_logits else C
         out = self.loss_mil.forward_logits(bag_logits, ins_off, valid, labels, C, w, partial,
                                            cfg.get('gt_loss_weight', 1.0), cfg.get('neg_loss_weight', 1.0),
                                            want_bag_ws=save is not None, bags=bags, centres=centres,
@@ -434,21 +495,24 @@ class CPRHead(nn.Module):
         """Extraction + PointRefiner of get_bboxes: returns the kernel outputs for all gts of the batch
         (gts, bag pts (G,Kt,2), refine_pts (G,2), scores (G), not_refine (G) u8, chosen (G,Kt) u8)."""
         assert len(cls_feat) == 1
-        ex, C, stride, pr = self.refine_pts_extractor, self.num_classes, self.strides[0], self.point_refiner
+        ex, C, stride, pr = self.refine_pts_extractor, self.num_cls_out, self.strides[0], self.point_refiner
         feat = ops.from_nchw(cls_feat[0])
         dev = feat.device
-        lmap = self._logit_map(feat)
+        # the refiner reads class probabilities only (cpr_head.py:780-850): with two towers the class tower's logits suffice
+        part = None if self.ins_share_head_feat else 'cls'
+        lmap = self._logit_map(feat, part=part)
         gts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev)
         # PointRefiner.refine_single asserts gt_r_pts == gt_r_points[:, :1] (cpr_head.py:809): with CirclePtFeatGenerator
         # bags it only accepts one point per gt; the grid generators keep one annotated point per bag and take R > 1
         assert ex.pos_is_grid or gts.R == 1, 'num_refine > 1 inputs cannot be refined (the reference asserts: cpr_head.py:809)'
-        pts, valid, bag_logits, (Rv, Kv) = self._bags(ex, feat, lmap, gts, stride)
+        pts, valid, bag_logits, (Rv, Kv) = self._bags(ex, feat, lmap, gts, stride, part=part)
         # the grid (negative) branch is computed but unused by the reference at refine time (cpr_head.py:794-804)
         nr_in = None if not_refine is None else torch.cat(list(not_refine)).to(torch.uint8).to(dev).contiguous()
         rp, sc, nr, chosen = ops.refine(bag_logits, pts, valid, gts.points, gts.labels, gts.gt_img, gts.gt_start,
                                         gts.img_hw, C, pr['gt_alpha'], pr['merge_th'], pr['refine_th'],
                                         pr['nearest_filter'], pr['classify_filter'], nr_in, sub_bags=Rv,
-                                        ctr_stride=gts.R, prob_type=self.prob_type, norm_p=self.norm_p)
+                                        ctr_stride=gts.R, prob_type=self.prob_type, norm_p=self.norm_p,
+                                        score_max=pr['return_score_type'] == 'max')
         return gts, pts, rp, sc, nr, chosen
 
     def get_bboxes(self, cls_feat, ins_feat, img_metas, cfg=None, rescale=False, with_nms=True, gt_bboxes=None,

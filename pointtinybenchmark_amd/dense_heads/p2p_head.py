@@ -152,7 +152,7 @@ class P2PHead(nn.Module):
             all_valid = bool(valid.all())
         masked = not all_valid
         out = proposals.new_zeros((B, M), dtype=torch.long)
-        costs, where = [], []
+        costs, where, costs_t, where_t = [], [], [], []
         for b in range(B):
             idx = torch.nonzero(valid[b], as_tuple=False).squeeze(1) if masked else None
             if masked:
@@ -163,14 +163,23 @@ class P2PHead(nn.Module):
                 continue
             if Mb < G:
                 if a.topk_k == 1:
-                    raise NotImplementedError('fewer proposals than gts with topk_k == 1 (scipy solves the transposed '
-                                              'problem there; the device LSA needs M >= G)')
+                    # linear_sum_assignment on the (Mb, G) cost (hungarian_assigner.py:229-240): every proposal gets a
+                    # distinct gt (HungarianAssignerV2.transposed_inds)
+                    costs_t.append(a.cost_t(props.contiguous(), c.contiguous(), gt_points[b], gt_labels[b], img_metas[b]))
+                    where_t.append((b, idx))
+                # topk_k > 1: `cost_new.shape[0] // num_gts != 0` is false at once, nothing is assigned (:245-248)
                 continue
             costs.append(a.cost_t(props.contiguous(), c.contiguous(), gt_points[b], gt_labels[b], img_metas[b]))
             where.append((b, idx))
         if costs:
             inds, _ = ops.lsa_topk(costs, a.topk_k)
             for (b, idx), gi in zip(where, inds):
+                if idx is None:
+                    out[b] = gi
+                else:
+                    out[b][idx] = gi
+        if costs_t:
+            for (b, idx), gi in zip(where_t, a.transposed_inds(costs_t)):
                 if idx is None:
                     out[b] = gi
                 else:

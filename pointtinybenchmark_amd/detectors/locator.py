@@ -135,7 +135,8 @@ class BasicLocator(nn.Module):
         for m in img_metas:
             m['batch_input_shape'] = batch_input_shape
         if (self.use_graph or os.environ.get('CPR_GRAPH', '0') == '1') and img.is_cuda and not torch.is_grad_enabled() \
-                and hasattr(self.bbox_head, 'forward_train_lazy') and getattr(self.bbox_head, 'num_cls_fcs', 1) == 0:
+                and hasattr(self.bbox_head, 'forward_train_lazy') and getattr(self.bbox_head, 'num_cls_fcs', 1) == 0 \
+                and getattr(self.bbox_head, 'ins_share_head_feat', True):
             raw, ab, lmap = self._graphed_logit_map(img)
             return self.bbox_head.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas,
                                        gt_bboxes_ignore=gt_bboxes_ignore, gt_true_bboxes=gt_true_bboxes, lmap=lmap)

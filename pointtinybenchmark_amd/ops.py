@@ -412,9 +412,10 @@ PROB_TYPES = {'sigmoid': 0, 'softmax': 1, 'normed_sigmoid': 2, 'identity': 3}
 
 
 def neg_mask_loss(logit_map, centers, labels, gt_start, pad_hw, num_classes, stride, d2_thr, eps=1e-6,
-                  class_wise=True, prob_type='sigmoid', norm_p=1.0):
+                  class_wise=True, prob_type='sigmoid', norm_p=1.0, mask_classes=None):
     """logit_map (N,H,W,J) -> mask (N*H*W, C) uint8, partial sums (double).  centers/labels/gt_start: the annotated
-    points in CSR form (with num_refine > 1: every refine point, carrying its gt's label)."""
+    points in CSR form (with num_refine > 1: every refine point, carrying its gt's label).  mask_classes=1 with
+    num_classes=2: out_bg_cls, the single class's validity covers the [class, background] outputs."""
     N, H, W, J = _check(logit_map).shape
     C = num_classes
     mask = torch.empty((N * H * W, C), device=logit_map.device, dtype=torch.uint8)
@@ -422,7 +423,7 @@ def neg_mask_loss(logit_map, centers, labels, gt_start, pad_hw, num_classes, str
     partial = torch.empty((N * nblk,), device=logit_map.device, dtype=torch.float64)
     _lib.call('cpr_neg_mask_loss', _ptr(logit_map), J, _ptr(centers), _ptr(labels), _ptr(gt_start), _ptr(pad_hw),
               _ptr(mask), _ptr(partial), N, H, W, C, float(stride), float(d2_thr), float(eps), int(class_wise),
-              PROB_TYPES[prob_type], float(norm_p), None, _stream())
+              PROB_TYPES[prob_type], float(norm_p), C if mask_classes is None else int(mask_classes), None, _stream())
     return mask, partial
 
 
@@ -483,7 +484,7 @@ def mil_loss(logits, ins_off, valid, labels, num_classes, neg_partial, w_mil, w_
 
 def refine(logits, pts, valid, centers, labels, gt_img, gt_start, img_hw, num_classes, gt_alpha, merge_th, refine_th,
            use_nearest=True, use_classify=False, not_refine_in=None, sub_bags=1, ctr_stride=None, prob_type='sigmoid',
-           norm_p=1.0):
+           norm_p=1.0, score_max=False):
     """logits (G,Kt,J): a gt owns Kt = sub_bags*Kv entries; centers holds ctr_stride points per gt (default sub_bags)."""
     G, Kt, J = _check(logits).shape
     Rv = int(sub_bags)
@@ -498,7 +499,7 @@ def refine(logits, pts, valid, centers, labels, gt_img, gt_start, img_hw, num_cl
     _lib.call('cpr_refine', _ptr(logits), J, _ptr(pts), _ptr(valid), _ptr(centers), Rv, ctr_stride, _ptr(labels),
               _ptr(gt_img), _ptr(gt_start), _ptr(img_hw), _ptr(not_refine_in), _ptr(rp), _ptr(sc), _ptr(nr),
               _ptr(chosen), G, Kt, Kt // Rv, num_classes, PROB_TYPES[prob_type], float(norm_p), float(gt_alpha),
-              float(merge_th), float(refine_th), int(use_nearest), int(use_classify), _stream())
+              float(merge_th), float(refine_th), int(use_nearest), int(use_classify), int(score_max), _stream())
     return rp, sc, nr, chosen
 
 

@@ -97,10 +97,13 @@ def fpn_state_dict(in_channels, out_channels=256, start_level=0, num_outs=1, see
 
 
 def cpr_head_state_dict(num_classes=1, in_channels=256, feat_channels=256, stacked_convs=4, seed=2,
-                        prefix='bbox_head.', std=0.01, num_cls_fcs=0, fc_out_channels=1024, binary_ins=False):
+                        prefix='bbox_head.', std=0.01, num_cls_fcs=0, fc_out_channels=1024, binary_ins=False,
+                        ins_tower=False, out_bg_cls=False):
     """Normal(0, std) on Conv2d/Linear, cls_out bias = bias_init_with_prob(0.01)
     (T/mmdet/models/point/dense_heads/cpr_head.py:939-948).  ``std`` larger than the reference's
-    0.01 makes the synthetic logits spread out (used by tests to exercise the refine filters)."""
+    0.01 makes the synthetic logits spread out (used by tests to exercise the refine filters).
+    ins_tower: ins_share_head_feat=False -- a second tower ``ins_convs`` / ``ins_fcs`` (cpr_head.py:992-1008);
+    out_bg_cls: one more classifier output (cpr_head.py:953)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     chn = in_channels
@@ -112,9 +115,20 @@ def cpr_head_state_dict(num_classes=1, in_channels=256, feat_channels=256, stack
         sd['%scls_fcs.%d.weight' % (prefix, i)] = torch.randn((fc_out_channels, chn), generator=g) * (2.0 / chn) ** 0.5
         sd['%scls_fcs.%d.bias' % (prefix, i)] = torch.randn((fc_out_channels,), generator=g) * 0.1
         chn = fc_out_channels
-    sd[prefix + 'cls_out.weight'] = torch.randn((num_classes, chn), generator=g) * std
-    sd[prefix + 'cls_out.bias'] = torch.full((num_classes,), -math.log((1 - 0.01) / 0.01))
-    n_ins = num_classes * 2 if binary_ins else num_classes          # cpr_head.py:1009-1011
+    if ins_tower:
+        c2 = in_channels
+        for i in range(stacked_convs):
+            sd['%sins_convs.%d.conv.weight' % (prefix, i)] = torch.randn((feat_channels, c2, 3, 3), generator=g) * 0.01
+            _gn(sd, '%sins_convs.%d.gn' % (prefix, i), feat_channels, g)
+            c2 = feat_channels
+        for i in range(num_cls_fcs):
+            sd['%sins_fcs.%d.weight' % (prefix, i)] = torch.randn((fc_out_channels, c2), generator=g) * (2.0 / c2) ** 0.5
+            sd['%sins_fcs.%d.bias' % (prefix, i)] = torch.randn((fc_out_channels,), generator=g) * 0.1
+            c2 = fc_out_channels
+    n_cls = num_classes + 1 if out_bg_cls else num_classes
+    sd[prefix + 'cls_out.weight'] = torch.randn((n_cls, chn), generator=g) * std
+    sd[prefix + 'cls_out.bias'] = torch.full((n_cls,), -math.log((1 - 0.01) / 0.01))
+    n_ins = n_cls * 2 if binary_ins else n_cls          # cpr_head.py:1009-1011
     sd[prefix + 'ins_out.weight'] = torch.randn((n_ins, chn), generator=g) * std
     sd[prefix + 'ins_out.bias'] = torch.zeros(n_ins)
     return sd
@@ -139,12 +153,13 @@ def p2p_head_state_dict(num_classes=1, num_points=1, in_channels=256, feat_chann
 
 
 def locator_state_dict(depth=50, num_classes=1, start_level=0, head='cpr', seed=0, head_std=0.01, num_points=1,
-                       num_cls_fcs=0, fc_out_channels=1024, binary_ins=False):
+                       num_cls_fcs=0, fc_out_channels=1024, binary_ins=False, ins_tower=False, out_bg_cls=False):
     sd = resnet_state_dict(depth, seed)
     sd.update(fpn_state_dict(backbone_out_channels(depth), 256, start_level, 1, seed + 1))
     if head == 'cpr':
         sd.update(cpr_head_state_dict(num_classes, seed=seed + 2, std=head_std, num_cls_fcs=num_cls_fcs,
-                                      fc_out_channels=fc_out_channels, binary_ins=binary_ins))
+                                      fc_out_channels=fc_out_channels, binary_ins=binary_ins, ins_tower=ins_tower,
+                                      out_bg_cls=out_bg_cls))
     else:
         sd.update(p2p_head_state_dict(num_classes, num_points, seed=seed + 3, std=head_std))
     return sd

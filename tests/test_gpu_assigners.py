@@ -128,6 +128,28 @@ def test_hungarian_v2_vs_reference_fixture(golden_dir, case, record_property):
     assert np.array_equal(res.labels.cpu().numpy(), labels_ref)
 
 
+@pytest.mark.parametrize('case', range(3))
+def test_hungarian_v2_fewer_proposals_than_gts_topk1(golden_dir, case):
+    """topk_k == 1 with fewer proposals than gts (hungarian_assigner.py:229-240): scipy solves the problem with the proposals
+    as rows; fixtures = the reference's own HungarianAssignerV2 (oracle/gen_golden_r2.py ha_transposed)."""
+    from oracle.gen_golden_r2 import HA_T_CASES
+    g = np.load(os.path.join(golden_dir, 'assigner_transposed.npz'))
+    n_side, G, C = HA_T_CASES[case]
+    pred, logits, gt, labels, shp = assigner_inputs(300 + case, n_side, 4, G, C)
+    res = _ha(1).assign(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
+    inds = res.gt_inds.cpu().numpy()
+    assert np.array_equal(inds, g['hat%d_gt_inds' % case]), (inds, g['hat%d_gt_inds' % case])
+    assert np.array_equal(res.labels.cpu().numpy(), g['hat%d_labels' % case])
+    assert len(set(inds.tolist())) == n_side * n_side and inds.min() >= 1          # every proposal a distinct gt
+    # scipy on the device's own cost matrix (the unconditional link of the parity chain, as for the ordinary orientation)
+    from scipy.optimize import linear_sum_assignment
+    cost = _ha(1).cost_t(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp)).t().cpu().numpy()
+    r, c = linear_sum_assignment(cost)
+    want = np.zeros(n_side * n_side, dtype=np.int64)
+    want[r] = c + 1
+    assert np.array_equal(inds, want)
+
+
 @pytest.mark.parametrize('seed', range(8))
 def test_hungarian_v2_vs_oracle_seeds(seed, record_property):
     """Extra seeds against the oracle executed on THIS host (the GPU box's CPU: its MKL log differs from the correctly

@@ -11,7 +11,8 @@ import pytest
 import torch
 
 from oracle.gen_golden import CPR_CASES
-from oracle.gen_golden_r2 import OPTION_CASES, REFINE_CASES, case_inputs, cpr_head_kwargs, not_refine_input, option_cfg
+from oracle.gen_golden_r2 import (OPTION_CASES, OPTION_CASES_R3, REFINE_CASES, case_inputs, cpr_head_kwargs, not_refine_input,
+                                  option_cfg)
 from pointtinybenchmark_amd import synthetic
 
 pytestmark = pytest.mark.gpu
@@ -56,9 +57,10 @@ def _kernel_on_reference_logits(g, p, cfg, batch, head):
     valid = torch.from_numpy(_mask(g, p + 'bag_valid', shape=(G, Kt)).astype(np.uint8)).cuda()
     pr = head.point_refiner
     rp, sc, nr, chosen = ops.refine(logits, pts, valid, gts.points, gts.labels, gts.gt_img, gts.gt_start, gts.img_hw,
-                                    cfg['num_classes'], pr['gt_alpha'], pr['merge_th'], pr['refine_th'],
+                                    head.num_cls_out, pr['gt_alpha'], pr['merge_th'], pr['refine_th'],
                                     pr['nearest_filter'], pr['classify_filter'], None, sub_bags=1, ctr_stride=gts.R,
-                                    prob_type=head.prob_type, norm_p=head.norm_p)
+                                    prob_type=head.prob_type, norm_p=head.norm_p,
+                                    score_max=pr['return_score_type'] == 'max')
     nbad = int((chosen.cpu().numpy().astype(bool) != chosen_ref).sum())
     assert nbad == 0, '%d of %d chosen flags differ from the reference on identical logits' % (nbad, chosen_ref.size)
     assert np.array_equal(nr.cpu().numpy().astype(bool), g[p + 'not_refine'])
@@ -111,7 +113,7 @@ def _end_to_end_refine(g, p, cfg, m, batch, seed):
         torch.cuda.synchronize()
     chosen_ref = _mask(g, p + 'chosen', p + 'chosen_shape')
     assert np.array_equal(pts.cpu().numpy(), g[p + 'bag_pts']), 'bag points must be bit-exact'
-    err = float(np.abs(head_logits(head, cls_feat, gts, cfg)[..., :cfg['num_classes']] - g[p + 'bag_cls_logit']).max())
+    err = float(np.abs(head_logits(head, cls_feat, gts, cfg)[..., :head.num_cls_out] - g[p + 'bag_cls_logit']).max())
     assert err <= _logit_bar(g, p), 'bag logits %.3e (bar %.1e)' % (err, _logit_bar(g, p))
     diff = chosen.cpu().numpy().astype(bool) != chosen_ref
     labels = torch.cat(batch['gt_labels'])
@@ -152,8 +154,9 @@ def _end_to_end_refine(g, p, cfg, m, batch, seed):
 def head_logits(head, cls_feat, gts, cfg):
     from pointtinybenchmark_amd import ops
     feat = ops.from_nchw(cls_feat[0])
-    lmap = head._logit_map(feat)
-    return head._bags(head.refine_pts_extractor, feat, lmap, gts, cfg['stride'])[2].cpu().numpy()
+    part = None if head.ins_share_head_feat else 'cls'
+    lmap = head._logit_map(feat, part=part)
+    return head._bags(head.refine_pts_extractor, feat, lmap, gts, cfg['stride'], part=part)[2].cpu().numpy()
 
 
 @pytest.mark.parametrize('name', list(REFINE_CASES))
@@ -171,27 +174,39 @@ def test_refine_selections_vs_reference(golden_dir, name, record_property):
     record_property('near_threshold_entries', nnear)
 
 
-@pytest.mark.parametrize('name', list(OPTION_CASES))
+@pytest.mark.parametrize('name', list(OPTION_CASES) + list(OPTION_CASES_R3))
 def test_cpr_options_vs_reference(golden_dir, name, record_property):
+    """(round 3: + return_score_type='max', ins_share_head_feat=False with and without FC layers, out_bg_cls for one class;
+    AnchorPtFeatGenerator(scale_factor != 1) raises in the reference -- the fixture holds its TypeError -- and is refused.)"""
     cfg = option_cfg(name)
-    g = np.load(os.path.join(golden_dir, 'cpr_options.npz'))
+    g = np.load(os.path.join(golden_dir, 'cpr_options.npz' if name in OPTION_CASES else 'cpr_options_r3.npz'))
     p = name + ':'
+    if (p + 'reference_error') in g.files:
+        assert 'TypeError' in str(g[p + 'reference_error'])
+        with pytest.raises(NotImplementedError):
+            build_hip(cfg)
+        return
     m, batch = build_hip(cfg)
-    head, C = m.bbox_head, cfg['num_classes']
+    head = m.bbox_head
+    C = head.num_cls_out                    # classifier outputs: num_classes (+ 1 with out_bg_cls)
     cb = cuda_batch(batch)
     from pointtinybenchmark_amd import ops
     with torch.no_grad():
         cls_feat, ins_feat = head(m.neck(m.backbone(cb['img'])))
         losses = head.loss(cls_feat, ins_feat, cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'])
         feat = ops.from_nchw(cls_feat[0])
-        lmap = head._logit_map(feat)
+        ifeat = None if head.ins_share_head_feat else ops.from_nchw(ins_feat[0])
+        lmap = head._lmap_all(feat, None, ifeat, None)
         gts = head._gt_tensors(cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'], feat.device)
         ex = head.train_pts_extractor
-        pts, valid, bag, view = head._bags(ex, feat, lmap, gts, cfg['stride'])
+        pts, valid, bag, view = head._bags(ex, feat, lmap, gts, cfg['stride'], ifeat=ifeat)
         mask, _ = ops.neg_mask_loss(lmap, gts.points, gts.pt_labels, gts.pt_start, gts.pad_hw, C, cfg['stride'],
                                     head._d2_threshold(cfg['stride'], ex.neg_radius), 1e-6, ex.neg_class_wise,
-                                    head.prob_type, head.norm_p)
+                                    head.prob_type, head.norm_p, mask_classes=head.num_classes)
         torch.cuda.synchronize()
+    if head.out_bg_cls:                     # the reference's (.., 1) validity broadcasts over [class, background]
+        assert bool((mask[:, 0] == mask[:, 1]).all())
+        mask = mask[:, :1]
     ref_pts = g[p + 'pos_pts']                                  # (G, R|1, K, 2)
     G = ref_pts.shape[0]
     assert np.array_equal(pts.cpu().numpy().reshape(ref_pts.shape), ref_pts), 'bag points must be bit-exact'

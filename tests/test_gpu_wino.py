@@ -131,10 +131,11 @@ def test_wino_blocked_layout_and_fused_affine(case):
 
 
 @pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, False), (1, 20, 40, 128, 64, True), (3, 18, 34, 64, 128, True), (1, 19, 21, 64, 64, True),
-                                  (2, 32, 32, 256, 256, False)])
+                                  (2, 32, 32, 256, 256, False), (5, 16, 16, 256, 256, True), (7, 24, 40, 128, 128, True)])
 def test_wino_wgrad_matches_autograd(case):
     """Winograd weight gradient (csrc/conv_wino_wgrad.hip) against fp64 autograd of the same conv, next to the direct kernel.
-    Stated bound: 2e-5 of the gradient's largest entry (sums of N*H*W products per entry; measured values are printed)."""
+    Stated bound: 2e-5 of the gradient's largest entry (sums of N*H*W products per entry; measured values are printed).
+    The last two cases have K slices that run across image boundaries (the fused affine table changes inside a slice)."""
     from pointtinybenchmark_amd import ops
     N, H, W, Cin, Cout, xf = case
     g = torch.Generator().manual_seed(N * 100 + W)

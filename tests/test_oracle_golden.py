@@ -173,8 +173,8 @@ def test_correctly_rounded_log_cost_vs_reference_cost_fixture(golden_dir):
 
 
 def _option_names():
-    from oracle.gen_golden_r2 import OPTION_CASES
-    return list(OPTION_CASES)
+    from oracle.gen_golden_r2 import OPTION_CASES, OPTION_CASES_R3
+    return list(OPTION_CASES) + list(OPTION_CASES_R3)
 
 
 @pytest.mark.parametrize('name', _option_names())
@@ -183,16 +183,22 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
     AllPosLoss) against what the reference's own classes computed (tests/golden/cpr_options.npz): bag points, validity,
     negative masks and the refiner's chosen-point masks bit for bit, losses to 3e-6."""
     from oracle import cpr_options_oracle as OO
-    from oracle.gen_golden_r2 import case_inputs, option_cfg
+    from oracle.gen_golden_r2 import OPTION_CASES, case_inputs, option_cfg
     cfg = option_cfg(name)
-    g = _load(golden_dir, 'cpr_options')
+    g = _load(golden_dir, 'cpr_options' if name in OPTION_CASES else 'cpr_options_r3')
     p = name + ':'
+    if (p + 'reference_error') in g.files:
+        # AnchorPtFeatGenerator(scale_factor != 1): the reference passes scale_factor as F.interpolate's `size` (cpr_head.py:229)
+        assert 'Error' in str(g[p + 'reference_error'])
+        return
     sd, batch = case_inputs(cfg)
     torch.set_num_threads(8)
     with torch.no_grad():
         feats = O.fpn_forward(sd, O.resnet_forward(sd, batch['img'], cfg['depth']), cfg['start_level'], 1)
         cls_feat, _ = O.cpr_head_forward(sd, feats)
-        losses, per = OO.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg)
+        ins_feat = OO.ins_tower_forward(sd, feats)[0] if cfg.get('ins_tower') else None
+        losses, per = OO.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg,
+                                  ins_feat=ins_feat)
     pts = torch.cat([q['pts'] for q in per]).numpy()
     assert np.array_equal(pts, g[p + 'pos_pts'])
     assert np.array_equal(torch.cat([q['valid'] for q in per]).numpy(), g[p + 'pos_valid'])
@@ -200,6 +206,7 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
     gv = np.unpackbits(g[p + 'neg_valid'])[:nv.size].reshape(nv.shape).astype(bool)
     assert np.array_equal(nv, gv) and int(nv.sum()) == int(g[p + 'neg_valid_count'])
     np.testing.assert_allclose(torch.cat([q['cls_logit'] for q in per]).numpy(), g[p + 'pos_cls_logit'], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(torch.cat([q['ins_logit'] for q in per]).numpy(), g[p + 'pos_ins_logit'], atol=2e-5, rtol=1e-5)
     for k, v in losses.items():
         np.testing.assert_allclose(float(v), float(g[p + 'loss_' + k]), rtol=3e-6, atol=1e-7)
     assert set('loss_' + k for k in losses) == set(k[len(p):] for k in g.files if k.startswith(p + 'loss_'))
@@ -208,7 +215,7 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
             OO.cpr_refine(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg)
         return
     with torch.no_grad():
-        ref = OO.cpr_refine(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg)
+        ref = OO.cpr_refine(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg, ins_feat=ins_feat)
     chosen = torch.cat([r['chosen'] for r in ref]).numpy()
     want = np.unpackbits(g[p + 'chosen'])[:chosen.size].reshape(chosen.shape).astype(bool)
     assert np.array_equal(chosen, want)
