@@ -45,7 +45,7 @@ def kernel_source_sha16(kernel_name='conv_mfma_kernel'):
     (tools/pmc_to_json.py), so a PMC figure measured on an older kernel is never replayed into a newer bench line."""
     import hashlib
     fname = 'conv_wino_wgrad.hip' if 'wino_wgrad' in kernel_name else 'conv_wino.hip' if 'wino' in kernel_name else \
-        'conv_mfma_bf16.hip' if 'bf16' in kernel_name else 'conv_mfma.hip'
+        'conv_bf16_dma.hip' if 'bf16_dma' in kernel_name else 'conv_mfma_bf16.hip' if 'bf16' in kernel_name else 'conv_mfma.hip'
     src = os.path.join(ROOT, 'pointtinybenchmark_amd', 'csrc', fname)
     return source_code_sha16(open(src).read())
 
@@ -78,6 +78,19 @@ def pmc_traffic(kernel_name, batch):
         return None
     return d['hbm_bytes_per_launch'] * batch / d['batch']
 GN = dict(type='GN', num_groups=32, requires_grad=True)
+
+
+def _reducer_summary(trainer):
+    """training.GradBuckets.timeline() of the last step, compacted for the JSON line (None without a process group)."""
+    buckets = getattr(trainer, 'buckets', None)
+    tl = buckets.timeline() if buckets is not None and hasattr(buckets, 'timeline') else None
+    if not tl:
+        return None
+    rows = tl['buckets']
+    return {'reducer': tl['reducer'], 'world_size': tl['world_size'], 'buckets': len(rows),
+            'mbytes': round(sum(r['mbytes'] for r in rows), 1), 'backward_ms': round(tl['backward_ms'], 2),
+            'exposed_ms': round(tl['exposed_ms'], 3),
+            'issued_ms': [round(r['issued_ms'], 2) for r in rows], 'done_ms': [round(r['done_ms'], 2) for r in rows]}
 
 
 def model_cfg(depth=50, num_classes=1):
@@ -466,6 +479,8 @@ def main():
     ap.add_argument('--small-batch', type=int, default=2,
                     help="also report this per-GPU batch (the reference's samples_per_gpu) as 'small_batch' (0 = skip)")
     ap.add_argument('--train-timeout', type=int, default=300, help='watchdog for the train_step extra (seconds)')
+    ap.add_argument('--reducer', default='all_reduce', choices=['all_reduce', 'reduce_scatter'],
+                    help='gradient reducer of the training step: one all-reduce per bucket, or reduce_scatter + all_gather')
     ap.add_argument('--train-steps', type=int, default=3,
                     help='after the timed region also time this many full training steps (0 = skip); reported under '
                          '"train_step", never in "value"')
@@ -531,7 +546,8 @@ def main():
         cls = P2PTrainer if args.model == 'p2p' else CprTrainer
         return cls(model, lr=1e-3 if args.model == 'cpr' else 1e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0,
                           two_streams=os.environ.get('CPR_TRAIN_STREAMS', '2') != '1',
-                          force_collectives=distributed and world == 1)
+                          force_collectives=distributed and world == 1,
+                          **({} if args.model == 'p2p' else dict(reducer=args.reducer, reducer_timing=distributed)))
 
     def train_step():
         losses = trainer.forward_backward(img, metas, gtb, gtl)
@@ -613,7 +629,10 @@ def main():
                     'ms_per_step': te / args.train_steps * 1e3, 'steps': args.train_steps,
                     'what': 'forward + loss + backward (layer2-4, FPN, head) + bucketed gradient all-reduce + '
                             'clip_grad_norm(35) + SGD(momentum 0.9, wd 1e-4), fp32',
-                    'grad_norm': trainer.grad_norm(), 'loss': float(sum(v for k, v in tl.items() if 'loss' in k))}
+                    'grad_norm': trainer.grad_norm(), 'loss': float(sum(v for k, v in tl.items() if 'loss' in k)),
+                    # rank 0's view of the last step: when each gradient bucket was final (= its reduction issued) and when the
+                    # main stream held its sum, relative to the start of the backward; exposed_ms = reducer time NOT hidden
+                    'reducer': _reducer_summary(trainer)}
         except Exception as e:   # noqa: BLE001 -- reported in the JSON line
             return {'error': repr(e)[:300]}
 

@@ -348,6 +348,7 @@ int cpr_conv_set_ablation(int mode);     /* loop ablations: results are WRONG wh
 int cpr_wgrad_set_ablation(int mode);    /* same for the weight-gradient kernel */
 int cpr_conv_set_extra_lds(int bytes);   /* occupancy probe: dynamic LDS added to every direct-conv launch */
 int cpr_wino_set_variant(int sched, int ablate); /* Winograd: sched 1 = the other placement of the patch transform (see conv_wino.hip); loop ablations */
+int cpr_bf16_set_dma(int on);            /* bf16 mode: 0 = every layer on the register-staged kernels (A/B of conv_bf16_dma.hip) */
 int cpr_wino_set_staging(int var, int tpx);      /* Winograd: staging variant (kernel template VAR) and cout tiles per XCD; -1 = the product's choice */
 #endif
 

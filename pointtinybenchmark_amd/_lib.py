@@ -82,6 +82,7 @@ BENCH_SIGNATURES = {
     'cpr_wino_set_variant': [_i, _i],
     'cpr_wino_set_staging': [_i, _i],
     'cpr_conv_set_extra_lds': [_i],
+    'cpr_bf16_set_dma': [_i],
 }
 BENCH_LIB_PATH = os.path.join(_HERE, 'csrc', 'libcprhip_bench.so')
 

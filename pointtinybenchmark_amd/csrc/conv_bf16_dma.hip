@@ -1,0 +1,341 @@
+// bf16 implicit-GEMM convolution, 256 x 256 output tiles staged by LDS-DMA (round 3; the big layers of the bf16 compute mode).
+//
+// Same call sites and arithmetic as conv_mfma_bf16.hip (v_mfma_f32_32x32x16_bf16, fp32 accumulate, fused scale / bias /
+// residual / ReLU, GroupNorm partial statistics from the fp32 accumulators); what changes is how the operands reach the
+// matrix cores.  conv_mfma_bf16_kernel<128,128> moves every byte global -> VGPR -> ds_write -> ds_read: at bf16 MFMA rates
+// (16x the fp32 rate) its four waves issue one staging instruction per MFMA and the matrix pipe is busy 43 % of the time
+// (profiles/round2_pmc_bf16_kernel.json: 0.35 of the 2.5 PFLOP/s peak).  Here
+//   * the tile is 256 (pixels) x 256 (couts) x 64 (K): 32 MFMAs per wave per K chunk against 8 LDS-DMA requests and 24
+//     ds_read_b128 (a 128 x 128 tile needs twice the operand bytes per MFMA);
+//   * both operands go global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KB per wave instruction, no staging registers, no
+//     ds_write); zero padding = the buffer range check, exactly as in the register-staged kernels;
+//   * the LDS image of a DMA is lane-linear (wave base + 16 lane), rows are 128 bytes and every lane of a fragment read
+//     wants the SAME 16-byte column of 32 different rows: un-swizzled that is an 8-way bank conflict.  The swizzle therefore
+//     sits on the SOURCE side: the lane that fills 16-byte unit u of row r fetches k-unit u ^ ((r >> 1) & 7), and the fragment
+//     read of k-unit q goes to unit q ^ ((r >> 1) & 7) -- two rows share a 256-byte bank row, so (r & 1, unit) is distinct
+//     over the 16 rows of every ds_read_b128 service group: conflict free, and each row's 128 bytes are still one full line;
+//   * two 64 KB stages, one wait + one barrier per chunk, placed before the LAST k-step: behind that k-step's MFMAs the wave
+//     reads the next chunk's first fragments and requests the chunk after it into the stage that has just become free
+//     (3.5 k-steps, ~0.8 us, to land).
+// 512 threads = 8 waves: wave (wm, wn) = (wave & 1, wave >> 1) owns pixels [128 wm, +128) x couts [64 wn, +64): 4 x 2 blocks of
+// 32 x 32 = 128 accumulator registers.  One workgroup per CU (128 KB of LDS), two waves per SIMD.
+// Used when Cout % 256 == 0 and Cin % 64 == 0 (the head towers, the FPN convs, the wide bottleneck convs); everything else
+// stays on conv_mfma_bf16.hip.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+struct ConvDmaParams {
+    const unsigned short* in;
+    const unsigned short* wgt;
+    void* out;
+    const float* scale;
+    const float* bias;
+    const unsigned short* residual;
+    float* gn_part;
+    int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, out_fp32;
+    int tilesM, tilesN;
+    int ablate;     // measurement builds only (results are then WRONG): 1 no wait for the DMA, 2 no barrier, 4 no DMA requests, 8 no fragment reads
+};
+
+constexpr int DBM = 256, DBN = 256, DBK = 64;
+constexpr int DSTAGE = (DBM + DBN) * DBK * 2;     // bytes per stage: 64 KB
+
+__device__ __forceinline__ float bf16f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+__global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
+
+    // XCD-aware tile order (block b runs on XCD b % 8; an XCD walks a contiguous run of tiles, cout tiles fastest)
+    const int T = p.tilesM * p.tilesN;
+    const int per = (T + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= T) return;
+    const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+    const int m0 = tm * DBM, n0 = tn * DBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- staging role: piece j (0..3) of an operand = rows 64 j + (tid >> 3), 16-byte unit (tid & 7) of the 128-byte row; the
+    // lane fetches the k-unit (tid & 7) ^ swz, swz = (row >> 1) & 7 = (tid >> 4) & 7 for every j
+    const int srow = tid >> 3;
+    const int sunit = (tid & 7) ^ ((tid >> 4) & 7);
+    const int ohw = p.OH * p.OW;
+    const bool gemm = (p.KH == 1) & (p.KW == 1) & (p.stride == 1) & (p.pad == 0);
+    int iy0[4], ix0[4], rowoff[4];
+    bool mok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + srow + 64 * j;
+        mok[j] = m < p.M;
+        const int mm = mok[j] ? m : 0;
+        if (gemm) {
+            iy0[j] = 0; ix0[j] = 0;
+            rowoff[j] = mm * p.Cin;
+        } else {
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            iy0[j] = oy * p.stride - p.pad;
+            ix0[j] = ox * p.stride - p.pad;
+            rowoff[j] = ((n * p.H + iy0[j]) * p.W + ix0[j]) * p.Cin;      // element offset, may be "negative" when padded
+        }
+    }
+    // buffer descriptors as four SGPR words (base, stride 0, num_records, raw dword format): out-of-range offsets read 0
+    const size_t in_addr = (size_t)p.in, w_addr = (size_t)p.wgt;
+    const i32x4v rs_in = {(int)(unsigned)in_addr, (int)(unsigned)(in_addr >> 32) & 0xffff,
+                          (int)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000};
+    const i32x4v rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32) & 0xffff,
+                         (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000};
+    int woff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = n0 + srow + 64 * j;
+        woff[j] = c < p.Cout ? (c * p.Kpad) * 2 + sunit * 16 : (int)0x80000000;
+    }
+    // K order: channel chunk OUTER, tap INNER.  Consecutive chunks then read the same 128-byte segments of pixels one tap
+    // apart, i.e. the lines the previous chunk brought into the XCD's L2 (2 MB of traffic ago).  Tap-major order re-touches a
+    // line only four chunks = 8 MB of L2 traffic later: measured on the head layer 4.8 GB of L2 misses per launch against
+    // 0.84 GB of input, TCC hit rate 64 % (gpurun_out/r3j PMC).  The weights are stored tap-major: chunk (c0, tap) sits at
+    // K offset tap * Cin + c0.
+    int kh = 0, kw = 0, c0 = 0;     // tap / channel chunk of the NEXT chunk to be requested (wave-uniform)
+    int wsoff = 0;                  // byte offset of that chunk inside a weight row
+    int voffA[4];
+    auto refresh_rows = [&]() {
+        const int tapshift = (kh * p.W + kw) * p.Cin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = iy0[j] + kh, ix = ix0[j] + kw;
+            const bool ok = mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            voffA[j] = ok ? (rowoff[j] + tapshift) * 2 + sunit * 16 : (int)0x80000000;
+        }
+    };
+    refresh_rows();
+    const int lds0 = (int)(unsigned)(size_t)smem;                 // LDS byte address of stage 0
+    // one LDS-DMA request: 1 KB of this wave (lane * 16 bytes from M0).  Inline asm: the compiler neither counts nor waits for
+    // it; every global load of the K loop is of this kind and the loop counts them by hand (dma_wait)
+    auto dma = [&](const i32x4v& rs, int voff, int soff, int lds_byte) {
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:0 lds"
+                     :: "s"(lds_byte), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    };
+    const int KT = p.Kpad / DBK;
+    // piece z = 0..7 of chunk kt (z < 4: activations, else weights) into stage `buf`; pieces are issued in order
+    auto stage_piece = [&](int kt, int buf, int z) {
+        if (p.ablate & 4) return;
+        const int base = lds0 + buf * DSTAGE + wave * 1024;
+        if (z < 4) {
+            if (z == 0) wsoff = ((kh * p.KW + kw) * p.Cin + c0) * 2;
+            dma(rs_in, voffA[z], c0 * 2, base + z * 8192);
+            if (z == 3) {            // after the last activation piece: advance the tap / channel state to the next chunk
+                if (++kw == p.KW) {
+                    kw = 0;
+                    if (++kh == p.KH) { kh = 0; c0 += DBK; }
+                }
+                if (p.KH * p.KW > 1) refresh_rows();
+            }
+        } else {
+            dma(rs_w, woff[z - 4], wsoff, base + DBM * DBK * 2 + (z - 4) * 8192);
+        }
+    };
+
+    // ---- MFMA role
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int rswz = (l31 >> 1) & 7;                              // (row >> 1) & 7 of the lane's fragment rows (all blocks alike)
+    // byte offset of k-unit 2 kk + half of the lane's row inside a row block: per kk, XORed with the row's swizzle
+    int koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = l31 * 128 + (((2 * kk + half) ^ rswz) * 16);
+    const unsigned char* a_base = smem + (wm * 128) * 128;
+    const unsigned char* b_base = smem + DBM * DBK * 2 + (wn * 64) * 128;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 fa0[4], fb0[2], fa1[4], fb1[2];
+    // fragment piece z of a k-step: 0, 1 = the two cout blocks, 2..5 = the four pixel blocks.  MFMA q of the NEXT k-step uses
+    // pixel block q >> 1 and cout block q & 1: with the cout blocks read first every operand is requested >= 6 MFMA slots
+    // (~200 cycles of this wave, as many of its partner) before its first use
+#define DFRAG(FA, FB, buf, kk, z)                                                                                     \
+    do {                                                                                                              \
+        if (p.ablate & 8) break;                                                                                      \
+        if ((z) >= 2) FA[(z) >= 2 ? (z) - 2 : 0] = *reinterpret_cast<const f32x4*>(a_base + (buf) * DSTAGE + ((z) >= 2 ? (z) - 2 : 0) * 4096 + koff[kk]); \
+        else FB[(z) < 2 ? (z) : 0] = *reinterpret_cast<const f32x4*>(b_base + (buf) * DSTAGE + ((z) < 2 ? (z) : 0) * 4096 + koff[kk]); \
+    } while (0)
+#define DMFMA(FA, FB, q)                                                                              \
+    acc[(q) >> 1][(q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                 \
+        __builtin_bit_cast(bf16x8, FA[(q) >> 1]), __builtin_bit_cast(bf16x8, FB[(q) & 1]), acc[(q) >> 1][(q) & 1], 0, 0, 0)
+
+    // prologue: chunk 0 -> stage 0 completely, the first three pieces of chunk 1 -> stage 1
+#pragma unroll
+    for (int z = 0; z < 8; ++z) stage_piece(0, 0, z);
+    if (KT > 1) {
+#pragma unroll
+        for (int z = 0; z < 3; ++z) stage_piece(1, 1, z);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // chunk 0 has landed, chunk 1's pieces stay in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+#pragma unroll
+    for (int z = 0; z < 6; ++z) DFRAG(fa0, fb0, 0, 0, z);
+
+    // One chunk kt (stage buf = kt & 1).  A burst of LDS-DMA requests stalls the wave AT the requests (each costs 100+ cycles
+    // of issue when eight follow each other, against 32 cycles per MFMA), so the eight pieces of a chunk are spread over three
+    // k-steps, one piece per MFMA slot at most, in the slots that carry no (or the last) fragment read:
+    //   k-step 0: MFMAs | the fragments of k-step 1 | pieces 3, 4, 5 of chunk kt+1 -> stage buf^1 (free since the last barrier)
+    //   k-step 1: MFMAs | the fragments of k-step 2 | pieces 6, 7 of chunk kt+1
+    //   k-step 2: MFMAs | the fragments of k-step 3 (the last reads of stage buf)
+    //   wait: this wave's pieces of chunk kt+1 have landed; barrier: true for every wave, and all reads of stage buf are done
+    //   k-step 3: MFMAs | the first fragments of chunk kt+1 | pieces 0, 1, 2 of chunk kt+2 -> stage buf
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < KT, more2 = kt + 2 < KT;        // wave-uniform
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            DMFMA(fa0, fb0, q);
+            if (q < 6) DFRAG(fa1, fb1, buf, 1, q);
+            if (more && q >= 5) stage_piece(kt + 1, buf ^ 1, q - 2);          // pieces 3, 4, 5
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            DMFMA(fa1, fb1, q);
+            if (q < 6) DFRAG(fa0, fb0, buf, 2, q);
+            if (more && q >= 6) stage_piece(kt + 1, buf ^ 1, q);              // pieces 6, 7
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            DMFMA(fa0, fb0, q);
+            if (q < 6) DFRAG(fa1, fb1, buf, 3, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            DMFMA(fa1, fb1, q);
+            if (q < 6 && more) DFRAG(fa0, fb0, buf ^ 1, 0, q);
+            if (more2 && q >= 5) stage_piece(kt + 2, buf, q - 5);             // pieces 0, 1, 2
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef DFRAG
+#undef DMFMA
+
+    // ---- epilogue.  D layout of a 32 x 32 block: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel).
+    // GroupNorm statistics: one slot per 128 pixels = per (tile, wm): a wave owns its slot's 64 channels outright.
+    unsigned short* out16 = reinterpret_cast<unsigned short*>(p.out);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)((size_t)p.M * p.Cout * (p.out_fp32 ? 4 : 2)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.residual ? p.residual : (const unsigned short*)p.out), 0,
+        (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = n0 + wn * 64 + j * 32 + l31;
+        const bool cok = c < p.Cout;
+        const int cc = cok ? c : p.Cout - 1;
+        const float sc = p.scale ? p.scale[cc] : 1.f;
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        float gsum = 0.f, gsq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rbase = m0 + wm * 128 + i * 32 + 4 * half;
+            const unsigned e0 = (unsigned)(rbase * p.Cout + c);
+            float res[16];
+            if (p.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    res[r] = bf16f(__builtin_amdgcn_raw_buffer_load_b16(
+                        rs_res, (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + (r & 3) + 8 * (r >> 2);
+                float x = acc[i][j][r] * sc + bi + res[r];
+                if (p.relu) x = fmaxf(x, 0.f);
+                v[r] = x;
+                if (p.gn_part) {
+                    const float u = (cok && m < p.M) ? x : 0.f;
+                    gsum += u;
+                    gsq += u * u;
+                }
+            }
+            if (p.out_fp32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, v[r]), rs_out,
+                        (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 4u : 0x80000000u), 0, 0);
+            } else {
+                // cout pairs packed into one dword: even lanes write the even registers, odd lanes the odd ones (Cout is even)
+                const unsigned ep = (unsigned)(rbase * p.Cout + (c & ~1));
+                const bool pok = (c & ~1) < p.Cout;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float nb = __shfl_xor(v[r], 1, 64);
+                    const bool mine = ((r & 1) == (lane & 1)) && pok;
+                    const bf16x2 pk = (lane & 1) ? bf16x2{(__bf16)nb, (__bf16)v[r]} : bf16x2{(__bf16)v[r], (__bf16)nb};
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, pk), rs_out,
+                        (int)(mine ? (ep + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0);
+                }
+            }
+        }
+        if (p.gn_part) {
+            gsum += __shfl_xor(gsum, 32, 64);
+            gsq += __shfl_xor(gsq, 32, 64);
+            if (half == 0 && cok) {
+                float* dst = p.gn_part + ((size_t)(tm * 2 + wm) * p.Cout + c) * 2;
+                dst[0] = gsum;
+                dst[1] = gsq;
+            }
+        }
+    }
+    (void)out16;
+}
+
+// The launcher of conv_mfma_bf16.hip calls this for the layers that fit the tile; returns CPR_ERR_UNSUPPORTED otherwise.
+int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+                         const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                         int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
+                         int ablate) {
+    if (Cout % DBN != 0 || Cin % DBK != 0 || Kpad != KH * KW * Cin) return CPR_ERR_UNSUPPORTED;
+    ConvDmaParams p;
+    p.in = (const unsigned short*)in; p.wgt = (const unsigned short*)wgt; p.out = out; p.scale = scale; p.bias = bias;
+    p.residual = (const unsigned short*)residual; p.gn_part = gn_part;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Kpad = Kpad; p.relu = relu; p.out_fp32 = out_fp32; p.ablate = ablate;
+    p.OH = (H + 2 * pad - KH) / stride + 1;
+    p.OW = (W + 2 * pad - KW) / stride + 1;
+    const long long M = (long long)N * p.OH * p.OW;
+    if ((long long)N * H * W * Cin * 2 >= (1ll << 31) || (long long)Cout * Kpad * 2 >= (1ll << 31) || M >= (1ll << 31) ||
+        M * Cout * (out_fp32 ? 4 : 2) >= (1ll << 31))
+        return CPR_ERR_UNSUPPORTED;
+    p.M = (int)M;
+    if (gn_part && (p.OH * p.OW) % 128 != 0) return CPR_ERR_UNSUPPORTED;
+    if (gn_part && M % 256 != 0) return CPR_ERR_UNSUPPORTED;      // both 128-pixel slots of every tile must exist
+    p.tilesM = (int)((M + DBM - 1) / DBM);
+    p.tilesN = Cout / DBN;
+    if (variant_out) *variant_out = 256 * 1000 + 256;
+    const int T = p.tilesM * p.tilesN;
+    const int grid = ((T + 7) / 8) * 8;
+    hipLaunchKernelGGL(conv_bf16_dma_kernel, dim3(grid), dim3(512), 0, stream, p);
+    CPR_LAUNCH_STATUS();
+}

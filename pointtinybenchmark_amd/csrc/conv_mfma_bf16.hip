@@ -314,6 +314,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
     }
 }
 
+// conv_bf16_dma.hip: 256 x 256 tiles staged by LDS-DMA (Cout % 256 == 0, Cin % 64 == 0); CPR_ERR_UNSUPPORTED otherwise
+int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+                         const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                         int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
+                         int ablate);
+#ifdef CPR_BENCH_HOOKS
+static int bf16_dma_on = 1, bf16_dma_ablate = 0;
+extern "C" int cpr_bf16_set_dma(int on) {   // measurement build: 0 = keep every layer on the register-staged kernels (A/B);
+    CPR_CHECK_ARG(on >= 0 && on < 32);       // bits 1..4 = loop ablations of the DMA kernel (results are then WRONG)
+    bf16_dma_on = on & 1;
+    bf16_dma_ablate = on >> 1;
+    return CPR_OK;
+}
+#else
+constexpr int bf16_dma_on = 1, bf16_dma_ablate = 0;
+#endif
+
 static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                                   const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
                                   int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream) {
@@ -334,6 +351,12 @@ static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, co
         return CPR_ERR_UNSUPPORTED;
     p.M = (int)M;
     if (gn_part) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
+    // the wide layers with enough 256 x 256 tiles for two rounds over the CUs: LDS-DMA staged kernel (conv_bf16_dma.hip)
+    if (bf16_dma_on && Cout % 256 == 0 && Cin % 64 == 0 && Kpad / BKH >= 2 && ((M + 255) / 256) * (Cout / 256) >= 384) {
+        const int rc = conv_bf16_dma_launch(in, wgt, out, scale, bias, residual, gn_part, N, H, W, Cin, Cout, KH, KW, stride,
+                                            pad, Kpad, relu, out_fp32, variant_out, stream, bf16_dma_ablate);
+        if (rc != CPR_ERR_UNSUPPORTED) return rc;
+    }
     const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
     const bool big = gn_part || (Kpad / BKH >= 8 && t128 >= 4096 && Cout > 64);
     const int bm = big ? 128 : 64, bn = big ? 128 : 64;

@@ -20,17 +20,29 @@ from .layers import bump_weight_epoch, folded_bn
 
 class GradBuckets:
     """Contiguous buckets over a flat gradient buffer.  ``ready(end)`` says gradients [0, end) are final; every bucket
-    fully below ``end`` is all-reduced asynchronously (on the process group's own stream).  Works on CPU tensors with
-    gloo (tests) and on device tensors with nccl (= RCCL)."""
+    fully below ``end`` is reduced asynchronously (on the process group's own stream).  Works on CPU tensors with
+    gloo (tests) and on device tensors with nccl (= RCCL).
 
-    def __init__(self, flat, bucket_elems, group=None, force=False):
+    reducer='all_reduce' (default): one ``dist.all_reduce`` per bucket -- what MMDistributedDataParallel's reducer does
+    (T/mmdet/apis/train.py:75-86).  reducer='reduce_scatter': the two halves of a ring all-reduce issued explicitly per
+    bucket, ``reduce_scatter_tensor`` into this rank's shard then ``all_gather_into_tensor`` back into the bucket (xGMI is
+    point to point: both halves move (N-1)/N of the bucket over each link once, and the split leaves room for a sharded
+    optimizer between them).  Same sums as all_reduce up to the ring's summation order -- bit-equal on 2 ranks, where a
+    sum has one order (tests/test_host_cpu.py).  timing=True (device tensors): per-bucket launch / completion events,
+    ``timeline()`` after ``finish()`` -- what an N-GPU run needs to report overlap, not just img/s."""
+
+    def __init__(self, flat, bucket_elems, group=None, force=False, reducer='all_reduce', timing=False):
         """force: issue the collectives even in a 1-rank group (a sum over one rank is the identity) -- lets a single GPU
         exercise the real RCCL path (tests)."""
-        self.flat, self.group, self.force = flat, group, force
+        assert reducer in ('all_reduce', 'reduce_scatter'), reducer
+        self.flat, self.group, self.force, self.reducer = flat, group, force, reducer
+        self.timing = bool(timing) and flat.is_cuda
         n = flat.numel()
         self.bounds = list(range(0, n, bucket_elems)) + [n]
         if len(self.bounds) > 2 and self.bounds[-1] - self.bounds[-2] < bucket_elems // 4:
             del self.bounds[-2]            # fold a small tail into the previous bucket
+        self._shards = {}
+        self._events, self._t0, self._t_end, self._last = [], None, None, None
         self.reset()
 
     @property
@@ -39,6 +51,34 @@ class GradBuckets:
 
     def reset(self):
         self.next, self.pending = 0, []
+
+    def start_step(self):
+        """timing: marks the start of the backward pass on the current stream (bucket times are relative to it)."""
+        if self.timing:
+            self._events = []
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record()
+
+    def _reduce(self, lo, hi):
+        """Issue the reduction of gradients [lo, hi); returns the work handles in issue order."""
+        if self.reducer == 'all_reduce':
+            return [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        world = self.world_size
+        m = (hi - lo) // world * world          # the part that splits evenly; a tail of < world elements is all-reduced
+        works = []
+        if m > 0:
+            shard = self._shards.get((lo, m))
+            if shard is None:
+                shard = self._shards[(lo, m)] = torch.empty((m // world,), device=self.flat.device, dtype=self.flat.dtype)
+            w = dist.reduce_scatter_tensor(shard, self.flat[lo:lo + m], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if dist.get_backend(self.group) != 'nccl':
+                w.wait()                        # host-side backends run async work on threads: order the two halves here
+            else:
+                works.append(w)                 # RCCL: both halves sit on the group's stream, in issue order
+            works.append(dist.all_gather_into_tensor(self.flat[lo:lo + m], shard, group=self.group, async_op=True))
+        if m < hi - lo:
+            works.append(dist.all_reduce(self.flat[lo + m:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return works
 
     @property
     def active(self):
@@ -54,18 +94,45 @@ class GradBuckets:
             return
         while self.next + 1 < len(self.bounds) and self.bounds[self.next + 1] <= end:
             lo, hi = self.bounds[self.next], self.bounds[self.next + 1]
-            self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                                async_op=True))
+            ev = None
+            if self.timing:
+                ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), lo, hi]
+                ev[0].record()                  # the gradients of this bucket are final at this point of the backward
+                self._events.append(ev)
+            self.pending.append((self._reduce(lo, hi), ev))
             self.next += 1
 
     def finish(self):
         """All buckets reduced and visible to the current stream.  The sum is NOT divided here: the optimizer kernel
         applies 1/world_size (``grad_scale``) while it reads the gradient."""
         self.ready(self.flat.numel())
-        for w in self.pending:
-            w.wait()
+        if self.timing:
+            self._t_end = torch.cuda.Event(enable_timing=True)
+            self._t_end.record()                # end of the backward pass on the current stream
+        for works, ev in self.pending:
+            for w in works:
+                w.wait()
+            if ev is not None:
+                ev[1].record()                  # the current stream has this bucket's sum
+        if self.timing:
+            self._last = (self._t0, self._t_end, self._events)
         self.reset()
         return 1.0 / self.world_size
+
+    def timeline(self):
+        """timing=True, after finish(): per bucket the time (ms since start_step) its gradients were final (= the reduction
+        was issued) and the time the main stream held its sum; ``exposed_ms`` = what the step waited for the reducer after
+        the backward had ended (0 = fully overlapped).  Synchronises the device."""
+        if not self._last or self._last[0] is None:
+            return None
+        t0, t_end, events = self._last
+        torch.cuda.synchronize()
+        bwd = t0.elapsed_time(t_end)
+        rows = [dict(bucket=i, mbytes=(hi - lo) * 4 / 1e6, issued_ms=t0.elapsed_time(a), done_ms=t0.elapsed_time(b))
+                for i, (a, b, lo, hi) in enumerate(events)]
+        done = max([r['done_ms'] for r in rows], default=bwd)
+        return dict(reducer=self.reducer, world_size=self.world_size, backward_ms=bwd, exposed_ms=max(0.0, done - bwd),
+                    buckets=rows)
 
 
 class StepLrSchedule:
@@ -106,7 +173,7 @@ class StepLrSchedule:
 
 class CprTrainer:
     def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_mb=25.0, group=None,
-                 two_streams=True, force_collectives=False, schedule=None):
+                 two_streams=True, force_collectives=False, schedule=None, reducer='all_reduce', reducer_timing=False):
         """schedule: a StepLrSchedule (or any object with ``lr(iteration)``); ``lr`` is then only the fallback of
         ``step(lr=...)``.  Constructing the trainer re-homes every trainable parameter: ``p.data`` becomes a view of ONE
         flat buffer (``flat_p``) and ``p.grad`` a view of ``flat_g``; do not re-bind them afterwards (``model.to()``,
@@ -132,7 +199,8 @@ class CprTrainer:
             p.grad = self.flat_g[off:off + k].view(p.shape)
             self.offset[id(p)] = (off, off + k)
             off += k
-        self.buckets = GradBuckets(self.flat_g, max(1, int(bucket_mb * (1 << 20) / 4)), group, force=force_collectives)
+        self.buckets = GradBuckets(self.flat_g, max(1, int(bucket_mb * (1 << 20) / 4)), group, force=force_collectives,
+                                   reducer=reducer, timing=reducer_timing)
         self.norm2 = torch.zeros((1,), device=dev, dtype=torch.float64)
         self._ws = torch.empty((1024,), device=dev, dtype=torch.float64)
         self.steps = 0
@@ -234,6 +302,7 @@ class CprTrainer:
         lazy = neck.forward_lazy(feats, tape=neck_tape)
         losses, saved = self._forward_head(head, lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes)
         self.buckets.reset()
+        self.buckets.start_step()
         dz = self._backward_head(head, saved)              # gradient wrt the (normalised) FPN output
         d_stage = self._backward_neck(neck, neck_tape, dz)
         self._backward_backbone(bb, bb_tape, d_stage)

@@ -65,6 +65,66 @@ def test_conv2d_bf16_vs_torch(case):
         np.testing.assert_allclose(s[..., 1].numpy(), (ref * ref).sum(dim=(2, 3)).numpy(), rtol=1e-3, atol=2e-2)
 
 
+# shapes that reach the LDS-DMA staged 256 x 256 kernel (csrc/conv_bf16_dma.hip: Cout % 256 == 0, Cin % 64 == 0, >= 384 tiles)
+DMA_CASES = [
+    (8, 64, 128, 128, 256, 3, 1, 1, 'gn'),              # 3x3, borders on every side, GroupNorm statistics (two slots per tile)
+    (8, 128, 128, 128, 256, 1, 1, 0, 'bn res relu'),    # plain GEMM path + residual
+    (10, 64, 121, 119, 256, 3, 1, 1, 'bias relu'),      # ragged M: the last tile is partial
+    (6, 64, 256, 192, 512, 3, 2, 1, 'bn'),              # stride 2, two cout tiles
+    (8, 256, 128, 128, 256, 1, 1, 0, 'bias f32out'),    # fp32 output (the logit-projection form)
+]
+
+
+@pytest.mark.parametrize('case', DMA_CASES, ids=lambda c: 'n%d_c%d_%dx%d_o%d_k%d_s%d_%s' % (c[:7] + (c[8].replace(' ', '-'),)))
+def test_conv2d_bf16_dma_kernel_vs_torch(case):
+    """The same bar as test_conv2d_bf16_vs_torch on shapes that dispatch to the LDS-DMA staged kernel (the launched template
+    instance is asserted through the variant word)."""
+    from pointtinybenchmark_amd import ops
+    N, Cin, H, W, Cout, k, stride, pad, flags = case
+    g = torch.Generator().manual_seed(sum(case[:8]))
+    x = torch.randn((N, Cin, H, W), generator=g).bfloat16()
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = F.conv2d(x.float(), w.float(), None, stride, pad)
+    scale = bias = res = None
+    if 'bn' in flags:
+        scale = torch.rand(Cout, generator=g) + 0.5
+        bias = torch.randn(Cout, generator=g)
+        ref = ref * scale[None, :, None, None] + bias[None, :, None, None]
+    elif 'bias' in flags:
+        bias = torch.randn(Cout, generator=g)
+        ref = ref + bias[None, :, None, None]
+    if 'res' in flags:
+        res = torch.randn(ref.shape, generator=g).bfloat16()
+        ref = ref + res.float()
+    if 'relu' in flags:
+        ref = F.relu(ref)
+    pc = ops.PackedConv(w.float().cuda(), stride, pad, torch.bfloat16)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    f32out = 'f32out' in flags
+    ops.TRACE_CONV_VARIANT[0] = True
+    try:
+        out = ops.conv2d(xin, pc, scale=None if scale is None else scale.cuda(), bias=None if bias is None else bias.cuda(),
+                         residual=None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda(), relu='relu' in flags,
+                         gn_part='gn' in flags, out_dtype=torch.float32 if f32out else None)
+        variant = ops.TRACE_CONV_VARIANT[1]
+    finally:
+        ops.TRACE_CONV_VARIANT[0] = False
+    assert variant == ('bf16', 256 * 1000 + 256), 'this shape must run the LDS-DMA staged instance, got %r' % (variant,)
+    part = None
+    if 'gn' in flags:
+        out, part = out
+    torch.cuda.synchronize()
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    tol = (1e-4 if f32out else 2.0 ** -7) * ref.abs() + 2e-3
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), 'max abs err %.3e, %d/%d over tol' % (float((got - ref).abs().max()), int(bad.sum()), bad.numel())
+    if part is not None:
+        s_ = part.reshape(N, -1, Cout, 2).sum(1).cpu()
+        np.testing.assert_allclose(s_[..., 0].numpy(), ref.sum(dim=(2, 3)).numpy(), rtol=1e-3, atol=5e-2)
+        np.testing.assert_allclose(s_[..., 1].numpy(), (ref * ref).sum(dim=(2, 3)).numpy(), rtol=1e-3, atol=5e-2)
+
+
 def test_bf16_aux_kernels():
     from pointtinybenchmark_amd import ops
     g = torch.Generator().manual_seed(2)

@@ -194,21 +194,32 @@ def test_rccl_bucket_path_single_rank():
     cb = to_cuda(batch)
     data = dict(img=cb['img'], img_metas=cb['img_metas'], gt_bboxes=cb['gt_bboxes'], gt_labels=cb['gt_labels'])
 
-    def run(force):
+    def run(force, reducer='all_reduce'):
         m, _ = build_hip_locator(cfg)
-        tr = CprTrainer(m, lr=0.01, bucket_mb=4.0, force_collectives=force)
+        tr = CprTrainer(m, lr=0.01, bucket_mb=4.0, force_collectives=force, reducer=reducer, reducer_timing=force)
         outs = [tr.train_step(dict(data))['log_vars']['loss'] for _ in range(2)]
         torch.cuda.synchronize()
-        return outs, tr.flat_p.clone(), len(tr.buckets.bounds) - 1
-    ref_losses, ref_p, _ = run(False)
+        return outs, tr.flat_p.clone(), len(tr.buckets.bounds) - 1, tr.buckets.timeline()
+    ref_losses, ref_p, _, tl0 = run(False)
+    assert tl0 is None                      # no process group: nothing is issued, nothing is timed
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
     dist.init_process_group('nccl', rank=0, world_size=1)
     try:
-        losses, p, nb = run(True)
+        losses, p, nb, tl = run(True)
+        losses_rs, p_rs, _, tl_rs = run(True, 'reduce_scatter')       # reduce_scatter_tensor + all_gather_into_tensor on RCCL
     finally:
         dist.destroy_process_group()
     assert nb >= 3, 'several buckets must be in play (%d)' % nb
+    # the per-bucket record an N-GPU run reports: issue times ascend with the backward, every bucket completes after its issue
+    for t in (tl, tl_rs):
+        rows = t['buckets']
+        assert len(rows) == nb and t['backward_ms'] > 0 and t['exposed_ms'] >= 0
+        assert all(r['done_ms'] >= r['issued_ms'] for r in rows)
+        assert all(a['issued_ms'] <= b['issued_ms'] for a, b in zip(rows, rows[1:]))
+        assert rows[0]['issued_ms'] < t['backward_ms'], 'the first bucket must be issued while the backward is still running'
+    assert tl_rs['reducer'] == 'reduce_scatter'
+    assert losses_rs[0] == ref_losses[0] and float((p_rs - ref_p).abs().max()) <= 1e-5 * float(ref_p.abs().max())
     # not bit-equal even run to run: the bilinear scatter of the loss backward sums with float atomics
     assert losses[0] == ref_losses[0] and abs(losses[1] - ref_losses[1]) <= 1e-5 * abs(ref_losses[1]), (losses, ref_losses)
     assert float((p - ref_p).abs().max()) <= 1e-5 * float(ref_p.abs().max())

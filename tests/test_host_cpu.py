@@ -169,6 +169,43 @@ def test_two_rank_gloo_gradient_buckets(tmp_path):
         assert p.returncode == 0, o
 
 
+_RS_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(sys.argv[1]); os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[2]
+dist.init_process_group('gloo', rank=rank, world_size=2)
+from pointtinybenchmark_amd.training import GradBuckets
+n = 951                                                            # odd: every bucket keeps a one-element tail
+g = torch.Generator().manual_seed(7 + rank)
+grads = torch.randn(n, generator=g)
+a, b = grads.clone(), grads.clone()
+ba = GradBuckets(a, bucket_elems=301)                              # the all-reduce reducer
+bb = GradBuckets(b, bucket_elems=301, reducer='reduce_scatter')    # reduce_scatter into this rank's shard + all_gather back
+assert ba.bounds == bb.bounds == [0, 301, 602, 951]
+for bk in (ba, bb):
+    bk.ready(400); assert bk.next == 1
+    assert bk.finish() == 0.5
+assert torch.equal(a, b), float((a - b).abs().max())               # two ranks: one summation order, bit-equal
+other = torch.randn(n, generator=torch.Generator().manual_seed(7 + 1 - rank))
+assert torch.equal(a, grads + other)
+b.copy_(grads); bb.ready(n); bb.finish(); assert torch.equal(a, b)  # the shard buffers are reused
+dist.barrier(); dist.destroy_process_group(); print('rank', rank, 'ok')
+'''
+
+
+def test_two_rank_gloo_reduce_scatter_reducer_equals_all_reduce(tmp_path):
+    """reducer='reduce_scatter' (reduce_scatter_tensor + all_gather_into_tensor per bucket, tails all-reduced) gives the
+    all-reduce reducer's sums bit for bit on two ranks."""
+    script = tmp_path / 'rsworker.py'
+    script.write_text(_RS_WORKER % ROOT)
+    port = str(33500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
 def test_gradient_buckets_single_process_is_a_no_op():
     from pointtinybenchmark_amd.training import GradBuckets
     flat = torch.ones(10)

@@ -24,7 +24,7 @@ for grp in ('sq', 'fetch', 'write'):
     res['duration_us_' + grp] = sum(dur) / len(dur) / 1e3
 simd_cycles = res['GRBM_GUI_ACTIVE'] / 8 * 1024
 out = {
-    'kernel': kernel.replace('void ', '').replace('(ConvParamsBf16)', '').replace('(ConvParams)', '').replace('(WinoParams)', '').replace('(WinoWgradParams)', ''), 'batch': batch,
+    'kernel': kernel.replace('void ', '').replace('(ConvParamsBf16)', '').replace('(ConvDmaParams)', '').replace('(ConvParams)', '').replace('(WinoParams)', '').replace('(WinoWgradParams)', ''), 'batch': batch,
     'shape': '3x3 256->256 on (B,160,160,256), GN stats epilogue (tools/conv_single.py %s)' % os.environ.get('CONV_ARGS', ''),
     'hbm_read_bytes_per_launch': res['FETCH_SIZE'] * 1024 * 2, 'hbm_write_bytes_per_launch': res['WRITE_SIZE'] * 1024,
     'hbm_bytes_per_launch': res['FETCH_SIZE'] * 1024 * 2 + res['WRITE_SIZE'] * 1024,
