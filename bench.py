@@ -174,22 +174,41 @@ class ConvProbe:
             OH, OW = pc.out_hw(H, W)
             kind, v = ops.TRACE_CONV_VARIANT[1]          # what the launcher returned through its out-parameter
             if kind == 'wino':       # template instance of csrc/conv_wino.hip: <ABL = 0, INB8, XF>
-                # <ABL = 0, INB8, XF, TSPREAD>; the launcher picks TSPREAD = 0 for the fused-affine instances, 1 for the plain ones
-                variant = 'conv_wino_kernel<0, %s, %s, %d>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false',
-                                                               0 if v & 4 else 1)
+                # <ABL = 0, INB8, XF, TSPREAD, VAR>; the launcher picks TSPREAD = 0 for the fused-affine instances, 1 for the plain
+                # ones; VAR = 4: weights staged by LDS-DMA (WINO_VAR_DEFAULT in conv_wino.hip)
+                variant = 'conv_wino_kernel<0, %s, %s, %d, 4>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false',
+                                                                  0 if v & 4 else 1)
             elif kind == 'bf16':
-                variant = 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
+                variant = 'conv_bf16_dma_kernel' if v == 256256 else 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
+            elif v % 10 == 2:    # dual-source launch (conv3 + projection shortcut): <BM, BN, MODE 0, XF false, PIPE 1, ABL 0, DUAL>
+                variant = 'conv_mfma_kernel<%d, %d, 0, false, 1, 0, true>' % (v // 1000000, v // 1000 % 1000)
             else:
-                variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
-                                                                      'true' if v // 10 % 10 else 'false', v % 10)
+                variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0, false>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
+                                                                             'true' if v // 10 % 10 else 'false', v % 10)
             kreal = pc.KH * pc.KW * (3 if pc.Cin == 4 else pc.Cin)
             probe.records.append((variant, 2.0 * N * OH * OW * pc.Cout * kreal, s, e, probe.key(x, pc)))
             return out
         ops.conv2d = conv2d   # callers use ``ops.conv2d(...)`` through the module object, so they see the probe
+        self._orig_dual = ops.conv2d_dual
+
+        def conv2d_dual(x, pc, x2, pc2, *a, **k):      # conv3 + projection shortcut in one launch: both GEMMs' flops
+            if probe.only is not None:
+                return probe._orig_dual(x, pc, x2, pc2, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = probe._orig_dual(x, pc, x2, pc2, *a, **k)
+            e.record()
+            kind, v = ops.TRACE_CONV_VARIANT[1]
+            variant = 'conv_mfma_kernel<%d, %d, 0, false, 1, 0, true>' % (v // 1000000, v // 1000 % 1000)
+            flops = 2.0 * out.shape[0] * out.shape[1] * out.shape[2] * pc.Cout * (pc.KH * pc.KW * pc.Cin + pc2.Cin)
+            probe.records.append((variant, flops, s, e, ('dual',) + probe.key(x, pc)))
+            return out
+        ops.conv2d_dual = conv2d_dual
 
     def remove(self):
         from pointtinybenchmark_amd import ops
         ops.conv2d = self._orig
+        ops.conv2d_dual = self._orig_dual
         ops.TRACE_CONV_VARIANT[0] = False
 
     def summary(self):
