@@ -45,6 +45,87 @@ constexpr int DSTAGE = (DBM + DBN) * DBK * 2;     // bytes per stage: 64 KB
 
 __device__ __forceinline__ float bf16f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
+// Epilogue shared by both kernels: y = acc * scale + bias (+ residual) (ReLU) -> bf16 (cout pairs packed) or fp32; GroupNorm
+// statistics from the fp32 values, one slot per 128 pixels = per (tile, wm): a wave owns its slot's 64 channels outright.
+__device__ __forceinline__ void dma_epilogue(const ConvDmaParams& p, f32x16 (&acc)[4][2], int tm, int m0, int n0, int wm,
+                                             int wn, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+    // D layout of a 32 x 32 block: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel)
+    unsigned short* out16 = reinterpret_cast<unsigned short*>(p.out);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)((size_t)p.M * p.Cout * (p.out_fp32 ? 4 : 2)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.residual ? p.residual : (const unsigned short*)p.out), 0,
+        (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = n0 + wn * 64 + j * 32 + l31;
+        const bool cok = c < p.Cout;
+        const int cc = cok ? c : p.Cout - 1;
+        const float sc = p.scale ? p.scale[cc] : 1.f;
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        float gsum = 0.f, gsq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rbase = m0 + wm * 128 + i * 32 + 4 * half;
+            const unsigned e0 = (unsigned)(rbase * p.Cout + c);
+            float res[16];
+            if (p.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    res[r] = bf16f(__builtin_amdgcn_raw_buffer_load_b16(
+                        rs_res, (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + (r & 3) + 8 * (r >> 2);
+                float x = acc[i][j][r] * sc + bi + res[r];
+                if (p.relu) x = fmaxf(x, 0.f);
+                v[r] = x;
+                if (p.gn_part) {
+                    const float u = (cok && m < p.M) ? x : 0.f;
+                    gsum += u;
+                    gsq += u * u;
+                }
+            }
+            if (p.out_fp32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, v[r]), rs_out,
+                        (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 4u : 0x80000000u), 0, 0);
+            } else {
+                // cout pairs packed into one dword: even lanes write the even registers, odd lanes the odd ones (Cout is even)
+                const unsigned ep = (unsigned)(rbase * p.Cout + (c & ~1));
+                const bool pok = (c & ~1) < p.Cout;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float nb = __shfl_xor(v[r], 1, 64);
+                    const bool mine = ((r & 1) == (lane & 1)) && pok;
+                    const bf16x2 pk = (lane & 1) ? bf16x2{(__bf16)nb, (__bf16)v[r]} : bf16x2{(__bf16)v[r], (__bf16)nb};
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, pk), rs_out,
+                        (int)(mine ? (ep + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0);
+                }
+            }
+        }
+        if (p.gn_part) {
+            gsum += __shfl_xor(gsum, 32, 64);
+            gsq += __shfl_xor(gsq, 32, 64);
+            if (half == 0 && cok) {
+                float* dst = p.gn_part + ((size_t)(tm * 2 + wm) * p.Cout + c) * 2;
+                dst[0] = gsum;
+                dst[1] = gsq;
+            }
+        }
+    }
+    (void)out16;
+}
+
 __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
 
@@ -234,82 +315,17 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
 #undef DFRAG
 #undef DMFMA
 
-    // ---- epilogue.  D layout of a 32 x 32 block: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel).
-    // GroupNorm statistics: one slot per 128 pixels = per (tile, wm): a wave owns its slot's 64 channels outright.
-    unsigned short* out16 = reinterpret_cast<unsigned short*>(p.out);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        p.out, 0, (int)((size_t)p.M * p.Cout * (p.out_fp32 ? 4 : 2)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(p.residual ? p.residual : (const unsigned short*)p.out), 0,
-        (int)((size_t)p.M * p.Cout * 2), 0x00020000);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = n0 + wn * 64 + j * 32 + l31;
-        const bool cok = c < p.Cout;
-        const int cc = cok ? c : p.Cout - 1;
-        const float sc = p.scale ? p.scale[cc] : 1.f;
-        const float bi = p.bias ? p.bias[cc] : 0.f;
-        float gsum = 0.f, gsq = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rbase = m0 + wm * 128 + i * 32 + 4 * half;
-            const unsigned e0 = (unsigned)(rbase * p.Cout + c);
-            float res[16];
-            if (p.residual) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    res[r] = bf16f(__builtin_amdgcn_raw_buffer_load_b16(
-                        rs_res, (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) res[r] = 0.f;
-            }
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = rbase + (r & 3) + 8 * (r >> 2);
-                float x = acc[i][j][r] * sc + bi + res[r];
-                if (p.relu) x = fmaxf(x, 0.f);
-                v[r] = x;
-                if (p.gn_part) {
-                    const float u = (cok && m < p.M) ? x : 0.f;
-                    gsum += u;
-                    gsq += u * u;
-                }
-            }
-            if (p.out_fp32) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(
-                        __builtin_bit_cast(unsigned, v[r]), rs_out,
-                        (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 4u : 0x80000000u), 0, 0);
-            } else {
-                // cout pairs packed into one dword: even lanes write the even registers, odd lanes the odd ones (Cout is even)
-                const unsigned ep = (unsigned)(rbase * p.Cout + (c & ~1));
-                const bool pok = (c & ~1) < p.Cout;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float nb = __shfl_xor(v[r], 1, 64);
-                    const bool mine = ((r & 1) == (lane & 1)) && pok;
-                    const bf16x2 pk = (lane & 1) ? bf16x2{(__bf16)nb, (__bf16)v[r]} : bf16x2{(__bf16)v[r], (__bf16)nb};
-                    __builtin_amdgcn_raw_buffer_store_b32(
-                        __builtin_bit_cast(unsigned, pk), rs_out,
-                        (int)(mine ? (ep + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0);
-                }
-            }
-        }
-        if (p.gn_part) {
-            gsum += __shfl_xor(gsum, 32, 64);
-            gsq += __shfl_xor(gsq, 32, 64);
-            if (half == 0 && cok) {
-                float* dst = p.gn_part + ((size_t)(tm * 2 + wm) * p.Cout + c) * 2;
-                dst[0] = gsum;
-                dst[1] = gsq;
-            }
-        }
-    }
-    (void)out16;
+    dma_epilogue(p, acc, tm, m0, n0, wm, wn, lane);
 }
+
+// (A variant with the two wave groups staggered by half a chunk -- activation halves A_g[2] + a ring of three weight stages =
+// all 160 KB of LDS, a barrier every two k-steps, each wave waiting down to its newest batch of four requests in front of every
+// barrier -- was built in round 3: bit-equal to this kernel on six shapes x six launches, and SLOWER (1.99 vs 1.84 ms on the
+// head layer).  With full-workgroup barriers between phases the group that reads its first fragments after a barrier is the
+// slower one of that phase and its partner waits at the next barrier: the exposed latency is not hidden, only moved, and the
+// barrier count doubles.  What the guide's 8-phase template does instead is a ping-pong -- memory part | barrier | MFMA cluster |
+// barrier, the partner one barrier behind -- i.e. a different kernel, not a re-timing of this one.  Removed; see git history and
+// profiles/round3_bf16_dma_kernel_development.txt.)
 
 // The launcher of conv_mfma_bf16.hip calls this for the layers that fit the tile; returns CPR_ERR_UNSUPPORTED otherwise.
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
