@@ -143,10 +143,12 @@ int cpr_neg_mask_loss(const float* logit, int J, const float* centers, const int
 
 /* CirclePtFeatGenerator.generate (cpr_head.py:453-497,172-199): bag points (rings + the point itself last), validity
  * and bilinear samples of a J-channel NHWC map, one bag per annotated / refine point.  offsets (K-1,2) from the host.
- * pts (G,K,2) valid (G,K) out (G,K,J) */
+ * pts (G,K,2) valid (G,K) out (G,K,J).  align_corners: the generators' align_corners=True form (cpr_head.py:81-84: grid
+ * 2x/(w-1)-1, zeros padding instead of the border clip); pad_value (J) or NULL: what a dropped tap contributes per unit of
+ * weight -- the projection's bias when the map holds logits (the reference samples zero FEATURES, then applies the Linear). */
 int cpr_bag_sample(const float* map, int J, const float* centers, const int* gt_img, const int* pad_hw,
                    const float* offsets, float* pts, unsigned char* valid, float* out, int G, int K, int H, int W,
-                   float stride, void* stream);
+                   float stride, int align_corners, const float* pad_value, void* stream);
 
 /* GridCirclesPtFeatGenerator.generate (cpr_head.py:296-352,405-438): per gt (R refine points each, points (G*R,2),
  * gt_img (G)) every grid point within radius_px of any of its refine points, row-major, zero-padded to Kmax, then the R
@@ -156,7 +158,7 @@ int cpr_bag_sample(const float* map, int J, const float* centers, const int* gt_
  * ws_cell (G,Kmax+R) int32 workspace. */
 int cpr_grid_bag(const float* map, int J, const float* points, const int* gt_img, int R, int Kmax, float radius_px,
                  const float* pad_value, float* pts, unsigned char* valid, int* ws_cell, int* count, float* out, int G,
-                 int H, int W, float stride, void* stream);
+                 int H, int W, float stride, int align_corners, void* stream);
 
 /* MILLoss.forward / AllPosLoss.forward + gt loss + neg normalisation (multi_instance_learning_loss.py:153-243,
  * cpr_head.py:1159-1228).  logits (entries,J): cls in [0,C), ins in [ins_off, ins_off + C*(1+binary_ins)).

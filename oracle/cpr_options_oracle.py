@@ -10,6 +10,7 @@ A functional torch-CPU restatement of CPRHead.loss / loss0 / get_bboxes + PointR
                                                                cpr_head.py:992-1008,1030-1043,1055-1072
   * (round 3) out_bg_cls=True for one class (a background output beside the class, never a label)   cpr_head.py:953
   * (round 3) PointRefiner(return_score_type='max')            cpr_head.py:840-842
+  * (round 3) generator align_corners=True (grid 2x/(w-1)-1, zeros padding)   cpr_head.py:73-93,126
 pinned by tests/golden/cpr_options.npz / cpr_options_r3.npz (the reference's own classes, oracle/gen_golden_r2.py) in
 tests/test_oracle_golden.py.  ``cfg`` is an oracle.gen_golden_r2 case dict."""
 import torch
@@ -29,7 +30,7 @@ def cls_prob(logit, cfg):
     return p
 
 
-def grid_circle_bag(feat, centers, radius, stride, max_pos_num):
+def grid_circle_bag(feat, centers, radius, stride, max_pos_num, align_corners=False):
     """GridPtFeatGenerator.generate + GridCirclesPtFeatGenerator.get_chosen_neighbours for one image.
     feat (1,C,H,W), centers (G,R,2) -> pts (G, Kmax+2R... , 2), valid, sampled feats (G, ., C)."""
     h, w = feat.shape[2:]
@@ -47,7 +48,7 @@ def grid_circle_bag(feat, centers, radius, stride, max_pos_num):
         out_pts[i, :len(sel)] = sel
         out_feat[i, :len(sel)] = fmap[chosens[i]]
         valid[i, len(sel):] = False
-    cfeat = O.sample_bilinear(feat, centers / stride)                                    # (G,R,C)
+    cfeat = O.sample_bilinear(feat, centers / stride, align_corners)                     # (G,R,C)
     out_pts = torch.cat([out_pts, centers.flip(dims=(1,))], dim=1)
     out_feat = torch.cat([out_feat, cfeat.flip(dims=(1,))], dim=1)
     valid = torch.cat([valid, torch.ones(G, R, dtype=torch.bool)], dim=1)
@@ -89,16 +90,19 @@ def extract(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, prefix='bbox_hea
         ph, pw = img_metas[b]['pad_shape'][:2]
         feat = cls_feat[b:b + 1]
         if cfg.get('pos') == 'GridCirclesPtFeatGenerator':
-            pts, valid, bag_feat = grid_circle_bag(feat, ctr, radius, stride, cfg.get('max_pos_num', -1))
+            pts, valid, bag_feat = grid_circle_bag(feat, ctr, radius, stride, cfg.get('max_pos_num', -1),
+                                                   cfg.get('align_corners', False))
             pts, valid, bag_feat = pts[:, None], valid[:, None], bag_feat[:, None]       # (G,1,K,.)
         else:
             pts = O.bag_points(ctr.reshape(-1, 2), radius, stride).reshape(G, R, -1, 2)
             valid = O.inside(pts, ph, pw)
-            bag_feat = O.sample_bilinear(feat, pts.reshape(G * R, -1, 2) / stride).reshape(G, R, pts.shape[2], -1)
+            bag_feat = O.sample_bilinear(feat, pts.reshape(G * R, -1, 2) / stride,
+                                         cfg.get('align_corners', False)).reshape(G, R, pts.shape[2], -1)
         ins_bag = bag_feat
         if ins_feat is not None:
             assert cfg.get('pos', 'CirclePtFeatGenerator') == 'CirclePtFeatGenerator'
-            ins_bag = O.sample_bilinear(ins_feat[b:b + 1], pts.reshape(G * R, -1, 2) / stride).reshape(bag_feat.shape)
+            ins_bag = O.sample_bilinear(ins_feat[b:b + 1], pts.reshape(G * R, -1, 2) / stride,
+                                        cfg.get('align_corners', False)).reshape(bag_feat.shape)
             ins_bag = _fc_stack(sd, ins_bag, 'ins_fcs', prefix)
         h, w = feat.shape[2:]
         # negative mask: every refine point counts, carrying its gt's label (cpr_head.py:271-275: centers.flatten(0, 1))

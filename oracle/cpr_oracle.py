@@ -117,11 +117,14 @@ def inside(pts, h, w):
     return (0 <= pts[..., 0]) & (pts[..., 0] < w) & (0 <= pts[..., 1]) & (pts[..., 1] < h)
 
 
-def sample_bilinear(feat, pts_over_stride):
-    """grid_sample wrapper of cpr_head.py:73-93 (align_corners=False, border padding).
+def sample_bilinear(feat, pts_over_stride, align_corners=False):
+    """grid_sample wrapper of cpr_head.py:73-93 (align_corners=False: border padding; True: zeros padding).
     feat (1,C,H,W); pts (G,K,2) already divided by the stride -> (G,K,C)."""
     h, w = feat.shape[2:]
     wh = feat.new_tensor([w, h])
+    if align_corners:
+        grid = 2 * pts_over_stride.unsqueeze(0) / (wh - 1) - 1
+        return F.grid_sample(feat, grid, align_corners=True, padding_mode='zeros').permute(0, 2, 3, 1)[0]
     grid = (2 * pts_over_stride.unsqueeze(0) + 1) / wh - 1
     return F.grid_sample(feat, grid, align_corners=False, padding_mode='border').permute(0, 2, 3, 1)[0]
 

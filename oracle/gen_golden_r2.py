@@ -67,6 +67,8 @@ OPTION_CASES_R3 = {
     'ins_tower': dict(ins_tower=True, seed=54),                                     # ins_share_head_feat=False, :992-1008,1037,1068
     'ins_tower_fc': dict(ins_tower=True, num_cls_fcs=1, fc_out_channels=64, seed=55),
     'bg_cls': dict(num_classes=1, out_bg_cls=True, seed=56),                        # cpr_head.py:953
+    'align_corners': dict(align_corners=True, seed=57),                             # cpr_head.py:73-93,126
+    'align_corners_grid': dict(align_corners=True, pos='GridCirclesPtFeatGenerator', radius=3, seed=58),
 }
 
 
@@ -83,6 +85,8 @@ def cpr_head_kwargs(cfg):
     pos = dict(type=cfg.get('pos', 'CirclePtFeatGenerator'), radius=r)
     if 'max_pos_num' in cfg:
         pos['max_pos_num'] = cfg['max_pos_num']
+    if cfg.get('align_corners', False):
+        pos['align_corners'] = True
     normal = dict(prob_cls_type=cfg.get('prob', 'sigmoid'), out_bg_cls=cfg.get('out_bg_cls', False))
     if 'norm_p' in cfg:
         normal['normed_sigmoid_p'] = cfg['norm_p']

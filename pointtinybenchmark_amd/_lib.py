@@ -37,8 +37,8 @@ SIGNATURES = {
     'cpr_box_centers': [_p, _p, _i, _p],
     'cpr_logit_project': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'cpr_neg_mask_loss': [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _f, _i, _p, _p],
-    'cpr_bag_sample': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    'cpr_grid_bag': [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    'cpr_bag_sample': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p],
+    'cpr_grid_bag': [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
     'cpr_mil_loss': [_p, _i, _i, _p, _p, _p, _p, _p] + [_i] * 10 + [_f, _i, _f, _i, _i, _f, _f, _f, _i, _p, _p],
     'cpr_refine': [_p, _i, _p, _p, _p, _i, _i] + [_p] * 9 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _i, _i, _p],
     'cpr_point_assign': [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p],

@@ -142,10 +142,39 @@ extern "C" int cpr_neg_mask_loss(const float* logit, int J, const float* centers
 // Bilinear sample of 4 channels of a J-channel NHWC map at image point (px, py) with the exact coordinate round trip of
 // cpr_head.py:73-93,182-199 (pt/stride -> normalise -> grid_sample un-normalise (align_corners=False) -> border clip,
 // 4-tap sum in nw,ne,sw,se order with ATen's vectorised weight formulas).
+// align != 0: the generators' align_corners=True form (cpr_head.py:81-84): grid = 2 x / (w - 1) - 1, grid_sample(align_corners=
+// True, padding_mode='zeros') -- no clip, a tap outside the map contributes nothing.  When the map holds LOGITS (the projected
+// map, see project.hip) a dropped tap must still contribute the projection's bias (the reference samples zero FEATURES and applies
+// the Linear afterwards): pad[c] * (weight of the dropped taps) is added when pad is given.
 __device__ __forceinline__ void sample_point4(const float* __restrict__ base, int H, int W, int J, float px, float py,
-                                              float stride, int ch, int nch, float* __restrict__ acc) {
-    // pt/stride -> (2x+1)/w - 1 -> ((g+1)*w - 1)/2 -> clip [0, w-1]
+                                              float stride, int ch, int nch, float* __restrict__ acc, int align = 0,
+                                              const float* __restrict__ pad = nullptr) {
     const float fw = (float)W, fh = (float)H;
+    if (align) {
+        const float gx = __fsub_rn(__fdiv_rn(2.f * __fdiv_rn(px, stride), fw - 1.f), 1.f);
+        const float gy = __fsub_rn(__fdiv_rn(2.f * __fdiv_rn(py, stride), fh - 1.f), 1.f);
+        const float ix = __fmul_rn(__fadd_rn(gx, 1.f), (fw - 1.f) * 0.5f), iy = __fmul_rn(__fadd_rn(gy, 1.f), (fh - 1.f) * 0.5f);
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float ww = __fsub_rn(ix, x0f), we = __fsub_rn(1.f, ww), wn_ = __fsub_rn(iy, y0f), ws = __fsub_rn(1.f, wn_);
+        const float wt[4] = {__fmul_rn(ws, we), __fmul_rn(ws, ww), __fmul_rn(wn_, we), __fmul_rn(wn_, ww)};   // nw ne sw se
+        // (float compares: a point far outside the map must not overflow an int)
+        const bool xin0 = (x0f >= 0.f) && (x0f <= fw - 1.f), xin1 = (x0f + 1.f >= 0.f) && (x0f + 1.f <= fw - 1.f);
+        const bool yin0 = (y0f >= 0.f) && (y0f <= fh - 1.f), yin1 = (y0f + 1.f >= 0.f) && (y0f + 1.f <= fh - 1.f);
+        const bool in[4] = {xin0 && yin0, xin1 && yin0, xin0 && yin1, xin1 && yin1};
+        const int x0 = xin0 ? (int)x0f : 0, x1 = xin1 ? (int)x0f + 1 : 0, y0 = yin0 ? (int)y0f : 0, y1 = yin1 ? (int)y0f + 1 : 0;
+        const float* tp[4] = {base + ((size_t)y0 * W + x0) * J + ch, base + ((size_t)y0 * W + x1) * J + ch,
+                              base + ((size_t)y1 * W + x0) * J + ch, base + ((size_t)y1 * W + x1) * J + ch};
+        float wout = 0.f;
+        for (int t = 0; t < 4; ++t) wout += in[t] ? 0.f : wt[t];
+        for (int c = 0; c < nch; ++c) {
+            float v = 0.f;
+            for (int t = 0; t < 4; ++t)
+                if (in[t]) v = __fadd_rn(v, __fmul_rn(tp[t][c], wt[t]));
+            acc[c] = pad ? __fadd_rn(v, __fmul_rn(pad[ch + c], wout)) : v;
+        }
+        return;
+    }
+    // pt/stride -> (2x+1)/w - 1 -> ((g+1)*w - 1)/2 -> clip [0, w-1]
     float gx = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(px, stride), 1.f), fw), 1.f);
     float gy = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(py, stride), 1.f), fh), 1.f);
     float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), fw), 1.f) * 0.5f;
@@ -177,7 +206,7 @@ __global__ void bag_sample_kernel(const float* __restrict__ map, int J, const fl
                                   const int* __restrict__ gt_img, const int* __restrict__ pad_hw,
                                   const float* __restrict__ offs, float* __restrict__ pts,
                                   unsigned char* __restrict__ valid, float* __restrict__ out, int G, int K, int H,
-                                  int W, float stride) {
+                                  int W, float stride, int align, const float* __restrict__ pad) {
     const int J4 = (J + 3) >> 2;
     const long long total = (long long)G * K * J4;
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -199,20 +228,21 @@ __global__ void bag_sample_kernel(const float* __restrict__ map, int J, const fl
     const int ch = j4 * 4;
     const int nch = min(4, J - ch);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    sample_point4(map + (size_t)n * H * W * J, H, W, J, px, py, stride, ch, nch, acc);
+    sample_point4(map + (size_t)n * H * W * J, H, W, J, px, py, stride, ch, nch, acc, align, pad);
     float* dst = out + gk * J + ch;
     for (int c = 0; c < nch; ++c) dst[c] = acc[c];
 }
 
 extern "C" int cpr_bag_sample(const float* map, int J, const float* centers, const int* gt_img, const int* pad_hw,
                               const float* offsets, float* pts, unsigned char* valid, float* out, int G, int K,
-                              int H, int W, float stride, hipStream_t stream) {
+                              int H, int W, float stride, int align_corners, const float* pad_value, hipStream_t stream) {
     CPR_CHECK_ARG(G >= 0 && K > 0 && J > 0 && H > 0 && W > 0 && stride > 0);
+    CPR_CHECK_ARG(!align_corners || (H > 1 && W > 1));
     if (G == 0) return CPR_OK;
     CPR_CHECK_ARG(map && centers && gt_img && pad_hw && pts && valid && out && (K == 1 || offsets));
     const long long total = (long long)G * K * ((J + 3) / 4);
     hipLaunchKernelGGL(bag_sample_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, map, J, centers,
-                       gt_img, pad_hw, offsets, pts, valid, out, G, K, H, W, stride);
+                       gt_img, pad_hw, offsets, pts, valid, out, G, K, H, W, stride, align_corners, pad_value);
     CPR_LAUNCH_STATUS();
 }
 
@@ -279,7 +309,7 @@ __global__ void grid_select_kernel(const float* __restrict__ ctr, const int* __r
 __global__ void grid_gather_kernel(const float* __restrict__ map, int J, const float* __restrict__ pts,
                                    const int* __restrict__ cell, const int* __restrict__ gt_img,
                                    const float* __restrict__ pad_value, float* __restrict__ out, long long total,
-                                   int Kt, int H, int W, float stride) {
+                                   int Kt, int H, int W, float stride, int align) {
     const int J4 = (J + 3) >> 2;
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -293,7 +323,7 @@ __global__ void grid_gather_kernel(const float* __restrict__ map, int J, const f
     if (c >= 0) {
         for (int q = 0; q < nch; ++q) acc[q] = base[(size_t)c * J + ch + q];
     } else if (c <= -2) {
-        sample_point4(base, H, W, J, pts[e * 2], pts[e * 2 + 1], stride, ch, nch, acc);
+        sample_point4(base, H, W, J, pts[e * 2], pts[e * 2 + 1], stride, ch, nch, acc, align, pad_value);
     } else if (pad_value) {   // padding slots hold zero FEATURES in the reference: on a projected map that is the bias
         for (int q = 0; q < nch; ++q) acc[q] = pad_value[ch + q];
     }
@@ -302,15 +332,17 @@ __global__ void grid_gather_kernel(const float* __restrict__ map, int J, const f
 
 extern "C" int cpr_grid_bag(const float* map, int J, const float* points, const int* gt_img, int R, int Kmax,
                             float radius_px, const float* pad_value, float* pts, unsigned char* valid, int* ws_cell,
-                            int* count, float* out, int G, int H, int W, float stride, hipStream_t stream) {
+                            int* count, float* out, int G, int H, int W, float stride, int align_corners,
+                            hipStream_t stream) {
     CPR_CHECK_ARG(G >= 0 && R > 0 && Kmax > 0 && J > 0 && H > 0 && W > 0 && stride > 0 && radius_px >= 0);
+    CPR_CHECK_ARG(!align_corners || (H > 1 && W > 1));
     if (G == 0) return CPR_OK;
     CPR_CHECK_ARG(map && points && gt_img && pts && valid && ws_cell && count && out);
     hipLaunchKernelGGL(grid_select_kernel, dim3(cdiv(G, 4)), dim3(256), 0, stream, points, gt_img, R, Kmax, pts, valid,
                        ws_cell, count, G, H, W, stride, radius_px);
     const long long total = (long long)G * (Kmax + R) * ((J + 3) / 4);
     hipLaunchKernelGGL(grid_gather_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, map, J, pts,
-                       ws_cell, gt_img, pad_value, out, total, Kmax + R, H, W, stride);
+                       ws_cell, gt_img, pad_value, out, total, Kmax + R, H, W, stride, align_corners);
     CPR_LAUNCH_STATUS();
 }
 

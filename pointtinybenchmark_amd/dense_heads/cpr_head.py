@@ -14,6 +14,7 @@ Options beyond the shipped configs, all on the same kernel
 ``normed_sigmoid`` class probabilities, ``binary_ins``, ``AllPosLoss``, ``num_cls_fcs > 0``; round 3:
 ``ins_share_head_feat=False`` (a second tower ``ins_convs`` / ``ins_fcs`` for the instance classifier, cpr_head.py:992-1008,
 1037,1068), ``out_bg_cls=True`` for one class (:953), ``PointRefiner(return_score_type='max')`` (:840-842).
+generator ``align_corners=True`` (:73-93,126).
 ``AnchorPtFeatGenerator(scale_factor != 1)`` and ``GridEllipsePtFeatGenerator`` raise in the reference itself and are refused."""
 import math
 
@@ -76,7 +77,9 @@ class _Extractor:
             raise NotImplementedError('GridEllipsePtFeatGenerator raises inside the reference itself (cpr_head.py:382-402)')
         assert ptype in ('CirclePtFeatGenerator', 'GridCirclesPtFeatGenerator'), ptype
         assert ntype in _NEG_GENERATORS, ntype
-        assert not pg.pop('align_corners', False) and not ng.get('align_corners', False), 'align_corners=True is not built'
+        # align_corners=True (PtFeatGenerator, cpr_head.py:126-127,73-93): grid 2x/(w-1)-1 and zeros padding for the bilinear
+        # samples of the positive generator; the grid (negative) generators take cell values and never sample
+        self.align_corners = bool(pg.pop('align_corners', False))
         self.pos_is_grid = ptype == 'GridCirclesPtFeatGenerator'
         self.pos_radius = pg.pop('radius')
         if self.pos_is_grid:
@@ -212,7 +215,7 @@ class CPRHead(nn.Module):
         """The hand-written backward (training.CprTrainer) covers the shipped configs' options."""
         return (self.prob_type == 'sigmoid' and not self.binary_ins and not self.loss_mil.allpos and
                 self.num_cls_fcs == 0 and not self.train_pts_extractor.pos_is_grid and self.ins_share_head_feat and
-                not self.out_bg_cls)
+                not self.out_bg_cls and not self.train_pts_extractor.align_corners)
 
     # ------------------------------------------------------------------ init (cpr_head.py:939-948)
     def init_weights(self):
@@ -337,19 +340,21 @@ class CPRHead(nn.Module):
         return torch.cat([self._logit_map(feat, ab, 'cls'), self._logit_map(ifeat, iab, 'ins')], dim=-1).contiguous()
 
     def _sample(self, ex, src, gts, stride, pad):
-        """The positive generator on one map: bag points, validity, samples and the bag view."""
+        """The positive generator on one map: bag points, validity, samples and the bag view.  pad: what a slot / tap without
+        a feature contributes (the projection's bias on a logit map, nothing on a feature map)."""
         if ex.pos_is_grid:
             # the reference pads to max_pos_num + num_refine grid slots and THEN appends the num_refine points (cpr_head.py:325-349)
             kmax = ex.max_pos_num + gts.R
             pts, valid, out, count = ops.grid_bag(src, gts.points, gts.gt_img, gts.R, kmax, ex.pos_radius * stride, stride,
-                                                  pad_value=pad)
+                                                  pad_value=pad, align_corners=ex.align_corners)
             # the reference fails inside generate() when a bag overflows (cpr_head.py:331-333: shape mismatch on assignment)
             worst = int(count.max().item()) if count.numel() else 0
             if worst > kmax:
                 raise RuntimeError('GridCirclesPtFeatGenerator: %d grid points in one bag > max_pos_num + num_refine = %d'
                                    % (worst, kmax))
             return pts, valid, out, (1, kmax + gts.R)
-        pts, valid, out = ops.bag_sample(src, gts.points, gts.pt_img, gts.pad_hw, ex.offsets(stride, src.device), stride)
+        pts, valid, out = ops.bag_sample(src, gts.points, gts.pt_img, gts.pad_hw, ex.offsets(stride, src.device), stride,
+                                         align_corners=ex.align_corners, pad_value=pad if ex.align_corners else None)
         return pts, valid, out, (gts.R, pts.shape[1])
 
     def _bags(self, ex, feat, lmap, gts, stride, ifeat=None, part=None):
@@ -361,7 +366,7 @@ class CPRHead(nn.Module):
         if self.num_cls_fcs == 0:
             # padding slots hold zero features in the reference (:323-324): on the projected map that is the projection's bias
             pad = None
-            if ex.pos_is_grid:
+            if ex.pos_is_grid or ex.align_corners:
                 pad = self._proj(lmap.dtype, part)[1] if (self.ins_share_head_feat or part is not None) else \
                     torch.cat([self._proj(lmap.dtype, 'cls')[1], self._proj(lmap.dtype, 'ins')[1]])
             pts, valid, out, view = self._sample(ex, lmap, gts, stride, pad)

@@ -427,8 +427,10 @@ def neg_mask_loss(logit_map, centers, labels, gt_start, pad_hw, num_classes, str
     return mask, partial
 
 
-def bag_sample(fmap, centers, gt_img, pad_hw, offsets, stride):
-    """fmap (N,H,W,J); one bag per row of centers; returns pts (G,K,2), valid (G,K) uint8, sampled (G,K,J)."""
+def bag_sample(fmap, centers, gt_img, pad_hw, offsets, stride, align_corners=False, pad_value=None):
+    """fmap (N,H,W,J); one bag per row of centers; returns pts (G,K,2), valid (G,K) uint8, sampled (G,K,J).
+    align_corners: the generators' align_corners=True sampling (zeros padding); pad_value (J,): contribution of a dropped tap per
+    unit of weight (the projection's bias when fmap is the logit map)."""
     N, H, W, J = _check(fmap).shape
     G = centers.shape[0]
     K = (offsets.shape[0] if offsets is not None else 0) + 1
@@ -436,11 +438,11 @@ def bag_sample(fmap, centers, gt_img, pad_hw, offsets, stride):
     valid = torch.empty((G, K), device=fmap.device, dtype=torch.uint8)
     out = torch.empty((G, K, J), device=fmap.device, dtype=torch.float32)
     _lib.call('cpr_bag_sample', _ptr(fmap), J, _ptr(centers), _ptr(gt_img), _ptr(pad_hw), _ptr(offsets), _ptr(pts),
-              _ptr(valid), _ptr(out), G, K, H, W, float(stride), _stream())
+              _ptr(valid), _ptr(out), G, K, H, W, float(stride), int(align_corners), _ptr(pad_value), _stream())
     return pts, valid, out
 
 
-def grid_bag(fmap, points, gt_img, num_refine, max_pos_num, radius_px, stride, pad_value=None):
+def grid_bag(fmap, points, gt_img, num_refine, max_pos_num, radius_px, stride, pad_value=None, align_corners=False):
     """GridCirclesPtFeatGenerator bags: fmap (N,H,W,J), points (G*R,2), gt_img (G) -> pts (G,Kmax+R,2),
     valid (G,Kmax+R) uint8, sampled (G,Kmax+R,J), count (G) int32 (grid points found per gt).  pad_value (J,): what the
     padding slots hold (default zeros)."""
@@ -456,7 +458,8 @@ def grid_bag(fmap, points, gt_img, num_refine, max_pos_num, radius_px, stride, p
     out = torch.empty((G, Kt, J), device=dev, dtype=torch.float32)
     assert pad_value is None or pad_value.numel() == J
     _lib.call('cpr_grid_bag', _ptr(fmap), J, _ptr(_check(points)), _ptr(gt_img), R, int(max_pos_num), float(radius_px),
-              _ptr(pad_value), _ptr(pts), _ptr(valid), _ptr(cell), _ptr(count), _ptr(out), G, H, W, float(stride), _stream())
+              _ptr(pad_value), _ptr(pts), _ptr(valid), _ptr(cell), _ptr(count), _ptr(out), G, H, W, float(stride),
+              int(align_corners), _stream())
     return pts, valid, out, count
 
 
