@@ -165,3 +165,39 @@ def test_wino_wgrad_matches_autograd(case):
     acc = base.clone()
     ops.conv3x3_wino_wgrad(dy, x, shape, in_ab=ab, in_relu=True, grad=acc)
     torch.testing.assert_close(acc - base, gw, rtol=1e-4, atol=1e-4 * m)
+
+
+def test_lds_dma_staged_kernels_are_repeatable_under_memory_pressure():
+    """The Winograd forward stages its weight image, and the bf16 256x256 kernel both operands, by LDS-DMA issued from inline
+    asm with hand-counted vmcnt waits (csrc/conv_wino.hip, csrc/conv_bf16_dma.hip).  A wrong count or a missing barrier would
+    show as a timing-dependent difference, not on every launch: 60 launches of each kernel, while a second stream saturates
+    HBM with copies (latencies of the DMA requests vary by several x), must all be BIT-equal to the first quiet launch."""
+    from pointtinybenchmark_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((6, 96, 112, 128), generator=g).cuda()
+    w = (torch.randn((256, 128, 3, 3), generator=g) * 0.03).cuda()
+    a = (torch.rand((6, 128), generator=g) + 0.5).cuda()
+    b = torch.randn((6, 128), generator=g).cuda()
+    pc = ops.PackedConv(w, 1, 1, torch.float32)
+    xb8 = _to_b8(x)
+    xh = torch.randn((8, 128, 128, 64), generator=g).bfloat16().cuda()
+    wh = (torch.randn((256, 64, 3, 3), generator=g) * 0.04).cuda()
+    pch = ops.PackedConv(wh, 1, 1, torch.bfloat16)
+    runs = {
+        'wino plain': lambda: ops.conv3x3_wino(x, pc, gn_part=True),
+        'wino blocked + fused affine': lambda: ops.conv3x3_wino(xb8, pc, gn_part=True, in_ab=(a, b), in_relu=True, out_b8=True),
+        'bf16 dma': lambda: ops.conv2d(xh, pch, gn_part=True),
+    }
+    ref = {k: [t.clone() for t in f()] for k, f in runs.items()}
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    src = torch.empty((256 << 20,), dtype=torch.uint8, device='cuda')
+    dst = torch.empty_like(src)
+    for k, f in runs.items():
+        for it in range(60):
+            if it % 2 == 0:                      # every other launch runs beside a 256 MB device copy
+                with torch.cuda.stream(side):
+                    dst.copy_(src)
+            out = f()
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, r) for o, r in zip(out, ref[k])), '%s: launch %d differs from the first one' % (k, it)

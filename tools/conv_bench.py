@@ -23,13 +23,17 @@ def main():
     ap.add_argument('--pipeline', type=int, default=1)
     ap.add_argument('--tile', default='0,0')
     ap.add_argument('--extra-lds', type=int, default=0, help='occupancy probe: dynamic LDS bytes added to every direct-conv launch')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
+    ap.add_argument('--bf16-dma', type=int, default=1, help='bf16 mode: 0 = every layer on the register-staged kernels (A/B)')
     args = ap.parse_args()
     from pointtinybenchmark_amd import _lib
+    _lib.call('cpr_bf16_set_dma', args.bf16_dma)
     _lib.call('cpr_conv_set_pipeline', args.pipeline)
     _lib.call('cpr_conv_force_tile', *[int(v) for v in args.tile.split(',')])
     _lib.call('cpr_conv_set_extra_lds', args.extra_lds)
     model = P.build_detector(bench.model_cfg()).cuda()
     model.load_state_dict(synthetic.locator_state_dict(50, 1, 0, 'cpr', 0), strict=True)
+    model.set_compute_dtype(args.dtype)
     batch = synthetic.synthetic_batch(args.batch, 640, 640, 32, 1, 0)
     img = batch['img'].cuda()
     gtb = [b.cuda() for b in batch['gt_bboxes']]
@@ -79,7 +83,9 @@ def main():
         e.record()
         torch.cuda.synchronize()
         t = s.elapsed_time(e) / args.iters * 1e-3
-        roof = max(flops / 157.3e12, byts / 6.3e12)
+        if args.dtype == 'bf16':
+            byts *= 0.5
+        roof = max(flops / (2500e12 if (args.dtype == 'bf16' and Cin != 4) else 157.3e12), byts / 6.3e12)
         rows.append(dict(key=str(key), count=cnt, ms=t * 1e3, tflops=flops / t / 1e12, gbs=byts / t / 1e9,
                          roof_frac=roof / t, gflop=flops / 1e9, mb=byts / 1e6))
         tot_t += cnt * t
