@@ -51,3 +51,18 @@ for wstd in (0.01, 0.05):
         x = torch.relu(gn(y)); xd = torch.relu(gn(yd))
     logit = torch.einsum('jc,chw->jhw', wl, x); logitd = torch.einsum('jc,chw->jhw', wl.double(), xd)
     print('direct fp32 wstd', wstd, 'chained feature abs err %.2e'%float((x.double()-xd).abs().max()), 'logit abs err %.2e'%float((logit.double()-logitd).abs().max()))
+
+# Logit error at the classifier scales the parity fixtures use (tests/golden: head_std 0.3 in the base cases, up to 1.5 in the
+# refine-filter cases) -- the 1e-4 logit bar is absolute, so the error budget shrinks as the classifier weights grow.
+ws = [torch.randn(C, C, 3, 3) * 0.01 for _ in range(5)]
+for cstd in (0.01, 0.3, 1.5):
+    wl = torch.randn(3, C) * cstd
+    for name, (BTm, Gm, ATm, m) in {'F(2x2)': (BT2, G2, AT2, 2), 'F(4x4)': (BT, G, AT, 4)}.items():
+        x = x0.clone(); xd = x0.double()
+        for wt in ws:
+            y = wino(x, wt, BTm, Gm, ATm, m); yd = torch.nn.functional.conv2d(xd[None], wt.double(), padding=1)[0]
+            x = torch.relu(gn(y)); xd = torch.relu(gn(yd))
+        logit = torch.einsum('jc,chw->jhw', wl, x); logitd = torch.einsum('jc,chw->jhw', wl.double(), xd)
+        e = (logit.double() - logitd).abs()
+        print('classifier std %.2f %s: |logit| max %.1f  abs err max %.2e  mean %.2e  entries over 1e-4: %d of %d'
+              % (cstd, name, float(logitd.abs().max()), float(e.max()), float(e.mean()), int((e > 1e-4).sum()), e.numel()))
