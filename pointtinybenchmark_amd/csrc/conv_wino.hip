@@ -29,6 +29,28 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed fp32 vector ops (two floats per lane per instruction): the input transform and the fused affine work on register pairs,
+// half the instructions in the K loop.  Next to v_mfma_f32_32x32x2_f32 a packed add costs about two scalar ones
+// (tools/diag/mfma_shadow), so the gain is the issue slots only: 0.4-0.7 % (tools/wino_packed_ab.py).  a - b is a + (-b)
+// exactly, so the results are the scalar code's bit for bit.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+// column pass of B^T d B on a row (t0, t1 | t2, t3): (t0 - t2, t1 + t2) and (t2 - t1, t1 - t3); op_sel picks the half of each source
+__device__ __forceinline__ f32x2 pk_col01(f32x2 t01, f32x2 t23) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(t01), "v"(t23)); return r;
+}
+__device__ __forceinline__ f32x2 pk_col23(f32x2 t01, f32x2 t23) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(t01), "v"(t23)); return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
 
 struct WinoParams {
     const float* in;      // NHWC, or channel-blocked [N][Cin/8][H][W][8] (in_b8)
@@ -86,7 +108,11 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 // lines) instead of 32 bytes out of every pixel's Cin*4-byte row (half the L2 requests).
 // XF: fused per-(image, channel) affine (+ReLU) on the input = GroupNorm apply of the producing layer.
 // ABL (benchmark-only, results are then WRONG): bit0 = no global loads / transform / LDS writes, bit1 = no fragment reads,
-// bit2 = no barrier, bit3 = no patch loads, bit4 = no output stores, bit5 = no epilogue at all.  ABL = 0 in every product launch.
+// bit2 = no barrier, bit3 = no patch loads, bit4 = no output stores, bit5 = no epilogue at all, bit6 = the input transform and the fused affine in scalar instructions (results
+// identical).  ABL = 0 in every product launch.
+// Tried and not kept (round 3): the patch by LDS-DMA as well (one request per 18-pixel patch row into raw[k % 2], the fused affine
+// then in place on the thread's own units behind one more barrier per chunk): bit-equal, plain input -1.3 %, fused-affine input +4 %
+// (profiles/round3_wino_staging_variants.txt).
 // VAR (staging depth, results identical): bit0 = the patch of chunk c+4 (not c+3) is requested during chunk c (two register
 // sets, 1.75 chunk periods for a request to land instead of 0.75); bit1 = ONE weight register set (chunk c+2 requested during
 // chunk c); bit2 = the weight image goes global -> LDS by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write).
@@ -193,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
                           // prefetched (DEEP: chunk k lives in set k % 2, two chunks in flight)
     f32x4 su[(USINGLE || UDMA) ? 1 : 2][4];   // weight pieces: chunk k lives in set k % 2 (USINGLE: one set; UDMA: unused)
     float tab_a = 0.f, tab_b = 0.f;   // XF: this thread's entry of the next image's (a, b) table
-    float d[16];          // T: the 4 x 4 patch of (tile, channel)
+    f32x2 d[4][2];        // T: the 4 x 4 patch of (tile, channel), rows as two register pairs
     if (ABL & 9) { sp[0][0] = f32x4{1.f, 1.f, 1.f, 1.f}; sp[0][1] = sp[0][0]; sp[1][0] = sp[0][0]; sp[1][1] = sp[0][0]; }
     Tile cur = setup(blockIdx.x);
     auto ld_a = [&](const Tile& t, int ck, int k) {
@@ -246,7 +272,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
     };
     auto affine = [&](f32x4 v, f32x4 a4, f32x4 b4, int k) {   // the producer's GroupNorm apply (+ReLU); padding stays 0
-        v = v * a4 + b4;
+        if (ABL & 64) v = v * a4 + b4;
+        else {
+            const f32x2 lo = pk_fma(f32x2{v.x, v.y}, f32x2{a4.x, a4.y}, f32x2{b4.x, b4.y});
+            const f32x2 hi = pk_fma(f32x2{v.z, v.w}, f32x2{a4.z, a4.w}, f32x2{b4.z, b4.w});
+            v = f32x4{lo.x, lo.y, hi.x, hi.y};
+        }
         v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
         if (cur.any_pad) {   // interior regions skip the selects with one scalar branch (the empty asm keeps it a branch)
             asm volatile("");
@@ -282,20 +313,34 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
     };
     auto t_read = [&](int buf, int r) {                // T, patch row r -> registers
 #pragma unroll
-        for (int s = 0; s < 4; ++s) d[r * 4 + s] = t_rd[buf * RAWBUF + r * RAWROW + s * 8];
+        for (int s = 0; s < 2; ++s)
+            d[r][s] = f32x2{t_rd[buf * RAWBUF + r * RAWROW + (2 * s) * 8], t_rd[buf * RAWBUF + r * RAWROW + (2 * s + 1) * 8]};
     };
     auto t_row = [&](int buf, int i) {                 // T, row i of B^T d, then the column pass: frequencies (i, 0..3)
-        float t[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float d0 = d[s], d1 = d[4 + s], d2 = d[8 + s], d3 = d[12 + s];
-            t[s] = i == 0 ? d0 - d2 : i == 1 ? d1 + d2 : i == 2 ? d2 - d1 : d1 - d3;
-        }
         float* dst = Vs + buf * WBUF + (i * 4) * 512 + v_wr;
-        dst[0 * 512] = t[0] - t[2];
-        dst[1 * 512] = t[1] + t[2];
-        dst[2 * 512] = t[2] - t[1];
-        dst[3 * 512] = t[1] - t[3];
+        if (ABL & 64) {   // the scalar form (measurement build: A/B of the packed instructions; same bits)
+            float ts[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float d0 = d[0][s >> 1][s & 1], d1 = d[1][s >> 1][s & 1], d2 = d[2][s >> 1][s & 1], d3 = d[3][s >> 1][s & 1];
+                ts[s] = i == 0 ? d0 - d2 : i == 1 ? d1 + d2 : i == 2 ? d2 - d1 : d1 - d3;
+            }
+            dst[0 * 512] = ts[0] - ts[2];
+            dst[1 * 512] = ts[1] + ts[2];
+            dst[2 * 512] = ts[2] - ts[1];
+            dst[3 * 512] = ts[1] - ts[3];
+            return;
+        }
+        f32x2 t[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            t[s] = i == 0 ? pk_sub(d[0][s], d[2][s]) : i == 1 ? pk_add(d[1][s], d[2][s]) : i == 2 ? pk_sub(d[2][s], d[1][s])
+                                                                                                  : pk_sub(d[1][s], d[3][s]);
+        const f32x2 o01 = pk_col01(t[0], t[1]), o23 = pk_col23(t[0], t[1]);
+        dst[0 * 512] = o01.x;
+        dst[1 * 512] = o01.y;
+        dst[2 * 512] = o23.x;
+        dst[3 * 512] = o23.y;
     };
     // ---- MFMA operand fragments: A[m = lane & 31][k = lane >> 5] = V row (tile), B = U row (cout)
     const int l31 = lane & 31, half = lane >> 5;
@@ -539,7 +584,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(WinoParams p) {
 #ifdef CPR_BENCH_HOOKS   // measurement build only (libcprhip_bench.so): register-set A/B and loop ablations, process-global
 static int wino_sched = 0, wino_ablate = 0, wino_var = -1, wino_tpx = -1;
 extern "C" int cpr_wino_set_variant(int sched, int ablate) {   // sched 1: the other placement of the patch transform (TSPREAD flipped)
-    CPR_CHECK_ARG(sched >= 0 && sched <= 2 && ablate >= 0 && ablate <= 32);
+    CPR_CHECK_ARG(sched >= 0 && sched <= 2 && ablate >= 0 && ablate <= 64);
     wino_sched = sched;
     wino_ablate = ablate;
     return CPR_OK;
@@ -634,6 +679,7 @@ static int wino_fwd_launch(const float* in, const float* u, float* out, const fl
             case 8: WLAUNCH(8, 0); break;
             case 16: WLAUNCH(16, 0); break;
             case 32: WLAUNCH(32, 0); break;
+            case 64: WLAUNCH(64, 0); break;   // scalar transform / affine (same bits as the product's packed form)
             default: WLAUNCH(7, 0); break;
         }
     } else
