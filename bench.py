@@ -182,6 +182,8 @@ class ConvProbe:
                 variant = 'conv_bf16_dma_kernel' if v == 256256 else 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
             elif v % 10 == 2:    # dual-source launch (conv3 + projection shortcut): <BM, BN, MODE 0, XF false, PIPE 1, ABL 0, DUAL>
                 variant = 'conv_mfma_kernel<%d, %d, 0, false, 1, 0, true>' % (v // 1000000, v // 1000 % 1000)
+            elif v % 10 == 3:    # streamed 1x1 (csrc/conv1x1_stream.hip): <K = 8192 / BM>
+                variant = 'conv1x1_stream_kernel<%d>' % (8192 // (v // 1000000))
             else:
                 variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0, false>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
                                                                              'true' if v // 10 % 10 else 'false', v % 10)

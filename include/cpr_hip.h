@@ -55,6 +55,15 @@ int cpr_conv2d_dual_fwd(const float* in, const float* wgt, const float* in2, con
                         int Cin, int Cout, int KH, int KW, int stride, int pad, int Kpad, int H2, int W2, int Cin2,
                         int stride2, int Kpad2, int flags, int* variant_out, void* stream);
 
+/* The HBM-bound 1x1 convs of the bottleneck (conv3 + bn3 + shortcut add + ReLU and the like, T/mmdet/models/backbones/resnet.py:
+ * 262-302) as a stream: one persistent workgroup per CU, weight panel resident in LDS, pixel tiles through LDS-DMA
+ * (csrc/conv1x1_stream.hip).  in [M][Cin], wgt [Cout][Cin], out / residual [M][Cout]; Cin in {64, 128}, M a multiple of
+ * 8192 / Cin, Cout a multiple of 16384 / Cin, flags = CPR_CONV_RELU | CPR_CONV_RES_MASK; CPR_ERR_UNSUPPORTED otherwise.
+ * cpr_conv2d_fwd takes this path by itself for such shapes when the launch has >= 1024 tiles; the results are bit-identical to
+ * its tiled kernel (same accumulation order, same epilogue), this entry exists for tests and tools. */
+int cpr_conv1x1_stream_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
+                           const float* residual, long long M, int Cin, int Cout, int flags, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies than
  * cpr_conv2d_fwd; same call sites: the CPR head towers cpr_head.py:1033-1043, the FPN output conv fpn.py:190-194, the 3x3 of
  * every stride-1 bottleneck resnet.py:630-645).  The transforms only add/subtract, the result differs from the direct fp32
@@ -346,6 +355,7 @@ int cpr_clip_flip_boxes(float* boxes, const int* img_of, const int* flip, const 
 #ifdef CPR_BENCH_HOOKS
 int cpr_conv_force_tile(int bm, int bn); /* force the conv output tile (0 = heuristic, 64, 128) */
 int cpr_conv_set_pipeline(int mode);     /* K-loop schedule: 1 = interleaved (product), 0 = phase-separated */
+int cpr_conv_set_stream(int on);         /* 0 = the streamed 1x1 kernel (conv1x1_stream.hip) is never chosen by cpr_conv2d_fwd (A/B) */
 int cpr_conv_set_ablation(int mode);     /* loop ablations: results are WRONG when non-zero */
 int cpr_wgrad_set_ablation(int mode);    /* same for the weight-gradient kernel */
 int cpr_conv_set_extra_lds(int bytes);   /* occupancy probe: dynamic LDS added to every direct-conv launch */

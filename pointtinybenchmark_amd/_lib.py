@@ -19,6 +19,7 @@ SIGNATURES = {
     'cpr_version': [],
     'cpr_conv2d_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
     'cpr_conv2d_dual_fwd': [_p] * 9 + [_i] * 16 + [_p, _p],
+    'cpr_conv1x1_stream_fwd': [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p],
     'cpr_wino_pack_weights': [_p, _p, _i, _i, _i, _p],
     'cpr_conv3x3_wino_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_conv3x3_wino_wgrad_workspace': [_i, _i, _i, _i, _i],
@@ -77,6 +78,7 @@ SIGNATURES = {
 BENCH_SIGNATURES = {
     'cpr_conv_force_tile': [_i, _i],
     'cpr_conv_set_pipeline': [_i],
+    'cpr_conv_set_stream': [_i],
     'cpr_conv_set_ablation': [_i],
     'cpr_wgrad_set_ablation': [_i],
     'cpr_wino_set_variant': [_i, _i],

@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 // thread-safe, which is acceptable for a single-threaded measurement script and for nothing else.
 #ifdef CPR_BENCH_HOOKS
 static int force_tile_bm = 0, force_tile_bn = 0;  // cpr_conv_force_tile, 0 = heuristic
+static int conv_stream_on = 1;                     // cpr_conv_set_stream: 0 = the streamed 1x1 kernel is never chosen (A/B)
 static int conv_pipeline = 1;                      // 1 = interleaved K loop (default), 0 = phase-separated (A/B reference)
 static int conv_ablate = 0;                        // cpr_conv_set_ablation
 static int conv_extra_lds = 0;                     // cpr_conv_set_extra_lds: dynamic LDS bytes added to every launch (occupancy probe)
@@ -554,6 +555,11 @@ extern "C" int cpr_conv_set_ablation(int mode) {
     conv_ablate = mode;
     return CPR_OK;
 }
+extern "C" int cpr_conv_set_stream(int on) {
+    CPR_CHECK_ARG(on == 0 || on == 1);
+    conv_stream_on = on;
+    return CPR_OK;
+}
 extern "C" int cpr_conv_set_pipeline(int mode) {
     CPR_CHECK_ARG(mode == 0 || mode == 1);
     conv_pipeline = mode;
@@ -566,8 +572,14 @@ extern "C" int cpr_conv_force_tile(int bm, int bn) {
     return CPR_OK;
 }
 #else
-constexpr int force_tile_bm = 0, force_tile_bn = 0, conv_pipeline = 1, conv_ablate = 0, conv_extra_lds = 0;
+constexpr int force_tile_bm = 0, force_tile_bn = 0, conv_pipeline = 1, conv_ablate = 0, conv_extra_lds = 0, conv_stream_on = 1;
 #endif
+
+// csrc/conv1x1_stream.hip: the HBM-bound 1x1 shapes as a stream (CPR_ERR_UNSUPPORTED = not one of its shapes)
+int conv1x1_stream_launch(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
+                          const float* residual, long long M, int Cin, int Cout, int relu, int res_mask, int min_tiles,
+                          hipStream_t stream);
+constexpr int STREAM_MIN_TILES = 1024;   // four tiles per persistent workgroup; smaller launches keep the 64x64 tiles (4 workgroups / CU)
 
 // one launch: every tensor below 2 GiB.  bm_fix > 0: the M tile of an earlier chunk of the same call (column-sum slots must line up)
 static int conv2d_fwd_launch(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
@@ -604,6 +616,16 @@ static int conv2d_fwd_launch(const float* in, const float* wgt, float* out, cons
     }
     if ((gn_part && !colsum_mode) || in_a) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
     if (in_a) CPR_CHECK_ARG(in_b && p.OH == H && p.OW == W && Cin <= 512);
+    // plain 1x1 GEMMs with 64 / 128 input channels are HBM-bound: streamed (bit-identical to the tiled kernel, see conv1x1_stream.hip)
+    if (conv_stream_on && !mode1 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && !in_a && !gn_part && !p.out_bf16 &&
+        !force_tile_bm && !conv_ablate) {
+        const int rc = conv1x1_stream_launch(in, wgt, out, scale, bias, residual, M, Cin, Cout, p.relu, p.res_mask,
+                                             STREAM_MIN_TILES, stream);
+        if (rc != CPR_ERR_UNSUPPORTED) {
+            if (variant_out) *variant_out = (8192 / Cin) * 1000000 + (16384 / Cin) * 1000 + 3;   // BM, BN, 3 = streamed
+            return rc;
+        }
+    }
     // tile selection (measured per layer on MI355X, profiles/round1_tile_sweep.txt): 64x64 tiles run 4 workgroups per CU
     // (36.9 KB LDS, 74 VGPRs) and win on everything except very large, long-K problems -- finer granularity against
     // tile quantisation and 4 waves/SIMD to hide the prologue/epilogue latency of short-K 1x1 convs.  128x128 is kept for

@@ -281,6 +281,18 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     return (out, part) if gn_part else out
 
 
+def conv1x1_stream(x, pc, scale=None, bias=None, residual=None, relu=False, res_mask=False):
+    """The streamed 1x1 kernel (csrc/conv1x1_stream.hip) called explicitly -- ``conv2d`` takes it by itself for large launches;
+    tests compare the two kernels bit for bit.  x (N, H, W, Cin) fp32, Cin in {64, 128}."""
+    N, H, W, Cin = x.shape
+    assert pc.KH == 1 and pc.stride == 1 and pc.padding == 0 and pc.Kpad == Cin and x.dtype == torch.float32
+    out = torch.empty((N, H, W, pc.Cout), device=x.device, dtype=torch.float32)
+    flags = (CONV_RELU if relu else 0) | (CONV_RES_MASK if res_mask else 0)
+    _lib.call('cpr_conv1x1_stream_fwd', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
+              N * H * W, Cin, pc.Cout, flags, _stream())
+    return out
+
+
 def conv2d_dual(x, pc, x2, pc2, scale=None, bias=None, scale2=None, bias2=None, relu=False, out=None):
     """relu?((conv(x, pc) * scale + bias) + (conv1x1(x2, pc2) * scale2 + bias2)) in one launch: conv3 + bn3 of a stage's first
     bottleneck together with its projection shortcut (resnet.py:262-302) -- the shortcut map never reaches HBM.  Bit-identical

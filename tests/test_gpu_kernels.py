@@ -103,6 +103,75 @@ def test_conv2d_dual_bit_equal_to_two_launches(case):
     _cmp('dual conv', one.permute(0, 3, 1, 2), ref, atol=3e-5, rtol=3e-5)
 
 
+STREAM_CASES = [
+    # N, H, W, Cin, Cout, residual mode (0 none, 1 add, 2 ReLU mask), relu
+    (2, 32, 32, 64, 256, 1, True),       # conv3 + shortcut add + ReLU of layer1 (resnet.py:262-302)
+    (1, 16, 24, 64, 256, 0, False),      # 3 pixel tiles: some workgroups idle
+    (3, 32, 32, 64, 512, 2, False),      # two cout panels; data gradient with the ReLU mask epilogue
+    (2, 16, 32, 128, 512, 1, True),      # layer2: four cout panels of 128
+    (5, 8, 8, 128, 128, 0, True),        # one panel, 5 tiles of 64 pixels
+    (64, 16, 16, 64, 256, 1, True),      # 128 tiles over 128 workgroups ... and enough rows to wrap the double buffer
+    (9, 32, 32, 128, 256, 1, False),     # odd tile counts per workgroup
+]
+
+
+@pytest.mark.parametrize('case', STREAM_CASES, ids=lambda c: 'n%d_%dx%d_c%d_o%d_r%d_%s' % c)
+def test_streamed_1x1_bit_equal_to_tiled_kernel(case):
+    """csrc/conv1x1_stream.hip (persistent workgroups, weight panel resident in LDS, pixel tiles by LDS-DMA) == the tiled kernel
+    BIT for bit (same accumulation order, same epilogue) -- these launches are small enough that ops.conv2d itself still takes the
+    tiled kernel -- and both agree with torch."""
+    ops = _ops()
+    N, H, W, Cin, Cout, rmode, relu = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 1, 1), generator=g) / Cin ** 0.5
+    sc, bi = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = torch.randn((N, Cout, H, W), generator=g) if rmode else None
+    pc = ops.PackedConv(w.cuda(), 1, 0)
+    xc = _nhwc(x)
+    rc = _nhwc(res) if res is not None else None
+    ops.TRACE_CONV_VARIANT[0] = True
+    try:
+        tiled = ops.conv2d(xc, pc, scale=sc.cuda(), bias=bi.cuda(), residual=rc, relu=relu, res_mask=rmode == 2)
+        assert ops.TRACE_CONV_VARIANT[1][1] % 10 != 3, 'this launch was meant to run the tiled kernel'
+    finally:
+        ops.TRACE_CONV_VARIANT[0] = False
+    stream = ops.conv1x1_stream(xc, pc, scale=sc.cuda(), bias=bi.cuda(), residual=rc, relu=relu, res_mask=rmode == 2)
+    torch.cuda.synchronize()
+    assert torch.equal(stream, tiled), 'streamed 1x1 differs from the tiled kernel: max %.3e' % float((stream - tiled).abs().max())
+    ref = F.conv2d(x, w) * sc[None, :, None, None] + bi[None, :, None, None]
+    if rmode == 1:
+        ref = ref + res
+    elif rmode == 2:
+        ref = torch.where(res > 0, ref, torch.zeros_like(ref))
+    if relu:
+        ref = F.relu(ref)
+    _cmp('streamed 1x1', stream.permute(0, 3, 1, 2), ref, atol=3e-5, rtol=3e-5)
+
+
+def test_conv2d_takes_the_streamed_kernel_for_large_1x1_launches():
+    """A launch with >= 1024 tiles of a streamed shape goes to conv1x1_stream_kernel through ops.conv2d (variant code ...3) and
+    every image of the batch equals the same image run alone through the tiled kernel."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    N, H, W, Cin, Cout = 16, 96, 96, 64, 256       # 1152 tiles of 128 pixels
+    x = _nhwc(torch.randn((N, Cin, H, W), generator=g))
+    w = torch.randn((Cout, Cin, 1, 1), generator=g) / 8
+    res = _nhwc(torch.randn((N, Cout, H, W), generator=g))
+    sc, bi = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+    pc = ops.PackedConv(w.cuda(), 1, 0)
+    ops.TRACE_CONV_VARIANT[0] = True
+    try:
+        big = ops.conv2d(x, pc, scale=sc, bias=bi, residual=res, relu=True)
+        assert ops.TRACE_CONV_VARIANT[1][1] % 10 == 3, 'expected the streamed kernel, got variant %r' % (ops.TRACE_CONV_VARIANT[1],)
+        one = ops.conv2d(x[5:6].contiguous(), pc, scale=sc, bias=bi, residual=res[5:6].contiguous(), relu=True)
+        assert ops.TRACE_CONV_VARIANT[1][1] % 10 != 3
+    finally:
+        ops.TRACE_CONV_VARIANT[0] = False
+    torch.cuda.synchronize()
+    assert torch.equal(big[5:6], one)
+
+
 def test_conv_fused_groupnorm_chain():
     """conv -> GN stats in the epilogue -> finalize -> next conv applies GN+ReLU on load, vs the unfused torch ops."""
     ops = _ops()

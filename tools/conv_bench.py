@@ -25,9 +25,11 @@ def main():
     ap.add_argument('--extra-lds', type=int, default=0, help='occupancy probe: dynamic LDS bytes added to every direct-conv launch')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
     ap.add_argument('--bf16-dma', type=int, default=1, help='bf16 mode: 0 = every layer on the register-staged kernels (A/B)')
+    ap.add_argument('--stream', type=int, default=1, help='0 = the streamed 1x1 kernel is never chosen (A/B of conv1x1_stream.hip)')
     args = ap.parse_args()
     from pointtinybenchmark_amd import _lib
     _lib.call('cpr_bf16_set_dma', args.bf16_dma)
+    _lib.call('cpr_conv_set_stream', args.stream)
     _lib.call('cpr_conv_set_pipeline', args.pipeline)
     _lib.call('cpr_conv_force_tile', *[int(v) for v in args.tile.split(',')])
     _lib.call('cpr_conv_set_extra_lds', args.extra_lds)
