@@ -293,7 +293,9 @@ class CprTrainer:
         over ranks once ``step`` has waited for the buckets)."""
         m = self.model
         head, neck, bb = m.bbox_head, m.neck, m.backbone
-        assert bb.compute_dtype == torch.float32, 'the backward pass is fp32 (bf16 training: SURVEY.md §8f, later round)'
+        # bf16 compute mode = mixed precision (the reference analogue is mmcv's Fp16OptimizerHook, mmdet/apis/train.py:116-119): the
+        # recorded forward runs on the bf16 kernels, the backward kernels are fp32 and read the recorded (bf16-rounded) maps
+        # through ``_f32`` just in time; weights, gradients and the optimizer state stay fp32.
         batch_input_shape = tuple(img[0].size()[-2:])
         for meta in img_metas:
             meta['batch_input_shape'] = batch_input_shape
@@ -310,16 +312,22 @@ class CprTrainer:
             torch.cuda.current_stream().wait_stream(self.side)
         return losses
 
+    @staticmethod
+    def _f32(t):
+        """A recorded map as the fp32 backward kernels read it (a bf16 map of the mixed-precision forward is widened, exactly)."""
+        return t if t is None or t.dtype == torch.float32 else t.float()
+
     def _gn_conv_backward(self, rec, dz, relu, need_dx):
         """Backward of conv -> GN (-> ReLU) given dz wrt the module output.  Writes the three parameter gradients;
         returns the gradient wrt the conv INPUT as the consumer saw it (after the producer's pending affine, if any)."""
         cm = rec['module']
         w, gn = cm.conv.weight, cm.gn
         assert cm.conv.bias is None
-        draw, _, _ = ops.gn_bwd(rec['raw'], dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
+        draw, _, _ = ops.gn_bwd(self._f32(rec['raw']), dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
                                 out_dgamma=gn.weight.grad, out_dbeta=gn.bias.grad)
-        self._param_side(lambda: ops.conv2d_wgrad(draw, rec['x'], w.shape, cm.conv.stride[0], cm.conv.padding[0],
-                                                  in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=w.grad), draw)
+        x = self._f32(rec['x'])
+        self._param_side(lambda: ops.conv2d_wgrad(draw, x, w.shape, cm.conv.stride[0], cm.conv.padding[0],
+                                                  in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=w.grad), draw, x)
         if not need_dx:
             return None
         pt = ops.dgrad_pack(w, cm.conv.stride[0], cm.conv.padding[0])
@@ -352,7 +360,7 @@ class CprTrainer:
         wcat = head.cls_out.weight if shared else torch.cat([head.cls_out.weight, head.ins_out.weight], 0)
         wpad = torch.zeros((Jd, wcat.shape[1], 1, 1), device=wcat.device, dtype=torch.float32)
         wpad[:J, :, 0, 0] = wcat.detach()
-        gw = ops.conv2d_wgrad(dmap, s['feat'], wpad.shape, 1, 0, in_ab=s['ab'], in_relu=True)
+        gw = ops.conv2d_wgrad(dmap, self._f32(s['feat']), wpad.shape, 1, 0, in_ab=s['ab'], in_relu=True)
         _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
         head.cls_out.weight.grad.copy_(gw[:C, :, 0, 0])
         head.cls_out.bias.grad.copy_(gb[:C])
@@ -376,7 +384,7 @@ class CprTrainer:
         Cp = dout_pad.shape[-1]
         wpad = torch.zeros((Cp,) + tuple(w.shape[1:]), device=w.device, dtype=torch.float32)
         wpad[:n_out] = w.detach()
-        x, ab = rec['x'], rec['in_ab']
+        x, ab = self._f32(rec['x']), rec['in_ab']
 
         def param_grads():
             gw = ops.conv2d_wgrad(dout_pad, x, wpad.shape, conv.stride[0], conv.padding[0], in_ab=ab, in_relu=True)
@@ -453,18 +461,19 @@ class CprTrainer:
         return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
 
     def _block_backward(self, cache, blk, rec, dout, need_dx):
-        x = rec['x']
-        g3, cs3 = ops.relu_bwd_colsum(dout, rec['out'])            # also the shortcut gradient
+        x = self._f32(rec['x'])
+        g3, cs3 = ops.relu_bwd_colsum(dout, self._f32(rec['out']))            # also the shortcut gradient
+        o1 = self._f32(rec['o1'])
         if blk.kind == 'bottleneck':
-            g2, cs2 = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, rec['o2'], True, mask=rec['o2'],
-                                             want_colsum=True)
-            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, rec['o1'], True, mask=rec['o1'],
-                                             want_colsum=True)
+            o2 = self._f32(rec['o2'])
+            g2, cs2 = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, o2, True, mask=o2, want_colsum=True)
+            del o2
+            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, o1, True, mask=o1, want_colsum=True)
             last = blk.bn3
         else:
-            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, rec['o1'], True, mask=rec['o1'],
-                                             want_colsum=True)
+            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, o1, True, mask=o1, want_colsum=True)
             last = blk.bn2
+        del o1
         self._done(last.bias if last.bias.requires_grad else blk.conv2.weight)
         if blk.downsample is not None:     # the shortcut conv sees the same g3 (no activation on that branch)
             dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx)

@@ -113,6 +113,48 @@ def test_train_steps_match_torch_sgd():
 
 
 @pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
+def test_mixed_precision_step_tracks_the_fp32_step(name):
+    """bf16 compute mode in the trainer = mixed precision (reference analogue: mmcv Fp16OptimizerHook, mmdet/apis/train.py:116-119):
+    recorded forward on the bf16 kernels, fp32 backward kernels over the widened recorded maps, fp32 weights / gradients /
+    optimizer.  The gradient of the same weights and batch must point where the fp32 gradient points (bf16 keeps 8 bits: the
+    bar is a cosine of 0.99 over all parameters and 0.25 relative L2 per tensor with a non-negligible gradient), the losses
+    agree to 5 %, and an optimisation step keeps every parameter finite and the weights fp32."""
+    from pointtinybenchmark_amd.training import CprTrainer
+    cfg = CPR_CASES[name]
+    m, _ = build_hip_locator(cfg)
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'], cfg.get('ragged', False))
+    cb = to_cuda(batch)
+    tr = CprTrainer(m, lr=1e-3)
+    l32 = {k: float(v) for k, v in tr.forward_backward(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels']).items()}
+    torch.cuda.synchronize()
+    g32 = tr.flat_g.clone()
+    m.set_compute_dtype('bf16')
+    l16 = {k: float(v) for k, v in tr.forward_backward(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels']).items()}
+    torch.cuda.synchronize()
+    g16 = tr.flat_g.clone()
+    assert torch.isfinite(g16).all()
+    for k in l32:
+        if 'loss' in k:
+            assert abs(l16[k] - l32[k]) <= 5e-2 * max(1.0, abs(l32[k])), (k, l16[k], l32[k])
+    cos = float(torch.dot(g16.double(), g32.double()) / (g16.double().norm() * g32.double().norm()))
+    assert cos >= 0.99, 'mixed-precision gradient direction: cosine %.4f' % cos
+    worst, gmax = 0.0, max(float(p.grad.norm()) for p in m.parameters() if p.requires_grad)
+    off = 0
+    for p_ in tr.params:
+        n = p_.numel()
+        a, b = g16[off:off + n].double(), g32[off:off + n].double()
+        off += n
+        if float(b.norm()) >= 1e-2 * gmax:
+            worst = max(worst, float((a - b).norm() / b.norm()))
+    assert worst <= 0.25, 'mixed-precision gradient, worst relative L2 over the large tensors: %.3f' % worst
+    tr.step()
+    torch.cuda.synchronize()
+    for k, p_ in m.named_parameters():
+        assert p_.dtype == torch.float32 and torch.isfinite(p_).all(), k
+
+
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
 def test_backward_matches_reference_autograd_golden(name):
     """HIP gradients against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_grads_*.npz, produced
     in the build container by oracle.gen_golden): total loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the
