@@ -299,6 +299,7 @@ class CprTrainer:
         batch_input_shape = tuple(img[0].size()[-2:])
         for meta in img_metas:
             meta['batch_input_shape'] = batch_input_shape
+        self._mixed = bb.compute_dtype == torch.bfloat16
         bb_tape, neck_tape = [], []
         feats = bb(img, tape=bb_tape)
         lazy = neck.forward_lazy(feats, tape=neck_tape)
@@ -330,8 +331,20 @@ class CprTrainer:
                                                   in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=w.grad), draw, x)
         if not need_dx:
             return None
+        if rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and w.shape[0] % 64 == 0:
+            return self._dgrad_bf16(draw, w, cm.conv.padding[0])
         pt = ops.dgrad_pack(w, cm.conv.stride[0], cm.conv.padding[0])
         return ops.conv2d_dgrad(draw, pt, (rec['x'].shape[1], rec['x'].shape[2]), cm.conv.stride[0])
+
+    @staticmethod
+    def _dgrad_bf16(dy, w, padding):
+        """Mixed precision: the data gradient of a stride-1 conv on the bf16 matrix pipe -- a forward conv of the bf16-rounded
+        gradient map with the rotated weights (channels swapped, taps flipped, padding K-1-p), fp32 out.  The weight gradient
+        next to it keeps reading the fp32 map."""
+        k = w.shape[2]
+        wt = w.detach().flip(2, 3).permute(1, 0, 2, 3)
+        pc = ops.PackedConv(wt, 1, k - 1 - padding, torch.bfloat16)
+        return ops.conv2d(dy.to(torch.bfloat16), pc, out_dtype=torch.float32)
 
     # ------------------------------------------------------------------ CPR head
     @staticmethod
@@ -456,6 +469,19 @@ class CprTrainer:
             self._param_side(param_grads, g, colsum)
         if not need_dx:
             return None
+        if self._mixed and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and add is None:
+            # mixed precision: the 3x3 data gradient on the bf16 matrix pipe (its fp32 form cannot be a Winograd launch: the mask /
+            # column-sum epilogue), the ReLU mask and the column sums as one streaming pass over the (small) result
+            def pack16():
+                wt = (w.detach() * scale[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3)
+                return ops.PackedConv(wt, 1, 2 - conv.padding[0], torch.bfloat16)
+            pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16)
+            dx = ops.conv2d(g.to(torch.bfloat16), pc16, out_dtype=torch.float32)
+            if mask is None and not want_colsum:
+                return dx
+            gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
+            dx = gm if mask is not None else dx
+            return (dx, cs) if want_colsum else dx
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
                        lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
         return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
