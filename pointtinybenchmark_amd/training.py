@@ -201,6 +201,7 @@ class CprTrainer:
             off += k
         self.buckets = GradBuckets(self.flat_g, max(1, int(bucket_mb * (1 << 20) / 4)), group, force=force_collectives,
                                    reducer=reducer, timing=reducer_timing)
+        self._mixed, self._wide = False, {}     # set per step by forward_backward (bf16 compute mode = mixed precision)
         self.norm2 = torch.zeros((1,), device=dev, dtype=torch.float64)
         self._ws = torch.empty((1024,), device=dev, dtype=torch.float64)
         self.steps = 0
@@ -300,6 +301,7 @@ class CprTrainer:
         for meta in img_metas:
             meta['batch_input_shape'] = batch_input_shape
         self._mixed = bb.compute_dtype == torch.bfloat16
+        self._wide = {}      # id(recorded bf16 map) -> its fp32 copy, while a second reader is still to come
         bb_tape, neck_tape = [], []
         feats = bb(img, tape=bb_tape)
         lazy = neck.forward_lazy(feats, tape=neck_tape)
@@ -313,10 +315,17 @@ class CprTrainer:
             torch.cuda.current_stream().wait_stream(self.side)
         return losses
 
-    @staticmethod
-    def _f32(t):
-        """A recorded map as the fp32 backward kernels read it (a bf16 map of the mixed-precision forward is widened, exactly)."""
-        return t if t is None or t.dtype == torch.float32 else t.float()
+    def _f32(self, t, keep=False):
+        """A recorded map as the fp32 backward kernels read it (a bf16 map of the mixed-precision forward is widened, exactly).
+        keep: the same recorded tensor is read again by the NEXT backward rule (a block's input is the output of the block
+        before it) -- the widened copy is held until then instead of being made twice."""
+        if t is None or t.dtype == torch.float32:
+            return t
+        hit = self._wide.pop(id(t), None)
+        w = hit if hit is not None else t.float()
+        if keep:
+            self._wide[id(t)] = w
+        return w
 
     def _gn_conv_backward(self, rec, dz, relu, need_dx):
         """Backward of conv -> GN (-> ReLU) given dz wrt the module output.  Writes the three parameter gradients;
@@ -487,7 +496,7 @@ class CprTrainer:
         return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
 
     def _block_backward(self, cache, blk, rec, dout, need_dx):
-        x = self._f32(rec['x'])
+        x = self._f32(rec['x'], keep=True)       # = the output of the block below: its backward reads it next
         g3, cs3 = ops.relu_bwd_colsum(dout, self._f32(rec['out']))            # also the shortcut gradient
         o1 = self._f32(rec['o1'])
         if blk.kind == 'bottleneck':
