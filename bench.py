@@ -646,14 +646,35 @@ def main():
                 t = torch.tensor([te], device='cuda', dtype=torch.float64)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
                 te = float(t.item())
-            return {'value': args.batch * world * args.train_steps / te, 'unit': 'img/s',
-                    'ms_per_step': te / args.train_steps * 1e3, 'steps': args.train_steps,
-                    'what': 'forward + loss + backward (layer2-4, FPN, head) + bucketed gradient all-reduce + '
-                            'clip_grad_norm(35) + SGD(momentum 0.9, wd 1e-4), fp32',
-                    'grad_norm': trainer.grad_norm(), 'loss': float(sum(v for k, v in tl.items() if 'loss' in k)),
-                    # rank 0's view of the last step: when each gradient bucket was final (= its reduction issued) and when the
-                    # main stream held its sum, relative to the start of the backward; exposed_ms = reducer time NOT hidden
-                    'reducer': _reducer_summary(trainer)}
+            res = {'value': args.batch * world * args.train_steps / te, 'unit': 'img/s',
+                   'ms_per_step': te / args.train_steps * 1e3, 'steps': args.train_steps,
+                   'what': 'forward + loss + backward (layer2-4, FPN, head) + bucketed gradient all-reduce + '
+                           'clip_grad_norm(35) + SGD(momentum 0.9, wd 1e-4), fp32',
+                   'grad_norm': trainer.grad_norm(), 'loss': float(sum(v for k, v in tl.items() if 'loss' in k)),
+                   # rank 0's view of the last step: when each gradient bucket was final (= its reduction issued) and when the
+                   # main stream held its sum, relative to the start of the backward; exposed_ms = reducer time NOT hidden
+                   'reducer': _reducer_summary(trainer)}
+            # the same trainer in the bf16 compute mode = mixed precision (bf16 recorded forward and stride-1 data gradients,
+            # fp32 weight gradients / weights / optimizer); NOT the fp32 arithmetic of the reference, reported beside it
+            try:
+                model.set_compute_dtype('bf16')
+                train_step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.train_steps):
+                    tl = train_step()
+                barrier()
+                tm = time.perf_counter() - t1
+                if distributed:
+                    t = torch.tensor([tm], device='cuda', dtype=torch.float64)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    tm = float(t.item())
+                res['mixed_precision'] = {'value': args.batch * world * args.train_steps / tm, 'unit': 'img/s',
+                                          'ms_per_step': tm / args.train_steps * 1e3,
+                                          'loss': float(sum(v for k, v in tl.items() if 'loss' in k))}
+            finally:
+                model.set_compute_dtype(args.dtype)
+            return res
         except Exception as e:   # noqa: BLE001 -- reported in the JSON line
             return {'error': repr(e)[:300]}
 

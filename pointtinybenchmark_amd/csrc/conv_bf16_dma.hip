@@ -38,6 +38,13 @@ struct ConvDmaParams {
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, out_fp32;
     int tilesM, tilesN;
     int ablate;     // measurement builds only (results are then WRONG): 1 no wait for the DMA, 2 no barrier, 4 no DMA requests, 8 no fragment reads
+    // NT-GEMM mode (the bf16 weight gradient, csrc/conv_wgrad_bf16.hip): out[split][tap][m][n] = sum over the split's K range of
+    // in[m][k] * wgt_tap[n][k], both operands rows of Kpad (= Cin) elements.  Tiles = splits x taps x tilesM x tilesN.
+    int nt_taps;        // 0 = convolution mode
+    int nt_k;           // tap grid is nt_k x nt_k: tap t reads copy t % nt_k of the right operand, shifted by (t / nt_k - nt_pad) rows of nt_Wp
+    int nt_pad, nt_Wp;
+    int nt_chunks;      // 64-element K chunks per split
+    long long nt_copy;  // elements between the copies of the right operand
 };
 
 constexpr int DBM = 256, DBN = 256, DBK = 64;
@@ -130,10 +137,23 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
 
     // XCD-aware tile order (block b runs on XCD b % 8; an XCD walks a contiguous run of tiles, cout tiles fastest)
-    const int T = p.tilesM * p.tilesN;
-    const int per = (T + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= T) return;
+    const bool nt = p.nt_taps > 0;
+    const int TMN = p.tilesM * p.tilesN;
+    int tile, st = 0, nt_split = 0, nt_tap = 0;
+    if (nt) {
+        // splits are dealt to the XCDs (block b runs on XCD b % 8; the host makes the split count a multiple of 8): the taps and
+        // tiles of one split are neighbours on one XCD and read the same K range of both operands within one L2
+        const int idx = blockIdx.x >> 3, per_split = p.nt_taps * TMN;
+        nt_split = (idx / per_split) * 8 + (blockIdx.x & 7);
+        const int rem = idx % per_split;
+        nt_tap = rem / TMN;
+        tile = rem - nt_tap * TMN;
+        st = nt_split * p.nt_taps + nt_tap;
+    } else {
+        const int per = (TMN + 7) >> 3;
+        tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (tile >= TMN) return;
+    }
     const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
     const int m0 = tm * DBM, n0 = tn * DBN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -165,7 +185,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
         }
     }
     // buffer descriptors as four SGPR words (base, stride 0, num_records, raw dword format): out-of-range offsets read 0
-    const size_t in_addr = (size_t)p.in, w_addr = (size_t)p.wgt;
+    const size_t in_addr = (size_t)p.in;
+    const size_t w_addr = (size_t)(p.wgt + (nt ? (long long)(nt_tap % p.nt_k) * p.nt_copy + (nt_tap / p.nt_k - p.nt_pad) * p.nt_Wp : 0));
     const i32x4v rs_in = {(int)(unsigned)in_addr, (int)(unsigned)(in_addr >> 32) & 0xffff,
                           (int)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000};
     const i32x4v rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32) & 0xffff,
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
     // line only four chunks = 8 MB of L2 traffic later: measured on the head layer 4.8 GB of L2 misses per launch against
     // 0.84 GB of input, TCC hit rate 64 % (gpurun_out/r3j PMC).  The weights are stored tap-major: chunk (c0, tap) sits at
     // K offset tap * Cin + c0.
-    int kh = 0, kw = 0, c0 = 0;     // tap / channel chunk of the NEXT chunk to be requested (wave-uniform)
+    int kh = 0, kw = 0, c0 = nt ? nt_split * p.nt_chunks * DBK : 0;     // tap / channel chunk of the NEXT chunk to be requested (wave-uniform)
     int wsoff = 0;                  // byte offset of that chunk inside a weight row
     int voffA[4];
     auto refresh_rows = [&]() {
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:0 lds"
                      :: "s"(lds_byte), "v"(voff), "s"(rs), "s"(soff) : "memory");
     };
-    const int KT = p.Kpad / DBK;
+    const int KT = nt ? p.nt_chunks : p.Kpad / DBK;
     // piece z = 0..7 of chunk kt (z < 4: activations, else weights) into stage `buf`; pieces are issued in order
     auto stage_piece = [&](int kt, int buf, int z) {
         if (p.ablate & 4) return;
@@ -315,6 +336,12 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
 #undef DFRAG
 #undef DMFMA
 
+    if (nt) {   // this (split, tap)'s fp32 partial
+        ConvDmaParams q = p;
+        q.out = (float*)p.out + (size_t)st * p.M * p.Cout;
+        dma_epilogue(q, acc, tm, m0, n0, wm, wn, lane);
+        return;
+    }
     dma_epilogue(p, acc, tm, m0, n0, wm, wn, lane);
 }
 
@@ -338,6 +365,7 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
     p.residual = (const unsigned short*)residual; p.gn_part = gn_part;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.Kpad = Kpad; p.relu = relu; p.out_fp32 = out_fp32; p.ablate = ablate;
+    p.nt_taps = 0; p.nt_k = 1; p.nt_pad = 0; p.nt_Wp = 0; p.nt_chunks = 0; p.nt_copy = 0;
     p.OH = (H + 2 * pad - KH) / stride + 1;
     p.OW = (W + 2 * pad - KW) / stride + 1;
     const long long M = (long long)N * p.OH * p.OW;
@@ -353,5 +381,26 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
     hipLaunchKernelGGL(conv_bf16_dma_kernel, dim3(grid), dim3(512), 0, stream, p);
+    CPR_LAUNCH_STATUS();
+}
+
+// NT-GEMM launch for the bf16 weight gradient (csrc/conv_wgrad_bf16.hip): part[split][tap][m][n] (fp32) = sum over the split's
+// K range of a[m][k] * b_tap[n][k]; a: M rows of `rs` bf16 elements (k = 0 at a), b: `k` copies (`copy` elements apart) of N rows
+// of `rs` elements, tap t = (t / k, t % k) reads copy t % k shifted by (t / k - pad) * Wp elements.  N % 256 == 0.
+int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, int N, long long rs, int k, int pad, int Wp,
+                            long long copy, int splits, int chunks, hipStream_t stream) {
+    if (N % DBN != 0 || rs % 8 != 0 || M <= 0 || splits <= 0 || splits % 8 != 0 || chunks <= 0) return CPR_ERR_UNSUPPORTED;
+    if ((long long)M * rs * 2 >= (1ll << 31) || (long long)N * rs * 2 >= (1ll << 31) || rs >= (1ll << 30)) return CPR_ERR_UNSUPPORTED;
+    ConvDmaParams p;
+    p.in = (const unsigned short*)a; p.wgt = (const unsigned short*)b; p.out = part; p.scale = nullptr; p.bias = nullptr;
+    p.residual = nullptr; p.gn_part = nullptr;
+    p.N = 1; p.H = 1; p.W = M; p.Cin = (int)rs; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.Kpad = (int)rs; p.relu = 0; p.out_fp32 = 1; p.ablate = 0;
+    p.OH = 1; p.OW = M; p.M = M;
+    p.tilesM = (M + DBM - 1) / DBM; p.tilesN = N / DBN;
+    p.nt_taps = k * k; p.nt_k = k; p.nt_pad = pad; p.nt_Wp = Wp; p.nt_chunks = chunks; p.nt_copy = copy;
+    const long long blocks = (long long)splits * p.nt_taps * p.tilesM * p.tilesN;
+    if (blocks >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_bf16_dma_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }

@@ -1,0 +1,178 @@
+// Weight gradient of a stride-1 convolution (1x1, or 3x3 with padding 1) on the bf16 matrix cores -- the mixed-precision
+// training step (pointtinybenchmark_amd/training.py; reference analogue: torch autograd under mmcv's Fp16OptimizerHook,
+// T/mmdet/apis/train.py:116-119).
+//
+//   dW[co][kh][kw][ci] = sum over pixels of dy[n, y, x, co] * x[n, y + kh - p, x + kw - p, ci]
+//
+// is a GEMM whose reduction runs over PIXELS, the slow dimension of both NHWC operands, while v_mfma_f32_32x32x16_bf16 wants 8
+// consecutive k per lane.  Instead of transposing inside the GEMM the operands are rewritten once, channel-major over a padded
+// pixel axis q = (n (H + 2p) + y + p) Wp + x + p (Wp = W + 2p rounded up to 8; border cells are zeros):
+//   dyT[co][q]            (bf16, from the fp32 gradient map)
+//   xT_kw[ci][q] = x at cell q + kw - p   (one copy per kw: the DMA reads 16-byte units, a one-element shift cannot be an offset)
+// and every tap is a plain NT GEMM with contiguous K:  dW_tap[co][ci] = sum_q dyT[co][q] * xT_kw[ci][q + (kh - p) Wp]
+// (zero padding = the zero border cells; the row shift is a multiple of 8 elements).  The GEMM is conv_bf16_dma_kernel in its
+// NT mode (256 x 256 x 64 tiles, both operands by LDS-DMA), split over the pixel axis into `splits` workgroup rows whose fp32
+// partials are summed -- and laid out as the [Cout][Cin][k][k] gradient -- by wgrad_bf16_reduce_kernel.
+#include "common.h"
+
+int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, int N, long long rs, int k, int pad, int Wp,
+                            long long copy, int splits, int chunks, hipStream_t stream);
+
+struct WgradBf16Plan {
+    int pad, Hp, Wp, G, splits, chunks, taps;
+    long long Q, Qk, rs;          // real cells, cells covered by the K loop, row length (elements, guards included)
+    long long off_dy, off_x, off_part, bytes;   // workspace layout
+};
+
+static bool wgrad_bf16_plan(int N, int H, int W, int Cin, int Cout, int k, WgradBf16Plan* pl) {
+    if (!(k == 1 || k == 3) || N <= 0 || H <= 0 || W <= 0 || Cin % 256 != 0 || Cout % 64 != 0) return false;
+    pl->pad = k / 2;
+    pl->Hp = H + 2 * pl->pad;
+    pl->Wp = (W + 2 * pl->pad + 7) / 8 * 8;
+    pl->G = pl->Wp + 8;                                  // guard in front of and behind the cells: |shift| <= Wp + 1
+    pl->Q = (long long)N * pl->Hp * pl->Wp;
+    pl->taps = k * k;
+    const long long tilesMN = (long long)((Cout + 255) / 256) * (Cin / 256);
+    const long long chunks_all = (pl->Q + 63) / 64;
+    // equal workgroups: as many splits (a multiple of 8: one share per XCD) as fill four rounds of 256 CUs without starting a
+    // fifth, each of at least 8 chunks
+    long long splits = 1024 / (8 * pl->taps * tilesMN) * 8;
+    if (splits > chunks_all / 8 / 8 * 8) splits = chunks_all / 8 / 8 * 8;
+    if (splits < 8) splits = 8;
+    pl->splits = (int)splits;
+    pl->chunks = (int)((chunks_all + splits - 1) / splits);
+    pl->Qk = (long long)pl->splits * pl->chunks * 64;
+    pl->rs = pl->G + pl->Qk + pl->G;
+    pl->rs = (pl->rs + 63) / 64 * 64;
+    if (pl->rs >= (1ll << 30) || (long long)Cout * pl->rs * 2 >= (1ll << 31) || (long long)Cin * pl->rs * 2 >= (1ll << 31)) return false;
+    pl->off_dy = 0;
+    pl->off_x = (long long)Cout * pl->rs * 2;
+    pl->off_part = pl->off_x + (long long)k * Cin * pl->rs * 2;
+    pl->bytes = pl->off_part + (long long)pl->splits * pl->taps * Cout * Cin * 4;
+    return true;
+}
+
+// src (N,H,W,C) NHWC (fp32 or bf16) -> NC copies dst_j[c][rs] bf16 (copy j at dst + j * copy): dst_j[c][G + q] = src at cell
+// (q + j - NC / 2), zero at border / guard cells.  One workgroup = 64 positions x 64 channels through LDS: 16-byte reads along the
+// channels, 16-byte writes along the cells; the source cells (64 + NC - 1 of them) are read once for all copies.
+template <bool SRC_BF16, int NC>
+__global__ __launch_bounds__(256) void wgrad_bf16_transpose_kernel(const void* __restrict__ src, unsigned short* __restrict__ dst,
+                                                                   int N, int H, int W, int C, int pad, int Hp, int Wp, int G,
+                                                                   long long rs, long long copy) {
+    constexpr int ROWS = 64 + NC - 1;
+    __shared__ unsigned short tile[ROWS][72];    // [cell][channel], rows padded against bank conflicts of the column reads
+    const long long r0 = (long long)blockIdx.x * 64;     // first row position of this block (0 = start of the leading guard)
+    const int c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    {
+        const int c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < (ROWS + 15) / 16; ++j) {
+            const int t = (tid >> 4) + 16 * j;
+            if (t >= ROWS) break;
+            const int q = (int)(r0 + t) - G - NC / 2;           // padded cell of tile row t (the plan keeps rs < 2^30)
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q >= 0 && q < N * Hp * Wp) {
+                const int n = q / (Hp * Wp);
+                const int rem = q - n * Hp * Wp;
+                const int yp = rem / Wp, xp = rem - yp * Wp;
+                const int y = yp - pad, x = xp - pad;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                    const size_t e = (((size_t)n * H + y) * W + x) * C + c0 + c4;
+                    if (SRC_BF16) {
+                        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(src) + e);
+                        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+                        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+                    } else {
+                        const f32x4 f = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + e);
+                        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[t][c4 + e] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);
+        }
+    }
+    __syncthreads();
+    {
+        const int q8 = (tid & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = (tid >> 3) + 32 * j;
+#pragma unroll
+            for (int cp = 0; cp < NC; ++cp) {       // copy cp at position i shows tile row i + cp
+                unsigned short o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = tile[q8 + e + cp][ch];
+                uint4 w;
+                w.x = o[0] | ((unsigned)o[1] << 16); w.y = o[2] | ((unsigned)o[3] << 16);
+                w.z = o[4] | ((unsigned)o[5] << 16); w.w = o[6] | ((unsigned)o[7] << 16);
+                *reinterpret_cast<uint4*>(dst + (size_t)cp * copy + (size_t)(c0 + ch) * rs + r0 + q8) = w;
+            }
+        }
+    }
+}
+
+// part [splits][taps][Cout][Cin] fp32 -> grad [Cout][Cin][k][k] (the nn.Conv2d weight layout), summed over the splits: a block sums
+// 64 consecutive elements, its four 64-thread rows take every fourth split
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int splits,
+                                                                int taps, int Cout, int Cin, int accumulate) {
+    __shared__ float red[4][64];
+    const long long per = (long long)Cout * Cin;
+    const long long i = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // (tap, co, ci), ci fastest; per % 64 == 0
+    const int row = threadIdx.x >> 6;
+    const int tap = (int)(i / per);
+    const long long r = i - (long long)tap * per;
+    float s = 0.f;
+    if (i < per * taps)
+        for (int sp = row; sp < splits; sp += 4) s += part[((long long)sp * taps + tap) * per + r];
+    red[row][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (row == 0 && i < per * taps) {
+        s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float* g = grad + r * taps + tap;
+        *g = accumulate ? *g + s : s;
+    }
+}
+
+// workspace size in units of 256 bytes (the byte count of a B=64 head layer does not fit the int every entry point returns)
+extern "C" int cpr_conv_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout, int k) {
+    WgradBf16Plan pl;
+    if (!wgrad_bf16_plan(N, H, W, Cin, Cout, k, &pl)) return CPR_ERR_UNSUPPORTED;
+    const long long units = (pl.bytes + 255) / 256;
+    return units < (1ll << 31) ? (int)units : CPR_ERR_UNSUPPORTED;
+}
+
+// dy (N,H,W,Cout) fp32; x (N,H,W,Cin) fp32 or bf16 (x_bf16); grad [Cout][Cin][k][k] fp32 (accumulate: += ); ws: workspace of
+// cpr_conv_wgrad_bf16_workspace x 256 bytes, 256-byte aligned.  k in {1, 3}, stride 1, padding k / 2, Cin % 256 == 0, Cout % 64 == 0.
+extern "C" int cpr_conv_wgrad_bf16(const float* dy, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W,
+                                   int Cin, int Cout, int k, int accumulate, hipStream_t stream) {
+    CPR_CHECK_ARG(dy && x && grad && ws);
+    WgradBf16Plan pl;
+    if (!wgrad_bf16_plan(N, H, W, Cin, Cout, k, &pl)) return CPR_ERR_UNSUPPORTED;
+    unsigned short* dyT = reinterpret_cast<unsigned short*>((char*)ws + pl.off_dy);
+    unsigned short* xT = reinterpret_cast<unsigned short*>((char*)ws + pl.off_x);
+    float* part = reinterpret_cast<float*>((char*)ws + pl.off_part);
+    const unsigned rows = (unsigned)(pl.rs / 64);
+    const long long copy = (long long)Cin * pl.rs;
+    hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<false, 1>), dim3(rows, Cout / 64), dim3(256), 0, stream, dy, dyT, N, H, W, Cout,
+                       pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, 0ll);
+    if (k == 3) {
+        if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<true, 3>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H,
+                                       W, Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);
+        else hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<false, 3>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H, W,
+                                Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);
+    } else {
+        if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<true, 1>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H,
+                                       W, Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);
+        else hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<false, 1>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H, W,
+                                Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);
+    }
+    const int rc = conv_bf16_dma_nt_launch(dyT + pl.G, xT + pl.G, part, Cout, Cin, pl.rs, k, pl.pad, pl.Wp, copy, pl.splits, pl.chunks,
+                                           stream);
+    if (rc != CPR_OK) return rc;
+    const long long n = (long long)pl.taps * Cout * Cin;
+    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, part, grad, pl.splits,
+                       pl.taps, Cout, Cin, accumulate);
+    CPR_LAUNCH_STATUS();
+}

@@ -748,6 +748,33 @@ def conv2d_dgrad(dy, pc_t, in_hw, stride=1, mask=None, add=None, colsum=False):
     return out
 
 
+def conv_wgrad_bf16_supported(x_shape, weight_shape, stride, padding):
+    """Shapes csrc/conv_wgrad_bf16.hip takes: stride 1, 1x1 or 3x3 / padding 1, Cin % 256 == 0, Cout % 64 == 0."""
+    Cout, Cin, KH, KW = weight_shape
+    if KH == 1 and Cout < 256:      # measured (tools/wgrad_bf16_bench.py): the two rewrites cost what the bf16 GEMM saves
+        return False
+    return stride == 1 and KH == KW and KH in (1, 3) and padding == KH // 2 and Cin % 256 == 0 and Cout % 64 == 0 and \
+        _lib.call('cpr_conv_wgrad_bf16_workspace', x_shape[0], x_shape[1], x_shape[2], Cin, Cout, KH, positive=True) > 0
+
+
+def conv_wgrad_bf16(dy, x, weight_shape, out=None, accumulate=False):
+    """Weight gradient of a stride-1 conv on the bf16 matrix cores (mixed-precision training step): dy (N,H,W,Cout) fp32,
+    x (N,H,W,Cin) bf16 or fp32 (rounded to bf16 on the way in) -> [Cout][Cin][k][k] fp32."""
+    N, H, W, Cin = x.shape
+    Cout, Cin_w, KH, KW = weight_shape
+    assert Cin_w == Cin and tuple(dy.shape) == (N, H, W, Cout) and dy.dtype == torch.float32 and KH == KW
+    assert x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and dy.is_contiguous()
+    units = _lib.call('cpr_conv_wgrad_bf16_workspace', N, H, W, Cin, Cout, KH, positive=True)
+    ws = torch.empty((units * 256,), device=x.device, dtype=torch.uint8)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
+    assert tuple(out.shape) == tuple(weight_shape) and out.is_contiguous() and out.dtype == torch.float32
+    _lib.call('cpr_conv_wgrad_bf16', _ptr(dy), _ptr(x), int(x.dtype == torch.bfloat16), _ptr(out), _ptr(ws), N, H, W, Cin, Cout,
+              KH, int(accumulate), _stream())
+    return out
+
+
 def conv3x3_wino_wgrad(dy, x, weight_shape, in_ab=None, in_relu=False, grad=None, out=None):
     """Weight gradient of a 3x3 / stride 1 / pad 1 conv as fused Winograd F(2x2,3x3) (csrc/conv_wino_wgrad.hip: 16 GEMMs over
     the tiles, 2.25x fewer multiplies).  Same arguments as conv2d_wgrad; Cin % 64 == 0, Cout % 64 == 0."""

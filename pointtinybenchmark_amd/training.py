@@ -11,11 +11,16 @@ moment their gradient becomes final during the backward (head first, backbone st
 flat buffers of the same layout.  Buckets are contiguous ranges of the gradient buffer: each is all-reduced (RCCL) as
 soon as its last gradient has been enqueued, overlapping with the rest of the backward; the optimizer is one kernel over
 the flat buffers (the clip coefficient is read from the device, no host sync)."""
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import ops
 from .layers import bump_weight_epoch, folded_bn
+
+
+WINO_DGRAD = [os.environ.get('CPR_WINO_DGRAD', '1') == '1']     # A/B switch (tools): 3x3 data gradients as Winograd + a mask pass
 
 
 class GradBuckets:
@@ -335,9 +340,14 @@ class CprTrainer:
         assert cm.conv.bias is None
         draw, _, _ = ops.gn_bwd(self._f32(rec['raw']), dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
                                 out_dgamma=gn.weight.grad, out_dbeta=gn.bias.grad)
-        x = self._f32(rec['x'])
-        self._param_side(lambda: ops.conv2d_wgrad(draw, x, w.shape, cm.conv.stride[0], cm.conv.padding[0],
-                                                  in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=w.grad), draw, x)
+        if rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
+                rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0]):
+            x = rec['x']       # mixed precision: the weight gradient on the bf16 matrix pipe, straight from the recorded map
+            self._param_side(lambda: ops.conv_wgrad_bf16(draw, x, w.shape, out=w.grad), draw, x)
+        else:
+            x = self._f32(rec['x'])
+            self._param_side(lambda: ops.conv2d_wgrad(draw, x, w.shape, cm.conv.stride[0], cm.conv.padding[0],
+                                                      in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=w.grad), draw, x)
         if not need_dx:
             return None
         if rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and w.shape[0] % 64 == 0:
@@ -472,7 +482,10 @@ class CprTrainer:
 
             def param_grads():
                 cs = colsum.reduce() if isinstance(colsum, ops.TilePartials) else colsum
-                ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=w.grad)
+                if self._mixed and ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0]):
+                    ops.conv_wgrad_bf16(g, x, w.shape, out=w.grad)      # (x is the widened recorded map: rounds back exactly)
+                else:
+                    ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=w.grad)
                 ops.bn_fold_bwd(w.grad, w, scale, bn.running_mean, inv_sigma, cs,
                                 out_dgamma=bn.weight.grad if aff else None, out_dbeta=bn.bias.grad if aff else None)
             self._param_side(param_grads, g, colsum)
@@ -493,6 +506,14 @@ class CprTrainer:
             return (dx, cs) if want_colsum else dx
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
                        lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
+        if WINO_DGRAD[0] and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and add is None and \
+                (mask is not None or want_colsum) and ops.wino_eligible(pt, x.shape[1], x.shape[2], torch.float32):
+            # a 3x3 stride-1 data gradient with a mask / column-sum epilogue would run the direct kernel (2.25x the multiplies of
+            # the Winograd launch the plain form gets); the epilogue as one streaming pass over the result is cheaper
+            dx = ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), 1)
+            gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
+            dx = gm if mask is not None else dx
+            return (dx, cs) if want_colsum else dx
         return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
 
     def _block_backward(self, cache, blk, rec, dout, need_dx):

@@ -181,3 +181,47 @@ def test_bf16_path_vs_fp32_oracle(cfg):
         assert abs(a - b) <= 3e-2 * max(abs(b), 1e-3), (k, a, b)
         assert abs(float(fused[k]) - a) <= 1e-5 * max(abs(a), 1e-6)
     assert all(bool(torch.isfinite(d).all()) for d, _ in dets)
+
+
+WGRAD_BF16_CASES = [
+    # N, H, W, Cin, Cout, k, x dtype
+    (2, 16, 16, 256, 256, 3, 'bf16'),      # the head / FPN shape in small: 9 taps, three kw copies
+    (3, 13, 21, 256, 128, 3, 'bf16'),      # ragged map (Wp = 24), fewer gradient rows than a tile
+    (1, 8, 40, 512, 64, 3, 'f32'),         # two cin tiles, fp32 x rounded on the way in
+    (2, 24, 24, 256, 512, 1, 'bf16'),      # 1x1 (a lateral): one tap, no border
+    (4, 10, 10, 256, 320, 3, 'bf16'),      # Cout not a multiple of the 256-row tile
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_BF16_CASES, ids=lambda c: 'n%d_%dx%d_c%d_o%d_k%d_%s' % c)
+def test_conv_wgrad_bf16_vs_fp64(case):
+    """csrc/conv_wgrad_bf16.hip (mixed-precision step): channel-major zero-bordered bf16 copies of both maps + one NT GEMM per tap on
+    the LDS-DMA kernel, split over the pixels, fp32 partial sums.  Against torch's fp64 weight gradient of the SAME bf16-rounded
+    operands only the fp32 summation order differs: 2e-4 of the gradient's max; against the unrounded operands bf16's 8 bits show
+    (3e-2 relative L2).  Accumulating into an existing gradient adds exactly."""
+    from pointtinybenchmark_amd import ops
+    N, H, W, Cin, Cout, k, xdt = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn((N, Cin, H, W), generator=g)
+    dy = torch.randn((N, Cout, H, W), generator=g) * 0.1
+    assert ops.conv_wgrad_bf16_supported((N, H, W, Cin), (Cout, Cin, k, k), 1, k // 2)
+    xr, dyr = x.bfloat16().double(), dy.bfloat16().double()
+    wz = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wz, padding=k // 2).backward(dyr)
+    ref = wz.grad
+    xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    if xdt == 'bf16':
+        xc = xc.bfloat16()
+    dyc = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    got = ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k))
+    torch.cuda.synchronize()
+    err = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-4, 'bf16 weight gradient vs fp64 on the rounded operands: %.3e of the max' % err
+    wf = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wf, padding=k // 2).backward(dy.double())
+    rel = float((got.cpu().double() - wf.grad).norm() / wf.grad.norm())
+    assert rel <= 3e-2, rel
+    acc = got.clone()
+    ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k), out=acc, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(acc, got + got)
