@@ -18,7 +18,6 @@
 // The accumulation order per output element is the tiled kernel's (8-wide k groups, lanes < 32 take k0..k0+3, lanes >= 32
 // k0+4..k0+7, four MFMAs per group) and so is the epilogue arithmetic: results are BIT-IDENTICAL to conv_mfma_kernel, which
 // keeps serving the shapes this kernel does not take (tests/test_gpu_kernels.py compares the two).
-#include <type_traits>
 #include "common.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));

@@ -1,14 +1,15 @@
 """Mixed-precision training step (bf16 recorded forward, fp32 backward) against the fp32 step on the same weights and batch:
 losses, cosine of the full gradient, relative L2 per large tensor (measurement tool; the bars live in
-tests/test_gpu_train_step.py::test_mixed_precision_step_tracks_the_fp32_step).
-  python tools/mixed_precision_grad_check.py"""
+tests/test_gpu_train_step.py::test_mixed_precision_step_tracks_the_fp32_step; lives under tests/ because it shares the parity tests'
+case table and model builder).
+  python tests/report_mixed_precision_grads.py"""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.gen_golden import CPR_CASES  # noqa: E402  (case definitions only; no oracle arithmetic runs here)
+from oracle.gen_golden import CPR_CASES  # noqa: E402  (case definitions only)
 from pointtinybenchmark_amd import synthetic  # noqa: E402
 from pointtinybenchmark_amd.training import CprTrainer  # noqa: E402
 from tests.test_gpu_cpr_parity import build_hip_locator, to_cuda  # noqa: E402
