@@ -586,6 +586,7 @@ class P2PTrainer(CprTrainer):
     @staticmethod
     def _forward_head(head, lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes):
         assert len(lazy) == 1 and head.num_points == 1, 'single level, one point per cell (the shipped P2P configs)'
+        assert lazy[0][0].dtype == torch.float32, 'the mixed-precision step covers the CPR locator; P2PNet trains in fp32'
         raw, (a, b) = lazy[0]
         x = ops.gn_apply(raw, a, b, relu=False)                   # FPN output, materialised once for the two towers
         cls_tape, reg_tape, save = [], [], {}
