@@ -57,8 +57,8 @@ int cpr_conv2d_dual_fwd(const float* in, const float* wgt, const float* in2, con
 
 /* The HBM-bound 1x1 convs of the bottleneck (conv3 + bn3 + shortcut add + ReLU and the like, T/mmdet/models/backbones/resnet.py:
  * 262-302) as a stream: one persistent workgroup per CU, weight panel resident in LDS, pixel tiles through LDS-DMA
- * (csrc/conv1x1_stream.hip).  in [M][Cin], wgt [Cout][Cin], out / residual [M][Cout]; Cin in {64, 128}, M a multiple of
- * 8192 / Cin, Cout a multiple of 16384 / Cin, flags = CPR_CONV_RELU | CPR_CONV_RES_MASK; CPR_ERR_UNSUPPORTED otherwise.
+ * (csrc/conv1x1_stream.hip).  in [M][Cin], wgt [Cout][Cin], out / residual [M][Cout]; Cin in {64, 128}: M a multiple of
+ * 8192 / Cin, Cout a multiple of 16384 / Cin; Cin = 256: M a multiple of 128, Cout of 64 (a power of two up to 2048); flags = CPR_CONV_RELU | CPR_CONV_RES_MASK; CPR_ERR_UNSUPPORTED otherwise.
  * cpr_conv2d_fwd takes this path by itself for such shapes when the launch has >= 1024 tiles; the results are bit-identical to
  * its tiled kernel (same accumulation order, same epilogue), this entry exists for tests and tools. */
 int cpr_conv1x1_stream_fwd(const float* in, const float* wgt, float* out, const float* scale, const float* bias,

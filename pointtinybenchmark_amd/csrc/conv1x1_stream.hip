@@ -14,7 +14,8 @@
 //   tile t: request tile t+1 | request the residual rows of tile t (they fly during the MFMAs) | MFMAs over the whole K |
 //           wait + ONE barrier | affine + residual + ReLU, stores.  In flight per CU during the MFMAs: the next pixel tile,
 //           this tile's residual and the previous tile's stores (~290 KB).
-// K = Cin in {64, 128}: BM x BN = 128 x 256 / 64 x 128 (weight panel and each pixel tile are 64 KB / 32 KB for both).
+// K = Cin in {64, 128}: BM x BN = 128 x 256 / 64 x 128 (weight panel and each pixel tile are 64 KB / 32 KB for both); K = 256: a
+// second kernel below streams the tile in four k chunks.
 // The accumulation order per output element is the tiled kernel's (8-wide k groups, lanes < 32 take k0..k0+3, lanes >= 32
 // k0+4..k0+7, four MFMAs per group) and so is the epilogue arithmetic: results are BIT-IDENTICAL to conv_mfma_kernel, which
 // keeps serving the shapes this kernel does not take (tests/test_gpu_kernels.py compares the two).
@@ -187,26 +188,148 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(StreamParams p) 
     }
 }
 
+// K = 256 (conv1 of the 256-channel stages, conv3 of layer3: 160x160 256->64 / ->128, 40x40 256->1024 + shortcut): the weight panel
+// is [64 couts][256] (64 KB, stored as four 64-wide k chunks), a pixel tile [128][256] streams through as four chunks of [128][64]
+// (32 KB each, double-buffered) -- one barrier per chunk, 32 MFMAs per wave between barriers, 8 waves = 4 (pixels) x 2 (couts), one
+// 32 x 32 block each.  The chunk stream runs across tiles (the first chunk of tile t+1 is requested behind the last MFMAs of tile t);
+// the residual rows of a tile are requested behind its first chunk.  Same accumulation order as the tiled kernel (k ascending).
+__global__ __launch_bounds__(512, 1) void conv1x1_stream_k256_kernel(StreamParams p) {
+    constexpr int K = 256, BM = 128, BN = 64, KC = 64, NCH = K / KC;
+    __shared__ __attribute__((aligned(16))) float smem[BN * K + 2 * BM * KC];
+    float* Bs = smem;                 // [chunk][64][64]
+    float* As = smem + BN * K;        // [2][128][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int NT = p.tilesN, G = gridDim.x;
+    const int b = blockIdx.x;
+    const int tn = (b >> 3) % NT;
+    const int s0 = (b & 7) + 8 * ((b >> 3) / NT), sstep = G / NT;
+    const int n0 = tn * BN;
+
+    // LDS-DMA: a [rows][64] chunk block = 16 units of 16 bytes per row; piece q = units 512 q + tid -> row 32 q + tid / 16, slot
+    // tid % 16 holding the row's unit slot ^ (row & 15); global rows are K floats apart, the chunk is a 256-byte column offset
+    const int prow = tid >> 4, pslot = tid & 15;
+    const int voff = prow * (K * 4) + ((pslot ^ (prow & 15)) << 4);
+    const size_t in_addr = (size_t)p.in, w_addr = (size_t)p.wgt;
+    const i32x4 rs_in = {(int)(unsigned)in_addr, (int)(unsigned)(in_addr >> 32) & 0xffff, (int)((size_t)p.M * K * 4), 0x00020000};
+    const i32x4 rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32) & 0xffff, (int)((size_t)p.Cout * K * 4), 0x00020000};
+    const int lds_b = (int)(unsigned)(size_t)Bs, lds_a = (int)(unsigned)(size_t)As;
+    auto dma = [&](const i32x4& rs, int lds_dst, int row0, int kc, int q) {
+        const int m0v = __builtin_amdgcn_readfirstlane(lds_dst + q * 8192 + wave * 1024);
+        const int soff = __builtin_amdgcn_readfirstlane((row0 + 32 * q) * (K * 4) + kc * (KC * 4));
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:0 lds"
+                     :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    };
+    auto dma_chunk = [&](int mt, int kc, int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma(rs_in, lds_a + buf * (BM * KC * 4), mt * BM, kc, q);
+    };
+    const int hx = half ^ (l31 & 15);
+    const float* a_row = As + (wm * 32 + l31) * KC;
+    const float* b_row = Bs + (wn * 32 + l31) * KC;
+
+    const unsigned row_bytes = (unsigned)p.Cout * 4u;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual : p.out), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+    const int cch = n0 + wn * 32 + l31;
+    const float sc = p.scale ? p.scale[cch] : 1.f, bi = p.bias ? p.bias[cch] : 0.f;
+
+    if (s0 < p.tilesM) {
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) dma(rs_w, lds_b + kc * (BN * KC * 4), n0, kc, q);
+        dma_chunk(s0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int buf = 0;
+    for (int mt = s0; mt < p.tilesM; mt += sstep) {
+        const int m0 = mt * BM;
+        const unsigned off0 = (unsigned)((m0 + wm * 32 + 4 * half) * p.Cout + cch) * 4u;
+        float res[16];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) {
+            // the next chunk of the stream -> the other buffer (every wave is past its reads of it: barrier at the end of the last chunk)
+            if (kc + 1 < NCH) dma_chunk(mt, kc + 1, buf ^ 1);
+            else if (mt + sstep < p.tilesM) dma_chunk(mt + sstep, 0, buf ^ 1);
+            if (kc == 0) {
+                if (p.residual) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rs_res, (int)off0, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes), 0));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) res[r] = 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4 fa0, fb0, fa1, fb1;
+            const float* ap = a_row + buf * (BM * KC);
+            const float* bp = b_row + kc * (BN * KC);
+            fa0 = *reinterpret_cast<const f32x4*>(ap + ((0 ^ hx) << 2));
+            fb0 = *reinterpret_cast<const f32x4*>(bp + ((0 ^ hx) << 2));
+#pragma unroll
+            for (int kk = 0; kk < 8; kk += 2) {
+                fa1 = *reinterpret_cast<const f32x4*>(ap + (((2 * (kk + 1)) ^ hx) << 2));
+                fb1 = *reinterpret_cast<const f32x4*>(bp + (((2 * (kk + 1)) ^ hx) << 2));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc, 0, 0, 0);
+                if (kk + 2 < 8) {
+                    fa0 = *reinterpret_cast<const f32x4*>(ap + (((2 * (kk + 2)) ^ hx) << 2));
+                    fb0 = *reinterpret_cast<const f32x4*>(bp + (((2 * (kk + 2)) ^ hx) << 2));
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc, 0, 0, 0);
+            }
+            // the next chunk has landed (behind the first chunk of a tile its 16 residual requests are younger and may stay in flight)
+            if (kc == 0 && p.residual) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r] * sc + bi;
+            if (p.res_mask) v = res[r] > 0.f ? v : 0.f;
+            else v += res[r];
+            if (p.relu) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, (int)off0,
+                                                  (int)((unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes), 0);
+        }
+    }
+}
+
 // Takes the launch when it is one of the streamed shapes; CPR_ERR_UNSUPPORTED = not ours (the caller runs the tiled kernel).
 int conv1x1_stream_launch(const float* in, const float* wgt, float* out, const float* scale, const float* bias,
                           const float* residual, long long M, int Cin, int Cout, int relu, int res_mask, int min_tiles,
                           hipStream_t stream) {
-    if (!(Cin == 64 || Cin == 128)) return CPR_ERR_UNSUPPORTED;
-    const int bm = 8192 / Cin, bn = 16384 / Cin;
+    if (!(Cin == 64 || Cin == 128 || Cin == 256)) return CPR_ERR_UNSUPPORTED;
+    const int bm = Cin == 256 ? 128 : 8192 / Cin, bn = Cin == 256 ? 64 : 16384 / Cin;
     if (M <= 0 || M % bm != 0 || Cout % bn != 0) return CPR_ERR_UNSUPPORTED;
     if (M * Cin * 4 >= (1ll << 31) || M * Cout * 4 >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
     StreamParams p;
     p.in = in; p.wgt = wgt; p.out = out; p.scale = scale; p.bias = bias; p.residual = residual;
     p.M = (int)M; p.Cout = Cout; p.relu = relu; p.res_mask = res_mask;
     p.tilesM = (int)(M / bm); p.tilesN = Cout / bn;
-    if (p.tilesN > 8 || 32 % p.tilesN != 0) return CPR_ERR_UNSUPPORTED;         // panels of a pixel tile share an XCD: 8 NT | grid
+    if (p.tilesN > 32 || 32 % p.tilesN != 0) return CPR_ERR_UNSUPPORTED;        // panels of a pixel tile share an XCD: 8 NT | grid
     if ((long long)p.tilesM * p.tilesN < min_tiles) return CPR_ERR_UNSUPPORTED;  // too few tiles to fill 256 persistent workgroups
     if (res_mask && !residual) return CPR_ERR_ARG;
     int grid = 256;                                                              // one workgroup per CU, a multiple of 8 NT
     const long long need = ((long long)p.tilesM + 7) / 8 * 8 * p.tilesN;
     if (need < grid) grid = (int)need;
     if (Cin == 64) hipLaunchKernelGGL(conv1x1_stream_kernel<64>, dim3(grid), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL(conv1x1_stream_kernel<128>, dim3(grid), dim3(512), 0, stream, p);
+    else if (Cin == 128) hipLaunchKernelGGL(conv1x1_stream_kernel<128>, dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(conv1x1_stream_k256_kernel, dim3(grid), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }
 

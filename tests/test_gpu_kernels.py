@@ -112,6 +112,10 @@ STREAM_CASES = [
     (5, 8, 8, 128, 128, 0, True),        # one panel, 5 tiles of 64 pixels
     (64, 16, 16, 64, 256, 1, True),      # 128 tiles over 128 workgroups ... and enough rows to wrap the double buffer
     (9, 32, 32, 128, 256, 1, False),     # odd tile counts per workgroup
+    (2, 32, 32, 256, 64, 0, True),       # K = 256: four k chunks stream through per 128-pixel tile (conv1 of a 256-channel stage)
+    (3, 16, 16, 256, 1024, 1, True),     # conv3 of layer3: 16 cout panels, shortcut add
+    (1, 16, 24, 256, 128, 2, False),     # three tiles, two panels, mask epilogue
+    (5, 32, 32, 256, 256, 1, False),     # 40 tiles x 4 panels: several tiles per workgroup, the chunk stream crosses tiles
 ]
 
 
