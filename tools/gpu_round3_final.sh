@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 evidence visit: full GPU suite, smoke, default bench line, kernel-trace stats of the same command (B=64 and B=2), per-layer
-# conv table, PMC passes REGENERATED for the dominant (Winograd) kernel and the bf16 DMA kernel, training / bf16 / P2P / R101 lines.
+# conv table, PMC passes REGENERATED for the dominant (Winograd) kernel and the bf16 DMA kernel, training / bf16 / P2P / R101 lines,
+# the mixed-precision step, the bf16 weight gradient and the streamed 1x1 A/B.
 # Everything lands in gpurun_out/ (copy the summaries to profiles/).
 set -u
 cd "$(dirname "$0")/.."
@@ -27,6 +28,14 @@ timeout 300 python tools/conv_bench.py --batch 64 > gpurun_out/${TAG}_convbench.
 for m in "--model p2p --batch 16" "--model p2p --mode infer --batch 16" "--dtype bf16 --batch 64" "--depth 101 --size 1024 --batch 8" "--depth 101 --size 1024 --batch 8 --dtype bf16" "--mode train --batch 64"; do
   n=$(echo $m | tr -d ' -'); timeout 400 python bench.py $m --steps 8 --warmup 3 --no-cpu-baseline --no-probe --train-steps 0 --small-batch 0 --batch-sweep '' 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$n.json; cut -c1-200 gpurun_out/${TAG}_bench_$n.json; echo
 done
+# mixed-precision training step (bf16 compute mode in the trainer) next to the fp32 one, the bf16 weight gradient per layer, the
+# streamed 1x1 kernels against the tiled one
+for m in "--mode train --batch 64 --dtype bf16" "--mode train --depth 101 --size 1024 --batch 8 --dtype bf16" "--mode train --depth 101 --size 1024 --batch 8"; do
+  n=$(echo $m | tr -d ' -'); timeout 600 python bench.py $m --steps 6 --warmup 2 --no-cpu-baseline --no-probe 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$n.json; cut -c1-200 gpurun_out/${TAG}_bench_$n.json; echo
+done
+timeout 300 python tools/wgrad_bf16_bench.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_wgrad_bf16_bench.txt
+timeout 300 python tests/report_mixed_precision_grads.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_mixed_precision_grad_check.txt
+for s in 1 0; do timeout 300 python tools/conv_bench.py --batch 64 --stream $s 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_convbench_stream$s.txt; done
 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29621 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-probe --small-batch 0 --batch-sweep '' --train-steps 4 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_torchrun_1rank.json
 cut -c1-200 gpurun_out/${TAG}_bench_torchrun_1rank.json; echo
 ls gpurun_out | grep ${TAG}
