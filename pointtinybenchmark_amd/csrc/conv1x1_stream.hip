@@ -11,7 +11,8 @@
 //   staging registers, no ds_write, nothing in front of the MFMAs); rows are K floats, the 16-byte unit u of row r sits at
 //   u ^ (r & 15) -- applied on the SOURCE side of the DMA, whose LDS image is lane-linear -- so the 16 lanes of a
 //   ds_read_b128 service group hit 16 different slots.
-//   tile t: request tile t+1 | request the residual rows of tile t (they fly during the MFMAs) | MFMAs over the whole K |
+//   tile t: request tile t+1 | request the residual rows of tile t (they fly during the MFMAs; by LDS-DMA too where the
+//           tile's residual fits the 32 KB of LDS left, i.e. K = 128 and K = 256, else 16 dword loads per block) | MFMAs over the whole K |
 //           wait + ONE barrier | affine + residual + ReLU, stores.  In flight per CU during the MFMAs: the next pixel tile,
 //           this tile's residual and the previous tile's stores (~290 KB).
 // K = Cin in {64, 128}: BM x BN = 128 x 256 / 64 x 128 (weight panel and each pixel tile are 64 KB / 32 KB for both); K = 256: a
@@ -40,9 +41,11 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(StreamParams p) 
     constexpr int WM = BM / 2, WN = BN / 4;        // 8 waves = 2 (pixels) x 4 (couts)
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int KK = K / 8;                      // 8-wide k groups
-    __shared__ __attribute__((aligned(16))) float smem[(BN + 2 * BM) * K];
+    constexpr bool RLDS = BM * BN * 4 <= 32768;    // the tile's residual rows fit the 32 KB of LDS left: they come by LDS-DMA too
+    __shared__ __attribute__((aligned(16))) float smem[(BN + 2 * BM) * K + (RLDS ? BM * BN : 0)];
     float* Bs = smem;
     float* As = smem + BN * K;
+    float* Rs = smem + (BN + 2 * BM) * K;          // RLDS: [BM pixels][BN couts], the tile's rows of the residual map as they lie in HBM
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,6 +78,22 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(StreamParams p) 
     auto dma_tile = [&](int mt, int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dma(rs_in, lds_a + buf * (BM * K * 4), mt * BM, q);
+    };
+    // RLDS: piece q of the residual tile = 512 units of 16 bytes; a row of the tile is BN / 4 units, unit P = 512 q + tid -> row
+    // P / (BN / 4), unit P % (BN / 4); rows are Cout floats apart in HBM
+    const size_t r_addr = (size_t)(p.residual ? p.residual : p.out);
+    const i32x4 rs_r = {(int)(unsigned)r_addr, (int)(unsigned)(r_addr >> 32) & 0xffff, (int)((size_t)p.M * p.Cout * 4), 0x00020000};
+    constexpr int RUPR = BN / 4, RPIECES = RLDS ? BM * BN * 4 / 8192 : 0;
+    const int rvoff = ((tid / RUPR) * p.Cout + (tid % RUPR) * 4) * 4;
+    const int lds_r = (int)(unsigned)(size_t)Rs;
+    auto dma_res = [&](int mt) {
+#pragma unroll
+        for (int q = 0; q < RPIECES; ++q) {
+            const int m0v = __builtin_amdgcn_readfirstlane(lds_r + q * 8192 + wave * 1024);
+            const int soff = __builtin_amdgcn_readfirstlane(((mt * BM + q * (512 / RUPR)) * p.Cout + n0) * 4);
+            asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:0 lds"
+                         :: "s"(m0v), "v"(rvoff), "s"(rs_r), "s"(soff) : "memory");
+        }
     };
 
     // ---- fragments: A[m = l31][k], B[cout = l31][k]; lane reads the 4 floats k0 + 4 half .. +3 of an 8-wide group
@@ -126,7 +145,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(StreamParams p) 
                 const int c = n0 + wn * WN + j * 32 + l31;
                 const int rbase = m0 + wm * WM + i * 32 + 4 * half;
                 off0[i][j] = (unsigned)(rbase * p.Cout + c) * 4u;
-                if (p.residual) {
+                if (RLDS) {
+                } else if (p.residual) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         res[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -136,6 +156,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(StreamParams p) 
                     for (int r = 0; r < 16; ++r) res[i][j][r] = 0.f;
                 }
             }
+        if (RLDS && p.residual) dma_res(mt);     // (the residual buffer is free: barrier behind the previous tile's reads of it)
         __builtin_amdgcn_sched_barrier(0);
 
         f32x16 acc[MI][NI];
@@ -171,6 +192,19 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(StreamParams p) 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (RLDS) {      // residual values of this lane's outputs from LDS; a second barrier frees the buffer for the next tile's request
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[i][j][r] = p.residual ? Rs[(wm * WM + i * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) * BN + wn * WN + j * 32 + l31]
+                                                  : 0.f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
 
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -195,9 +229,10 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(StreamParams p) 
 // the residual rows of a tile are requested behind its first chunk.  Same accumulation order as the tiled kernel (k ascending).
 __global__ __launch_bounds__(512, 1) void conv1x1_stream_k256_kernel(StreamParams p) {
     constexpr int K = 256, BM = 128, BN = 64, KC = 64, NCH = K / KC;
-    __shared__ __attribute__((aligned(16))) float smem[BN * K + 2 * BM * KC];
+    __shared__ __attribute__((aligned(16))) float smem[BN * K + 2 * BM * KC + BM * BN];
     float* Bs = smem;                 // [chunk][64][64]
     float* As = smem + BN * K;        // [2][128][64]
+    float* Rs = As + 2 * BM * KC;     // [128 pixels][64 couts]: the tile's rows of the residual map, by LDS-DMA like the operands
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
@@ -226,14 +261,26 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_k256_kernel(StreamParam
 #pragma unroll
         for (int q = 0; q < 4; ++q) dma(rs_in, lds_a + buf * (BM * KC * 4), mt * BM, kc, q);
     };
+    // residual tile: 16 units of 16 bytes per row (64 couts), piece q = rows 32 q + tid / 16; rows are Cout floats apart in HBM
+    const size_t r_addr = (size_t)(p.residual ? p.residual : p.out);
+    const i32x4 rs_r = {(int)(unsigned)r_addr, (int)(unsigned)(r_addr >> 32) & 0xffff, (int)((size_t)p.M * p.Cout * 4), 0x00020000};
+    const int rvoff = ((tid >> 4) * p.Cout + (tid & 15) * 4) * 4;
+    const int lds_r = (int)(unsigned)(size_t)Rs;
+    auto dma_res = [&](int mt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m0v = __builtin_amdgcn_readfirstlane(lds_r + q * 8192 + wave * 1024);
+            const int soff = __builtin_amdgcn_readfirstlane(((mt * BM + 32 * q) * p.Cout + n0) * 4);
+            asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:0 lds"
+                         :: "s"(m0v), "v"(rvoff), "s"(rs_r), "s"(soff) : "memory");
+        }
+    };
     const int hx = half ^ (l31 & 15);
     const float* a_row = As + (wm * 32 + l31) * KC;
     const float* b_row = Bs + (wn * 32 + l31) * KC;
 
     const unsigned row_bytes = (unsigned)p.Cout * 4u;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.residual ? p.residual : p.out), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
     const int cch = n0 + wn * 32 + l31;
     const float sc = p.scale ? p.scale[cch] : 1.f, bi = p.bias ? p.bias[cch] : 0.f;
 
@@ -260,18 +307,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_k256_kernel(StreamParam
             // the next chunk of the stream -> the other buffer (every wave is past its reads of it: barrier at the end of the last chunk)
             if (kc + 1 < NCH) dma_chunk(mt, kc + 1, buf ^ 1);
             else if (mt + sstep < p.tilesM) dma_chunk(mt + sstep, 0, buf ^ 1);
-            if (kc == 0) {
-                if (p.residual) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rs_res, (int)off0, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * row_bytes), 0));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) res[r] = 0.f;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (kc == 0 && p.residual) dma_res(mt);      // four more requests, younger than the chunk's: they may stay in flight below
             f32x4 fa0, fb0, fa1, fb1;
             const float* ap = a_row + buf * (BM * KC);
             const float* bp = b_row + kc * (BN * KC);
@@ -290,13 +326,21 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_k256_kernel(StreamParam
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc, 0, 0, 0);
             }
-            // the next chunk has landed (behind the first chunk of a tile its 16 residual requests are younger and may stay in flight)
-            if (kc == 0 && p.residual) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            // the next chunk has landed (behind the first chunk of a tile its 4 residual requests are younger and may stay in flight)
+            if (kc == 0 && p.residual) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             buf ^= 1;
         }
+        // residual values of this lane's outputs (landed: the waits of chunks 1..3 drained the queue); the barrier frees the buffer
+        // for the next tile's request
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            res[r] = p.residual ? Rs[(wm * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) * BN + wn * 32 + l31] : 0.f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[r] * sc + bi;
