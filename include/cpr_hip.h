@@ -65,14 +65,14 @@ int cpr_conv1x1_stream_fwd(const float* in, const float* wgt, float* out, const 
                            const float* residual, long long M, int Cin, int Cout, int flags, void* stream);
 
 /* Weight gradient of a stride-1 conv (k = 1, or k = 3 with padding 1) on the bf16 matrix cores -- the mixed-precision training
- * step (reference analogue: torch autograd under mmcv's Fp16OptimizerHook, T/mmdet/apis/train.py:116-119).  dy (N,H,W,Cout) fp32,
- * x (N,H,W,Cin) fp32 or bf16 (x_bf16), grad [Cout][Cin][k][k] fp32 (accumulate: +=), Cin % 256 == 0, Cout % 64 == 0.  Both maps
+ * step (reference analogue: torch autograd under mmcv's Fp16OptimizerHook, T/mmdet/apis/train.py:116-119).  dy (N,H,W,Cout) and
+ * x (N,H,W,Cin) fp32 or bf16 (dy_bf16, x_bf16; fp32 maps are rounded on the way in), grad [Cout][Cin][k][k] fp32 (accumulate: +=), Cin % 256 == 0, Cout % 64 == 0.  Both maps
  * are rewritten channel-major over a zero-bordered pixel axis (bf16), every tap is an NT GEMM on the LDS-DMA kernel split over
  * the pixels, the partials are summed in fp32 (csrc/conv_wgrad_bf16.hip).  ws: cpr_conv_wgrad_bf16_workspace(...) x 256 bytes
  * (the query returns units of 256 bytes; negative = unsupported shape). */
 int cpr_conv_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout, int k);
-int cpr_conv_wgrad_bf16(const float* dy, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W, int Cin, int Cout,
-                        int k, int accumulate, void* stream);
+int cpr_conv_wgrad_bf16(const void* dy, int dy_bf16, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W, int Cin,
+                        int Cout, int k, int accumulate, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies than
  * cpr_conv2d_fwd; same call sites: the CPR head towers cpr_head.py:1033-1043, the FPN output conv fpn.py:190-194, the 3x3 of

@@ -143,9 +143,9 @@ extern "C" int cpr_conv_wgrad_bf16_workspace(int N, int H, int W, int Cin, int C
     return units < (1ll << 31) ? (int)units : CPR_ERR_UNSUPPORTED;
 }
 
-// dy (N,H,W,Cout) fp32; x (N,H,W,Cin) fp32 or bf16 (x_bf16); grad [Cout][Cin][k][k] fp32 (accumulate: += ); ws: workspace of
+// dy (N,H,W,Cout) fp32 or bf16 (dy_bf16); x (N,H,W,Cin) fp32 or bf16 (x_bf16); grad [Cout][Cin][k][k] fp32 (accumulate: += ); ws: workspace of
 // cpr_conv_wgrad_bf16_workspace x 256 bytes, 256-byte aligned.  k in {1, 3}, stride 1, padding k / 2, Cin % 256 == 0, Cout % 64 == 0.
-extern "C" int cpr_conv_wgrad_bf16(const float* dy, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W,
+extern "C" int cpr_conv_wgrad_bf16(const void* dy, int dy_bf16, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W,
                                    int Cin, int Cout, int k, int accumulate, hipStream_t stream) {
     CPR_CHECK_ARG(dy && x && grad && ws);
     WgradBf16Plan pl;
@@ -155,8 +155,10 @@ extern "C" int cpr_conv_wgrad_bf16(const float* dy, const void* x, int x_bf16, f
     float* part = reinterpret_cast<float*>((char*)ws + pl.off_part);
     const unsigned rows = (unsigned)(pl.rs / 64);
     const long long copy = (long long)Cin * pl.rs;
-    hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<false, 1>), dim3(rows, Cout / 64), dim3(256), 0, stream, dy, dyT, N, H, W, Cout,
-                       pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, 0ll);
+    if (dy_bf16) hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<true, 1>), dim3(rows, Cout / 64), dim3(256), 0, stream, dy, dyT, N, H, W,
+                                    Cout, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, 0ll);
+    else hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<false, 1>), dim3(rows, Cout / 64), dim3(256), 0, stream, dy, dyT, N, H, W, Cout,
+                            pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, 0ll);
     if (k == 3) {
         if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<true, 3>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H,
                                        W, Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);

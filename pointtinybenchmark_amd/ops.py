@@ -758,20 +758,21 @@ def conv_wgrad_bf16_supported(x_shape, weight_shape, stride, padding):
 
 
 def conv_wgrad_bf16(dy, x, weight_shape, out=None, accumulate=False):
-    """Weight gradient of a stride-1 conv on the bf16 matrix cores (mixed-precision training step): dy (N,H,W,Cout) fp32,
+    """Weight gradient of a stride-1 conv on the bf16 matrix cores (mixed-precision training step): dy (N,H,W,Cout) and
     x (N,H,W,Cin) bf16 or fp32 (rounded to bf16 on the way in) -> [Cout][Cin][k][k] fp32."""
     N, H, W, Cin = x.shape
     Cout, Cin_w, KH, KW = weight_shape
-    assert Cin_w == Cin and tuple(dy.shape) == (N, H, W, Cout) and dy.dtype == torch.float32 and KH == KW
-    assert x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and dy.is_contiguous()
+    assert Cin_w == Cin and tuple(dy.shape) == (N, H, W, Cout) and KH == KW
+    assert x.dtype in (torch.float32, torch.bfloat16) and dy.dtype in (torch.float32, torch.bfloat16)
+    assert x.is_contiguous() and dy.is_contiguous()
     units = _lib.call('cpr_conv_wgrad_bf16_workspace', N, H, W, Cin, Cout, KH, positive=True)
     ws = torch.empty((units * 256,), device=x.device, dtype=torch.uint8)
     if out is None:
         assert not accumulate
         out = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
     assert tuple(out.shape) == tuple(weight_shape) and out.is_contiguous() and out.dtype == torch.float32
-    _lib.call('cpr_conv_wgrad_bf16', _ptr(dy), _ptr(x), int(x.dtype == torch.bfloat16), _ptr(out), _ptr(ws), N, H, W, Cin, Cout,
-              KH, int(accumulate), _stream())
+    _lib.call('cpr_conv_wgrad_bf16', _ptr(dy), int(dy.dtype == torch.bfloat16), _ptr(x), int(x.dtype == torch.bfloat16), _ptr(out),
+              _ptr(ws), N, H, W, Cin, Cout, KH, int(accumulate), _stream())
     return out
 
 

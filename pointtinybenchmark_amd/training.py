@@ -340,18 +340,21 @@ class CprTrainer:
         assert cm.conv.bias is None
         draw, _, _ = ops.gn_bwd(self._f32(rec['raw']), dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
                                 out_dgamma=gn.weight.grad, out_dbeta=gn.bias.grad)
+        d16 = None             # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight and data gradients
+        dgrad16 = need_dx and rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and w.shape[0] % 64 == 0
         if rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
                 rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0]):
-            x = rec['x']       # mixed precision: the weight gradient on the bf16 matrix pipe, straight from the recorded map
-            self._param_side(lambda: ops.conv_wgrad_bf16(draw, x, w.shape, out=w.grad), draw, x)
+            x = rec['x']       # the weight gradient on the bf16 matrix pipe, straight from the recorded map
+            d16 = draw.to(torch.bfloat16)
+            self._param_side(lambda: ops.conv_wgrad_bf16(d16, x, w.shape, out=w.grad), d16, x)
         else:
             x = self._f32(rec['x'])
             self._param_side(lambda: ops.conv2d_wgrad(draw, x, w.shape, cm.conv.stride[0], cm.conv.padding[0],
                                                       in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=w.grad), draw, x)
         if not need_dx:
             return None
-        if rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and w.shape[0] % 64 == 0:
-            return self._dgrad_bf16(draw, w, cm.conv.padding[0])
+        if dgrad16:
+            return self._dgrad_bf16(draw if d16 is None else d16, w, cm.conv.padding[0])
         pt = ops.dgrad_pack(w, cm.conv.stride[0], cm.conv.padding[0])
         return ops.conv2d_dgrad(draw, pt, (rec['x'].shape[1], rec['x'].shape[2]), cm.conv.stride[0])
 
@@ -363,7 +366,7 @@ class CprTrainer:
         k = w.shape[2]
         wt = w.detach().flip(2, 3).permute(1, 0, 2, 3)
         pc = ops.PackedConv(wt, 1, k - 1 - padding, torch.bfloat16)
-        return ops.conv2d(dy.to(torch.bfloat16), pc, out_dtype=torch.float32)
+        return ops.conv2d(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), pc, out_dtype=torch.float32)
 
     # ------------------------------------------------------------------ CPR head
     @staticmethod
@@ -477,28 +480,32 @@ class CprTrainer:
         inv_sigma = cache.get(('bn_is', id(bn)), [bn.running_var],
                               lambda: ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, True)[2])
         w = conv.weight
+        # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight gradient and the bf16 3x3 data gradient
+        w16 = w.requires_grad and self._mixed and ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0])
+        d16 = need_dx and self._mixed and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and add is None
+        g16 = g.to(torch.bfloat16) if (w16 or d16) else None
         if w.requires_grad:
             aff = bn.weight.requires_grad
 
             def param_grads():
                 cs = colsum.reduce() if isinstance(colsum, ops.TilePartials) else colsum
-                if self._mixed and ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0]):
-                    ops.conv_wgrad_bf16(g, x, w.shape, out=w.grad)      # (x is the widened recorded map: rounds back exactly)
+                if w16:
+                    ops.conv_wgrad_bf16(g16, x, w.shape, out=w.grad)    # (x is the widened recorded map: rounds back exactly)
                 else:
                     ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=w.grad)
                 ops.bn_fold_bwd(w.grad, w, scale, bn.running_mean, inv_sigma, cs,
                                 out_dgamma=bn.weight.grad if aff else None, out_dbeta=bn.bias.grad if aff else None)
-            self._param_side(param_grads, g, colsum)
+            self._param_side(param_grads, g, colsum, g16)
         if not need_dx:
             return None
-        if self._mixed and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and add is None:
+        if d16:
             # mixed precision: the 3x3 data gradient on the bf16 matrix pipe (its fp32 form cannot be a Winograd launch: the mask /
             # column-sum epilogue), the ReLU mask and the column sums as one streaming pass over the (small) result
             def pack16():
                 wt = (w.detach() * scale[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3)
                 return ops.PackedConv(wt, 1, 2 - conv.padding[0], torch.bfloat16)
             pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16)
-            dx = ops.conv2d(g.to(torch.bfloat16), pc16, out_dtype=torch.float32)
+            dx = ops.conv2d(g16, pc16, out_dtype=torch.float32)
             if mask is None and not want_colsum:
                 return dx
             gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
