@@ -170,7 +170,7 @@ def test_wino_wgrad_matches_autograd(case):
 def test_lds_dma_staged_kernels_are_repeatable_under_memory_pressure():
     """The Winograd forward stages its weight image, and the bf16 256x256 kernel both operands, by LDS-DMA issued from inline
     asm with hand-counted vmcnt waits (csrc/conv_wino.hip, csrc/conv_bf16_dma.hip).  A wrong count or a missing barrier would
-    show as a timing-dependent difference, not on every launch: 60 launches of each kernel, while a second stream saturates
+    show as a timing-dependent difference, not on every launch: 60 launches of each such kernel, while a second stream saturates
     HBM with copies (latencies of the DMA requests vary by several x), must all be BIT-equal to the first quiet launch."""
     from pointtinybenchmark_amd import ops
     g = torch.Generator().manual_seed(11)
@@ -183,10 +183,21 @@ def test_lds_dma_staged_kernels_are_repeatable_under_memory_pressure():
     xh = torch.randn((8, 128, 128, 64), generator=g).bfloat16().cuda()
     wh = (torch.randn((256, 64, 3, 3), generator=g) * 0.04).cuda()
     pch = ops.PackedConv(wh, 1, 1, torch.bfloat16)
+    # the streamed 1x1 kernels (csrc/conv1x1_stream.hip: operands AND residual tile by LDS-DMA) and the NT mode of the bf16 kernel
+    # under the bf16 weight gradient (csrc/conv_wgrad_bf16.hip) count the same way
+    xs = {K: torch.randn((6, 32, 32, K), generator=g).cuda() for K in (64, 128, 256)}
+    ws = {K: ops.PackedConv((torch.randn((512, K, 1, 1), generator=g) / K ** 0.5).cuda(), 1, 0) for K in (64, 128, 256)}
+    rs = torch.randn((6, 32, 32, 512), generator=g).cuda()
+    dyw = (torch.randn((4, 24, 24, 128), generator=g) * 0.1).cuda()
+    xw = torch.randn((4, 24, 24, 256), generator=g).bfloat16().cuda()
     runs = {
         'wino plain': lambda: ops.conv3x3_wino(x, pc, gn_part=True),
         'wino blocked + fused affine': lambda: ops.conv3x3_wino(xb8, pc, gn_part=True, in_ab=(a, b), in_relu=True, out_b8=True),
         'bf16 dma': lambda: ops.conv2d(xh, pch, gn_part=True),
+        'streamed 1x1 K=64': lambda: (ops.conv1x1_stream(xs[64], ws[64], residual=rs, relu=True),),
+        'streamed 1x1 K=128': lambda: (ops.conv1x1_stream(xs[128], ws[128], residual=rs, relu=True),),
+        'streamed 1x1 K=256': lambda: (ops.conv1x1_stream(xs[256], ws[256], residual=rs, relu=True),),
+        'bf16 weight gradient': lambda: (ops.conv_wgrad_bf16(dyw, xw, (128, 256, 3, 3)),),
     }
     ref = {k: [t.clone() for t in f()] for k, f in runs.items()}
     torch.cuda.synchronize()
