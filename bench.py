@@ -93,27 +93,29 @@ def _reducer_summary(trainer):
             'issued_ms': [round(r['issued_ms'], 2) for r in rows], 'done_ms': [round(r['done_ms'], 2) for r in rows]}
 
 
-def model_cfg(depth=50, num_classes=1):
-    """Key/values of T/configs2/TinyPersonV2/coarsepointv2/coarse_point_refine_r50_fpns4_1x_TinyPersonV2_640.py."""
+def model_cfg(depth=50, num_classes=1, start_level=0, stride=4, radius=5):
+    """Key/values of T/configs2/TinyPersonV2/coarsepointv2/coarse_point_refine_r50_fpns4_1x_TinyPersonV2_640.py (defaults:
+    BASELINE.json configs[1]); ``num_classes=80, start_level=1, stride=8, radius=8`` are the values of
+    T/configs2/COCO/coarsepointv2/coarse_point_refine_r50_fpn_1x_coco400.py:20,51,75-96 (configs[2])."""
     alpha = 0.25
     from pointtinybenchmark_amd import synthetic
     return dict(
         type='BasicLocator',
         backbone=dict(type='ResNet', depth=depth, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
                       norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'),
-        neck=dict(type='FPN', in_channels=synthetic.backbone_out_channels(depth), out_channels=256, start_level=0,
+        neck=dict(type='FPN', in_channels=synthetic.backbone_out_channels(depth), out_channels=256, start_level=start_level,
                   add_extra_convs='on_input', num_outs=1, norm_cfg=GN),
         bbox_head=dict(
             type='CPRHead', norm_cfg=GN, num_classes=num_classes, in_channels=256, feat_channels=256, stacked_convs=4,
-            num_cls_fcs=0, strides=[4], loss_mil=dict(type='MILLoss', binary_ins=False, loss_weight=alpha),
+            num_cls_fcs=0, strides=[stride], loss_mil=dict(type='MILLoss', binary_ins=False, loss_weight=alpha),
             loss_type=0,
             loss_cfg=dict(with_neg=True, neg_loss_weight=1 - alpha, refine_bag_policy='independent_with_gt_bag',
                           random_remove_rate=0.4, with_gt_loss=True, gt_loss_weight=alpha, with_mil_loss=True),
             normal_cfg=dict(prob_cls_type='sigmoid', out_bg_cls=False),
-            train_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=5),
-                                     neg_generator=dict(type='OutCirclePtFeatGenerator', radius=5, class_wise=True)),
-            refine_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=5),
-                                      neg_generator=dict(type='OutCirclePtFeatGenerator', radius=5, keep_wh=True,
+            train_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=radius),
+                                     neg_generator=dict(type='OutCirclePtFeatGenerator', radius=radius, class_wise=True)),
+            refine_pts_extractor=dict(pos_generator=dict(type='CirclePtFeatGenerator', radius=radius),
+                                      neg_generator=dict(type='OutCirclePtFeatGenerator', radius=radius, keep_wh=True,
                                                          class_wise=True)),
             point_refiner=dict(merge_th=0.1, refine_th=0.1, classify_filter=True)))
 
@@ -182,8 +184,9 @@ class ConvProbe:
                 variant = 'conv_bf16_dma_kernel' if v == 256256 else 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
             elif v % 10 == 2:    # dual-source launch (conv3 + projection shortcut): <BM, BN, MODE 0, XF false, PIPE 1, ABL 0, DUAL>
                 variant = 'conv_mfma_kernel<%d, %d, 0, false, 1, 0, true>' % (v // 1000000, v // 1000 % 1000)
-            elif v % 10 == 3:    # streamed 1x1 (csrc/conv1x1_stream.hip): <K = 8192 / BM>
-                variant = 'conv1x1_stream_kernel<%d>' % (8192 // (v // 1000000))
+            elif v % 10 == 3:    # streamed 1x1 (csrc/conv1x1_stream.hip): (BM, BN) = (128, 256) K 64 / (64, 128) K 128 / (128, 64) K 256
+                variant = {(128, 256): 'conv1x1_stream_kernel<64>', (64, 128): 'conv1x1_stream_kernel<128>',
+                           (128, 64): 'conv1x1_stream_k256_kernel'}[(v // 1000000, v // 1000 % 1000)]
             else:
                 variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0, false>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
                                                                              'true' if v // 10 % 10 else 'false', v % 10)
@@ -225,76 +228,81 @@ class ConvProbe:
                 for v, d in agg.items()}
 
 
-def hbm_probe(batch, size):
+def hbm_probe(batch, height, width=None, stride=4, num_classes=1, radius=5):
     """The HBM-bound kernels of the step, each timed alone with HIP events on its real shape: algorithmic bytes (one read
     of every input, one write of every output) / time vs the 8 TB/s roof (reported separately from the
     MFMA-bound convs).  Every case rotates over enough distinct copies of its tensors that consecutive launches touch
     more than 1 GiB: the 256 MB Infinity Cache cannot serve the re-reads, so the figures are HBM rates, not L3 rates."""
     from pointtinybenchmark_amd import ops
     dev = 'cuda'
-    h = size // 4
+    width = height if width is None else width
+    h, wd = height // stride, width // stride
+    C = int(num_classes)
     g = torch.Generator(device=dev).manual_seed(0)
     gam, bet = torch.ones(256, device=dev), torch.zeros(256, device=dev)
     a = torch.rand((batch, 256), device=dev, generator=g) + 0.5
     b = torch.randn((batch, 256), device=dev, generator=g)
     from pointtinybenchmark_amd.datasets import GpuImagePipeline
     pipe = GpuImagePipeline(device=dev)
-    nb = batch * h * h * 256 * 4
+    nb = batch * h * wd * 256 * 4
 
     def rot(working_set_bytes):
         return max(2, min(16, -(-(1 << 30) // max(int(working_set_bytes), 1))))
 
     def maps(n, k=1):
-        return [tuple(torch.randn((batch, h, h, 256), device=dev, generator=g) for _ in range(k)) for _ in range(n)]
+        return [tuple(torch.randn((batch, h, wd, 256), device=dev, generator=g) for _ in range(k)) for _ in range(n)]
     xs = maps(rot(2 * nb))
     x0 = xs[0][0]
     part = ops.gn_stats(x0)
-    _, _, mean, rstd = ops.gn_finalize(part, gam, bet, batch, h * h, 32, 1e-5, want_stats=True)
+    _, _, mean, rstd = ops.gn_finalize(part, gam, bet, batch, h * wd, 32, 1e-5, want_stats=True)
     x2 = maps(rot(5 * nb), 2)
-    stems = [torch.randn((batch, size // 2, size // 2, 64), device=dev, generator=g) for _ in range(rot(batch * size * size * 80))]
-    imgs = [torch.randn((batch, 3, size, size), device=dev, generator=g) for _ in range(rot(batch * size * size * 28))]
-    u8s = [torch.randint(0, 256, (batch, size, size, 3), device=dev, dtype=torch.uint8, generator=g)
-           for _ in range(rot(batch * size * size * 19))]
-    pre_outs = [torch.empty((batch, size, size, 4), device=dev) for _ in u8s]
+    px = height * width
+    stems = [torch.randn((batch, height // 2, width // 2, 64), device=dev, generator=g) for _ in range(rot(batch * px * 80))]
+    imgs = [torch.randn((batch, 3, height, width), device=dev, generator=g) for _ in range(rot(batch * px * 28))]
+    u8s = [torch.randint(0, 256, (batch, height, width, 3), device=dev, dtype=torch.uint8, generator=g)
+           for _ in range(rot(batch * px * 19))]
+    pre_outs = [torch.empty((batch, height, width, 4), device=dev) for _ in u8s]
     cases = [
         ('gn_apply_kernel (GroupNorm apply + ReLU, head map)', len(xs), lambda i: ops.gn_apply(xs[i][0], a, b, relu=True), 2 * nb),
         ('gn_stats_kernel (statistics pass)', len(xs), lambda i: ops.gn_stats(xs[i][0]), nb),
         ('maxpool3x3s2_kernel (stem)', len(stems), lambda i: ops.maxpool3x3s2(stems[i]), stems[0].numel() * 4 * 1.25),
         ('nchw_to_nhwc4_kernel (network input)', len(imgs), lambda i: ops.nchw_to_nhwc(imgs[i]), imgs[0].numel() * 4 * (1 + 4 / 3)),
         ('preprocess_u8_kernel (uint8 HWC -> normalised NHWC4)', len(u8s),
-         lambda i: pipe._launch(u8s[i], None, pre_outs[i], batch, size, size, size, size), u8s[0].numel() + pre_outs[0].numel() * 4),
+         lambda i: pipe._launch(u8s[i], None, pre_outs[i], batch, height, width, height, width), u8s[0].numel() + pre_outs[0].numel() * 4),
         ('gn_bwd (stats + apply passes of the GroupNorm backward)', len(x2),
          lambda i: ops.gn_bwd(x2[i][0], x2[i][1], a, b, mean, rstd, gam, True), 5 * nb),
         ('relu_bwd_colsum_kernel (ReLU backward + column sums)', len(x2), lambda i: ops.relu_bwd_colsum(x2[i][1], x2[i][0]), 3 * nb),
     ]
-    # the CPR-specific stage on its real shapes (C = 1, 32 gts per image): these launches move a few MB and finish in tens of
-    # microseconds, i.e. they are launch-latency bound -- listed so that the stage is accounted for, not as roofline claims
+    # the CPR-specific stage on its real shapes (C classes, 32 gts per image): these launches move a few MB and finish in tens
+    # of microseconds, i.e. they are launch-latency bound -- listed so that the stage is accounted for, not as roofline claims
     from pointtinybenchmark_amd.dense_heads.cpr_head import circle_offsets, sqrt_threshold
     G = 32 * batch
-    lmap = torch.randn((batch, h, h, 2), device=dev, generator=g)
-    ctr = torch.rand((G, 2), device=dev, generator=g) * (size - 16) + 8
-    lab = torch.zeros((G,), device=dev, dtype=torch.int32)
+    lmap = torch.randn((batch, h, wd, 2 * C), device=dev, generator=g)
+    ctr = torch.rand((G, 2), device=dev, generator=g) * torch.tensor([width - 16.0, height - 16.0], device=dev) + 8
+    lab = torch.randint(0, C, (G,), device=dev, generator=g).to(torch.int32) if C > 1 else torch.zeros((G,), device=dev, dtype=torch.int32)
     gt_img = torch.arange(batch, device=dev, dtype=torch.int32).repeat_interleave(32)
     gt_start = torch.arange(batch + 1, device=dev, dtype=torch.int32) * 32
-    pad_hw = torch.full((batch * 2,), size, device=dev, dtype=torch.int32)
-    offs = circle_offsets(5, 4).to(dev)
-    thr = sqrt_threshold(20.0)
-    _, valid_b, bag_l = ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, 4)
+    pad_hw = torch.tensor([height, width] * batch, device=dev, dtype=torch.int32)
+    offs = circle_offsets(radius, stride).to(dev)
+    thr = sqrt_threshold(float(stride * radius))
+    _, valid_b, bag_l = ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, stride)
     K = bag_l.shape[1]
     feat = xs[0][0]
     head_ab = (a, b)
     cases += [
         ('logit projection (256 -> 2C channels of the head map, GroupNorm + ReLU applied on load)', len(xs),
-         lambda i: ops.logit_project(xs[i][0], proj_w, proj_b, head_ab) if hasattr(ops, 'logit_project') else None, nb + batch * h * h * 8),
+         lambda i: ops.logit_project(xs[i][0], proj_w, proj_b, head_ab) if hasattr(ops, 'logit_project') else None,
+         nb + batch * h * wd * 8 * C),
         ('neg_mask_loss_kernel (negative grid: distance mask + sigmoid + gfocal partials)', 1,
-         lambda i: ops.neg_mask_loss(lmap, ctr, lab, gt_start, pad_hw, 1, 4, thr, 1e-6, True), lmap.numel() * 4 + batch * h * h),
+         lambda i: ops.neg_mask_loss(lmap, ctr, lab, gt_start, pad_hw, C, stride, thr, 1e-6, True),
+         batch * h * wd * C * 4 + batch * h * wd * C),
         ('bag_sample_kernel (bag points + bilinear samples of the logit map)', 1,
-         lambda i: ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, 4), G * K * (4 * 2 * 4 + 2 * 4 + 8 + 1)),
+         lambda i: ops.bag_sample(lmap, ctr, gt_img, pad_hw, offs, stride), G * K * (4 * 2 * C * 4 + 2 * 4 + 8 * C + 1)),
         ('mil_bag + loss_finalize kernels (MIL / gt losses, one wave per bag)', 1,
-         lambda i: ops.mil_loss(bag_l, 1, valid_b, lab, 1, None, 0.25, 0.25, 0.75), G * K * (2 * 4 + 1)),
+         lambda i: ops.mil_loss(bag_l, C, valid_b, lab, C, None, 0.25, 0.25, 0.75), G * K * (2 * C * 4 + 1)),
     ]
-    proj_w = torch.randn((2, 256), device=dev, generator=g) * 0.01
-    proj_b = torch.zeros((2,), device=dev)
+    proj_w = torch.randn((2 * C, 256), device=dev, generator=g) * 0.01
+    proj_b = torch.zeros((2 * C,), device=dev)
     out = []
     for name, n, fn, byts in cases:
         if fn(0) is None and 'projection' in name:
@@ -333,30 +341,46 @@ def host_cpu_info():
     return model, phys
 
 
-def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None):
-    """The CPU oracle on this box's host cores: same synthetic workload, bounded sample.  The box reports 256 logical
-    CPUs but torch/oneDNN throughput is far from monotone in the thread count there (cgroup quota, SMT, NUMA), so the
-    whole step is timed once at several thread counts and the fastest is kept and re-timed, with the backbone / neck /
-    head towers / point stage split.  ``hip_losses_fn(batch)``: the HIP path on the SAME sample -- the
-    parity gate of the bench run (losses of the two paths side by side)."""
+def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None, depth=50, height=640, width=640,
+                 num_classes=1, start_level=0, stride=4, radius=5, model='cpr'):
+    """The CPU oracle on this box's host cores: same synthetic workload (same depth / size / classes / stride / radius as the
+    timed configuration), bounded sample.  The box reports 256 logical CPUs but torch/oneDNN throughput is far from monotone
+    in the thread count there (cgroup quota, SMT, NUMA), so the whole step is timed once at several thread counts and the
+    fastest is kept and re-timed, with the backbone / neck / head towers / point stage split.
+    ``hip_losses_fn(batch)``: the HIP path on the SAME sample -- the parity gate of the bench run (losses of the two paths
+    side by side).  model='p2p': backbone + neck + both P2PHead towers + the Hungarian assignment of every image (the
+    focal / SmoothL1 sums that follow are a few microseconds of host time and are not restated)."""
     from oracle import cpr_oracle as O
     from pointtinybenchmark_amd import synthetic
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    sd = synthetic.locator_state_dict(50, 1, 0, 'cpr', 0)
-    batch = synthetic.synthetic_batch(batch_size, 640, 640, num_gts, 1, 0)
+    sd = synthetic.locator_state_dict(depth, num_classes, start_level, model, 0, **({'head_std': 0.05} if model == 'p2p' else {}))
+    batch = synthetic.synthetic_batch(batch_size, height, width, num_gts, num_classes, 0)
     last = {}
 
     def one(threads):
         torch.set_num_threads(threads)
         with torch.no_grad():
             t0 = time.perf_counter()
-            c = O.resnet_forward(sd, batch['img'], 50)
+            c = O.resnet_forward(sd, batch['img'], depth)
             t1 = time.perf_counter()
-            feats = O.fpn_forward(sd, c, 0, 1)
+            feats = O.fpn_forward(sd, c, start_level, 1)
             t2 = time.perf_counter()
-            cls_feat, _ = O.cpr_head_forward(sd, feats)
-            t3 = time.perf_counter()
-            losses, _ = O.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], 4, 5, 1)
+            if model == 'p2p':
+                cls, reg = O.p2p_head_forward(sd, feats)
+                t3 = time.perf_counter()
+                h, w = cls[0].shape[-2:]
+                anchor = O.p2p_grid_points(h, w, stride)[:, :2]
+                for b in range(batch_size):
+                    pred = anchor + reg[0][b].permute(1, 2, 0).reshape(-1, 2) * stride
+                    ctr = (batch['gt_bboxes'][b][:, :2] + batch['gt_bboxes'][b][:, 2:]) / 2
+                    O.hungarian_assign_v2(pred, cls[0][b].permute(1, 2, 0).reshape(-1, num_classes), ctr, batch['gt_labels'][b],
+                                          (height, width, 3), topk_k=5)
+                losses = {}
+            else:
+                cls_feat, _ = O.cpr_head_forward(sd, feats)
+                t3 = time.perf_counter()
+                losses, _ = O.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], stride, radius,
+                                       num_classes)
             t4 = time.perf_counter()
         last.update(split=dict(backbone=t1 - t0, neck=t2 - t1, head_towers=t3 - t2, points_and_losses=t4 - t3),
                     losses={k: float(v) for k, v in losses.items()})
@@ -371,18 +395,27 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None):
             break      # out of budget, or two thread counts in a row slower than the best (256 threads took ~55 s/step here)
         trials[t] = one(t)
         worse = worse + 1 if trials[t] > min(trials.values()) else 0
+    if not trials:
+        trials[min(16, avail)] = one(min(16, avail))
     best = min(trials, key=trials.get)
     times = [trials[best]]
     while len(times) < 4 and time.perf_counter() - t_start < seconds_budget:
         times.append(one(best))
     dt = sorted(times)[len(times) // 2]
-    model, phys = host_cpu_info()
+    cpu_model, phys = host_cpu_info()
     out = dict(value=batch_size / dt, unit='img/s', cores=best, kind='port',
-               sample='median of %d step(s) of B=%d 640x640 tiles at %d threads (%.2f s/step); thread count = fastest of '
-                      '%s s/step out of %d logical CPUs; oracle = torch-CPU restatement executing the reference op '
-                      'sequence' % (len(times), batch_size, best, dt,
-                                    {k: round(v, 2) for k, v in trials.items()}, os.cpu_count() or 1),
-               host_cpu=model, physical_cores=phys, logical_cpus=os.cpu_count() or 1,
+               # profiles/round3_cpu_reference_vs_port.json (tools/ref_vs_port_cpu.py, build container, 8 threads, B=2 640x640):
+               # the reference's own classes 1.362 s/step, this port 1.270 s/step, identical losses
+               note="port = oracle/cpr_oracle.py, the torch-CPU restatement of the reference's op sequence; it runs 1.07x the "
+                    "speed of the reference's own classes on the build host (profiles/round3_cpu_reference_vs_port.json); "
+                    "/root/reference does not exist on the GPU box",
+               sample='median of %d step(s) of B=%d %dx%d tiles (ResNet-%d, %d classes, stride %d, radius %d%s) at %d threads '
+                      '(%.2f s/step); thread count = fastest of %s s/step out of %d logical CPUs; oracle = torch-CPU '
+                      'restatement executing the reference op sequence' % (
+                          len(times), batch_size, height, width, depth, num_classes, stride, radius,
+                          ', P2PHead towers + Hungarian assignment' if model == 'p2p' else '', best, dt,
+                          {k: round(v, 2) for k, v in trials.items()}, os.cpu_count() or 1),
+               host_cpu=cpu_model, physical_cores=phys, logical_cpus=os.cpu_count() or 1,
                split_s={k: round(v, 4) for k, v in last['split'].items()})
     if hip_losses_fn is not None:          # parity gate: the HIP path on the very sample the oracle was timed on
         try:
@@ -395,12 +428,12 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None):
     return out
 
 
-def measure_small_batch(model, b, size, num_gts, steps=30, graph_too=True):
+def measure_small_batch(model, b, size, num_gts, steps=30, graph_too=True, width=None, num_classes=1):
     """The reference's own per-GPU batch (samples_per_gpu = 2, T/configs2/TinyPersonV2/coarsepointv2/
     coarse_point_refine_base_TinyPersonV2_640.py:50).  ~150 launches of a few microseconds: launch-bound when issued one by
     one, so the step is also timed as ONE hipGraph replay (backbone .. logit projection) + the eager 5-launch loss tail."""
     from pointtinybenchmark_amd import synthetic
-    batch = synthetic.synthetic_batch(b, size, size, num_gts, 1, seed=123)
+    batch = synthetic.synthetic_batch(b, size, size if width is None else width, num_gts, num_classes, seed=123)
     img, metas = batch['img'].cuda(), batch['img_metas']
     gtb, gtl = [x.cuda() for x in batch['gt_bboxes']], [x.cuda() for x in batch['gt_labels']]
     res = {'B': b}
@@ -425,6 +458,37 @@ def measure_small_batch(model, b, size, num_gts, steps=30, graph_too=True):
         res['error'] = repr(e)[:300]
     model.use_graph = keep
     return res
+
+
+def baseline_config_name(args):
+    """Which BASELINE.json configs[i] shape a non-headline line is (or 'other')."""
+    key = (args.model, args.depth, args.height, args.width, args.classes, args.stride, args.radius)
+    return {('cpr', 18, 640, 640, 1, 4, 5): 'configs[0] shape on the GPU', ('cpr', 50, 800, 1344, 80, 8, 8): 'configs[2] shape, one GPU',
+            ('p2p', 50, 640, 640, 1, 4, 5): 'configs[3]',
+            ('cpr', 101, 1024, 1024, 1, 4, 5): 'configs[4] shape' + (', bf16' if args.dtype == 'bf16' else ', fp32 parity mode')
+            }.get(key, 'other shape')
+
+
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return '.'.join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def device_identity(local):
+    """A string that is distinct per physical GPU: the device UUID when torch exposes it, else PCI bus id / name + index."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        for attr in ('uuid', 'pci_bus_id'):
+            v = getattr(pr, attr, None)
+            if v is not None:
+                extra = '%s:%s' % (getattr(pr, 'pci_domain_id', ''), getattr(pr, 'pci_device_id', '')) if attr == 'pci_bus_id' else ''
+                return '%s=%s%s' % (attr, v, extra)
+        return '%s#%d' % (pr.name, local)
+    except Exception as e:   # noqa: BLE001
+        return 'unknown#%d (%s)' % (local, type(e).__name__)
 
 
 def dry_run(args, world, rank):
@@ -487,7 +551,18 @@ def main():
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
                     help="fp32 = the headline metric (exact fp32 MFMA); bf16 = the bf16 compute mode of configs[4]")
     ap.add_argument('--depth', type=int, default=50)
-    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--size', type=int, default=640, help='square input size; --height / --width override it')
+    ap.add_argument('--height', type=int, default=None)
+    ap.add_argument('--width', type=int, default=None)
+    ap.add_argument('--classes', type=int, default=1, help='num_classes of the head (COCO-style configs[2]: 80)')
+    ap.add_argument('--stride', type=int, default=4, help='stride of the single FPN level the head reads (configs[2]: 8)')
+    ap.add_argument('--radius', type=int, default=5, help='radius of the circle generators in grid cells (configs[2]: 8)')
+    ap.add_argument('--start-level', type=int, default=None,
+                    help='FPN start_level (default: log2(stride) - 2, i.e. 0 for stride 4, 1 for stride 8)')
+    ap.add_argument('--config', default=None, choices=['cfg0', 'cfg1', 'cfg2', 'cfg3', 'cfg4'],
+                    help="shorthand for BASELINE.json configs[i] at its own shape: cfg0 = R18 640x640 B=2; cfg1 = the headline; "
+                         "cfg2 = R50 800x1344 C=80 stride 8 radius 8 B=8 (samples_per_gpu of the COCO config); cfg3 = P2PNet R50 "
+                         "640x640 B=16; cfg4 = R101 1024x1024 bf16 B=8.  Explicit flags given after it win")
     ap.add_argument('--model', default='cpr', choices=['cpr', 'p2p'],
                     help="cpr = the headline (configs[1]); p2p = P2PNet R50-FPN (configs[3]): forward + Hungarian assignment + "
                          "loss, or with --mode infer forward + top-k + pseudo-box NMS")
@@ -506,6 +581,21 @@ def main():
                     help='after the timed region also time this many full training steps (0 = skip); reported under '
                          '"train_step", never in "value"')
     args = ap.parse_args()
+    if args.config:
+        preset = {'cfg0': dict(depth=18, size=640, batch=2), 'cfg1': {},
+                  'cfg2': dict(depth=50, height=800, width=1344, classes=80, stride=8, radius=8, batch=8),
+                  'cfg3': dict(model='p2p', batch=16), 'cfg4': dict(depth=101, size=1024, dtype='bf16', batch=8)}[args.config]
+        given = {a.split('=')[0].lstrip('-').replace('-', '_') for a in sys.argv[1:] if a.startswith('--')}
+        for k, v in preset.items():
+            if k not in given:
+                setattr(args, k, v)
+    args.height = args.height or args.size
+    args.width = args.width or args.size
+    if args.start_level is None:
+        args.start_level = {4: 0, 8: 1, 16: 2, 32: 3}[args.stride]
+    assert args.stride == 4 << args.start_level, 'the head reads FPN level start_level: stride must be 4 << start_level'
+    headline = (args.model, args.mode, args.depth, args.height, args.width, args.dtype, args.classes, args.stride, args.radius) == \
+        ('cpr', 'fwd_loss', 50, 640, 640, 'fp32', 1, 4, 5)
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks ourselves (one process per GPU under
@@ -542,16 +632,17 @@ def main():
     import pointtinybenchmark_amd as P
     from pointtinybenchmark_amd import synthetic
     if args.model == 'p2p':
+        assert (args.classes, args.stride) == (1, 4), 'the P2P line is the shipped TinyPersonV2 config (1 class, stride 4)'
         model = P.build_detector(p2p_model_cfg(args.depth)).cuda()
         model.load_state_dict(synthetic.locator_state_dict(args.depth, 1, 0, 'p2p', 0, head_std=0.05), strict=True)
     else:
         assert args.mode != 'infer'
-        model = P.build_detector(model_cfg(args.depth)).cuda()
-        model.load_state_dict(synthetic.locator_state_dict(args.depth, 1, 0, 'cpr', 0), strict=True)
+        model = P.build_detector(model_cfg(args.depth, args.classes, args.start_level, args.stride, args.radius)).cuda()
+        model.load_state_dict(synthetic.locator_state_dict(args.depth, args.classes, args.start_level, 'cpr', 0), strict=True)
     model.train()
     model.set_compute_dtype(args.dtype)
     model.use_graph = bool(args.graph)
-    batch = synthetic.synthetic_batch(args.batch, args.size, args.size, args.num_gts, 1, seed=rank)   # per-rank shard
+    batch = synthetic.synthetic_batch(args.batch, args.height, args.width, args.num_gts, args.classes, seed=rank)   # per-rank shard
     img = batch['img'].cuda()
     # per-image gt lists as the device pipeline hands them over (datasets.GpuImagePipeline: ONE device tensor, torch.split
     # into per-image views) -- the head re-joins such views without a copy
@@ -621,6 +712,12 @@ def main():
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    ranks_seen, distinct_devices = world, 1
+    if distributed:      # what the group really spans: every rank reports its device's identity (multi-GPU readiness check)
+        ids = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(ids, device_identity(local))
+        ranks_seen, distinct_devices = len(ids), len(set(ids))
+
     def _val(v):
         if isinstance(v, (list, tuple)):
             return [_val(e) for e in v]
@@ -671,7 +768,11 @@ def main():
                     tm = float(t.item())
                 res['mixed_precision'] = {'value': args.batch * world * args.train_steps / tm, 'unit': 'img/s',
                                           'ms_per_step': tm / args.train_steps * 1e3,
+                                          'what': 'the same step in the bf16 compute mode (bf16 recorded forward, bf16 data / weight '
+                                                  'gradients of the stride-1 layers, fp32 normalisation backward / weights / optimizer)',
                                           'loss': float(sum(v for k, v in tl.items() if 'loss' in k))}
+            except Exception as e:   # noqa: BLE001 -- a failure of the bf16 step must not discard the fp32 result above
+                res['mixed_precision'] = {'error': repr(e)[:300]}
             finally:
                 model.set_compute_dtype(args.dtype)
             return res
@@ -682,20 +783,24 @@ def main():
     if rank == 0:
         total_imgs = args.batch * world * args.steps
         out = {
-            'metric': 'img/s (640x640) CPR R50-FPN fwd+loss' if (args.mode, args.model) == ('fwd_loss', 'cpr')
-            else 'img/s (640x640) %s R50-FPN %s (NOT the headline metric)' % (
-                args.model.upper(), {'train': 'training step', 'infer': 'forward + top-k + NMS',
-                                     'fwd_loss': 'forward + assignment + loss'}[args.mode]),
+            'metric': 'img/s (640x640) CPR R50-FPN fwd+loss' if headline
+            else 'img/s (%dx%d) %s R%d-FPN %s (NOT the headline metric)' % (
+                args.height, args.width, args.model.upper(), args.depth,
+                {'train': 'training step', 'infer': 'forward + top-k + NMS',
+                 'fwd_loss': 'fwd+loss' if args.model == 'cpr' else 'forward + assignment + loss'}[args.mode]),
             'value': total_imgs / elapsed, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': '%s ResNet-%d + FPN(num_outs=1, stride 4) + %s, %dx%d, %s%s' % (
-                args.model.upper(), args.depth, 'CPRHead' if args.model == 'cpr' else 'P2PHead', args.size, args.size,
+            'config': {'workload': '%s ResNet-%d + FPN(num_outs=1, start_level %d, stride %d) + %s(%d class%s, radius %d), %dx%d, %s%s' % (
+                args.model.upper(), args.depth, args.start_level, args.stride, 'CPRHead' if args.model == 'cpr' else 'P2PHead',
+                args.classes, '' if args.classes == 1 else 'es', args.radius, args.height, args.width,
                 {'fwd_loss': 'forward + loss', 'train': 'training step', 'infer': 'inference'}[args.mode],
-                ' (configs[1])' if (args.model, args.mode, args.depth, args.size, args.dtype) == ('cpr', 'fwd_loss', 50, 640, 'fp32')
-                else ' (NOT the headline config)'), 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
+                ' (configs[1])' if headline else ' (%s; NOT the headline config)' % baseline_config_name(args)),
+                       'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'gts_per_image': args.num_gts, 'parallelism': 'dp%d' % world,
                        'weights': 'random init (synthetic.locator_state_dict seed 0)'},
+            # multi-GPU readiness: what the process group really spans (filled below when a group exists)
+            'n_ranks_seen': ranks_seen, 'distinct_devices_seen': distinct_devices, 'rccl_version': rccl_version(),
             'losses': loss_vals,
         }
         if probe:
@@ -737,15 +842,17 @@ def main():
             out['end_to_end_effective_tflops'] = conv_f / (elapsed / args.steps) / 1e12   # algorithmic conv FLOPs of a step / step time
         if world == 1 and not args.no_probe:
             try:
-                out['hbm_kernels'] = hbm_probe(args.batch, args.size)
+                out['hbm_kernels'] = hbm_probe(args.batch, args.height, args.width, args.stride, args.classes, args.radius)
             except Exception as e:   # noqa: BLE001
                 out['hbm_kernels'] = {'error': repr(e)[:200]}
-        if world == 1 and args.small_batch > 0 and (args.model, args.mode) == ('cpr', 'fwd_loss'):
-            out['small_batch'] = measure_small_batch(model, args.small_batch, args.size, args.num_gts)
+        if world == 1 and args.small_batch > 0 and args.small_batch != args.batch and (args.model, args.mode) == ('cpr', 'fwd_loss'):
+            out['small_batch'] = measure_small_batch(model, args.small_batch, args.height, args.num_gts, width=args.width,
+                                                     num_classes=args.classes)
         if world == 1 and args.batch_sweep and (args.model, args.mode) == ('cpr', 'fwd_loss'):
             out['batch_sweep'] = {}
             for bs in [int(v) for v in args.batch_sweep.split(',') if v and int(v) != args.batch]:
-                r = measure_small_batch(model, bs, args.size, args.num_gts, steps=8, graph_too=False)
+                r = measure_small_batch(model, bs, args.height, args.num_gts, steps=8, graph_too=False, width=args.width,
+                                        num_classes=args.classes)
                 out['batch_sweep'][str(bs)] = r.get('eager', r)
         if world == 1 and not args.no_cpu_baseline:
             def hip_losses(b):
@@ -754,8 +861,10 @@ def main():
                     r = model.forward_train(b['img'].cuda(), b['img_metas'], [x.cuda() for x in b['gt_bboxes']],
                                             [x.cuda() for x in b['gt_labels']])
                     return {k: float(v) for k, v in r.items()}
+            # parity gate: every fp32 CPR configuration (bf16 has its own stated tolerance, tests/test_gpu_bf16.py)
             out['cpu_baseline'] = cpu_baseline(2, args.num_gts, hip_losses_fn=hip_losses if (
-                args.model, args.dtype, args.depth, args.size) == ('cpr', 'fp32', 50, 640) else None)
+                args.model, args.dtype) == ('cpr', 'fp32') else None, depth=args.depth, height=args.height, width=args.width,
+                num_classes=args.classes, start_level=args.start_level, stride=args.stride, radius=args.radius, model=args.model)
     # last of all, under a watchdog: if the training step (first use of the collective library at N > 1) wedges, the headline
     # line is still printed and every rank leaves
     import threading

@@ -622,7 +622,8 @@ static int conv2d_fwd_launch(const float* in, const float* wgt, float* out, cons
         const int rc = conv1x1_stream_launch(in, wgt, out, scale, bias, residual, M, Cin, Cout, p.relu, p.res_mask,
                                              STREAM_MIN_TILES, stream);
         if (rc != CPR_ERR_UNSUPPORTED) {
-            if (variant_out) *variant_out = (8192 / Cin) * 1000000 + (16384 / Cin) * 1000 + 3;   // BM, BN, 3 = streamed
+            // BM, BN of conv1x1_stream_launch (K = 64: 128 x 256, K = 128: 64 x 128, K = 256: 128 x 64 in four k chunks), 3 = streamed
+            if (variant_out) *variant_out = (Cin == 256 ? 128 : 8192 / Cin) * 1000000 + (Cin == 256 ? 64 : 16384 / Cin) * 1000 + 3;
             return rc;
         }
     }
@@ -711,7 +712,8 @@ extern "C" int cpr_conv2d_fwd(const float* in, const float* wgt, float* out, con
                                          in_b ? in_b + (size_t)n0 * Cin : nullptr, part, n, H, W, Cin, Cout, KH, KW, stride, pad,
                                          Kpad, flags, in_relu, bm_fix, &variant, stream);
         if (rc != CPR_OK) return rc;
-        if (n0 == 0) { bm_fix = variant / 1000000; if (variant_out) *variant_out = variant; }
+        // only the column-sum slots tie later chunks to the first chunk's M tile (never a streamed launch: those carry no partials)
+        if (n0 == 0) { if (flags & CPR_CONV_COLSUM) bm_fix = variant / 1000000; if (variant_out) *variant_out = variant; }
     }
     return CPR_OK;
 }

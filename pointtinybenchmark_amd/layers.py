@@ -32,10 +32,28 @@ class _PackCache:
             ver = ver + (_WEIGHT_EPOCH[0],)
         hit = self._d.get(key)
         if hit is not None and hit[0] == ver:
+            self._order_behind(hit)
             return hit[1]
         val = make()
-        self._d[key] = (ver, val)
+        # whatever make() enqueued (pack kernels, torch ops building a bf16 pack / a folded norm / a bias vector) ran on the
+        # CURRENT stream: a reader on another stream (sub-batches of CPR_STREAMS > 1, the trainer's side stream) must order
+        # itself behind it -- the event lives with the entry until it has completed
+        ev = None
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+        self._d[key] = [ver, val, ev, torch.cuda.current_stream().cuda_stream if ev is not None else None]
         return val
+
+    @staticmethod
+    def _order_behind(entry):
+        ev = entry[2]
+        if ev is None or torch.cuda.is_current_stream_capturing():     # (a capture starts after a synchronised warm-up)
+            return
+        if ev.query():
+            entry[2] = None
+        elif torch.cuda.current_stream().cuda_stream != entry[3]:
+            torch.cuda.current_stream().wait_event(ev)
 
 
 def packed_conv(cache, conv, dtype=torch.float32):

@@ -283,7 +283,7 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
 
 def conv1x1_stream(x, pc, scale=None, bias=None, residual=None, relu=False, res_mask=False):
     """The streamed 1x1 kernel (csrc/conv1x1_stream.hip) called explicitly -- ``conv2d`` takes it by itself for large launches;
-    tests compare the two kernels bit for bit.  x (N, H, W, Cin) fp32, Cin in {64, 128}."""
+    tests compare the two kernels bit for bit.  x (N, H, W, Cin) fp32, Cin in {64, 128, 256}."""
     N, H, W, Cin = x.shape
     assert pc.KH == 1 and pc.stride == 1 and pc.padding == 0 and pc.Kpad == Cin and x.dtype == torch.float32
     out = torch.empty((N, H, W, pc.Cout), device=x.device, dtype=torch.float32)

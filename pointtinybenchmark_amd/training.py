@@ -36,16 +36,22 @@ class GradBuckets:
     sum has one order (tests/test_host_cpu.py).  timing=True (device tensors): per-bucket launch / completion events,
     ``timeline()`` after ``finish()`` -- what an N-GPU run needs to report overlap, not just img/s."""
 
-    def __init__(self, flat, bucket_elems, group=None, force=False, reducer='all_reduce', timing=False):
+    def __init__(self, flat, bucket_elems, group=None, force=False, reducer='all_reduce', timing=False, bounds=None):
         """force: issue the collectives even in a 1-rank group (a sum over one rank is the identity) -- lets a single GPU
-        exercise the real RCCL path (tests)."""
+        exercise the real RCCL path (tests).  bounds: explicit bucket boundaries (element offsets, 0 .. numel, ascending) --
+        ``layout_buckets`` places them on parameter boundaries; default: uniform ``bucket_elems`` buckets."""
         assert reducer in ('all_reduce', 'reduce_scatter'), reducer
         self.flat, self.group, self.force, self.reducer = flat, group, force, reducer
         self.timing = bool(timing) and flat.is_cuda
         n = flat.numel()
-        self.bounds = list(range(0, n, bucket_elems)) + [n]
-        if len(self.bounds) > 2 and self.bounds[-1] - self.bounds[-2] < bucket_elems // 4:
-            del self.bounds[-2]            # fold a small tail into the previous bucket
+        if bounds is not None:
+            self.bounds = [int(b) for b in bounds]
+            assert self.bounds[0] == 0 and self.bounds[-1] == n and all(a < b for a, b in zip(self.bounds, self.bounds[1:])), \
+                'bucket bounds must ascend from 0 to numel'
+        else:
+            self.bounds = list(range(0, n, bucket_elems)) + [n]
+            if len(self.bounds) > 2 and self.bounds[-1] - self.bounds[-2] < bucket_elems // 4:
+                del self.bounds[-2]            # fold a small tail into the previous bucket
         self._shards = {}
         self._events, self._t0, self._t_end, self._last = [], None, None, None
         self.reset()
@@ -140,6 +146,39 @@ class GradBuckets:
                     buckets=rows)
 
 
+def layout_buckets(sizes, max_elems, min_elems, tail_elems):
+    """Bucket boundaries on PARAMETER boundaries of a flat gradient buffer whose parameters (``sizes``, elements each) lie in
+    the order their gradients become final.  A bucket is closed as soon as it holds ``min_elems`` (so the head's first tower
+    layer -- 2.4 MB, final a few milliseconds into the backward -- is on the wire while the rest of the head, 63 % of the
+    backward's time, still computes) and never grows past ``max_elems`` unless one parameter alone is larger; the LAST bucket
+    -- the only one whose reduction cannot overlap with any backward work, because its gradients are the last to be computed
+    -- is cut to at most ``tail_elems``: the exposed part of the reducer is then bounded by design (a <= 1 MB all-reduce)
+    instead of being whatever the uniform split left over (27 MB in round 3)."""
+    ends, acc = [], 0
+    for k in sizes:
+        ends.append(acc + k)
+        acc += k
+    n = acc
+    # tail: the longest suffix of whole parameters that fits tail_elems (at least the last parameter)
+    tail_start = len(sizes) - 1
+    t = sizes[-1]
+    while tail_start > 0 and t + sizes[tail_start - 1] <= tail_elems:
+        tail_start -= 1
+        t += sizes[tail_start]
+    bounds, lo = [0], 0
+    for i, e in enumerate(ends[:tail_start]):
+        nxt = ends[i + 1] if i + 1 < tail_start else None
+        if e - lo >= min_elems or (nxt is not None and nxt - lo > max_elems):
+            bounds.append(e)
+            lo = e
+    head_end = ends[tail_start - 1] if tail_start > 0 else 0
+    if head_end > bounds[-1]:
+        bounds.append(head_end)
+    if n > bounds[-1]:
+        bounds.append(n)
+    return bounds
+
+
 class StepLrSchedule:
     """The reference's learning-rate policy (``lr_config = dict(policy='step', warmup='linear', warmup_iters=500,
     warmup_ratio=0.001, step=[8, 11])``, T/configs2/TinyPersonV2/coarsepointv2/coarse_point_refine_base_TinyPersonV2_640.py:
@@ -178,7 +217,8 @@ class StepLrSchedule:
 
 class CprTrainer:
     def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_mb=25.0, group=None,
-                 two_streams=True, force_collectives=False, schedule=None, reducer='all_reduce', reducer_timing=False):
+                 two_streams=True, force_collectives=False, schedule=None, reducer='all_reduce', reducer_timing=False,
+                 min_bucket_mb=4.0, tail_bucket_mb=1.0):
         """schedule: a StepLrSchedule (or any object with ``lr(iteration)``); ``lr`` is then only the fallback of
         ``step(lr=...)``.  Constructing the trainer re-homes every trainable parameter: ``p.data`` becomes a view of ONE
         flat buffer (``flat_p``) and ``p.grad`` a view of ``flat_g``; do not re-bind them afterwards (``model.to()``,
@@ -204,8 +244,11 @@ class CprTrainer:
             p.grad = self.flat_g[off:off + k].view(p.shape)
             self.offset[id(p)] = (off, off + k)
             off += k
-        self.buckets = GradBuckets(self.flat_g, max(1, int(bucket_mb * (1 << 20) / 4)), group, force=force_collectives,
-                                   reducer=reducer, timing=reducer_timing)
+        mb = (1 << 20) / 4
+        self.buckets = GradBuckets(self.flat_g, max(1, int(bucket_mb * mb)), group, force=force_collectives,
+                                   reducer=reducer, timing=reducer_timing,
+                                   bounds=layout_buckets([p.numel() for p in order], max(1, int(bucket_mb * mb)),
+                                                         max(1, int(min_bucket_mb * mb)), max(1, int(tail_bucket_mb * mb))))
         self._mixed, self._wide = False, {}     # set per step by forward_backward (bf16 compute mode = mixed precision)
         self.norm2 = torch.zeros((1,), device=dev, dtype=torch.float64)
         self._ws = torch.empty((1024,), device=dev, dtype=torch.float64)
@@ -470,6 +513,7 @@ class CprTrainer:
             assert dx is not None, 'no gradient reaches backbone stage %d' % stage
             need_dx = idx > 0
             dx = self._block_backward(c, blk, rec, dx, need_dx)
+        self._wide = {}      # nothing below the lowest trainable block reads a widened copy
 
     def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx, mask=None, add=None, want_colsum=False):
         """conv -> folded eval-BN given g = d(pre-activation output) (un-scaled) and its column sums.  Parameter
@@ -495,7 +539,8 @@ class CprTrainer:
                     ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=w.grad)
                 ops.bn_fold_bwd(w.grad, w, scale, bn.running_mean, inv_sigma, cs,
                                 out_dgamma=bn.weight.grad if aff else None, out_dbeta=bn.bias.grad if aff else None)
-            self._param_side(param_grads, g, colsum, g16)
+            # x may be a widened fp32 temporary of the mixed-precision step that the main stream frees right after this call
+            self._param_side(param_grads, g, colsum, g16, x)
         if not need_dx:
             return None
         if d16:
@@ -524,7 +569,8 @@ class CprTrainer:
         return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
 
     def _block_backward(self, cache, blk, rec, dout, need_dx):
-        x = self._f32(rec['x'], keep=True)       # = the output of the block below: its backward reads it next
+        # x = the output of the block below: when that block is trainable too (need_dx) its backward reads it next
+        x = self._f32(rec['x'], keep=need_dx)
         g3, cs3 = ops.relu_bwd_colsum(dout, self._f32(rec['out']))            # also the shortcut gradient
         o1 = self._f32(rec['o1'])
         if blk.kind == 'bottleneck':

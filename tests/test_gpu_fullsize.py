@@ -260,6 +260,10 @@ def test_full_size_conv_linearity():
     # aligned, so this also covers the unfused GroupNorm-statistics path at full size.
     ('coco_style_800x1344', dict(depth=50, num_classes=80, start_level=1, stride=8, radius=8, head_std=0.3, seed=41,
                                  batch=1, height=800, width=1344, num_gts=24)),
+    # BASELINE.json configs[0] at ITS OWN shape on the GPU: ResNet-18 (BasicBlock, T/mmdet/models/backbones/resnet.py:13-93,
+    # 360-366) + FPN(in_channels 64..512), 640x640, samples_per_gpu = 2, 32 gts per image
+    ('r18_640_b2', dict(depth=18, num_classes=1, start_level=0, stride=4, radius=5, head_std=0.3, seed=47, batch=2,
+                        height=640, width=640, num_gts=32)),
     # configs[4] backbone at a small size (fast) ...
     ('r101_384', dict(depth=101, num_classes=1, start_level=0, stride=4, radius=5, head_std=0.3, seed=43, batch=1,
                       height=384, width=384, num_gts=12)),
@@ -292,6 +296,55 @@ def test_other_baseline_configs_parity_with_oracle(name, cfg):
     with torch.no_grad():
         err_l, mag = _logit_map_vs_oracle(m, sd, cls_feat, ref_feat, cfg['num_classes'])
     assert err_l <= 1e-4 * max(1.0, mag / 16.0), '%s: logit map max abs err %.3e (|logit| max %.2f)' % (name, err_l, mag)
+
+
+def test_coco_style_800x1344_batch_8_vs_single_images_and_oracle():
+    """BASELINE.json configs[2] at ITS OWN batch: R50, 800x1344 (1333x800 padded to /32), 80 classes, stride 8 (start_level 1),
+    radius 8, samples_per_gpu = 8 (T/configs2/COCO/coarsepointv2/coarse_point_refine_r50_fpn_1x_coco400.py:20,51,75-96).  The
+    100x168 head map is not 128-pixel aligned: GroupNorm statistics take the separate pass and the producer affine is applied by
+    gn_apply, at a real batch.  Images 0, 3 and 7 of the 8-batch must equal their single-image runs bit for bit; the oracle
+    then pins the last two images (features, the full 160-channel logit map, the losses of that sub-batch) and the whole
+    batch's losses must equal forward_train's lazy path."""
+    from pointtinybenchmark_amd import ops
+    cfg = dict(depth=50, num_classes=80, start_level=1, stride=8, radius=8, head_std=0.3, seed=49, batch=8, height=800,
+               width=1344, num_gts=24)
+    m, sd = build_hip_locator(cfg)
+    B = cfg['batch']
+    batch = synthetic.synthetic_batch(B, 800, 1344, 24, 80, cfg['seed'], ragged=True)
+    cb = to_cuda(batch)
+    head = m.bbox_head
+    with torch.no_grad():
+        cls8, ins8 = head(m.neck(m.backbone(cb['img'])))
+        assert tuple(cls8[0].shape) == (B, 256, 100, 168)
+        lmap8 = head._logit_map(ops.from_nchw(cls8[0]))
+        losses8 = head.loss(cls8, ins8, cb['gt_bboxes'], cb['gt_labels'], cb['img_metas'])
+        lazy8 = m.forward_train(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+        torch.cuda.synchronize()
+        for k, v in losses8.items():
+            assert bool(torch.isfinite(v).all()), k
+            # the lazy path never materialises the normalised maps: same values up to the rounding of the fused affine
+            assert abs(float(v) - float(lazy8[k])) <= 2e-5 * max(abs(float(v)), 1e-6), (k, float(v), float(lazy8[k]))
+        for i in (0, 3, 7):
+            one, _ = head(m.neck(m.backbone(cb['img'][i:i + 1].contiguous())))
+            assert torch.equal(one[0][0], cls8[0][i]), 'image %d of the 8-batch differs from its single-image run' % i
+            assert torch.equal(head._logit_map(ops.from_nchw(one[0]))[0], lmap8[i])
+        sub = {k: v[6:8] for k, v in batch.items()}
+        sc = to_cuda(sub)
+        l2 = head.loss([cls8[0][6:8]], [ins8[0][6:8]], sc['gt_bboxes'], sc['gt_labels'], sc['img_metas'])
+        torch.cuda.synchronize()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref_losses, ref_feat, _ = O.locator_forward_train(sd, sub, 50, 1, 8, 8, 80)
+        err_l, mag = _logit_map_vs_oracle(m, sd, cls8[0][6:8], ref_feat, 80)
+    scale = max(1.0, float(ref_feat.abs().max()))
+    err = float((cls8[0][6:8].cpu() - ref_feat).abs().max())
+    assert err <= 3e-4 * scale, 'images 6-7 of the 8-batch: cls_feat max abs err %.3e (scale %.2e)' % (err, scale)
+    assert err_l <= 1e-4 * max(1.0, mag / 16.0), 'images 6-7: logit map max abs err %.3e (|logit| max %.2f)' % (err_l, mag)
+    for k in ('gt_loss', 'pos_loss', 'neg_loss', 'bag_acc'):
+        a, b = float(l2[k]), float(ref_losses[k])
+        assert abs(a - b) <= 5e-4 * max(abs(b), 1e-6), (k, a, b)
+    del cls8, ins8, lmap8
+    torch.cuda.empty_cache()
 
 
 def test_p2p_r50_640_full_network_vs_oracle():
