@@ -314,13 +314,18 @@ int cpr_phase_scatter_add(const float* src, float* dst, int N, int Hs, int Ws, i
  * stride-1 conv over the dilated gradient) */
 int cpr_zero_insert(const float* dy, float* out, int N, int OH, int OW, int C, int H, int W, int s, void* stream);
 /* d(gt_loss + pos_loss + neg_loss)/d(logit map) of CPRHead.loss (cpr_head.py:1101-1229): negative-grid term, MIL bag
- * and gt-centre terms scattered back through the bilinear taps (float atomics).  Inputs are the forward's own buffers
- * (neg mask, out5, bag logits, valid, bag_ws).  dbag_ws (G,K,J) workspace; dmap (N,H,W,Jd), Jd >= J, fully written. */
+ * and gt-centre terms taken back through the bilinear taps -- deterministically: every bag's taps are gathered into a
+ * win x win cell window (win >= 2 * ceil(max |offset| / stride) + 3; win_ws (G, win, win, J) fp32 and win_org (G, 2) int32
+ * are caller workspaces), the windows are added per image in gt order (gt_img must ascend).  Inputs are the forward's own
+ * buffers (neg mask, out5, bag logits, valid, bag_ws).  dbag_ws (G,K,J) workspace; dmap (N,H,W,Jd), Jd >= J, fully written.
+ * upstream: NULL (the three losses enter the total with weight 1) or [device] 5 floats, the gradient of the total wrt
+ * (gt_loss, pos_loss, bag_acc, neg_loss, num_sample) as torch autograd hands it to the head's loss Function; entries 2 and 4
+ * carry no gradient and are ignored. */
 int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* out5, const float* bag_logits,
                  const unsigned char* valid, const int* labels, const float* gt_weight, const float* bag_ws,
-                 const float* centers, const int* gt_img, const float* offsets, float* dbag_ws, float* dmap, int N,
-                 int H, int W, int J, int Jd, int ins_off, int G, int K, int C, float stride, float eps, float w_mil,
-                 float w_gt, float w_neg, void* stream);
+                 const float* centers, const int* gt_img, const float* offsets, float* dbag_ws, float* dmap, float* win_ws,
+                 int* win_org, int win, int N, int H, int W, int J, int Jd, int ins_off, int G, int K, int C, float stride,
+                 float eps, float w_mil, float w_gt, float w_neg, const float* upstream, void* stream);
 /* OIHW fp32 master weights -> the conv kernels' layout [rows][KH][KW][cols'] (row stride Kpad, zero padded).
  * transpose 0: forward pack (rows = O).  transpose 1: data-gradient pack (rows = I, taps flipped, optional per-O scale =
  * the folded BatchNorm scale of the forward conv).  colsp = padded column count (4 for <= 4 channels). */
@@ -333,11 +338,13 @@ int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const 
 /* gradient of sum_b (loss_cls[b] + loss_pts[b]) of cpr_p2p_loss wrt the class logits (B*M, C) and the regression output
  * (p2p_head.py:220-248; sigmoid focal loss with its un-detached focal weight, SmoothL1 through
  * pred = anchor + (point_anchor + reg*gamma_p)*stride).  npos: device scalar, positives in the batch.  dcls (B*M, Cp),
- * dreg (B*M, Rp): channel-padded for the conv gradient kernels, padding columns written as zero. */
+ * dreg (B*M, Rp): channel-padded for the conv gradient kernels, padding columns written as zero.  upstream: NULL (every loss
+ * term enters the total with weight 1) or [device] (B, 2) gradients of the total wrt (loss_cls[b], loss_pts[b]) -- what
+ * torch autograd hands the head's loss Function (replaces loss.backward() through p2p_head.py:220-248). */
 int cpr_p2p_loss_bwd(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
                      const int* gt_labels, const int* gt_start, const float* npos, float* dcls, float* dreg, int B, int M,
                      int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w, float neg_w, float reg_norm,
-                     float w_cls, float w_reg, float gamma_p, void* stream);
+                     float w_cls, float w_reg, float gamma_p, const float* upstream, void* stream);
 /* sum of squares of a flat gradient buffer into out[0] (double; accumulate across buffers); ws_partial 1024 doubles */
 int cpr_grad_sumsq(const float* g, long long n, double* ws_partial, double* out, int accumulate, void* stream);
 /* torch.optim.SGD step (momentum, weight decay) with clip_grad_norm_'s coefficient taken from norm2 on the device:

@@ -65,13 +65,13 @@ SIGNATURES = {
     'cpr_axpby': [_p, _p, _f, _f, _l, _p],
     'cpr_phase_scatter_add': [_p, _p] + [_i] * 11 + [_p],
     'cpr_zero_insert': [_p, _p] + [_i] * 7 + [_p],
-    'cpr_loss_bwd': [_p] * 13 + [_i] * 9 + [_f] * 5 + [_p],
+    'cpr_loss_bwd': [_p] * 15 + [_i] * 10 + [_f] * 5 + [_p, _p],
     # data side
     'cpr_preprocess_u8': [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     'cpr_clip_flip_boxes': [_p, _p, _p, _p, _i, _i, _p],
     'cpr_pack_weights': [_p, _p, _p] + [_i] * 7 + [_p],
     'cpr_bn_fold': [_p, _p, _p, _p, _f, _p, _p, _p, _i, _p],
-    'cpr_p2p_loss_bwd': [_p] * 9 + [_i] * 5 + [_f] * 9 + [_p],
+    'cpr_p2p_loss_bwd': [_p] * 9 + [_i] * 5 + [_f] * 9 + [_p, _p],
     'cpr_grad_sumsq': [_p, _l, _p, _p, _i, _p],
     'cpr_sgd_step': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p],
 }

@@ -148,24 +148,33 @@ class ResNet(nn.Module):
                     nn.init.constant_((blk.bn3 if blk.kind == 'bottleneck' else blk.bn2).weight, 0)
         bump_weight_epoch()
 
-    def forward(self, x, tape=None):
-        """x: (N,3,H,W) -> tuple of NCHW-shaped (channels_last) stage outputs.
-        tape (list): training mode -- one record per block with trainable parameters, in forward order."""
+    def stem(self, x):
+        """(N,3,H,W) image -> the NHWC map after conv1 + bn1 + ReLU + max-pool (resnet.py:630-637)."""
         c = self._cache
         # (N,3,H,W) float image -> NHWC4; a 4-channel channels-last view (datasets.GpuImagePipeline output) is taken as is
         x = ops.from_nchw(x) if (x.shape[1] > 4 or (x.shape[1] == 4 and x.stride(1) == 1)) else ops.nchw_to_nhwc(x)
         s, b = folded_bn(c, self.bn1)
         # bf16 compute mode: the 3-channel stem stays on the fp32 kernel and emits a bf16 map
         x = ops.conv2d(x, packed_conv(c, self.conv1), scale=s, bias=b, relu=True, out_dtype=self.compute_dtype)
-        x = ops.maxpool3x3s2(x)
+        return ops.maxpool3x3s2(x)
+
+    def run_stage(self, i, x, tape=None):
+        """Stage ``i`` (``layer{i+1}``) on an NHWC map.  tape (list): one record per block with trainable parameters."""
+        for blk in getattr(self, self.res_layers[i]):
+            rec = None
+            if tape is not None and blk.conv1.weight.requires_grad:
+                rec = dict(stage=i)
+                tape.append(rec)
+            x = blk.run(self._cache, x, rec)
+        return x
+
+    def forward(self, x, tape=None):
+        """x: (N,3,H,W) -> tuple of NCHW-shaped (channels_last) stage outputs.
+        tape (list): training mode -- one record per block with trainable parameters, in forward order."""
+        x = self.stem(x)
         outs = []
-        for i, name in enumerate(self.res_layers):
-            for blk in getattr(self, name):
-                rec = None
-                if tape is not None and blk.conv1.weight.requires_grad:
-                    rec = dict(stage=i)
-                    tape.append(rec)
-                x = blk.run(c, x, rec)
+        for i in range(len(self.res_layers)):
+            x = self.run_stage(i, x, tape)
             if i in self.out_indices:
                 outs.append(ops.as_nchw(x))
         return tuple(outs)

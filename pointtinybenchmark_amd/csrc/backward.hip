@@ -438,7 +438,8 @@ extern "C" int cpr_zero_insert(const float* dy, float* out, int N, int OH, int O
 // bag scatter can accumulate on top.  dmap (N,HW,Jd), Jd >= J (padded so the conv data/weight-gradient kernels can eat it).
 __global__ void neg_loss_bwd_kernel(const float* __restrict__ logit, const unsigned char* __restrict__ mask,
                                     const float* __restrict__ out5, float* __restrict__ dmap, long long NP, int J, int Jd,
-                                    int C, float eps, float w_neg) {
+                                    int C, float eps, float w_neg, const float* __restrict__ up) {
+    if (up) w_neg *= up[3];          // upstream gradient of neg_loss (autograd bridge; 1.0 multiplies exactly)
     const float scale = w_neg / out5[4];
     const long long total = NP * Jd;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -466,8 +467,10 @@ __device__ __forceinline__ float gfocal_dp(float p, float q, float eps) {
 __global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int ins_off,
                                     const unsigned char* __restrict__ valid, const int* __restrict__ labels,
                                     const float* __restrict__ gt_weight, const float* __restrict__ bag,
-                                    float* __restrict__ dbag, int G, int K, int C, float eps, float w_mil, float w_gt) {
+                                    float* __restrict__ dbag, int G, int K, int C, float eps, float w_mil, float w_gt,
+                                    const float* __restrict__ up) {
     __shared__ double red[2][4];
+    if (up) { w_gt *= up[0]; w_mil *= up[1]; }     // upstream gradients of gt_loss / pos_loss
     // num_sample / num_pos_gt: deterministic block-local recount of the forward's per-bag flags
     double ns = 0, ng = 0;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
@@ -543,56 +546,119 @@ __global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int
     }
 }
 
-// scatter dbag (G,K,J) through the bilinear taps of bag_sample onto dmap (N,H,W,J) with float atomics
-__global__ void bag_scatter_bwd_kernel(const float* __restrict__ dbag, int J, const float* __restrict__ ctr,
-                                       const int* __restrict__ gt_img, const float* __restrict__ offs,
-                                       float* __restrict__ dmap, int Jd, int G, int K, int H, int W, float stride) {
-    const long long total = (long long)G * K * J;
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int j = (int)(i % J);
-    const long long gk = i / J;
-    const int k = (int)(gk % K), g = (int)(gk / K);
-    const float d = dbag[i];
-    if (d == 0.f) return;
-    const int n = gt_img[g];
+// dbag (G,K,J) back through the bilinear taps of bag_sample onto dmap (N,H,W,Jd) -- DETERMINISTIC (round 4; the round-1..3
+// form scattered with float atomics, so two runs of the same step differed in the last bits and nothing downstream of the loss
+// could be held bit-equal between the trainer and the autograd bridge).  Two launches:
+//   bag_window_kernel      one workgroup per bag.  The K points of a bag lie within `radius` cells of their centre, so all their
+//                          taps fall into a WIN x WIN window (WIN = 2*radius + 3) whose origin is the smallest tap cell of the
+//                          bag.  Tap cells / weights of the K points go to LDS once; thread (cell, j) then GATHERS: it walks the
+//                          points in k order and sums the taps that land on its cell -- one owner per output, fixed order.
+//   bag_window_add_kernel  one workgroup per image: adds the windows of the image's bags onto dmap bag after bag (barrier in
+//                          between: overlapping bags are summed in gt order).
+// The tap arithmetic is bag_sample's (grid_sample coordinate round trip, border clamp, align_corners = False).
+__global__ void bag_window_kernel(const float* __restrict__ dbag, int J, const float* __restrict__ ctr,
+                                  const float* __restrict__ offs, float* __restrict__ win, int* __restrict__ win_org, int WIN,
+                                  int K, int H, int W, float stride) {
+    extern __shared__ unsigned char smem_raw[];
+    int* tx0 = reinterpret_cast<int*>(smem_raw);                 // [K] tap cell x0
+    int* ty0 = tx0 + K;                                           // [K] tap cell y0
+    float* tww = reinterpret_cast<float*>(ty0 + K);               // [K] weight of x0 + 1
+    float* twn = tww + K;                                         // [K] weight of y0 + 1
+    __shared__ int org[2];
+    const int g = blockIdx.x;
+    if (threadIdx.x == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
+    __syncthreads();
     const float cx = ctr[g * 2], cy = ctr[g * 2 + 1];
-    const float px = (k < K - 1) ? __fadd_rn(offs[k * 2], cx) : cx;
-    const float py = (k < K - 1) ? __fadd_rn(offs[k * 2 + 1], cy) : cy;
     const float fw = (float)W, fh = (float)H;
-    float gx = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(px, stride), 1.f), fw), 1.f);
-    float gy = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(py, stride), 1.f), fh), 1.f);
-    float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), fw), 1.f) * 0.5f;
-    float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), fh), 1.f) * 0.5f;
-    ix = fminf(fw - 1.f, fmaxf(ix, 0.f));
-    iy = fminf(fh - 1.f, fmaxf(iy, 0.f));
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-    const float ww = ix - x0f, we = 1.f - ww, wn_ = iy - y0f, ws = 1.f - wn_;
-    const bool x1ok = x1 < W, y1ok = y1 < H;
-    float* base = dmap + (size_t)n * H * W * Jd + j;
-    atomicAdd(base + ((size_t)y0 * W + x0) * Jd, d * ws * we);
-    if (x1ok) atomicAdd(base + ((size_t)y0 * W + x1) * Jd, d * ws * ww);
-    if (y1ok) atomicAdd(base + ((size_t)y1 * W + x0) * Jd, d * wn_ * we);
-    if (x1ok && y1ok) atomicAdd(base + ((size_t)y1 * W + x1) * Jd, d * wn_ * ww);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float px = (k < K - 1) ? __fadd_rn(offs[k * 2], cx) : cx;
+        const float py = (k < K - 1) ? __fadd_rn(offs[k * 2 + 1], cy) : cy;
+        float gx = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(px, stride), 1.f), fw), 1.f);
+        float gy = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(py, stride), 1.f), fh), 1.f);
+        float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), fw), 1.f) * 0.5f;
+        float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), fh), 1.f) * 0.5f;
+        ix = fminf(fw - 1.f, fmaxf(ix, 0.f));
+        iy = fminf(fh - 1.f, fmaxf(iy, 0.f));
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        tx0[k] = (int)x0f;
+        ty0[k] = (int)y0f;
+        tww[k] = ix - x0f;
+        twn[k] = iy - y0f;
+        atomicMin(&org[0], (int)x0f);        // integer minimum: order-independent
+        atomicMin(&org[1], (int)y0f);
+    }
+    __syncthreads();
+    const int ox = org[0], oy = org[1];
+    if (threadIdx.x == 0) { win_org[g * 2] = ox; win_org[g * 2 + 1] = oy; }
+    const float* D = dbag + (size_t)g * K * J;
+    float* Wg = win + (size_t)g * WIN * WIN * J;
+    const int total = WIN * WIN * J;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int j = i % J, cell = i / J;
+        const int x = ox + cell % WIN, y = oy + cell / WIN;
+        float acc = 0.f;
+        if (x < W && y < H) {
+            for (int k = 0; k < K; ++k) {
+                const unsigned dx = (unsigned)(x - tx0[k]), dy = (unsigned)(y - ty0[k]);
+                if (dx > 1u || dy > 1u) continue;
+                const float d = D[(size_t)k * J + j];
+                if (d == 0.f) continue;
+                const float ww = tww[k], wn_ = twn[k];
+                const float wy = dy ? wn_ : 1.f - wn_, wx = dx ? ww : 1.f - ww;
+                acc += d * wy * wx;
+            }
+        }
+        Wg[i] = acc;
+    }
+}
+__global__ void __launch_bounds__(1024) bag_window_add_kernel(const float* __restrict__ win, const int* __restrict__ win_org, int WIN, int J,
+                                      const int* __restrict__ gt_img, float* __restrict__ dmap, int Jd, int G, int H, int W) {
+    __shared__ int range[2];
+    const int n = blockIdx.x;
+    if (threadIdx.x == 0) {        // the bags of image n (gt_img ascends: CSR order)
+        int lo = 0;
+        while (lo < G && gt_img[lo] < n) ++lo;
+        int hi = lo;
+        while (hi < G && gt_img[hi] == n) ++hi;
+        range[0] = lo;
+        range[1] = hi;
+    }
+    __syncthreads();
+    const int lo = range[0], hi = range[1];
+    float* base = dmap + (size_t)n * H * W * Jd;
+    const int total = WIN * WIN * J;
+    for (int g = lo; g < hi; ++g) {
+        const int ox = win_org[g * 2], oy = win_org[g * 2 + 1];
+        const float* Wg = win + (size_t)g * total;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int j = i % J, cell = i / J;
+            const int x = ox + cell % WIN, y = oy + cell / WIN;
+            const float v = Wg[i];
+            if (v != 0.f && x < W && y < H) base[((size_t)y * W + x) * Jd + j] += v;
+        }
+        __syncthreads();           // the next bag may touch the same cells (workgroup-scope fence + barrier)
+    }
 }
 
 extern "C" int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* out5, const float* bag_logits,
                             const unsigned char* valid, const int* labels, const float* gt_weight, const float* bag_ws,
                             const float* centers, const int* gt_img, const float* offsets, float* dbag_ws, float* dmap,
+                            float* win_ws, int* win_org, int win,
                             int N, int H, int W, int J, int Jd, int ins_off, int G, int K, int C, float stride, float eps,
-                            float w_mil, float w_gt, float w_neg, hipStream_t stream) {
+                            float w_mil, float w_gt, float w_neg, const float* upstream, hipStream_t stream) {
     CPR_CHECK_ARG(lmap && neg_mask && out5 && bag_logits && valid && labels && bag_ws && centers && gt_img && dbag_ws && dmap);
+    CPR_CHECK_ARG(win_ws && win_org && win >= 3 && (size_t)K * 16 <= 60000);
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && G > 0 && K > 0 && C > 0 && J >= ins_off + C && Jd >= J && (K == 1 || offsets));
     const long long NP = (long long)N * H * W;
     const int grid = (int)(cdivll(NP * Jd, 256) < 32768 ? cdivll(NP * Jd, 256) : 32768);
     hipLaunchKernelGGL(neg_loss_bwd_kernel, dim3(grid), dim3(256), 0, stream, lmap, neg_mask, out5, dmap, NP, J, Jd, C,
-                       eps, w_neg);
+                       eps, w_neg, upstream);
     hipLaunchKernelGGL(bag_loss_bwd_kernel, dim3(cdiv(G, 4)), dim3(256), 0, stream, bag_logits, J, ins_off, valid, labels,
-                       gt_weight, bag_ws, dbag_ws, G, K, C, eps, w_mil, w_gt);
-    const long long total = (long long)G * K * J;
-    hipLaunchKernelGGL(bag_scatter_bwd_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, dbag_ws, J,
-                       centers, gt_img, offsets, dmap, Jd, G, K, H, W, stride);
+                       gt_weight, bag_ws, dbag_ws, G, K, C, eps, w_mil, w_gt, upstream);
+    hipLaunchKernelGGL(bag_window_kernel, dim3(G), dim3(256), (size_t)K * 16, stream, dbag_ws, J, centers, offsets, win_ws,
+                       win_org, win, K, H, W, stride);
+    hipLaunchKernelGGL(bag_window_add_kernel, dim3(N), dim3(win * win * J >= 4096 ? 1024 : 256), 0, stream, win_ws, win_org,
+                       win, J, gt_img, dmap, Jd, G, H, W);
     CPR_LAUNCH_STATUS();
 }
 
@@ -673,10 +739,12 @@ __global__ void p2p_loss_bwd_kernel(const float* __restrict__ logits, const floa
                                     const int* __restrict__ gt_labels, const int* __restrict__ gt_start,
                                     const float* __restrict__ npos, float* __restrict__ dcls, float* __restrict__ dreg,
                                     int M, int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w,
-                                    float neg_w, float reg_norm, float w_cls, float w_reg, float gamma_p) {
+                                    float neg_w, float reg_norm, float w_cls, float w_reg, float gamma_p,
+                                    const float* __restrict__ up) {
     const int b = blockIdx.y;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
+    if (up) { w_cls *= up[b * 2]; w_reg *= up[b * 2 + 1]; }     // upstream gradients of this image's (loss_cls, loss_pts)
     const size_t r = (size_t)b * M + m;
     const float inv_n = 1.f / fmaxf(npos[0], 1.f);
     const long long gi = gt_inds[r];
@@ -713,11 +781,12 @@ __global__ void p2p_loss_bwd_kernel(const float* __restrict__ logits, const floa
 extern "C" int cpr_p2p_loss_bwd(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
                                 const int* gt_labels, const int* gt_start, const float* npos, float* dcls, float* dreg,
                                 int B, int M, int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w,
-                                float neg_w, float reg_norm, float w_cls, float w_reg, float gamma_p, hipStream_t stream) {
+                                float neg_w, float reg_norm, float w_cls, float w_reg, float gamma_p, const float* upstream,
+                                hipStream_t stream) {
     CPR_CHECK_ARG(B > 0 && M > 0 && C > 0 && Cp >= C && Rp >= 2 && beta > 0);
     CPR_CHECK_ARG(logits && pred && gt_inds && gt_pts && gt_labels && gt_start && npos && dcls && dreg);
     hipLaunchKernelGGL(p2p_loss_bwd_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, stream, logits, pred, gt_inds, gt_pts,
                        gt_labels, gt_start, npos, dcls, dreg, M, C, Cp, Rp, alpha, gamma, beta, pos_w, neg_w, reg_norm,
-                       w_cls, w_reg, gamma_p);
+                       w_cls, w_reg, gamma_p, upstream);
     CPR_LAUNCH_STATUS();
 }

@@ -485,13 +485,19 @@ class CPRHead(nn.Module):
             out, bag_ws = out
             save.update(feat=feat, ab=ab, lmap=lmap, neg_mask=neg_mask, out5=out, bag_logits=bag_logits, valid=valid,
                         labels=labels, gt_weight=w, bag_ws=bag_ws, centers=gts.points, gt_img=gts.gt_img,
-                        offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride)
+                        offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride, radius_cells=ex.pos_radius)
+        return self._loss_dict(out)
+
+    def _loss_dict(self, out):
+        """The (gt_loss, pos_loss, bag_acc, neg_loss, num_sample) vector of the loss kernels -> the reference's dict
+        (cpr_head.py:1131-1229: only the enabled terms appear)."""
+        cfg = self.loss_cfg
         losses = {}
-        if with_gt:
+        if cfg.get('with_gt_loss', False):
             losses['gt_loss'] = out[0]
-        if with_mil:
+        if cfg.get('with_mil_loss', True):
             losses['pos_loss'], losses['bag_acc'] = out[1], out[2]
-        if with_neg:
+        if cfg.get('with_neg', True):
             losses['neg_loss'] = out[3]
         return losses
 

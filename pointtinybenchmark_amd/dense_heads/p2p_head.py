@@ -206,7 +206,7 @@ class P2PHead(nn.Module):
         B = out.shape[0]
         if save is not None:      # what the loss backward re-reads (training.P2PTrainer)
             save.update(cls=cls.contiguous(), pred=pred, gt_inds=gt_inds.contiguous(), gt_pts=torch.cat(gt_points).contiguous(),
-                        gt_labels=torch.cat(gt_labels).to(torch.int32).contiguous(), gt_start=start)
+                        gt_labels=torch.cat(gt_labels).to(torch.int32).contiguous(), gt_start=start, out=out)
         return {'loss_cls': [out[b, 0] for b in range(B)], 'loss_pts': [out[b, 1] for b in range(B)]}
 
     def get_targets(self, pred_pts, valid_flag_list, cls_outs_list, gt_points, gt_labels, img_metas,

@@ -140,6 +140,16 @@ class BasicLocator(nn.Module):
             raw, ab, lmap = self._graphed_logit_map(img)
             return self.bbox_head.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas,
                                        gt_bboxes_ignore=gt_bboxes_ignore, gt_true_bboxes=gt_true_bboxes, lmap=lmap)
+        if torch.is_grad_enabled() and img.is_cuda and any(p.requires_grad for p in self.parameters()):
+            # autograd is on: the losses must carry a graph, as the reference's do (its driver calls loss.backward():
+            # T/mmdet/models/detectors/base.py:214-247 + mmcv OptimizerHook).  The recorded forward / HIP backward pair sits
+            # behind torch.autograd.Functions (autograd_bridge.py); same loss values as the forward-only path below
+            from .. import autograd_bridge
+            why = autograd_bridge.unsupported_reason(self, gt_bboxes, gt_labels)
+            if why is None:
+                return autograd_bridge.forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore,
+                                                     gt_true_bboxes)
+            autograd_bridge.warn_once(why)
         k = int(os.environ.get('CPR_STREAMS', self.num_streams))
         if k > 1 and img.is_cuda and hasattr(self.bbox_head, 'loss'):
             outs = self._towers_multistream(img, k)
@@ -195,6 +205,8 @@ class BasicLocator(nn.Module):
         return loss, log_vars
 
     def train_step(self, data, optimizer=None):
+        """base.py:214-247.  With autograd enabled (how mmcv's runner calls it) ``loss`` carries a graph: ``loss.backward()``
+        fills ``p.grad`` of every trainable parameter through the HIP backward kernels (autograd_bridge.py)."""
         losses = self(**data)
         loss, log_vars = self._parse_losses(losses)
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))

@@ -44,10 +44,9 @@ class FPN(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def _run(self, inputs, lazy, tape=None, out_b8=False):
-        assert len(inputs) == len(self.in_channels)
+    def run_laterals(self, xs, tape=None):
+        """xs: the NHWC stage outputs from ``start_level`` on -> the top-down lateral sums, finest first (fpn.py:166-188)."""
         c = self._cache
-        xs = [ops.from_nchw(inputs[i + self.start_level]) for i in range(len(self.lateral_convs))]
         # top-down: coarsest level first; GN-apply of level i and "+= upsample(level i+1)" in one kernel
         lat = [None] * len(xs)
         for i in range(len(xs) - 1, -1, -1):
@@ -57,6 +56,13 @@ class FPN(nn.Module):
                 rec = dict(kind='lateral', level=i)
                 tape.append(rec)
             lat[i] = conv_gn(c, self.lateral_convs[i], xs[i], up=up, save=rec)
+        return lat
+
+    def _run(self, inputs, lazy, tape=None, out_b8=False):
+        assert len(inputs) == len(self.in_channels)
+        c = self._cache
+        xs = [ops.from_nchw(inputs[i + self.start_level]) for i in range(len(self.lateral_convs))]
+        lat = self.run_laterals(xs, tape)
         used = min(len(lat), self.num_outs)
         outs = []
         for i in range(used):

@@ -884,29 +884,41 @@ def axpby(y, x, alpha=1.0, beta=1.0):
 
 
 def cpr_loss_bwd(lmap, neg_mask, out5, bag_logits, valid, labels, bag_ws, centers, gt_img, offsets, ins_off, num_classes,
-                 stride, w_mil, w_gt, w_neg, Jd, gt_weight=None, eps=1e-6):
-    """-> dmap (N,H,W,Jd): gradient of gt_loss + pos_loss + neg_loss wrt the logit map (channels >= J are zero)."""
+                 stride, w_mil, w_gt, w_neg, Jd, gt_weight=None, eps=1e-6, upstream=None, radius_cells=None):
+    """-> dmap (N,H,W,Jd): gradient of gt_loss + pos_loss + neg_loss wrt the logit map (channels >= J are zero).
+    radius_cells: the bag radius in grid cells (every offset lies within radius_cells * stride of its centre): the taps of a
+    bag are gathered in a (2 * radius_cells + 3)^2 window -- deterministic, no float atomics.  gt_img must ascend.
+    upstream (5,) fp32 device tensor: gradient of the caller's total wrt the forward's (gt_loss, pos_loss, bag_acc, neg_loss,
+    num_sample) vector -- the autograd bridge passes what torch hands it; None = unit weights."""
+    assert upstream is None or (upstream.numel() == 5 and upstream.dtype == torch.float32 and upstream.is_contiguous())
     N, H, W, J = _check(lmap).shape
     G, K, _ = bag_logits.shape
     dmap = torch.empty((N, H, W, Jd), device=lmap.device, dtype=torch.float32)
     dbag = torch.empty((G, K, J), device=lmap.device, dtype=torch.float32)
+    assert radius_cells is not None and radius_cells >= 0, 'the bag radius (in cells) sizes the gather window'
+    win = 2 * int(radius_cells) + 3
+    win_ws = torch.empty((G, win, win, J), device=lmap.device, dtype=torch.float32)
+    win_org = torch.empty((G, 2), device=lmap.device, dtype=torch.int32)
     _lib.call('cpr_loss_bwd', _ptr(lmap), _ptr(neg_mask), _ptr(out5), _ptr(bag_logits), _ptr(valid), _ptr(labels),
-              _ptr(gt_weight), _ptr(bag_ws), _ptr(centers), _ptr(gt_img), _ptr(offsets), _ptr(dbag), _ptr(dmap), N, H, W,
-              J, Jd, ins_off, G, K, num_classes, float(stride), float(eps), float(w_mil), float(w_gt), float(w_neg),
-              _stream())
+              _ptr(gt_weight), _ptr(bag_ws), _ptr(centers), _ptr(gt_img), _ptr(offsets), _ptr(dbag), _ptr(dmap), _ptr(win_ws),
+              _ptr(win_org), win, N, H, W, J, Jd, ins_off, G, K, num_classes, float(stride), float(eps), float(w_mil),
+              float(w_gt), float(w_neg), _ptr(upstream), _stream())
     return dmap, dbag
 
 
 def p2p_loss_bwd(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, beta, pos_w, neg_w, reg_norm, w_cls,
-                 w_reg, gamma_p, Cp, Rp):
-    """-> (dcls (B,M,Cp), dreg (B,M,Rp)): gradient of the summed P2P losses wrt class logits / regression output."""
+                 w_reg, gamma_p, Cp, Rp, upstream=None):
+    """-> (dcls (B,M,Cp), dreg (B,M,Rp)): gradient of the summed P2P losses wrt class logits / regression output.
+    upstream (B,2): gradient of the caller's total wrt each image's (loss_cls, loss_pts); None = unit weights."""
     B, M, C = _check(logits).shape
+    assert upstream is None or (tuple(upstream.shape) == (B, 2) and upstream.dtype == torch.float32 and upstream.is_contiguous())
     npos = (gt_inds > 0).sum().to(torch.float32).reshape(1)          # device scalar, no host sync
     dcls = torch.empty((B, M, Cp), device=logits.device, dtype=torch.float32)
     dreg = torch.empty((B, M, Rp), device=logits.device, dtype=torch.float32)
     _lib.call('cpr_p2p_loss_bwd', _ptr(logits), _ptr(_check(pred)), _ptr(gt_inds), _ptr(gt_pts), _ptr(gt_labels),
               _ptr(gt_start), _ptr(npos), _ptr(dcls), _ptr(dreg), B, M, C, Cp, Rp, float(alpha), float(gamma), float(beta),
-              float(pos_w), float(neg_w), float(reg_norm), float(w_cls), float(w_reg), float(gamma_p), _stream())
+              float(pos_w), float(neg_w), float(reg_norm), float(w_cls), float(w_reg), float(gamma_p), _ptr(upstream),
+              _stream())
     return dcls, dreg
 
 

@@ -215,7 +215,314 @@ class StepLrSchedule:
         return reg * (1 - (1 - it / self.warmup_iters) * (1 - self.warmup_ratio))
 
 
-class CprTrainer:
+class BackwardEngine:
+    """The backward rules of the recorded forward -- shared by ``CprTrainer`` (gradients written straight into the views of
+    its flat buffer, bucketed reducer, native optimizer) and by the autograd bridge (``autograd_bridge.py``: the same rules
+    behind ``torch.autograd.Function``s, gradients handed to torch, so that ``loss.backward()`` / DDP / torch.optim drive the
+    drop-in classes as they drive the reference's).  ``_g(p)`` is where the gradient of parameter ``p`` is written."""
+
+    def __init__(self, model, two_streams=True):
+        self.model = model
+        dev = next(model.parameters()).device
+        self._mixed, self._wide = False, {}     # set per step (bf16 compute mode = mixed precision)
+        self._sink = None                       # None: p.grad (CprTrainer); dict: id(p) -> fresh tensor (autograd bridge)
+        # weight gradients run on a second stream: they are off the critical path (nothing downstream of the backward
+        # chain reads them) and the deep layers' launches are too small to fill 256 CUs on their own
+        self.side = torch.cuda.Stream(device=dev) if two_streams and dev.type == 'cuda' else None
+
+    def _g(self, p):
+        """Where the gradient of ``p`` is written."""
+        if self._sink is None:
+            return p.grad
+        t = self._sink.get(id(p))
+        if t is None:
+            t = self._sink[id(p)] = torch.empty(p.shape, device=p.device, dtype=torch.float32)
+        return t
+
+    def collect(self, params):
+        """autograd bridge: the gradients written since the last call, in the order of ``params`` (None where no rule wrote
+        one), visible to the current stream."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        out = []
+        cur = torch.cuda.current_stream()
+        for p in params:
+            t = self._sink.pop(id(p), None)
+            if t is not None:
+                t.record_stream(cur)            # may have been allocated while the side stream was current
+            out.append(t)
+        return tuple(out)
+
+    def begin_step(self):
+        self._mixed = self.model.backbone.compute_dtype == torch.bfloat16
+        self._wide = {}
+
+    def _done(self, p):
+        """The gradient of ``p`` (and of everything before it in the trainer's flat order) has been enqueued."""
+
+
+    # ------------------------------------------------------------------ helpers
+    def _param_side(self, fn, *tensors):
+        """Run the parameter-gradient work ``fn`` on the side stream, ordered after everything enqueued so far on the
+        main stream.  ``tensors``: its inputs that may be released by the main stream before the side stream ran."""
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def _f32(self, t, keep=False):
+        """A recorded map as the fp32 backward kernels read it (a bf16 map of the mixed-precision forward is widened, exactly).
+        keep: the same recorded tensor is read again by the NEXT backward rule (a block's input is the output of the block
+        before it) -- the widened copy is held until then instead of being made twice."""
+        if t is None or t.dtype == torch.float32:
+            return t
+        hit = self._wide.pop(id(t), None)
+        w = hit if hit is not None else t.float()
+        if keep:
+            self._wide[id(t)] = w
+        return w
+
+    def _gn_conv_backward(self, rec, dz, relu, need_dx):
+        """Backward of conv -> GN (-> ReLU) given dz wrt the module output.  Writes the three parameter gradients;
+        returns the gradient wrt the conv INPUT as the consumer saw it (after the producer's pending affine, if any)."""
+        cm = rec['module']
+        w, gn = cm.conv.weight, cm.gn
+        assert cm.conv.bias is None
+        draw, _, _ = ops.gn_bwd(self._f32(rec['raw']), dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
+                                out_dgamma=self._g(gn.weight), out_dbeta=self._g(gn.bias))
+        d16 = None             # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight and data gradients
+        dgrad16 = need_dx and rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and w.shape[0] % 64 == 0
+        if rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
+                rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0]):
+            x = rec['x']       # the weight gradient on the bf16 matrix pipe, straight from the recorded map
+            d16 = draw.to(torch.bfloat16)
+            gw = self._g(w)
+            self._param_side(lambda: ops.conv_wgrad_bf16(d16, x, w.shape, out=gw), d16, x)
+        else:
+            x = self._f32(rec['x'])
+            gw = self._g(w)
+            self._param_side(lambda: ops.conv2d_wgrad(draw, x, w.shape, cm.conv.stride[0], cm.conv.padding[0],
+                                                      in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=gw), draw, x)
+        if not need_dx:
+            return None
+        if dgrad16:
+            return self._dgrad_bf16(draw if d16 is None else d16, w, cm.conv.padding[0])
+        pt = ops.dgrad_pack(w, cm.conv.stride[0], cm.conv.padding[0])
+        return ops.conv2d_dgrad(draw, pt, (rec['x'].shape[1], rec['x'].shape[2]), cm.conv.stride[0])
+
+    @staticmethod
+    def _dgrad_bf16(dy, w, padding):
+        """Mixed precision: the data gradient of a stride-1 conv on the bf16 matrix pipe -- a forward conv of the bf16-rounded
+        gradient map with the rotated weights (channels swapped, taps flipped, padding K-1-p), fp32 out.  The weight gradient
+        next to it keeps reading the fp32 map."""
+        k = w.shape[2]
+        wt = w.detach().flip(2, 3).permute(1, 0, 2, 3)
+        pc = ops.PackedConv(wt, 1, k - 1 - padding, torch.bfloat16)
+        return ops.conv2d(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), pc, out_dtype=torch.float32)
+
+    # ------------------------------------------------------------------ CPR head
+    @staticmethod
+    def _forward_head(head, lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes):
+        tape, save = [], {}
+        losses = head.forward_train_lazy(lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes,
+                                         tape=tape, save=save)
+        save['tape'] = tape
+        return losses, save
+
+    def _backward_head(self, head, s, upstream=None):
+        """upstream (5,): gradient of the caller's total wrt the forward's loss vector (autograd bridge); None = unit weights."""
+        head_tape = s['tape']
+        C = head.num_classes
+        cfg = head.loss_cfg
+        J = s['lmap'].shape[-1]
+        Jd = 4 if J <= 4 else (J + 31) // 32 * 32
+        w_mil = head.loss_mil.loss_weight if cfg.get('with_mil_loss', True) else 0.0
+        w_gt = cfg.get('gt_loss_weight', 1.0) if cfg.get('with_gt_loss', False) else 0.0
+        w_neg = cfg.get('neg_loss_weight', 1.0) if cfg.get('with_neg', True) else 0.0
+        assert s['neg_mask'] is not None, 'with_neg=False is not on the training path'
+        dmap, _ = ops.cpr_loss_bwd(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
+                                   s['bag_ws'], s['centers'], s['gt_img'], s['offsets'], s['ins_off'], C, s['stride'],
+                                   w_mil, w_gt, w_neg, Jd, gt_weight=s['gt_weight'], eps=head.loss_mil.eps,
+                                   upstream=upstream, radius_cells=s['radius_cells'])
+        # ---- logit projection (cls_out ++ ins_out as one 1x1 conv over the un-normalised last tower layer)
+        shared = head.ins_share_head_classifier
+        wcat = head.cls_out.weight if shared else torch.cat([head.cls_out.weight, head.ins_out.weight], 0)
+        wpad = torch.zeros((Jd, wcat.shape[1], 1, 1), device=wcat.device, dtype=torch.float32)
+        wpad[:J, :, 0, 0] = wcat.detach()
+        gw = ops.conv2d_wgrad(dmap, self._f32(s['feat']), wpad.shape, 1, 0, in_ab=s['ab'], in_relu=True)
+        _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
+        self._g(head.cls_out.weight).copy_(gw[:C, :, 0, 0])
+        self._g(head.cls_out.bias).copy_(gb[:C])
+        if not shared:
+            self._g(head.ins_out.weight).copy_(gw[C:2 * C, :, 0, 0])
+            self._g(head.ins_out.bias).copy_(gb[C:2 * C])
+        self._done(head.ins_out.bias if not shared else head.cls_out.bias)
+        dz = ops.conv2d_dgrad(dmap, ops.dgrad_pack(wpad, 1, 0), (dmap.shape[1], dmap.shape[2]))
+        # ---- tower, last layer first; layer 0 consumes the (un-activated) FPN output
+        for rec in reversed(head_tape):
+            dz = self._gn_conv_backward(rec, dz, relu=True, need_dx=True)
+            self._done(rec['module'].conv.weight)
+        return dz
+
+    def _out_conv_backward(self, rec, dout_pad, n_out):
+        """Backward of a biased output conv (nn.Conv2d) reading the un-normalised last tower layer with its GroupNorm
+        affine (+ReLU) applied on load.  dout_pad (N,H,W,Cp): gradient wrt the conv output, channels padded to what the
+        conv gradient kernels take (first n_out live).  Returns the gradient wrt the normalised, activated input."""
+        conv = rec['conv']
+        w = conv.weight
+        Cp = dout_pad.shape[-1]
+        wpad = torch.zeros((Cp,) + tuple(w.shape[1:]), device=w.device, dtype=torch.float32)
+        wpad[:n_out] = w.detach()
+        x, ab = self._f32(rec['x']), rec['in_ab']
+
+        def param_grads():
+            gw = ops.conv2d_wgrad(dout_pad, x, wpad.shape, conv.stride[0], conv.padding[0], in_ab=ab, in_relu=True)
+            _, gb = ops.relu_bwd_colsum(dout_pad, None, want_g=False)
+            self._g(w).copy_(gw[:n_out])
+            self._g(conv.bias).copy_(gb[:n_out])
+        self._param_side(param_grads, dout_pad, x)
+        return ops.conv2d_dgrad(dout_pad, ops.dgrad_pack(wpad, conv.stride[0], conv.padding[0]),
+                                (x.shape[1], x.shape[2]), conv.stride[0])
+
+    # ------------------------------------------------------------------ FPN, backbone
+    def _backward_neck(self, neck, neck_tape, dz):
+        """Output conv, then the top-down chain from the finest lateral to the coarsest -> {stage: d(stage output)}."""
+        lat_recs = {r['level']: r for r in neck_tape if r['kind'] == 'lateral'}
+        out_recs = {r['level']: r for r in neck_tape if r['kind'] == 'out'}
+        assert list(out_recs) == [0], 'num_outs == 1 (every shipped CPR config)'
+        dlat = self._backward_out_conv(out_recs[0], dz)
+        return self._backward_laterals(neck, lat_recs, dlat)
+
+    def _backward_out_conv(self, rec, dz):
+        """FPN output conv (3x3 + GN, no activation): dz wrt its normalised output -> gradient wrt the finest lateral sum."""
+        dlat = self._gn_conv_backward(rec, dz, relu=False, need_dx=True)
+        self._done(rec['module'].conv.weight)
+        return dlat
+
+    def _backward_laterals(self, neck, lat_recs, dlat, need_dx_of=None):
+        """The top-down chain from the finest lateral to the coarsest -> {stage: d(stage output) or None}.
+        need_dx_of(stage): whether the gradient wrt that backbone stage's output is wanted (default: the stage trains)."""
+        d_stage = {}
+        L = len(lat_recs)
+        for i in range(L):
+            rec = lat_recs[i]
+            stage = i + neck.start_level
+            need_dx = bool((need_dx_of or self._stage_trainable)(stage))
+            d_stage[stage] = self._gn_conv_backward(rec, dlat, relu=False, need_dx=need_dx)
+            self._done(rec['module'].conv.weight)
+            if i + 1 < L:
+                nxt = lat_recs[i + 1]['raw'].shape
+                dlat = ops.upsample_add_bwd(dlat, tuple(nxt))
+        return d_stage
+
+    def _stage_trainable(self, stage):
+        bb = self.model.backbone
+        return any(p.requires_grad for p in getattr(bb, bb.res_layers[stage]).parameters())
+
+    def _backward_backbone(self, bb, tape, d_stage):
+        c = bb._cache
+        dx = None            # gradient flowing down from the block above
+        cur_stage = None
+        for idx in range(len(tape) - 1, -1, -1):
+            rec = tape[idx]
+            blk, stage = rec['block'], rec['stage']
+            if stage != cur_stage:       # entering a stage from above: its output also feeds an FPN lateral
+                cur_stage = stage
+                lat = d_stage.get(stage)
+                if lat is not None:
+                    dx = lat if dx is None else ops.axpby(dx, lat, 1.0, 1.0)
+            assert dx is not None, 'no gradient reaches backbone stage %d' % stage
+            need_dx = idx > 0
+            dx = self._block_backward(c, blk, rec, dx, need_dx)
+        self._wide = {}      # nothing below the lowest trainable block reads a widened copy
+
+    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx, mask=None, add=None, want_colsum=False):
+        """conv -> folded eval-BN given g = d(pre-activation output) (un-scaled) and its column sums.  Parameter
+        gradients go to the side stream; returns the data gradient wrt x -- with ``mask`` (x itself, when x is the
+        output of a fused ReLU) already taken through that ReLU, with ``add`` summed in, with ``want_colsum`` as
+        (gradient, column sums): all three ride in the conv epilogue."""
+        scale, _ = folded_bn(cache, bn)
+        inv_sigma = cache.get(('bn_is', id(bn)), [bn.running_var],
+                              lambda: ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, True)[2])
+        w = conv.weight
+        # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight gradient and the bf16 3x3 data gradient
+        w16 = w.requires_grad and self._mixed and ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0])
+        d16 = need_dx and self._mixed and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and add is None
+        g16 = g.to(torch.bfloat16) if (w16 or d16) else None
+        if w.requires_grad:
+            aff = bn.weight.requires_grad
+
+            def param_grads():
+                cs = colsum.reduce() if isinstance(colsum, ops.TilePartials) else colsum
+                gw = self._g(w)
+                if w16:
+                    ops.conv_wgrad_bf16(g16, x, w.shape, out=gw)    # (x is the widened recorded map: rounds back exactly)
+                else:
+                    ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=gw)
+                ops.bn_fold_bwd(gw, w, scale, bn.running_mean, inv_sigma, cs,
+                                out_dgamma=self._g(bn.weight) if aff else None, out_dbeta=self._g(bn.bias) if aff else None)
+            # x may be a widened fp32 temporary of the mixed-precision step that the main stream frees right after this call
+            self._param_side(param_grads, g, colsum, g16, x)
+        if not need_dx:
+            return None
+        if d16:
+            # mixed precision: the 3x3 data gradient on the bf16 matrix pipe (its fp32 form cannot be a Winograd launch: the mask /
+            # column-sum epilogue), the ReLU mask and the column sums as one streaming pass over the (small) result
+            def pack16():
+                wt = (w.detach() * scale[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3)
+                return ops.PackedConv(wt, 1, 2 - conv.padding[0], torch.bfloat16)
+            pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16)
+            dx = ops.conv2d(g16, pc16, out_dtype=torch.float32)
+            if mask is None and not want_colsum:
+                return dx
+            gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
+            dx = gm if mask is not None else dx
+            return (dx, cs) if want_colsum else dx
+        pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
+                       lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
+        if WINO_DGRAD[0] and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and add is None and \
+                (mask is not None or want_colsum) and ops.wino_eligible(pt, x.shape[1], x.shape[2], torch.float32):
+            # a 3x3 stride-1 data gradient with a mask / column-sum epilogue would run the direct kernel (2.25x the multiplies of
+            # the Winograd launch the plain form gets); the epilogue as one streaming pass over the result is cheaper
+            dx = ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), 1)
+            gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
+            dx = gm if mask is not None else dx
+            return (dx, cs) if want_colsum else dx
+        return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
+
+    def _block_backward(self, cache, blk, rec, dout, need_dx, keep=None):
+        # x = the output of the block below: when that block's backward runs next (keep; default: whenever a gradient flows
+        # down, need_dx) it reads the same recorded tensor -- the widened copy of a bf16 map is then held for it
+        x = self._f32(rec['x'], keep=need_dx if keep is None else keep)
+        g3, cs3 = ops.relu_bwd_colsum(dout, self._f32(rec['out']))            # also the shortcut gradient
+        o1 = self._f32(rec['o1'])
+        if blk.kind == 'bottleneck':
+            o2 = self._f32(rec['o2'])
+            g2, cs2 = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, o2, True, mask=o2, want_colsum=True)
+            del o2
+            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, o1, True, mask=o1, want_colsum=True)
+            last = blk.bn3
+        else:
+            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, o1, True, mask=o1, want_colsum=True)
+            last = blk.bn2
+        del o1
+        self._done(last.bias if last.bias.requires_grad else blk.conv2.weight)
+        if blk.downsample is not None:     # the shortcut conv sees the same g3 (no activation on that branch)
+            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx)
+            dx = self._conv_bn_backward(cache, blk.downsample[0], blk.downsample[1], g3, cs3, x, need_dx, add=dx)
+            tail = blk.downsample[1].bias if blk.downsample[1].bias.requires_grad else blk.downsample[0].weight
+        else:
+            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx, add=g3)
+            tail = blk.bn1.bias if blk.bn1.bias.requires_grad else blk.conv1.weight
+        self._done(tail)
+        return dx
+
+
+class CprTrainer(BackwardEngine):
     def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_mb=25.0, group=None,
                  two_streams=True, force_collectives=False, schedule=None, reducer='all_reduce', reducer_timing=False,
                  min_bucket_mb=4.0, tail_bucket_mb=1.0):
@@ -223,7 +530,7 @@ class CprTrainer:
         ``step(lr=...)``.  Constructing the trainer re-homes every trainable parameter: ``p.data`` becomes a view of ONE
         flat buffer (``flat_p``) and ``p.grad`` a view of ``flat_g``; do not re-bind them afterwards (``model.to()``,
         ``.float()``, ``p.data = ...``) -- ``step`` checks and refuses.  ``state_dict()`` below returns detached clones."""
-        self.model = model
+        BackwardEngine.__init__(self, model, two_streams)
         self.schedule = schedule
         self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
         order = self._backward_order()
@@ -249,13 +556,9 @@ class CprTrainer:
                                    reducer=reducer, timing=reducer_timing,
                                    bounds=layout_buckets([p.numel() for p in order], max(1, int(bucket_mb * mb)),
                                                          max(1, int(min_bucket_mb * mb)), max(1, int(tail_bucket_mb * mb))))
-        self._mixed, self._wide = False, {}     # set per step by forward_backward (bf16 compute mode = mixed precision)
         self.norm2 = torch.zeros((1,), device=dev, dtype=torch.float64)
         self._ws = torch.empty((1024,), device=dev, dtype=torch.float64)
         self.steps = 0
-        # weight gradients run on a second stream: they are off the critical path (nothing downstream of the backward
-        # chain reads them) and the deep layers' launches are too small to fill 256 CUs on their own
-        self.side = torch.cuda.Stream(device=dev) if two_streams and dev.type == 'cuda' else None
         self.group = group
         self.sync_initial_state()
         bump_weight_epoch()
@@ -324,18 +627,6 @@ class CprTrainer:
             torch.cuda.current_stream().wait_stream(self.side)      # the collective must see the side stream's grads
         self.buckets.ready(end)
 
-    def _param_side(self, fn, *tensors):
-        """Run the parameter-gradient work ``fn`` on the side stream, ordered after everything enqueued so far on the
-        main stream.  ``tensors``: its inputs that may be released by the main stream before the side stream ran."""
-        if self.side is None:
-            return fn()
-        self.side.wait_stream(torch.cuda.current_stream())
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.side)
-        with torch.cuda.stream(self.side):
-            fn()
-
     # ------------------------------------------------------------------ forward (recorded) + backward
     def forward_backward(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
         """-> dict of losses (device scalars, identical to BasicLocator.forward_train); parameter .grad filled (summed
@@ -348,8 +639,7 @@ class CprTrainer:
         batch_input_shape = tuple(img[0].size()[-2:])
         for meta in img_metas:
             meta['batch_input_shape'] = batch_input_shape
-        self._mixed = bb.compute_dtype == torch.bfloat16
-        self._wide = {}      # id(recorded bf16 map) -> its fp32 copy, while a second reader is still to come
+        self.begin_step()    # mixed-precision flag; _wide: id(recorded bf16 map) -> its fp32 copy while a second reader is to come
         bb_tape, neck_tape = [], []
         feats = bb(img, tape=bb_tape)
         lazy = neck.forward_lazy(feats, tape=neck_tape)
@@ -362,237 +652,6 @@ class CprTrainer:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         return losses
-
-    def _f32(self, t, keep=False):
-        """A recorded map as the fp32 backward kernels read it (a bf16 map of the mixed-precision forward is widened, exactly).
-        keep: the same recorded tensor is read again by the NEXT backward rule (a block's input is the output of the block
-        before it) -- the widened copy is held until then instead of being made twice."""
-        if t is None or t.dtype == torch.float32:
-            return t
-        hit = self._wide.pop(id(t), None)
-        w = hit if hit is not None else t.float()
-        if keep:
-            self._wide[id(t)] = w
-        return w
-
-    def _gn_conv_backward(self, rec, dz, relu, need_dx):
-        """Backward of conv -> GN (-> ReLU) given dz wrt the module output.  Writes the three parameter gradients;
-        returns the gradient wrt the conv INPUT as the consumer saw it (after the producer's pending affine, if any)."""
-        cm = rec['module']
-        w, gn = cm.conv.weight, cm.gn
-        assert cm.conv.bias is None
-        draw, _, _ = ops.gn_bwd(self._f32(rec['raw']), dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
-                                out_dgamma=gn.weight.grad, out_dbeta=gn.bias.grad)
-        d16 = None             # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight and data gradients
-        dgrad16 = need_dx and rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and w.shape[0] % 64 == 0
-        if rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
-                rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0]):
-            x = rec['x']       # the weight gradient on the bf16 matrix pipe, straight from the recorded map
-            d16 = draw.to(torch.bfloat16)
-            self._param_side(lambda: ops.conv_wgrad_bf16(d16, x, w.shape, out=w.grad), d16, x)
-        else:
-            x = self._f32(rec['x'])
-            self._param_side(lambda: ops.conv2d_wgrad(draw, x, w.shape, cm.conv.stride[0], cm.conv.padding[0],
-                                                      in_ab=rec['in_ab'], in_relu=rec['in_relu'], out=w.grad), draw, x)
-        if not need_dx:
-            return None
-        if dgrad16:
-            return self._dgrad_bf16(draw if d16 is None else d16, w, cm.conv.padding[0])
-        pt = ops.dgrad_pack(w, cm.conv.stride[0], cm.conv.padding[0])
-        return ops.conv2d_dgrad(draw, pt, (rec['x'].shape[1], rec['x'].shape[2]), cm.conv.stride[0])
-
-    @staticmethod
-    def _dgrad_bf16(dy, w, padding):
-        """Mixed precision: the data gradient of a stride-1 conv on the bf16 matrix pipe -- a forward conv of the bf16-rounded
-        gradient map with the rotated weights (channels swapped, taps flipped, padding K-1-p), fp32 out.  The weight gradient
-        next to it keeps reading the fp32 map."""
-        k = w.shape[2]
-        wt = w.detach().flip(2, 3).permute(1, 0, 2, 3)
-        pc = ops.PackedConv(wt, 1, k - 1 - padding, torch.bfloat16)
-        return ops.conv2d(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), pc, out_dtype=torch.float32)
-
-    # ------------------------------------------------------------------ CPR head
-    @staticmethod
-    def _forward_head(head, lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes):
-        tape, save = [], {}
-        losses = head.forward_train_lazy(lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes,
-                                         tape=tape, save=save)
-        save['tape'] = tape
-        return losses, save
-
-    def _backward_head(self, head, s):
-        head_tape = s['tape']
-        C = head.num_classes
-        cfg = head.loss_cfg
-        J = s['lmap'].shape[-1]
-        Jd = 4 if J <= 4 else (J + 31) // 32 * 32
-        w_mil = head.loss_mil.loss_weight if cfg.get('with_mil_loss', True) else 0.0
-        w_gt = cfg.get('gt_loss_weight', 1.0) if cfg.get('with_gt_loss', False) else 0.0
-        w_neg = cfg.get('neg_loss_weight', 1.0) if cfg.get('with_neg', True) else 0.0
-        assert s['neg_mask'] is not None, 'with_neg=False is not on the training path'
-        dmap, _ = ops.cpr_loss_bwd(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
-                                   s['bag_ws'], s['centers'], s['gt_img'], s['offsets'], s['ins_off'], C, s['stride'],
-                                   w_mil, w_gt, w_neg, Jd, gt_weight=s['gt_weight'], eps=head.loss_mil.eps)
-        # ---- logit projection (cls_out ++ ins_out as one 1x1 conv over the un-normalised last tower layer)
-        shared = head.ins_share_head_classifier
-        wcat = head.cls_out.weight if shared else torch.cat([head.cls_out.weight, head.ins_out.weight], 0)
-        wpad = torch.zeros((Jd, wcat.shape[1], 1, 1), device=wcat.device, dtype=torch.float32)
-        wpad[:J, :, 0, 0] = wcat.detach()
-        gw = ops.conv2d_wgrad(dmap, self._f32(s['feat']), wpad.shape, 1, 0, in_ab=s['ab'], in_relu=True)
-        _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
-        head.cls_out.weight.grad.copy_(gw[:C, :, 0, 0])
-        head.cls_out.bias.grad.copy_(gb[:C])
-        if not shared:
-            head.ins_out.weight.grad.copy_(gw[C:2 * C, :, 0, 0])
-            head.ins_out.bias.grad.copy_(gb[C:2 * C])
-        self._done(head.ins_out.bias if not shared else head.cls_out.bias)
-        dz = ops.conv2d_dgrad(dmap, ops.dgrad_pack(wpad, 1, 0), (dmap.shape[1], dmap.shape[2]))
-        # ---- tower, last layer first; layer 0 consumes the (un-activated) FPN output
-        for rec in reversed(head_tape):
-            dz = self._gn_conv_backward(rec, dz, relu=True, need_dx=True)
-            self._done(rec['module'].conv.weight)
-        return dz
-
-    def _out_conv_backward(self, rec, dout_pad, n_out):
-        """Backward of a biased output conv (nn.Conv2d) reading the un-normalised last tower layer with its GroupNorm
-        affine (+ReLU) applied on load.  dout_pad (N,H,W,Cp): gradient wrt the conv output, channels padded to what the
-        conv gradient kernels take (first n_out live).  Returns the gradient wrt the normalised, activated input."""
-        conv = rec['conv']
-        w = conv.weight
-        Cp = dout_pad.shape[-1]
-        wpad = torch.zeros((Cp,) + tuple(w.shape[1:]), device=w.device, dtype=torch.float32)
-        wpad[:n_out] = w.detach()
-        x, ab = self._f32(rec['x']), rec['in_ab']
-
-        def param_grads():
-            gw = ops.conv2d_wgrad(dout_pad, x, wpad.shape, conv.stride[0], conv.padding[0], in_ab=ab, in_relu=True)
-            _, gb = ops.relu_bwd_colsum(dout_pad, None, want_g=False)
-            w.grad.copy_(gw[:n_out])
-            conv.bias.grad.copy_(gb[:n_out])
-        self._param_side(param_grads, dout_pad)
-        return ops.conv2d_dgrad(dout_pad, ops.dgrad_pack(wpad, conv.stride[0], conv.padding[0]),
-                                (x.shape[1], x.shape[2]), conv.stride[0])
-
-    # ------------------------------------------------------------------ FPN
-    def _backward_neck(self, neck, neck_tape, dz):
-        """Output conv, then the top-down chain from the finest lateral to the coarsest -> {stage: d(stage output)}."""
-        lat_recs = {r['level']: r for r in neck_tape if r['kind'] == 'lateral'}
-        out_recs = {r['level']: r for r in neck_tape if r['kind'] == 'out'}
-        assert list(out_recs) == [0], 'num_outs == 1 (every shipped CPR config)'
-        dlat = self._gn_conv_backward(out_recs[0], dz, relu=False, need_dx=True)
-        self._done(out_recs[0]['module'].conv.weight)
-        d_stage = {}
-        L = len(lat_recs)
-        for i in range(L):
-            rec = lat_recs[i]
-            stage = i + neck.start_level
-            need_dx = bool(self._stage_trainable(stage))
-            d_stage[stage] = self._gn_conv_backward(rec, dlat, relu=False, need_dx=need_dx)
-            self._done(rec['module'].conv.weight)
-            if i + 1 < L:
-                nxt = lat_recs[i + 1]['raw'].shape
-                dlat = ops.upsample_add_bwd(dlat, tuple(nxt))
-        return d_stage
-
-    def _stage_trainable(self, stage):
-        bb = self.model.backbone
-        return any(p.requires_grad for p in getattr(bb, bb.res_layers[stage]).parameters())
-
-    def _backward_backbone(self, bb, tape, d_stage):
-        c = bb._cache
-        dx = None            # gradient flowing down from the block above
-        cur_stage = None
-        for idx in range(len(tape) - 1, -1, -1):
-            rec = tape[idx]
-            blk, stage = rec['block'], rec['stage']
-            if stage != cur_stage:       # entering a stage from above: its output also feeds an FPN lateral
-                cur_stage = stage
-                lat = d_stage.get(stage)
-                if lat is not None:
-                    dx = lat if dx is None else ops.axpby(dx, lat, 1.0, 1.0)
-            assert dx is not None, 'no gradient reaches backbone stage %d' % stage
-            need_dx = idx > 0
-            dx = self._block_backward(c, blk, rec, dx, need_dx)
-        self._wide = {}      # nothing below the lowest trainable block reads a widened copy
-
-    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx, mask=None, add=None, want_colsum=False):
-        """conv -> folded eval-BN given g = d(pre-activation output) (un-scaled) and its column sums.  Parameter
-        gradients go to the side stream; returns the data gradient wrt x -- with ``mask`` (x itself, when x is the
-        output of a fused ReLU) already taken through that ReLU, with ``add`` summed in, with ``want_colsum`` as
-        (gradient, column sums): all three ride in the conv epilogue."""
-        scale, _ = folded_bn(cache, bn)
-        inv_sigma = cache.get(('bn_is', id(bn)), [bn.running_var],
-                              lambda: ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, True)[2])
-        w = conv.weight
-        # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight gradient and the bf16 3x3 data gradient
-        w16 = w.requires_grad and self._mixed and ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0])
-        d16 = need_dx and self._mixed and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and add is None
-        g16 = g.to(torch.bfloat16) if (w16 or d16) else None
-        if w.requires_grad:
-            aff = bn.weight.requires_grad
-
-            def param_grads():
-                cs = colsum.reduce() if isinstance(colsum, ops.TilePartials) else colsum
-                if w16:
-                    ops.conv_wgrad_bf16(g16, x, w.shape, out=w.grad)    # (x is the widened recorded map: rounds back exactly)
-                else:
-                    ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=w.grad)
-                ops.bn_fold_bwd(w.grad, w, scale, bn.running_mean, inv_sigma, cs,
-                                out_dgamma=bn.weight.grad if aff else None, out_dbeta=bn.bias.grad if aff else None)
-            # x may be a widened fp32 temporary of the mixed-precision step that the main stream frees right after this call
-            self._param_side(param_grads, g, colsum, g16, x)
-        if not need_dx:
-            return None
-        if d16:
-            # mixed precision: the 3x3 data gradient on the bf16 matrix pipe (its fp32 form cannot be a Winograd launch: the mask /
-            # column-sum epilogue), the ReLU mask and the column sums as one streaming pass over the (small) result
-            def pack16():
-                wt = (w.detach() * scale[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3)
-                return ops.PackedConv(wt, 1, 2 - conv.padding[0], torch.bfloat16)
-            pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16)
-            dx = ops.conv2d(g16, pc16, out_dtype=torch.float32)
-            if mask is None and not want_colsum:
-                return dx
-            gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
-            dx = gm if mask is not None else dx
-            return (dx, cs) if want_colsum else dx
-        pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
-                       lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
-        if WINO_DGRAD[0] and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and add is None and \
-                (mask is not None or want_colsum) and ops.wino_eligible(pt, x.shape[1], x.shape[2], torch.float32):
-            # a 3x3 stride-1 data gradient with a mask / column-sum epilogue would run the direct kernel (2.25x the multiplies of
-            # the Winograd launch the plain form gets); the epilogue as one streaming pass over the result is cheaper
-            dx = ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), 1)
-            gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
-            dx = gm if mask is not None else dx
-            return (dx, cs) if want_colsum else dx
-        return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
-
-    def _block_backward(self, cache, blk, rec, dout, need_dx):
-        # x = the output of the block below: when that block is trainable too (need_dx) its backward reads it next
-        x = self._f32(rec['x'], keep=need_dx)
-        g3, cs3 = ops.relu_bwd_colsum(dout, self._f32(rec['out']))            # also the shortcut gradient
-        o1 = self._f32(rec['o1'])
-        if blk.kind == 'bottleneck':
-            o2 = self._f32(rec['o2'])
-            g2, cs2 = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, o2, True, mask=o2, want_colsum=True)
-            del o2
-            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, o1, True, mask=o1, want_colsum=True)
-            last = blk.bn3
-        else:
-            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, o1, True, mask=o1, want_colsum=True)
-            last = blk.bn2
-        del o1
-        self._done(last.bias if last.bias.requires_grad else blk.conv2.weight)
-        if blk.downsample is not None:     # the shortcut conv sees the same g3 (no activation on that branch)
-            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx)
-            dx = self._conv_bn_backward(cache, blk.downsample[0], blk.downsample[1], g3, cs3, x, need_dx, add=dx)
-            tail = blk.downsample[1].bias if blk.downsample[1].bias.requires_grad else blk.downsample[0].weight
-        else:
-            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx, add=g3)
-            tail = blk.bn1.bias if blk.bn1.bias.requires_grad else blk.conv1.weight
-        self._done(tail)
-        return dx
 
     # ------------------------------------------------------------------ optimizer
     def step(self, lr=None):
@@ -622,10 +681,15 @@ class CprTrainer:
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
 
-class P2PTrainer(CprTrainer):
-    """The same training step for BasicLocator(P2PHead) (BASELINE.json configs[3]; T/configs2/**/p2p/*.py): two towers,
-    3x3 output convs with bias, sigmoid-focal + SmoothL1 loss on the device Hungarian assignment (the assignment itself
-    carries no gradient, as in the reference: it works on detached costs, hungarian_assigner.py:214-236)."""
+class P2PHeadRules:
+    """Head rules of BasicLocator(P2PHead) (BASELINE.json configs[3]; T/configs2/**/p2p/*.py): two towers, 3x3 output convs
+    with bias, sigmoid-focal + SmoothL1 loss on the device Hungarian assignment (the assignment itself carries no gradient,
+    as in the reference: it works on detached costs, hungarian_assigner.py:214-236).  Mixed into a BackwardEngine."""
+    loss_vector_key = 'out'        # P2PHead: (B, 2) = (loss_cls, loss_pts) per image
+
+    def loss_dict(self, out):
+        B = out.shape[0]
+        return {'loss_cls': [out[b, 0] for b in range(B)], 'loss_pts': [out[b, 1] for b in range(B)]}
 
     @staticmethod
     def _head_param_order(head, add):
@@ -649,7 +713,7 @@ class P2PTrainer(CprTrainer):
         save.update(cls_tape=cls_tape, reg_tape=reg_tape, hw=tuple(x.shape[1:3]))
         return losses, save
 
-    def _backward_head(self, head, s):
+    def _backward_head(self, head, s, upstream=None):
         from .dense_heads.p2p_head import _get
         lc, lr = head.loss_cls_cfg, head.loss_reg_cfg
         B, M, C = s['cls'].shape
@@ -659,7 +723,7 @@ class P2PTrainer(CprTrainer):
                                       lc.get('alpha', 0.25), lc.get('gamma', 2.0), lr.get('beta', 1.0),
                                       _get(head.train_cfg, 'pos_weight', 1.0), _get(head.train_cfg, 'neg_weight', 1.0),
                                       head.reg_norm, lc.get('loss_weight', 1.0), lr.get('loss_weight', 1.0),
-                                      head.pts_gamma, Cp, 4)
+                                      head.pts_gamma, Cp, 4, upstream=upstream)
         dz = None
         for tape, dout, n_out, last in ((s['reg_tape'], dreg.view(B, H, W, 4), 2, head.reg_convs[0]),
                                         (s['cls_tape'], dcls.view(B, H, W, Cp), C, head.cls_convs[0])):
@@ -670,3 +734,11 @@ class P2PTrainer(CprTrainer):
                 self._done(rec['module'].conv.weight)
             dz = d if dz is None else ops.axpby(dz, d, 1.0, 1.0)
         return dz
+
+
+class P2PTrainer(P2PHeadRules, CprTrainer):
+    """The same training step for BasicLocator(P2PHead)."""
+
+
+class P2PBackwardEngine(P2PHeadRules, BackwardEngine):
+    """The P2PNet backward rules without the trainer's flat buffers (autograd bridge)."""

@@ -323,7 +323,7 @@ def test_coco_style_800x1344_batch_8_vs_single_images_and_oracle():
         for k, v in losses8.items():
             assert bool(torch.isfinite(v).all()), k
             # the lazy path never materialises the normalised maps: same values up to the rounding of the fused affine
-            assert abs(float(v) - float(lazy8[k])) <= 2e-5 * max(abs(float(v)), 1e-6), (k, float(v), float(lazy8[k]))
+            assert abs(float(v) - float(lazy8[k])) <= 1e-4 * max(abs(float(v)), 1e-6), (k, float(v), float(lazy8[k]))
         for i in (0, 3, 7):
             one, _ = head(m.neck(m.backbone(cb['img'][i:i + 1].contiguous())))
             assert torch.equal(one[0][0], cls8[0][i]), 'image %d of the 8-batch differs from its single-image run' % i

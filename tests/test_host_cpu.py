@@ -206,6 +206,148 @@ def test_two_rank_gloo_reduce_scatter_reducer_equals_all_reduce(tmp_path):
         assert p.returncode == 0, o
 
 
+_DDP_WORKER = r'''
+import os, sys, torch, torch.nn as nn, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(sys.argv[1]); os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[2]
+dist.init_process_group('gloo', rank=rank, world_size=2)
+from pointtinybenchmark_amd import autograd_bridge as AB
+
+C = 6
+class Vec(nn.Module):
+    def __init__(self, seed, train=True):
+        super().__init__()
+        self.w = nn.Parameter(torch.randn(C, generator=torch.Generator().manual_seed(seed)), requires_grad=train)
+class Backbone(nn.Module):
+    res_layers = ['layer1', 'layer2', 'layer3']
+    def __init__(self):
+        super().__init__()
+        self.layer1, self.layer2, self.layer3 = Vec(1, train=False), Vec(2), Vec(3)      # layer1 frozen (frozen_stages)
+    def stem(self, img): return img * 0.5
+    def run_stage(self, i, x, tape=None): return x * getattr(self, self.res_layers[i]).w
+class Neck(nn.Module):
+    in_channels, start_level = [C, C, C], 1
+    def __init__(self):
+        super().__init__()
+        self.lateral_convs = nn.ModuleList([Vec(4), Vec(5)])
+        self.fpn_convs = nn.ModuleList([Vec(6)])
+class Head(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.cls = Vec(7)
+        self.never_used = Vec(8)          # find_unused_parameters: a trainable parameter no Function touches
+class Model(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone, self.neck, self.bbox_head = Backbone(), Neck(), Head()
+    def forward(self, img, scale):
+        return AB.forward_train(self, img, [dict(scale=scale)], None, None)
+
+class Engine:
+    """CPU stand-in for training.BackwardEngine: the same segment API on closed-form elementwise math, so that the bridge's
+    graph (parameters as Function inputs, gradients returned per segment) can be driven by torch DDP under gloo."""
+    loss_vector_key = 'out5'
+    def __init__(self, model): self.model, self._sink = model, {}
+    def begin_step(self): pass
+    def collect(self, params): return tuple(self._sink.pop(id(p), None) for p in params)
+    def forward_stage(self, i, x):
+        bb = self.model.backbone
+        return bb.run_stage(i, x), [dict(x=x, w=getattr(bb, bb.res_layers[i]).w)]
+    def backward_stage(self, tape, dout, need_in):
+        rec = tape[0]
+        self._sink[id(rec['w'])] = (dout * rec['x']).sum(0)
+        return dout * rec['w'].detach() if need_in else None
+    def forward_laterals(self, xs):
+        ws = [m.w for m in self.model.neck.lateral_convs]
+        return sum(x * w for x, w in zip(xs, ws)), dict(xs=list(xs), ws=ws)
+    def backward_laterals(self, recs, dlat, need):
+        for x, w in zip(recs['xs'], recs['ws']):
+            self._sink[id(w)] = (dlat * x).sum(0)
+        return [dlat * w.detach() if n else None for w, n in zip(recs['ws'], need)]
+    def forward_head_loss(self, lat0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
+        o, c = self.model.neck.fpn_convs[0].w, self.model.bbox_head.cls.w
+        t = lat0 * o * c * img_metas[0]['scale']
+        out = torch.stack([t.sum(), (t * t).sum(), t.mean(), t.abs().sum(), t.new_tensor(1.0)])
+        return out, dict(lat0=lat0, o=o, c=c, t=t, scale=img_metas[0]['scale'])
+    def backward_head_loss(self, st, up):
+        t = st['t']
+        dt = up[0] + up[1] * 2 * t + up[2] / t.numel() + up[3] * torch.sign(t)
+        o, c, lat0, sc = st['o'].detach(), st['c'].detach(), st['lat0'], st['scale']
+        self._sink[id(st['o'])] = (dt * lat0 * c * sc).sum(0)
+        self._sink[id(st['c'])] = (dt * lat0 * o * sc).sum(0)
+        return dt * o * c * sc
+    def loss_dict(self, out):
+        return {'gt_loss': out[0], 'pos_loss': out[1], 'bag_acc': out[2], 'neg_loss': out[3]}
+
+def reference(model, img, scale):          # the same math in plain torch autograd
+    bb, nk, hd = model.backbone, model.neck, model.bbox_head
+    x = img * 0.5
+    feats = []
+    for name in bb.res_layers:
+        x = x * getattr(bb, name).w
+        feats.append(x)
+    lat0 = sum(f * m.w for f, m in zip(feats[1:], nk.lateral_convs))
+    t = lat0 * nk.fpn_convs[0].w * hd.cls.w * scale
+    return t.sum() + (t * t).sum() + t.abs().sum()
+
+torch.manual_seed(0)
+model = Model()
+model._autograd_bridge_state = AB.Bridge(model, engine=Engine(model))
+imgs = [torch.randn(4, C, generator=torch.Generator().manual_seed(10 + r)) for r in range(2)]
+scales = [1.5, -0.75]
+# expected: DDP averages the per-rank gradients
+want = {}
+for r in range(2):
+    model.zero_grad()
+    reference(model, imgs[r], scales[r]).backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            want[k] = want.get(k, 0) + p.grad.clone() / 2
+model.zero_grad()
+ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True, bucket_cap_mb=1e-5)   # one bucket per tensor
+fired = []
+from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+def hook(state, bucket):
+    fired.append(bucket.buffer().numel())
+    return default_hooks.allreduce_hook(state, bucket)
+ddp.register_comm_hook(None, hook)
+losses = ddp(imgs[rank], scales[rank])
+assert set(losses) == {'gt_loss', 'pos_loss', 'bag_acc', 'neg_loss'} and all(v.requires_grad for v in losses.values())
+total = sum(v for k, v in losses.items() if 'loss' in k)         # BaseDetector._parse_losses: bag_acc is logged, not summed
+assert torch.allclose(total, reference(model, imgs[rank], scales[rank]).detach())
+total.backward()
+assert len(fired) >= 5, fired                                     # the reducer's hooks ran for the Functions' parameters
+for k, p in model.named_parameters():
+    if not p.requires_grad:
+        assert p.grad is None, k
+    elif k in want:
+        assert p.grad is not None and torch.allclose(p.grad, want[k], rtol=1e-5, atol=1e-6), (k, p.grad, want[k])
+    else:
+        assert k == 'bbox_head.never_used.w' and (p.grad is None or not p.grad.any()), k
+# a second step re-uses the bridge (fresh graph, the consumed one is gone)
+ddp.zero_grad()
+l2 = ddp(imgs[rank], scales[rank]); sum(v for k, v in l2.items() if 'loss' in k).backward()
+assert torch.allclose(model.backbone.layer2.w.grad, want['backbone.layer2.w'], rtol=1e-5, atol=1e-6)
+dist.barrier(); dist.destroy_process_group(); print('rank', rank, 'ok')
+'''
+
+
+def test_two_rank_gloo_ddp_drives_the_autograd_bridge(tmp_path):
+    """torch DistributedDataParallel (what mmcv's MMDistributedDataParallel subclasses, T/mmdet/apis/train.py:75-83) around a
+    model whose forward is ``autograd_bridge.forward_train``: the three Functions take the parameters as inputs, so the DDP
+    reducer's hooks fire on them, buckets are all-reduced and every rank ends with the AVERAGE of the per-rank gradients --
+    including a frozen stage (no gradient) and a trainable parameter nothing uses (find_unused_parameters).  The HIP engine
+    needs a GPU, so the segment API is served by a closed-form CPU stand-in; the Functions, the graph and DDP are real."""
+    script = tmp_path / 'ddpworker.py'
+    script.write_text(_DDP_WORKER % ROOT)
+    port = str(35500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
 def test_gradient_buckets_single_process_is_a_no_op():
     from pointtinybenchmark_amd.training import GradBuckets
     flat = torch.ones(10)
