@@ -221,12 +221,14 @@ int cpr_hungarian_cost(const float* pred, int pred_stride, const float* logits, 
  * each: problem b has costT at cost_off[b] (G_b x M_b, M_b >= G_b), column arrays at col_off[b], row arrays at
  * row_off[b].  gt_inds (sum M) int64: 0 background, j+1 = gt j.  status[b] != 0: infeasible.
  * Workspaces: per column ws_v/ws_spc (double), ws_path/ws_row4col/ws_cols/ws_remaining/ws_pos (int32), ws_sc/ws_active
- * (uint8); per row ws_u (double), ws_col4row (int32), ws_sr (uint8). */
+ * (uint8); per row ws_u (double), ws_col4row (int32), ws_sr (uint8).  max_cols / max_rows: [host] upper bounds of M_b / G_b
+ * over the batch (0 = unknown): when max_cols <= 32768 and topk * max_rows < 65534 the search state of a row lives in
+ * registers / LDS (one 4-byte cost read per column per scan instead of ~33 bytes of state; same results bit for bit). */
 int cpr_lsa_topk(const float* costT, const int* m_of, const int* g_of, const long long* cost_off,
                  const long long* col_off, const long long* row_off, int num_problems, int topk, long long* gt_inds,
                  double* ws_v, double* ws_spc, int* ws_path, int* ws_row4col, unsigned char* ws_sc,
                  unsigned char* ws_active, int* ws_cols, int* ws_remaining, int* ws_pos, double* ws_u,
-                 int* ws_col4row, unsigned char* ws_sr, int* status, void* stream);
+                 int* ws_col4row, unsigned char* ws_sr, int* status, int max_cols, int max_rows, void* stream);
 
 /* ---- P2P inference ---------------------------------------------------------------------------------------------
  * per-level top-k of P2PHead._get_bboxes_single (p2p_head.py:367-373): scores (n) -> k largest, sorted descending
@@ -246,6 +248,22 @@ int cpr_nms_candidates(const float* boxes, int box_stride, const float* scores, 
  * score order; num_keep (1) int32.  ws_order (n) int32, ws_boxes (n,4) float, ws_mask (n*ceil(n/64)) uint64. */
 int cpr_nms(const float* boxes, const float* scores, const int* labels, int n, float iou_thr, long long* keep_idx,
             int* num_keep, int* ws_order, float* ws_boxes, unsigned long long* ws_mask, void* stream);
+/* The same three stages for ALL images of a batch with no host round trip in between (P2PHead.get_bboxes loops
+ * _get_bboxes_single over the images, p2p_head.py:330-343; each image's torch.topk / nonzero / nms sync the host there):
+ *   cpr_topk_desc_batched        scores (B, n) -> vals (B, k), idx (B, k) (segment-relative), one workgroup per image
+ *   cpr_nms_candidates_batched   boxes (B, n, box_stride), scores (B, n, C+1), factors (B, n) or NULL -> slabs of capacity
+ *                                n * C per image: cand_boxes (B, n*C, 4), cand_scores / labels / inds (B, n*C), count (B) [device]
+ *   cpr_nms_batched              reads the per-image candidate counts n_dev (B) FROM THE DEVICE; keep_idx (B, cap) slab-relative,
+ *                                num_keep (B) [device]; ws_order (B, cap) int32, ws_boxes (B, cap, 4), ws_mask B * ws_stride
+ *                                64-bit words, ws_stride >= max(cap * ceil(cap / 64), next pow2 >= cap); cap <= 16384
+ * The caller reads (count, num_keep) once per batch. */
+int cpr_topk_desc_batched(const float* scores, int B, int n, int k, float* out_vals, long long* out_idx, void* stream);
+int cpr_nms_candidates_batched(const float* boxes, int box_stride, const float* scores, const float* factors, int B, int n,
+                               int C, float score_thr, float* cand_boxes, float* cand_scores, int* cand_labels,
+                               long long* cand_inds, int* count, void* stream);
+int cpr_nms_batched(const float* boxes, const float* scores, const int* labels, const int* n_dev, int B, int cap,
+                    float iou_thr, long long* keep_idx, int* num_keep, int* ws_order, float* ws_boxes,
+                    unsigned long long* ws_mask, long long ws_stride, void* stream);
 
 /* P2PHead.get_pred_points (p2p_head.py:125-170): reg (N,H,W,2k) -> pred (N,H*W*k,3) = anchor + point_anchor*stride +
  * reg*gamma*stride, third column = stride; anchor (same shape) optional.  point_anchor (k,2). */

@@ -46,10 +46,13 @@ SIGNATURES = {
     'cpr_refine': [_p, _i, _p, _p, _p, _i, _i] + [_p] * 9 + [_i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _i, _i, _p],
     'cpr_point_assign': [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p],
     'cpr_hungarian_cost': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _p],
-    'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i] + [_p] * 15,
+    'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i] + [_p] * 14 + [_i, _i, _p],
     'cpr_topk_desc': [_p, _i, _i, _p, _p, _p],
     'cpr_nms_candidates': [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p],
     'cpr_nms': [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
+    'cpr_topk_desc_batched': [_p, _i, _i, _i, _p, _p, _p],
+    'cpr_nms_candidates_batched': [_p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p],
+    'cpr_nms_batched': [_p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _l, _p],
     'cpr_p2p_decode': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'cpr_rowmax_sigmoid': [_p, _p, ctypes.c_longlong, _i, _p],
     'cpr_sigmoid': [_p, _p, ctypes.c_longlong, _p],

@@ -358,19 +358,272 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
     if (tid == 0 && status) status[b] = s_fail;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the same algorithm with the per-column state of a row search in REGISTERS.  The kernel above streams ~33 bytes per
+// column per scan through one CU's L2 port (v, shortest-path cost, path, row4col, visited flag, scan position, compaction
+// index, cost: 25 600 columns = 0.85 MB per scan, ~100 scans per round): 5.5 ms per launch at 16 images x 32 gts x 25 600
+// proposals, 15 % of the P2PNet step (profiles/round3_p2p_kernel_stats.csv).  Here thread t owns columns t + 1024 k
+// (k < KMAX) for a whole round and keeps for them
+//   spc[k]            the shortest-path cost (double) of the current search                       registers
+//   scbits / asgbits  visited-in-this-search / assigned (row4col != -1) flags                     one bit per column
+//   vbits             "the dual v of this column is non-zero": v is read from memory only then    (v != 0 only for the few
+//                     hundred columns a search has ever visited; v - 0.0 is exact, so skipping the read changes nothing)
+//   path              implicit: a column improved only by the first scan of a search has path = the inserted row; later
+//                     improvements store (stamp << 16 | row) with a per-search stamp, stale entries read as "first scan"
+//   scan position     pos[c] = Mc - 1 - c except for the <= G low columns the swap-with-last of scipy's `remaining` array
+//                     moved during THIS search: an LDS shadow of the first / last LSA_MAX_VIS entries of pos / remaining
+// so a scan reads 4 bytes per column (the cost) and thread 0's bookkeeping between two scans touches LDS only (the winner's
+// row4col rides in the arg-min record).  Arithmetic, comparison order and tie-breaking are the kernel above's, operation for
+// operation: the two are interchangeable bit for bit (tests/test_gpu_assigners.py runs both).
+struct ArgR {
+    double v;
+    int r4c;   // row4col of the column (-1 = unassigned)
+    int it;    // position in scipy's `remaining` array
+    int c;     // compact column id
+};
+__device__ __forceinline__ ArgR argr_min(ArgR a, ArgR b) {
+    if (b.v < a.v) return b;
+    if (b.v > a.v) return a;
+    const int ua = a.r4c == -1, ub = b.r4c == -1;
+    if (ub != ua) return ub > ua ? b : a;
+    if (ua) return b.it > a.it ? b : a;            // last unassigned in scan order
+    return b.it < a.it ? b : a;                    // first assigned in scan order
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(1024) lsa_topk_reg_kernel(
+        const float* __restrict__ costT_all, const int* __restrict__ m_of, const int* __restrict__ g_of,
+        const long long* __restrict__ cost_off, const long long* __restrict__ col_off, const long long* __restrict__ row_off,
+        int topk, long long* __restrict__ gt_inds_all, double* __restrict__ v_all, int* __restrict__ path_all,
+        int* __restrict__ row4col_all, unsigned char* __restrict__ active_all, int* __restrict__ cols_all,
+        double* __restrict__ u_all, int* __restrict__ status) {
+    constexpr int NT = 1024, S = LSA_MAX_VIS;
+    static_assert(S == NT, "slot 0 of a thread must hold exactly the columns of the LDS shadows");
+    __shared__ ArgR sh[16];
+    __shared__ int s_i, s_sink, s_fail, s_nact, s_base, s_wcnt[16], s_nvis, s_win;
+    __shared__ int s_vis[S], s_vq[S], s_vlast[S];     // visited columns of a search; the shadow entries each removal edited
+    __shared__ int s_pos[S], s_rem[S];                // pos[c] for c < S; remaining[Mc - 1 - q] for q < S
+    __shared__ int s_c4r[S];                          // col4row
+    __shared__ unsigned char s_sr[S];                 // SR: rows on the alternating tree of this search
+    __shared__ double s_minval, s_vspc[S], s_rowspc[S];   // spc of the k-th visited column; spc of the column a row was reached through
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int M = m_of[b], G = g_of[b];
+    const float* costT = costT_all + cost_off[b];
+    long long* gt_inds = gt_inds_all + col_off[b];
+    double* v = v_all + col_off[b];
+    int* path = path_all + col_off[b];
+    int* row4col = row4col_all + col_off[b];
+    unsigned char* active = active_all + col_off[b];
+    int* cols = cols_all + col_off[b];
+    double* u = u_all + row_off[b];
+
+    for (int j = tid; j < M; j += NT) { gt_inds[j] = 0; active[j] = 1; path[j] = 0; }
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (G == 0 || M == 0) return;
+    if (G + 1 > S || M > KMAX * NT || (long long)topk * G + 1 >= 65535) {      // never truncate: refuse (the launcher checks too)
+        if (tid == 0 && status) status[b] = 2;
+        return;
+    }
+    double spc[KMAX];
+
+    for (int round = 0; round < topk; ++round) {
+        // ordered compaction of the still-active proposals: cols[c] = original index of the c-th active one
+        if (tid == 0) s_base = 0;
+        __syncthreads();
+        for (int base = 0; base < M; base += NT) {
+            const int j = base + tid;
+            const bool a = j < M && active[j];
+            const unsigned long long bal = __ballot(a);
+            const int lane = tid & 63, w = tid >> 6;
+            if (lane == 0) s_wcnt[w] = __popcll(bal);
+            __syncthreads();
+            int off = s_base;
+            for (int q = 0; q < w; ++q) off += s_wcnt[q];
+            if (a) cols[off + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int q = 0; q < (NT >> 6); ++q) tot += s_wcnt[q];
+                s_base += tot;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_nact = s_base;
+        __syncthreads();
+        const int Mc = s_nact;
+        if (Mc / G == 0) break;  // cost_new.shape[0] // num_gts != 0
+        const bool compact = Mc != M;           // round 0: cols[c] == c
+        for (int c = tid; c < Mc; c += NT) { v[c] = 0.0; row4col[c] = -1; }
+        for (int i = tid; i < G; i += NT) { u[i] = 0.0; s_c4r[i] = -1; }
+        for (int q = tid; q < S; q += NT) { s_pos[q] = Mc - 1 - q; s_rem[q] = q; }
+        unsigned asgbits = 0, vbits = 0;
+        __syncthreads();
+        for (int cur = 0; cur < G; ++cur) {
+            const int stamp = round * G + cur + 1;
+            for (int i = tid; i < G; i += NT) s_sr[i] = 0;
+            if (tid == 0) { s_i = cur; s_sink = -1; s_minval = 0.0; s_nvis = 0; }
+            unsigned scbits = 0;
+            __syncthreads();
+            bool first = true;   // first scan of this row: shortestPathCosts = inf, path = -1 for every column (not stored)
+            while (true) {
+                const int i = s_i;
+                const double minval = s_minval, ui = u[i];
+                const float* crow = costT + (size_t)i * M;
+                ArgR best;
+                best.v = INFINITY; best.r4c = 0; best.it = INT_MAX; best.c = -1;
+                // opaque copy of the thread id, re-made per scan: the column addresses (4 arrays x KMAX 64-bit pointers) are then
+                // not loop-invariant, so the compiler computes them where they are used instead of hoisting ~200 registers of
+                // addresses out of the search loop (and spilling them)
+                int tq = tid;
+                asm volatile("" : "+v"(tq));
+                // chunks of CH columns: the CH cost loads of a chunk are issued together, then consumed; a scheduling barrier
+                // between chunks keeps the compiler from hoisting every load of the unrolled scan to the top (which spills)
+                constexpr int CH = 5;
+#pragma unroll
+                for (int kb = 0; kb < KMAX; kb += CH) {
+                    float cst[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const int c = tq + (kb + j) * NT;
+                        cst[j] = (kb + j < KMAX && c < Mc) ? crow[compact ? cols[c] : c] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const int k = kb + j;
+                        const int c = tq + k * NT;
+                        if (k < KMAX && c < Mc && !((scbits >> k) & 1u)) {
+                            const double vv = ((vbits >> k) & 1u) ? v[c] : 0.0;
+                            const double r = ((minval + (double)cst[j]) - ui) - vv;
+                            double s = first ? (double)INFINITY : spc[k];
+                            if (r < s) {
+                                s = r;
+                                if (!first) path[c] = (stamp << 16) | i;      // (first scan: path = cur, implied)
+                            }
+                            spc[k] = s;
+                            ArgR x;
+                            x.v = s; x.r4c = ((asgbits >> k) & 1u) ? row4col[c] : -1; x.it = (k == 0) ? s_pos[c] : Mc - 1 - c; x.c = c;      // (S == NT: slot 0 holds exactly the columns below S)
+                            best = (best.c < 0) ? x : argr_min(best, x);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                first = false;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    ArgR y;
+                    y.v = __shfl_xor(best.v, o, 64);
+                    y.r4c = __shfl_xor(best.r4c, o, 64);
+                    y.it = __shfl_xor(best.it, o, 64);
+                    y.c = __shfl_xor(best.c, o, 64);
+                    if (y.c >= 0) best = (best.c < 0) ? y : argr_min(best, y);
+                }
+                __syncthreads();
+                if ((tid & 63) == 0) sh[tid >> 6] = best;
+                __syncthreads();
+                if (tid == 0) {
+                    ArgR r = sh[0];
+                    for (int w = 1; w < NT / 64; ++w)
+                        if (sh[w].c >= 0) r = (r.c < 0) ? sh[w] : argr_min(r, sh[w]);
+                    s_sr[i] = 1;
+                    if (r.c < 0 || r.v == INFINITY) {
+                        s_fail = 1; s_sink = -2; s_win = -1;
+                    } else {
+                        s_minval = r.v;
+                        s_win = r.c;                                   // SC[r.c] = 1: the owner sets its bit below
+                        const int k = s_nvis;                          // removals so far: remaining[--n] sits at shadow slot k
+                        const int idx = r.c < S ? s_pos[r.c] : Mc - 1 - r.c, last = s_rem[k];
+                        const int q = Mc - 1 - idx;                    // remaining[idx] = last (positions outside the shadow are
+                        if (q < S) s_rem[q] = last;                    //   never read again in this search and are restored after it)
+                        s_pos[last] = idx;                             // last < S always: the tail holds low columns only
+                        s_vis[k] = r.c; s_vq[k] = q < S ? q : -1; s_vlast[k] = last; s_vspc[k] = r.v;
+                        s_nvis = k + 1;
+                        if (r.r4c == -1) s_sink = r.c; else { s_i = r.r4c; s_rowspc[r.r4c] = r.v; }
+                    }
+                }
+                __syncthreads();
+                const int win = s_win;
+                if (win >= 0 && (win & (NT - 1)) == tid) scbits |= 1u << (win >> 10);
+                if (s_sink != -1) break;
+            }
+            if (s_fail) break;
+            const double minval = s_minval;
+            const int nvis = s_nvis;
+            for (int i = tid; i < G; i += NT) {
+                if (i == cur) u[i] += minval;
+                else if (s_sr[i]) u[i] += minval - s_rowspc[i];        // = spc[col4row[i]]: the column row i was reached through
+            }
+            if (tid < nvis) {            // v[j] -= minVal - shortestPathCosts[j] for the scanned columns only
+                const int c = s_vis[tid];
+                v[c] -= minval - s_vspc[tid];
+            }
+            if (tid == 0) {
+                int j = s_sink;          // augment along the path
+                while (true) {
+                    const int pw = path[j];
+                    const int i = ((pw >> 16) == stamp) ? (pw & 0xffff) : cur;
+                    row4col[j] = i;
+                    const int t = s_c4r[i];
+                    s_c4r[i] = j;
+                    j = t;
+                    if (i == cur) break;
+                }
+            }
+            __syncthreads();
+            for (int k = 0; k < nvis; ++k) {     // owners refresh their flags: a visited column now has v != 0 and may be assigned
+                const int c = s_vis[k];
+                if ((c & (NT - 1)) == tid) {
+                    vbits |= 1u << (c >> 10);
+                    if (row4col[c] != -1) asgbits |= 1u << (c >> 10);
+                }
+            }
+            if (tid < nvis) {            // put the scan order shadows back
+                if (s_vq[tid] >= 0) s_rem[s_vq[tid]] = s_vq[tid];
+            }
+            __syncthreads();
+            if (tid < nvis) s_pos[s_vlast[tid]] = Mc - 1 - s_vlast[tid];
+            __syncthreads();
+        }
+        if (s_fail) break;
+        for (int i = tid; i < G; i += NT) {
+            const int c = s_c4r[i];
+            const int j = compact ? cols[c] : c;
+            gt_inds[j] = i + 1;
+            active[j] = 0;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && status) status[b] = s_fail;
+}
+
 extern "C" int cpr_lsa_topk(const float* costT, const int* m_of, const int* g_of, const long long* cost_off,
                             const long long* col_off, const long long* row_off, int num_problems, int topk,
                             long long* gt_inds, double* ws_v, double* ws_spc, int* ws_path, int* ws_row4col,
                             unsigned char* ws_sc, unsigned char* ws_active, int* ws_cols, int* ws_remaining,
-                            int* ws_pos, double* ws_u, int* ws_col4row, unsigned char* ws_sr, int* status,
-                            hipStream_t stream) {
+                            int* ws_pos, double* ws_u, int* ws_col4row, unsigned char* ws_sr, int* status, int max_cols,
+                            int max_rows, hipStream_t stream) {
     CPR_CHECK_ARG(num_problems >= 0 && topk >= 1);
     if (num_problems == 0) return CPR_OK;
     CPR_CHECK_ARG(costT && m_of && g_of && cost_off && col_off && row_off && gt_inds && ws_v && ws_spc && ws_path &&
                   ws_row4col && ws_sc && ws_active && ws_cols && ws_remaining && ws_pos && ws_u && ws_col4row && ws_sr);
-    hipLaunchKernelGGL(lsa_topk_kernel, dim3(num_problems), dim3(1024), 0, stream, costT, m_of, g_of, cost_off,
-                       col_off, row_off, topk, gt_inds, ws_v, ws_spc, ws_path, ws_row4col, ws_sc, ws_active, ws_cols,
-                       ws_remaining, ws_pos, ws_u, ws_col4row, ws_sr, status);
+    // max_cols / max_rows: [host] upper bounds of the problems' sizes (the per-problem tables live on the device); the register-
+    // resident kernel serves max_cols <= 32768 and topk * max_rows < 65534, anything else (or max_cols <= 0 = unknown) the
+    // memory-resident one.  Bit-identical results.
+    const bool reg_ok = max_cols > 0 && max_cols <= 32 * 1024 && max_rows > 0 && max_rows + 1 <= LSA_MAX_VIS &&
+                        (long long)topk * max_rows + 1 < 65535;
+#define LSA_REG(K)                                                                                                           \
+    hipLaunchKernelGGL((lsa_topk_reg_kernel<K>), dim3(num_problems), dim3(1024), 0, stream, costT, m_of, g_of, cost_off,     \
+                       col_off, row_off, topk, gt_inds, ws_v, ws_path, ws_row4col, ws_active, ws_cols, ws_u, status)
+    if (reg_ok && max_cols <= 8 * 1024) LSA_REG(8);
+    else if (reg_ok && max_cols <= 16 * 1024) LSA_REG(16);
+    else if (reg_ok && max_cols <= 25 * 1024) LSA_REG(25);
+    else if (reg_ok) LSA_REG(32);
+    else
+        hipLaunchKernelGGL(lsa_topk_kernel, dim3(num_problems), dim3(1024), 0, stream, costT, m_of, g_of, cost_off,
+                           col_off, row_off, topk, gt_inds, ws_v, ws_spc, ws_path, ws_row4col, ws_sc, ws_active, ws_cols,
+                           ws_remaining, ws_pos, ws_u, ws_col4row, ws_sr, status);
+#undef LSA_REG
     CPR_LAUNCH_STATUS();
 }
 

@@ -35,6 +35,10 @@ __device__ void block_bitonic_desc(unsigned long long* a, int P) {
 // radix-select the k-th largest key (4 x 8-bit passes), gather, bitonic-sort the k survivors in LDS.
 __global__ void topk_desc_kernel(const float* __restrict__ scores, int n, int k, float* __restrict__ out_vals,
                                  long long* __restrict__ out_idx) {
+    // one workgroup per segment (image): blockIdx.x selects scores[b * n ..], outputs [b * k ..]; indices are segment-relative
+    scores += (size_t)blockIdx.x * n;
+    out_vals += (size_t)blockIdx.x * k;
+    out_idx += (size_t)blockIdx.x * k;
     __shared__ unsigned long long sel[4096];
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_remaining, s_count, s_base, s_wcnt[16];
@@ -104,6 +108,15 @@ extern "C" int cpr_topk_desc(const float* scores, int n, int k, float* out_vals,
     hipLaunchKernelGGL(topk_desc_kernel, dim3(1), dim3(1024), 0, stream, scores, n, k, out_vals, out_idx);
     CPR_LAUNCH_STATUS();
 }
+// B equal-length segments in one launch (the images of a batch): scores (B, n) -> out_vals (B, k), out_idx (B, k) segment-relative
+extern "C" int cpr_topk_desc_batched(const float* scores, int B, int n, int k, float* out_vals, long long* out_idx,
+                                     hipStream_t stream) {
+    CPR_CHECK_ARG(B >= 0 && n >= 0 && k >= 0 && k <= n && k <= 4096);
+    if (k == 0 || B == 0) return CPR_OK;
+    CPR_CHECK_ARG(scores && out_vals && out_idx);
+    hipLaunchKernelGGL(topk_desc_kernel, dim3(B), dim3(1024), 0, stream, scores, n, k, out_vals, out_idx);
+    CPR_LAUNCH_STATUS();
+}
 
 // ------------------------------------------------------------------------------------------------
 // Candidate list of multiclass_nms (T/mmdet/core/post_processing/bbox_nms.py:28-60): every (proposal, class) pair whose
@@ -115,6 +128,17 @@ __global__ void nms_candidates_kernel(const float* __restrict__ boxes, int box_s
                                       float* __restrict__ cboxes, float* __restrict__ cscores,
                                       int* __restrict__ clabels, long long* __restrict__ cinds,
                                       int* __restrict__ count) {
+    {   // one workgroup per image: inputs (B, n, .), outputs (B, n * C, .) -- every image owns a slab of the capacity n * C
+        const size_t b = blockIdx.x, cap = (size_t)n * C;
+        boxes += b * n * box_stride;
+        scores += b * n * (C + 1);
+        if (factors) factors += b * n;
+        cboxes += b * cap * 4;
+        cscores += b * cap;
+        clabels += b * cap;
+        cinds += b * cap;
+        count += b;
+    }
     __shared__ int s_wcnt[16], s_base;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6;
     const long long total = (long long)n * C;
@@ -163,13 +187,47 @@ extern "C" int cpr_nms_candidates(const float* boxes, int box_stride, const floa
     CPR_LAUNCH_STATUS();
 }
 
+// all images of a batch in one launch, NO host read: cand_* are (B, n * C, .) slabs, count (B) stays on the device
+extern "C" int cpr_nms_candidates_batched(const float* boxes, int box_stride, const float* scores, const float* factors,
+                                          int B, int n, int C, float score_thr, float* cand_boxes, float* cand_scores,
+                                          int* cand_labels, long long* cand_inds, int* count, hipStream_t stream) {
+    CPR_CHECK_ARG(B >= 0 && n >= 0 && C > 0 && (box_stride == 4 || box_stride == 4 * C));
+    if (B == 0) return CPR_OK;
+    CPR_CHECK_ARG(count);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int) * B, stream);
+        return e == hipSuccess ? CPR_OK : -(int)e;
+    }
+    CPR_CHECK_ARG(boxes && scores && cand_boxes && cand_scores && cand_labels && cand_inds);
+    hipLaunchKernelGGL(nms_candidates_kernel, dim3(B), dim3(1024), 0, stream, boxes, box_stride, scores, factors, n, C,
+                       score_thr, cand_boxes, cand_scores, cand_labels, cand_inds, count);
+    CPR_LAUNCH_STATUS();
+}
+
 // ------------------------------------------------------------------------------------------------
+// The three NMS kernels serve one problem (cpr_nms: n on the host) or a batch (cpr_nms_batched: blockIdx selects the image,
+// n_b is READ FROM THE DEVICE -- the candidate count the kernel above left there -- so no host round trip separates the
+// stages; `cap` is the per-image slab size of every array, nblk_cap = ceil(cap / 64) the mask row stride).
+struct NmsBatch {
+    const int* n_dev;      // per-image candidate counts on the device (nullptr: single problem, n below)
+    int n, cap, nblk_cap;
+    size_t ws_stride;      // 64-bit words of mask / sort workspace per image
+};
+__device__ __forceinline__ int nms_n(const NmsBatch& nb, int b) { return nb.n_dev ? nb.n_dev[b] : nb.n; }
+
 __global__ void nms_prepare_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                   const int* __restrict__ labels, int n, int* __restrict__ order,
+                                   const int* __restrict__ labels, NmsBatch nb, int* __restrict__ order,
                                    float* __restrict__ sboxes, unsigned long long* __restrict__ ws) {
     __shared__ float red[16];
     __shared__ float s_max;
     const int tid = threadIdx.x;
+    const int n = nms_n(nb, blockIdx.x);
+    {
+        const size_t b = blockIdx.x;
+        boxes += b * nb.cap * 4; scores += b * nb.cap; labels += b * nb.cap; order += b * nb.cap; sboxes += b * nb.cap * 4;
+        ws += b * nb.ws_stride;
+    }
+    if (n == 0) return;
     float m = -INFINITY;
     for (int i = tid; i < n * 4; i += blockDim.x) m = fmaxf(m, boxes[i]);
     m = wave_max(m);
@@ -196,10 +254,13 @@ __global__ void nms_prepare_kernel(const float* __restrict__ boxes, const float*
     }
 }
 
-__global__ void nms_mask_kernel(const float* __restrict__ b, int n, float thr, unsigned long long* __restrict__ mask,
-                                int nblk) {
+__global__ void nms_mask_kernel(const float* __restrict__ b, NmsBatch nb, float thr, unsigned long long* __restrict__ mask) {
     const int rb = blockIdx.y, cb = blockIdx.x;
-    if (cb < rb) return;  // only j > i matters
+    const int n = nms_n(nb, blockIdx.z);
+    const int nblk = (n + 63) / 64;       // mask row stride of THIS image (the scan kernel derives the same value)
+    if (cb < rb || cb >= nblk) return;    // only j > i matters; tiles past this image's candidates do not exist
+    b += (size_t)blockIdx.z * nb.cap * 4;
+    mask += (size_t)blockIdx.z * nb.ws_stride;
     __shared__ float cbx[64 * 4];
     const int lane = threadIdx.x;
     const int cj = cb * 64 + lane;
@@ -228,10 +289,15 @@ __global__ void nms_mask_kernel(const float* __restrict__ b, int n, float thr, u
     mask[(size_t)i * nblk + cb] = bits;
 }
 
-__global__ void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order, int n,
-                                int nblk, long long* __restrict__ keep_idx, int* __restrict__ num_keep) {
+__global__ void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order, NmsBatch nb,
+                                long long* __restrict__ keep_idx, int* __restrict__ num_keep) {
     __shared__ unsigned long long removed[256];
     const int lane = threadIdx.x;
+    const int n = nms_n(nb, blockIdx.x), nblk = (n + 63) / 64;
+    {
+        const size_t b = blockIdx.x;
+        mask += b * nb.ws_stride; order += b * nb.cap; keep_idx += b * nb.cap; num_keep += b;
+    }
     for (int c = lane; c < nblk; c += 64) removed[c] = 0ull;
     __syncthreads();
     int cnt = 0;
@@ -258,10 +324,40 @@ extern "C" int cpr_nms(const float* boxes, const float* scores, const int* label
     }
     CPR_CHECK_ARG(boxes && scores && labels && keep_idx && ws_order && ws_boxes && ws_mask);
     const int nblk = cdiv(n, 64);
-    hipLaunchKernelGGL(nms_prepare_kernel, dim3(1), dim3(1024), 0, stream, boxes, scores, labels, n, ws_order, ws_boxes,
+    NmsBatch nb;
+    nb.n_dev = nullptr; nb.n = n; nb.cap = n; nb.nblk_cap = nblk; nb.ws_stride = 0;
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(1), dim3(1024), 0, stream, boxes, scores, labels, nb, ws_order, ws_boxes,
                        ws_mask);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, stream, ws_boxes, n, iou_thr, ws_mask, nblk);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, ws_mask, ws_order, n, nblk, keep_idx, num_keep);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, 1), dim3(64), 0, stream, ws_boxes, nb, iou_thr, ws_mask);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, ws_mask, ws_order, nb, keep_idx, num_keep);
+    CPR_LAUNCH_STATUS();
+}
+
+// B problems in one launch each, candidate counts read from the device (cpr_nms_candidates_batched's `count`): boxes (B, cap, 4),
+// scores / labels (B, cap) -> keep_idx (B, cap) (slab-relative, descending score), num_keep (B).  Workspaces: ws_order (B, cap)
+// int32, ws_boxes (B, cap, 4), ws_mask B * ws_stride 64-bit words with ws_stride >= max(cap * ceil(cap / 64), pow2 >= cap).
+// cap <= 16384.  No host synchronisation: the caller reads (count, num_keep) once per batch.
+extern "C" int cpr_nms_batched(const float* boxes, const float* scores, const int* labels, const int* n_dev, int B, int cap,
+                               float iou_thr, long long* keep_idx, int* num_keep, int* ws_order, float* ws_boxes,
+                               unsigned long long* ws_mask, long long ws_stride, hipStream_t stream) {
+    CPR_CHECK_ARG(B >= 0 && cap >= 0 && cap <= 16384);
+    if (B == 0) return CPR_OK;
+    CPR_CHECK_ARG(num_keep && n_dev);
+    if (cap == 0) {
+        hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int) * B, stream);
+        return e == hipSuccess ? CPR_OK : -(int)e;
+    }
+    CPR_CHECK_ARG(boxes && scores && labels && keep_idx && ws_order && ws_boxes && ws_mask);
+    const int nblk = cdiv(cap, 64);
+    int P = 1;
+    while (P < cap) P <<= 1;
+    CPR_CHECK_ARG(ws_stride >= (long long)cap * nblk && ws_stride >= P);
+    NmsBatch nb;
+    nb.n_dev = n_dev; nb.n = 0; nb.cap = cap; nb.nblk_cap = nblk; nb.ws_stride = (size_t)ws_stride;
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(1024), 0, stream, boxes, scores, labels, nb, ws_order, ws_boxes,
+                       ws_mask);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, B), dim3(64), 0, stream, ws_boxes, nb, iou_thr, ws_mask);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, stream, ws_mask, ws_order, nb, keep_idx, num_keep);
     CPR_LAUNCH_STATUS();
 }
 
@@ -380,19 +476,34 @@ __global__ void p2p_loss_kernel(const float* __restrict__ logits, const float* _
 // out (B,2): per image {loss_cls, loss_pts}; avg factor = total positives over the batch (p2p_head.py:199-200)
 __global__ void p2p_loss_finalize_kernel(const double* __restrict__ partial, int B, int nblk, float w_cls, float w_reg,
                                          float* __restrict__ out) {
+    // round 4: every sum is a fixed-shape tree (strided per-thread partials -> wave shuffle -> 16 wave totals in order) instead
+    // of one thread walking B * nblk doubles (171 us at B = 16); deterministic, double accumulation as before
+    __shared__ double red[16];
     __shared__ double s_np;
-    if (threadIdx.x == 0) {
-        double t = 0;
-        for (int i = 0; i < B * nblk; ++i) t += partial[(size_t)i * 3 + 2];
-        s_np = t;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double t = 0;
+    for (int i = tid; i < B * nblk; i += nt) t += partial[(size_t)i * 3 + 2];
+    t = wave_sum_d(t);
+    if ((tid & 63) == 0) red[tid >> 6] = t;
+    __syncthreads();
+    if (tid == 0) {
+        double r = 0;
+        for (int w = 0; w < (nt >> 6); ++w) r += red[w];
+        s_np = r;
     }
     __syncthreads();
-    const int b = threadIdx.x;
-    if (b < B) {
+    const double np_ = s_np;
+    // one wave per image (16 waves): lanes stride over the image's blocks
+    const int lane = tid & 63;
+    for (int b = tid >> 6; b < B; b += (nt >> 6)) {
         double lc = 0, lp = 0;
-        for (int i = 0; i < nblk; ++i) { lc += partial[((size_t)b * nblk + i) * 3]; lp += partial[((size_t)b * nblk + i) * 3 + 1]; }
-        out[b * 2] = (float)(lc / s_np * w_cls);
-        out[b * 2 + 1] = (float)(lp / s_np * w_reg);
+        for (int i = lane; i < nblk; i += 64) { lc += partial[((size_t)b * nblk + i) * 3]; lp += partial[((size_t)b * nblk + i) * 3 + 1]; }
+        lc = wave_sum_d(lc);
+        lp = wave_sum_d(lp);
+        if (lane == 0) {
+            out[b * 2] = (float)(lc / np_ * w_cls);
+            out[b * 2 + 1] = (float)(lp / np_ * w_reg);
+        }
     }
 }
 

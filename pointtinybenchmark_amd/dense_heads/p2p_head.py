@@ -15,9 +15,12 @@ import torch.nn as nn
 from .. import ops
 from ..core.assigners import HungarianAssignerV2
 from ..core.point_generator import PointGenerator
-from ..core.post_processing import multiclass_nms
+from ..core.post_processing import multiclass_nms, multiclass_nms_batched
 from ..layers import ConvModule, _PackCache, conv_gn, packed_conv
 from ..registry import HEADS, build_assigner, build_sampler
+
+
+BATCHED_POSTPROCESS = [True]     # test hook: False runs _get_bboxes_single image by image (the two must agree exactly)
 
 
 def _get(cfg, key, default=None):
@@ -237,6 +240,8 @@ class P2PHead(nn.Module):
     # ------------------------------------------------------------------ inference (p2p_head.py:330-423)
     def get_bboxes(self, cls_outs, pts_outs, img_metas, cfg=None, rescale=False, with_nms=True):
         anchor, pred, valid, cls = self.get_pred_points(cls_outs, pts_outs, img_metas)
+        if BATCHED_POSTPROCESS[0]:
+            return self._get_bboxes_batched(pred[..., :2], cls, img_metas, cfg, rescale, with_nms)
         res = []
         for b in range(len(img_metas)):
             pts_scores, labels = self._get_bboxes_single(pred[b][..., :2], valid[b], cls[b], img_metas[b]['img_shape'],
@@ -265,6 +270,47 @@ class P2PHead(nn.Module):
         dets, labels = multiclass_nms(boxes, scores, _get(cfg, 'score_thr'), _get(cfg, 'nms'), _get(cfg, 'max_per_img'))
         ctr = torch.stack([(dets[:, 0] + dets[:, 2]) * 0.5, (dets[:, 1] + dets[:, 3]) * 0.5, dets[:, 4]], dim=-1)
         return ctr, labels
+
+    def _get_bboxes_batched(self, pred_pts, cls, img_metas, cfg, rescale=False, with_nms=True):
+        """_get_bboxes_single (p2p_head.py:345-423) for the whole batch at once: one row-max-sigmoid, one top-k, one candidate
+        compaction and one NMS launch over all images, and a single host read (candidate + keep counts) where the per-image
+        loop pays two synchronisations per image.  pred_pts (B, M, 2), cls (B, M, C).  Same arithmetic per element as the
+        per-image path (``BATCHED_POSTPROCESS[0] = False`` keeps that one: tests compare the two)."""
+        cfg = self.test_cfg if cfg is None else cfg
+        assert with_nms
+        B, M, C = cls.shape
+        dev = cls.device
+        nms_pre = _get(cfg, 'nms_pre', -1)
+        logits = cls.contiguous()
+        if 0 < nms_pre < M:
+            rs = ops.rowmax_sigmoid(logits.view(B * M, C)).view(B, M)
+            _, topk_inds = ops.topk_desc_batched(rs, nms_pre)
+            logits = torch.gather(logits, 1, topk_inds[..., None].expand(-1, -1, C))
+            pred_pts = torch.gather(pred_pts, 1, topk_inds[..., None].expand(-1, -1, 2))
+        n = logits.shape[1]
+        flat = logits.reshape(B * n, C)
+        scores = (ops.rowmax_sigmoid(flat)[:, None] if self.num_cls_out == 1 else ops.sigmoid_exact(flat)).view(B, n, C)
+        shapes = [tuple(m['img_shape'][:2]) for m in img_metas]
+        if len(set(shapes)) == 1:
+            x = pred_pts[..., 0].clamp(min=0, max=shapes[0][1])
+            y = pred_pts[..., 1].clamp(min=0, max=shapes[0][0])
+        else:
+            lim = torch.tensor([[s[1], s[0]] for s in shapes], dtype=torch.float32).to(dev)          # (B, 2): (w, h)
+            x = torch.minimum(pred_pts[..., 0].clamp(min=0), lim[:, 0:1])
+            y = torch.minimum(pred_pts[..., 1].clamp(min=0), lim[:, 1:2])
+        pts = torch.stack([x, y], dim=-1)
+        if rescale:
+            sf = torch.tensor([list(m['scale_factor'][:2]) for m in img_metas], dtype=torch.float32).to(dev)
+            pts = pts / sf[:, None, :]
+        scores = torch.cat([scores, scores.new_zeros(B, n, 1)], dim=2)
+        wh = pts.new_tensor(_get(self.test_cfg, 'pseudo_wh', (16, 16)))
+        boxes = torch.cat([pts - wh / 2, pts + wh / 2], dim=-1)
+        res = []
+        for dets, labels in multiclass_nms_batched(boxes, scores, _get(cfg, 'score_thr'), _get(cfg, 'nms'),
+                                                   _get(cfg, 'max_per_img')):
+            ctr = torch.stack([(dets[:, 0] + dets[:, 2]) * 0.5, (dets[:, 1] + dets[:, 3]) * 0.5, dets[:, 4]], dim=-1)
+            res.append((self.center_to_pseudo_bbox([ctr])[0], labels))
+        return res
 
     def center_to_pseudo_bbox(self, center_scores):
         wh = center_scores[0].new_tensor(_get(self.test_cfg, 'pseudo_wh', (16, 16)))

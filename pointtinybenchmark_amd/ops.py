@@ -543,6 +543,9 @@ def hungarian_cost(pred, logits, gt, labels, w_cls=2.0, alpha=0.25, gamma=2.0, e
     return costT
 
 
+LSA_REGISTER_KERNEL = [True]     # test hook: False keeps the memory-resident kernel (the two must agree bit for bit)
+
+
 def lsa_topk(costT_list, topk):
     """Solve a batch of independent assignment problems (one workgroup each).  costT_list: list of (G_b, M_b)
     fp32 tensors with M_b >= G_b.  Returns list of gt_inds (M_b,) int64 (0 = background, j+1 = gt j)."""
@@ -577,7 +580,8 @@ def lsa_topk(costT_list, topk):
     _lib.call('cpr_lsa_topk', _ptr(flat), _ptr(t_m), _ptr(t_g), _ptr(t_off[0]), _ptr(t_off[1]), _ptr(t_off[2]), nb,
               int(topk), _ptr(gt_inds), _ptr(ws_v), _ptr(ws_spc),
               _ptr(ws_path), _ptr(ws_r4c), _ptr(ws_sc), _ptr(ws_act), _ptr(ws_cols[0]), _ptr(ws_cols[1]),
-              _ptr(ws_cols[2]), _ptr(ws_u), _ptr(ws_c4r), _ptr(ws_sr), _ptr(status), _stream())
+              _ptr(ws_cols[2]), _ptr(ws_u), _ptr(ws_c4r), _ptr(ws_sr), _ptr(status),
+              max(Ms) if LSA_REGISTER_KERNEL[0] else 0, max(Gs), _stream())
     return [gt_inds[col_off[i]:col_off[i + 1]] for i in range(nb)], status
 
 
@@ -628,6 +632,54 @@ def nms(boxes, scores, labels, iou_thr):
     _lib.call('cpr_nms', _ptr(_check(boxes)), _ptr(_check(scores)), _ptr(_check(labels, torch.int32)), n,
               float(iou_thr), _ptr(keep), _ptr(num), _ptr(order), _ptr(sboxes), _ptr(mask), _stream())
     return keep[:int(num.item())]
+
+
+def topk_desc_batched(scores, k):
+    """scores (B, n) fp32 -> (values (B, k), indices (B, k) int64): the k largest of every row, sorted descending, ties by
+    lower index -- one launch for the batch."""
+    B, n = _check(scores).shape
+    vals = torch.empty((B, k), device=scores.device, dtype=torch.float32)
+    idx = torch.empty((B, k), device=scores.device, dtype=torch.int64)
+    _lib.call('cpr_topk_desc_batched', _ptr(scores), B, n, int(k), _ptr(vals), _ptr(idx), _stream())
+    return vals, idx
+
+
+def nms_candidates_batched(boxes, scores, score_thr, factors=None):
+    """boxes (B, n, 4) or (B, n, 4C), scores (B, n, C+1) -> per-image slabs of capacity n * C: cand_boxes (B, cap, 4),
+    cand_scores (B, cap), cand_labels (B, cap) int32, cand_inds (B, cap) int64 and count (B) int32 ON THE DEVICE (no host read)."""
+    B, n, C = scores.shape[0], scores.shape[1], scores.shape[2] - 1
+    dev = scores.device
+    cap = max(n * C, 1)
+    cb = torch.empty((B, cap, 4), device=dev, dtype=torch.float32)
+    cs = torch.empty((B, cap), device=dev, dtype=torch.float32)
+    cl = torch.empty((B, cap), device=dev, dtype=torch.int32)
+    ci = torch.empty((B, cap), device=dev, dtype=torch.int64)
+    cnt = torch.zeros((B,), device=dev, dtype=torch.int32)
+    if n * C > 0:
+        _lib.call('cpr_nms_candidates_batched', _ptr(_check(boxes)), boxes.shape[2], _ptr(_check(scores)), _ptr(factors), B, n, C,
+                  float(score_thr), _ptr(cb), _ptr(cs), _ptr(cl), _ptr(ci), _ptr(cnt), _stream())
+    return cb, cs, cl, ci, cnt
+
+
+def nms_batched(boxes, scores, labels, counts, iou_thr):
+    """Class-aware greedy NMS of B candidate slabs (nms_candidates_batched outputs): the candidate counts are read on the device.
+    -> keep (B, cap) int64 slab-relative indices in descending score order, num_keep (B) int32 on the device."""
+    B, cap = scores.shape
+    dev = scores.device
+    keep = torch.empty((B, cap), device=dev, dtype=torch.int64)
+    num = torch.zeros((B,), device=dev, dtype=torch.int32)
+    nblk = (cap + 63) // 64
+    P = 1
+    while P < cap:
+        P <<= 1
+    stride = max(cap * nblk, P)
+    order = torch.empty((B, cap), device=dev, dtype=torch.int32)
+    sboxes = torch.empty((B, cap, 4), device=dev, dtype=torch.float32)
+    mask = torch.empty((B * stride,), device=dev, dtype=torch.int64)
+    _lib.call('cpr_nms_batched', _ptr(_check(boxes)), _ptr(_check(scores)), _ptr(_check(labels, torch.int32)),
+              _ptr(_check(counts, torch.int32)), B, cap, float(iou_thr), _ptr(keep), _ptr(num), _ptr(order), _ptr(sboxes),
+              _ptr(mask), stride, _stream())
+    return keep, num
 
 
 def p2p_decode(reg_nhwc, point_anchor, stride, gamma, want_anchor=False):

@@ -220,6 +220,7 @@ class BackwardEngine:
     its flat buffer, bucketed reducer, native optimizer) and by the autograd bridge (``autograd_bridge.py``: the same rules
     behind ``torch.autograd.Function``s, gradients handed to torch, so that ``loss.backward()`` / DDP / torch.optim drive the
     drop-in classes as they drive the reference's).  ``_g(p)`` is where the gradient of parameter ``p`` is written."""
+    _sink, side, _mixed = None, None, False
 
     def __init__(self, model, two_streams=True):
         self.model = model
@@ -259,6 +260,54 @@ class BackwardEngine:
 
     def _done(self, p):
         """The gradient of ``p`` (and of everything before it in the trainer's flat order) has been enqueued."""
+
+    # ------------------------------------------------------------------ segment API of the autograd bridge
+    # (autograd_bridge.py: one torch.autograd.Function per segment; each forward returns (output, state) and the matching
+    # backward consumes the state.  Every boundary carries a true gradient tensor.)
+    def forward_stage(self, i, x):
+        bb = self.model.backbone
+        tape = []
+        out = bb.run_stage(i, x, tape)
+        assert tape, 'a stage segment is only built for trainable stages'
+        return out, tape
+
+    def backward_stage(self, tape, dout, need_in):
+        cache = self.model.backbone._cache
+        dx = dout
+        for idx in range(len(tape) - 1, -1, -1):
+            rec = tape[idx]
+            dx = self._block_backward(cache, rec['block'], rec, dx, need_dx=(idx > 0 or need_in), keep=idx > 0)
+        return dx if need_in else None
+
+    def forward_laterals(self, xs):
+        tape = []
+        lat = self.model.neck.run_laterals(list(xs), tape)
+        return lat[0], {r['level']: r for r in tape}
+
+    def backward_laterals(self, recs, dlat, need):
+        """need[i]: whether the gradient wrt the i-th input (stage start_level + i) is wanted -> list of gradients / None."""
+        neck = self.model.neck
+        d_stage = self._backward_laterals(neck, recs, dlat, need_dx_of=lambda stage: need[stage - neck.start_level])
+        return [d_stage.get(i + neck.start_level) for i in range(len(need))]
+
+    def forward_head_loss(self, lat0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
+        """FPN output conv (lazy) -> head -> losses: returns the loss vector of the loss kernels and the backward state."""
+        from .layers import conv_gn
+        neck, head = self.model.neck, self.model.bbox_head
+        rec = dict(kind='out', level=0)
+        lazy = [conv_gn(neck._cache, neck.fpn_convs[0], lat0, materialize=False, save=rec)]
+        _, saved = self._forward_head(head, lazy, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes)
+        return saved[self.loss_vector_key], (rec, saved)
+
+    def backward_head_loss(self, state, upstream):
+        rec, saved = state
+        dz = self._backward_head(self.model.bbox_head, saved, upstream=upstream)
+        return self._backward_out_conv(rec, dz)
+
+    loss_vector_key = 'out5'       # CPRHead: (gt_loss, pos_loss, bag_acc, neg_loss, num_sample)
+
+    def loss_dict(self, out):
+        return self.model.bbox_head._loss_dict(out)
 
 
     # ------------------------------------------------------------------ helpers

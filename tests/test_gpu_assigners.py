@@ -159,6 +159,14 @@ def test_hungarian_v2_vs_oracle_seeds(seed, record_property):
     pred, logits, gt, labels, shp = assigner_inputs(900 + seed, n_side, 4, G, C)
     got, n_ent, n_idx = _check_hungarian(pred, logits, gt, labels, shp, k, record_property, 'seed%d' % seed)
     assert int((got > 0).sum()) == min(k, (n_side * n_side) // G) * G
+    # north star: "assigner indices bit-identical".  Links 1-2 above are host independent; THIS comparison is against the
+    # reference formula evaluated with this host's own fp32 log (MKL VML: 1 ulp off the correctly rounded value in up to a
+    # few per cent of the arguments on EPYC hosts).  A flipped index here means one of those last-bit differences landed on
+    # an exact tie of the assignment -- not a kernel defect, but the claim "bit-identical to the reference CPU path on this
+    # box" would then be false for this input, so it fails loudly instead of being written to a JSON nobody reads.
+    assert n_idx == 0, ('seed%d: %d assigner indices differ from the reference formula evaluated on THIS host (%d of %d cost '
+                        'entries differ by one rounding of the host log); the device indices still equal scipy on the '
+                        "device's own correctly-rounded-log costs" % (seed, n_idx, n_ent, n_side * n_side * G))
 
 
 @pytest.mark.parametrize('case', range(5))
@@ -174,6 +182,61 @@ def test_device_lsa_reproduces_scipy_on_identical_costs(golden_dir, case):
     assert int(status[0]) == 0
     assert torch.equal(got.cpu(), inds), '%d indices differ from scipy run on the same cost matrix' % int(
         (got.cpu() != inds).sum())
+
+
+def _lsa_both_kernels(costs, k):
+    """ops.lsa_topk on the register-resident kernel (round 4) and on the memory-resident one: outputs of both."""
+    from pointtinybenchmark_amd import ops
+    outs = []
+    for reg in (True, False):
+        ops.LSA_REGISTER_KERNEL[0] = reg
+        try:
+            o, status = ops.lsa_topk(costs, k)
+        finally:
+            ops.LSA_REGISTER_KERNEL[0] = True
+        assert int(status.abs().max()) == 0, status
+        outs.append([t.cpu() for t in o])
+    return outs
+
+
+@pytest.mark.parametrize('case', ['25600x100_k5', '25600x32_k5_batch4', 'ties', 'tiny', '32768x7_k3', '9000x255_k2'])
+def test_register_resident_lsa_equals_the_memory_resident_kernel_and_scipy(case):
+    """csrc/assign.hip holds two statements of scipy's shortest-augmenting-path solver: ``lsa_topk_kernel`` (all per-column
+    state in memory) and ``lsa_topk_reg_kernel`` (round 4: the search state of a row in registers / LDS).  Same arithmetic,
+    same comparison order, same tie rules: indices must agree BIT FOR BIT with each other and with scipy (oracle.lsa_topk)
+    on the same cost matrix -- full-size problems, a batch, integer costs full of exactly tied optima, and degenerate sizes."""
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    if case == '25600x100_k5':
+        specs, k = [(160, 100)], 5
+    elif case == '25600x32_k5_batch4':
+        specs, k = [(160, 32), (160, 17), (160, 32), (128, 40)], 5
+    elif case == 'tiny':
+        specs, k = [(2, 3), (3, 1), (1, 1), (4, 16)], 2            # fewer proposals than gts -> no round runs; 1 x 1; M == G
+    elif case == '32768x7_k3':
+        specs, k = [(None, 7)], 3                                   # the widest problem the register kernel takes
+    elif case == '9000x255_k2':
+        specs, k = [(None, 255)], 2
+    else:
+        specs, k = [(40, 12), (64, 30)], 4
+    costs, refs = [], []
+    for si, (n_side, G) in enumerate(specs):
+        if case == 'ties':            # small integer costs: almost every optimum is tied, the tie rules decide every index
+            M = n_side * n_side
+            cost = torch.randint(0, 4, (M, G), generator=g).float()
+        elif n_side is None:
+            M = 32768 if G == 7 else 9000
+            cost = torch.rand((M, G), generator=g) * 3 + (torch.randint(0, 3, (M, G), generator=g).float())
+        else:
+            pred, logits, gt, labels, shp = assigner_inputs(1300 + 10 * si + len(case), n_side, 4, G, 1)
+            _, _, cost = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=k, log_mode='cr')
+            if cost is None:
+                cost = torch.rand((n_side * n_side, G), generator=g)
+        costs.append(cost.t().contiguous().cuda())
+        refs.append(O.lsa_topk(cost, k))
+    reg, mem = _lsa_both_kernels(costs, k)
+    for i, (a, b, r) in enumerate(zip(reg, mem, refs)):
+        assert torch.equal(a, b), '%s[%d]: %d indices differ between the two kernels' % (case, i, int((a != b).sum()))
+        assert torch.equal(a, r), '%s[%d]: %d indices differ from scipy' % (case, i, int((a != r).sum()))
 
 
 def test_device_lsa_batched_problems():
