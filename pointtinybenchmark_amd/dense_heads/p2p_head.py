@@ -318,3 +318,51 @@ class P2PHead(nn.Module):
 
     def simple_test(self, feats, img_metas, rescale=False, **kwargs):
         return self.get_bboxes(*self(feats), img_metas, rescale=rescale)
+
+    # ------------------------------------------------------------------ tile / flip TTA merge (p2p_head.py:487-572)
+    @staticmethod
+    def bbox_mapping_back(bboxes, img_shape, scale_factor, flip, flip_direction, tile_offset=None):
+        """T/mmdet/core/bbox/transforms.py:5-31,62-80 (the fork adds ``tile_offset``): un-flip, divide by the test scale, move a
+        tile's detections to their place in the original image."""
+        new = bboxes
+        if flip:
+            assert flip_direction in ('horizontal', 'vertical', 'diagonal')
+            new = bboxes.clone()
+            if flip_direction in ('horizontal', 'diagonal'):
+                new[..., 0::4] = img_shape[1] - bboxes[..., 2::4]
+                new[..., 2::4] = img_shape[1] - bboxes[..., 0::4]
+            if flip_direction in ('vertical', 'diagonal'):
+                new[..., 1::4] = img_shape[0] - bboxes[..., 3::4]
+                new[..., 3::4] = img_shape[0] - bboxes[..., 1::4]
+        new = new.view(-1, 4) / new.new_tensor(scale_factor)
+        assert tile_offset is None or (isinstance(tile_offset, (tuple, list)) and len(tile_offset) == 2), \
+            'tile_offset must be None or (dx, dy) or [dx, dy]'
+        if tile_offset is not None:
+            dx, dy = tile_offset
+            new[:, [0, 2]] += dx
+            new[:, [1, 3]] += dy
+        return new.view(bboxes.shape)
+
+    def aug_test_bboxes(self, feats, img_metas, rescale=False):
+        """Test-time augmentation of the fork's tile inference (p2p_head.py:487-572): every augmentation (one image each) runs
+        forward + get_bboxes (top-k, pseudo-box NMS) in ITS frame, the surviving pseudo boxes are mapped back to the original
+        image (flip, scale, tile offset), and one more class-aware NMS runs over the union.  feats: list (augmentations) of
+        feature tuples; img_metas: list of one-element lists.  -> [(dets (n, 5), labels (n,))]."""
+        aug_bboxes, aug_scores = [], []
+        for x, img_meta in zip(feats, img_metas):
+            assert len(img_meta) == 1, 'one image per augmentation (dense_test_mixins.py:192)'
+            dets, labels = self.get_bboxes(*self(x), img_meta, self.test_cfg, False, True)[0]
+            scores = dets.new_zeros((dets.shape[0], self.num_classes))
+            scores[torch.arange(dets.shape[0], device=dets.device), labels] = dets[:, 4]
+            m = img_meta[0]
+            aug_bboxes.append(self.bbox_mapping_back(dets[:, :4], m['img_shape'], m['scale_factor'], m['flip'],
+                                                     m['flip_direction'], m.get('tile_offset', None)))
+            aug_scores.append(scores)
+        merged_bboxes, merged_scores = torch.cat(aug_bboxes, dim=0), torch.cat(aug_scores, dim=0)
+        merged_scores = torch.cat([merged_scores, merged_scores.new_zeros(merged_scores.shape[0], 1)], dim=1)   # bg column
+        det_bboxes, det_labels = multiclass_nms(merged_bboxes, merged_scores, _get(self.test_cfg, 'score_thr'),
+                                                _get(self.test_cfg, 'nms'), _get(self.test_cfg, 'max_per_img'))
+        if not rescale:
+            det_bboxes = det_bboxes.clone()
+            det_bboxes[:, :4] *= det_bboxes.new_tensor(img_metas[0][0]['scale_factor'])
+        return [(det_bboxes, det_labels)]
