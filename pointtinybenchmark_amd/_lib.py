@@ -81,6 +81,7 @@ SIGNATURES = {
 
 # measurement build only (-DCPR_BENCH_HOOKS -> libcprhip_bench.so, tools/*.py): NOT part of the product library
 BENCH_SIGNATURES = {
+    'cpr_lsa_phase_clocks': [_p, _i],
     'cpr_conv_force_tile': [_i, _i],
     'cpr_conv_set_pipeline': [_i],
     'cpr_conv_set_stream': [_i],

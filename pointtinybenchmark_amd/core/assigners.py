@@ -132,11 +132,13 @@ class HungarianAssignerV2:
                 inds[:] = 0
             return AssignResult(num_gts, inds, None, labels=labels)
         costT = None
-        if num_bboxes < num_gts:
-            if self.topk_k != 1:
+        if num_bboxes <= num_gts:
+            if self.topk_k != 1 and num_bboxes < num_gts:
                 inds[:] = 0  # the reference's loop condition fails immediately (hungarian_assigner.py:251)
                 return AssignResult(num_gts, inds, None, labels=labels)
-            # topk_k == 1 (hungarian_assigner.py:229-240): scipy keeps the FEWER proposals as rows, each gets a distinct gt
+            # topk_k == 1 (hungarian_assigner.py:229-240): scipy keeps the FEWER proposals as rows, each gets a distinct gt.
+            # As many proposals as gts (any topk_k: one round assigns everything): scipy does not transpose a square matrix
+            # either -- the proposals stay its rows, which decides WHICH of several exactly tied optima comes out
             costT = self.cost_t(bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta)
             inds = self.transposed_inds([costT])[0]
         else:

@@ -360,22 +360,47 @@ __global__ void lsa_topk_kernel(const float* __restrict__ costT_all, const int* 
 
 
 // ------------------------------------------------------------------------------------------------
-// Round 4: the same algorithm with the per-column state of a row search in REGISTERS.  The kernel above streams ~33 bytes per
-// column per scan through one CU's L2 port (v, shortest-path cost, path, row4col, visited flag, scan position, compaction
-// index, cost: 25 600 columns = 0.85 MB per scan, ~100 scans per round): 5.5 ms per launch at 16 images x 32 gts x 25 600
-// proposals, 15 % of the P2PNet step (profiles/round3_p2p_kernel_stats.csv).  Here thread t owns columns t + 1024 k
-// (k < KMAX) for a whole round and keeps for them
-//   spc[k]            the shortest-path cost (double) of the current search                       registers
-//   scbits / asgbits  visited-in-this-search / assigned (row4col != -1) flags                     one bit per column
-//   vbits             "the dual v of this column is non-zero": v is read from memory only then    (v != 0 only for the few
-//                     hundred columns a search has ever visited; v - 0.0 is exact, so skipping the read changes nothing)
-//   path              implicit: a column improved only by the first scan of a search has path = the inserted row; later
-//                     improvements store (stamp << 16 | row) with a per-search stamp, stale entries read as "first scan"
-//   scan position     pos[c] = Mc - 1 - c except for the <= G low columns the swap-with-last of scipy's `remaining` array
-//                     moved during THIS search: an LDS shadow of the first / last LSA_MAX_VIS entries of pos / remaining
-// so a scan reads 4 bytes per column (the cost) and thread 0's bookkeeping between two scans touches LDS only (the winner's
-// row4col rides in the arg-min record).  Arithmetic, comparison order and tie-breaking are the kernel above's, operation for
-// operation: the two are interchangeable bit for bit (tests/test_gpu_assigners.py runs both).
+// Round 4: the same algorithm with NO per-column search state in memory.  The kernel above streams ~33 bytes per column per
+// scan through one CU (v, shortest-path cost, path, row4col, visited flag, scan position, compaction index, cost: 0.85 MB per
+// scan, 161 scans per image) and waits for every one of them: 5.5 ms per launch at 16 images x 32 gts x 25 600 proposals, 15 %
+// of the P2PNet step (profiles/round3_p2p_kernel_stats.csv).  Two observations remove the state:
+//   * the shortest-path cost of column c after the n-th scan of a search is min over the scanned rows i_m of
+//     ((minval_m + cost[i_m][c]) - u[i_m]) - v[c], and path[c] is the FIRST row attaining it (the update is `r < s`, strict).
+//     Both are functions of the n (row, minval) pairs of the search -- kept in LDS -- so they are RECOMPUTED instead of stored:
+//     a scan reads n cost entries per column.  n is 1 for 99 % of the searches (a gt's best proposal is free), so a scan is one
+//     read of the cost row, 13 loads in flight per thread, and nothing else; the terms and their evaluation order are the
+//     stored form's, so every comparison sees the same doubles.
+//   * thread t owns columns t + 1024 k (k < KMAX) for a whole round and keeps their flags in registers, one bit per column:
+//     visited in this search / assigned (row4col != -1) / "dual v is non-zero" (v is read only then: v - 0.0 is exact; v != 0
+//     only for the few hundred columns a search has ever visited).  The scan position pos[c] = Mc - 1 - c differs only for the
+//     <= G low columns the swap-with-last of scipy's `remaining` array moved during THIS search: LDS shadows of the first /
+//     last LSA_MAX_VIS entries of pos / remaining.  u and col4row live in LDS; thread 0's bookkeeping between two scans touches
+//     LDS only (the winner's row4col rides in the arg-min record).
+// Arithmetic, comparison order and tie-breaking are the kernel above's, operation for operation: the two are interchangeable
+// bit for bit (tests/test_gpu_assigners.py runs both against each other and against scipy).
+#ifdef CPR_BENCH_HOOKS
+// measurement build only (libcprhip_bench.so): shader-clock time thread 0 of workgroup 0 spends in the phases of a row search
+__device__ long long lsa_phase_clk[8];
+#define LSA_T(k)                                                     \
+    do {                                                             \
+        if (tid == 0 && b == 0) {                                    \
+            const long long t_ = clock64();                          \
+            lsa_phase_clk[k] += t_ - t_last;                         \
+            t_last = t_;                                             \
+        }                                                            \
+    } while (0)
+extern "C" int cpr_lsa_phase_clocks(long long* host_out, int reset) {
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lsa_phase_clk), sizeof(long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lsa_phase_clk), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define LSA_T(k)
+#endif
+
 struct ArgR {
     double v;
     int r4c;   // row4col of the column (-1 = unassigned)
@@ -395,40 +420,47 @@ template <int KMAX>
 __global__ void __launch_bounds__(1024) lsa_topk_reg_kernel(
         const float* __restrict__ costT_all, const int* __restrict__ m_of, const int* __restrict__ g_of,
         const long long* __restrict__ cost_off, const long long* __restrict__ col_off, const long long* __restrict__ row_off,
-        int topk, long long* __restrict__ gt_inds_all, double* __restrict__ v_all, int* __restrict__ path_all,
-        int* __restrict__ row4col_all, unsigned char* __restrict__ active_all, int* __restrict__ cols_all,
-        double* __restrict__ u_all, int* __restrict__ status) {
+        int topk, long long* __restrict__ gt_inds_all, double* __restrict__ v_all, int* __restrict__ row4col_all,
+        unsigned char* __restrict__ active_all, int* __restrict__ cols_all, int* __restrict__ status) {
     constexpr int NT = 1024, S = LSA_MAX_VIS;
+    constexpr int CH = KMAX >= 20 ? (KMAX + 2) / 3 : (KMAX > 8 ? KMAX / 2 : KMAX);   // columns whose loads are in flight together (9 of 25)
     static_assert(S == NT, "slot 0 of a thread must hold exactly the columns of the LDS shadows");
     __shared__ ArgR sh[16];
-    __shared__ int s_i, s_sink, s_fail, s_nact, s_base, s_wcnt[16], s_nvis, s_win;
+    __shared__ int s_sink, s_fail, s_nact, s_base, s_wcnt[16], s_nvis, s_win, s_nrow;
     __shared__ int s_vis[S], s_vq[S], s_vlast[S];     // visited columns of a search; the shadow entries each removal edited
     __shared__ int s_pos[S], s_rem[S];                // pos[c] for c < S; remaining[Mc - 1 - q] for q < S
     __shared__ int s_c4r[S];                          // col4row
-    __shared__ unsigned char s_sr[S];                 // SR: rows on the alternating tree of this search
-    __shared__ double s_minval, s_vspc[S], s_rowspc[S];   // spc of the k-th visited column; spc of the column a row was reached through
+    __shared__ int s_row[S];                          // the rows scanned in this search, in scan order (s_row[0] = cur)
+    __shared__ double s_u[S];                         // row duals
+    __shared__ double s_rowmin[S];                    // minval when row s_row[m] was scanned (0 for the first)
+    __shared__ double s_vspc[S];                      // shortest-path cost of the k-th visited column (= minval at its selection)
     const int b = blockIdx.x, tid = threadIdx.x;
     const int M = m_of[b], G = g_of[b];
     const float* costT = costT_all + cost_off[b];
     long long* gt_inds = gt_inds_all + col_off[b];
     double* v = v_all + col_off[b];
-    int* path = path_all + col_off[b];
     int* row4col = row4col_all + col_off[b];
     unsigned char* active = active_all + col_off[b];
     int* cols = cols_all + col_off[b];
-    double* u = u_all + row_off[b];
 
-    for (int j = tid; j < M; j += NT) { gt_inds[j] = 0; active[j] = 1; path[j] = 0; }
+    for (int j = tid; j < M; j += NT) { gt_inds[j] = 0; active[j] = 1; }
     if (tid == 0) s_fail = 0;
     __syncthreads();
     if (G == 0 || M == 0) return;
-    if (G + 1 > S || M > KMAX * NT || (long long)topk * G + 1 >= 65535) {      // never truncate: refuse (the launcher checks too)
+    if (G + 1 > S || M > KMAX * NT) {      // never truncate: refuse (the launcher checks too)
         if (tid == 0 && status) status[b] = 2;
         return;
     }
-    double spc[KMAX];
+#ifdef CPR_BENCH_HOOKS
+    long long t_last = clock64();
+#endif
+    // the cost matrix through a buffer descriptor: one 32-bit lane offset per column + the row's scalar offset (64-bit per-lane
+    // addresses would double the registers the columns cost); G * M * 4 < 2^31 is checked by the launcher
+    const __amdgpu_buffer_rsrc_t rs_cost = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(costT), 0, G * M * 4, 0x00020000);
+    unsigned colreg[KMAX];                  // BYTE offset of the thread's k-th column in a cost row (4 * cols[c]); 0 past Mc (never used there)
 
     for (int round = 0; round < topk; ++round) {
+        LSA_T(7);
         // ordered compaction of the still-active proposals: cols[c] = original index of the c-th active one
         if (tid == 0) s_base = 0;
         __syncthreads();
@@ -454,62 +486,104 @@ __global__ void __launch_bounds__(1024) lsa_topk_reg_kernel(
         __syncthreads();
         const int Mc = s_nact;
         if (Mc / G == 0) break;  // cost_new.shape[0] // num_gts != 0
-        const bool compact = Mc != M;           // round 0: cols[c] == c
-        for (int c = tid; c < Mc; c += NT) { v[c] = 0.0; row4col[c] = -1; }
-        for (int i = tid; i < G; i += NT) { u[i] = 0.0; s_c4r[i] = -1; }
+        int tr = tid;                       // (opaque per round: keeps 3 x KMAX column addresses out of registers, see `tq` below)
+        asm volatile("" : "+v"(tr));
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = tr + k * NT;
+            colreg[k] = c < Mc ? (unsigned)cols[c] * 4u : 0u;
+            if (c < Mc) { v[c] = 0.0; row4col[c] = -1; }
+        }
+        for (int i = tid; i < G; i += NT) { s_u[i] = 0.0; s_c4r[i] = -1; }
         for (int q = tid; q < S; q += NT) { s_pos[q] = Mc - 1 - q; s_rem[q] = q; }
         unsigned asgbits = 0, vbits = 0;
         __syncthreads();
+        LSA_T(0);                                   // round set-up (compaction, state init)
         for (int cur = 0; cur < G; ++cur) {
-            const int stamp = round * G + cur + 1;
-            for (int i = tid; i < G; i += NT) s_sr[i] = 0;
-            if (tid == 0) { s_i = cur; s_sink = -1; s_minval = 0.0; s_nvis = 0; }
+            if (tid == 0) { s_row[0] = cur; s_rowmin[0] = 0.0; s_nrow = 1; s_sink = -1; s_nvis = 0; }
             unsigned scbits = 0;
             __syncthreads();
-            bool first = true;   // first scan of this row: shortestPathCosts = inf, path = -1 for every column (not stored)
+            LSA_T(1);                               // search set-up
             while (true) {
-                const int i = s_i;
-                const double minval = s_minval, ui = u[i];
-                const float* crow = costT + (size_t)i * M;
+                const int nrow = s_nrow;            // rows scanned so far, the current one included (its scan is this one)
                 ArgR best;
                 best.v = INFINITY; best.r4c = 0; best.it = INT_MAX; best.c = -1;
-                // opaque copy of the thread id, re-made per scan: the column addresses (4 arrays x KMAX 64-bit pointers) are then
-                // not loop-invariant, so the compiler computes them where they are used instead of hoisting ~200 registers of
-                // addresses out of the search loop (and spilling them)
+                // opaque copy of the thread id, re-made per scan: the column addresses into v / row4col (2 arrays x KMAX 64-bit
+                // pointers) are then not loop-invariant, so the compiler computes them where they are used instead of hoisting
+                // ~100 registers of addresses out of the search loop (and spilling them)
                 int tq = tid;
                 asm volatile("" : "+v"(tq));
-                // chunks of CH columns: the CH cost loads of a chunk are issued together, then consumed; a scheduling barrier
-                // between chunks keeps the compiler from hoisting every load of the unrolled scan to the top (which spills)
-                constexpr int CH = 5;
+                if (nrow == 1) {
+                    // the common case (99 % of the searches end after their first scan): one row -- every cost load of the thread
+                    // is issued before the first is consumed (KMAX registers, one memory latency per scan), candidates are
+                    // folded straight into the arg-min, no per-column minimum to carry
+                    const int i = __builtin_amdgcn_readfirstlane(s_row[0]);
+                    const double minval = s_rowmin[0], ui = s_u[i];
+                    const int row_off_b = i * M * 4;
+                    float cst[KMAX];
 #pragma unroll
-                for (int kb = 0; kb < KMAX; kb += CH) {
-                    float cst[CH];
+                    for (int k = 0; k < KMAX; ++k)
+                        cst[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_cost, (int)colreg[k], row_off_b, 0));
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        const int c = tq + (kb + j) * NT;
-                        cst[j] = (kb + j < KMAX && c < Mc) ? crow[compact ? cols[c] : c] : 0.f;
-                    }
-#pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        const int k = kb + j;
+                    for (int k = 0; k < KMAX; ++k) {
                         const int c = tq + k * NT;
-                        if (k < KMAX && c < Mc && !((scbits >> k) & 1u)) {
+                        if (c < Mc && !((scbits >> k) & 1u)) {
                             const double vv = ((vbits >> k) & 1u) ? v[c] : 0.0;
-                            const double r = ((minval + (double)cst[j]) - ui) - vv;
-                            double s = first ? (double)INFINITY : spc[k];
-                            if (r < s) {
-                                s = r;
-                                if (!first) path[c] = (stamp << 16) | i;      // (first scan: path = cur, implied)
-                            }
-                            spc[k] = s;
+                            double sp1 = (double)INFINITY;
+                            const double r = ((minval + (double)cst[k]) - ui) - vv;
+                            if (r < sp1) sp1 = r;
                             ArgR x;
-                            x.v = s; x.r4c = ((asgbits >> k) & 1u) ? row4col[c] : -1; x.it = (k == 0) ? s_pos[c] : Mc - 1 - c; x.c = c;      // (S == NT: slot 0 holds exactly the columns below S)
+                            x.v = sp1; x.r4c = ((asgbits >> k) & 1u) ? row4col[c] : -1;
+                            x.it = (k == 0) ? s_pos[c] : Mc - 1 - c; x.c = c;
                             best = (best.c < 0) ? x : argr_min(best, x);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < KMAX; kb += CH) {
+                        double sp[CH];
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) sp[j] = (double)INFINITY;
+                        // shortest-path cost of the chunk's columns = min over the scanned rows, rows in scan order, strict `<`
+                        for (int m = 0; m < nrow; ++m) {
+                            const int i = __builtin_amdgcn_readfirstlane(s_row[m]);      // uniform: the row offset is the load's scalar
+                            const double minval = s_rowmin[m], ui = s_u[i];               // offset, the column its 32-bit lane offset
+                            const int row_off_b = i * M * 4;
+                            float cst[CH];
+#pragma unroll
+                            for (int j = 0; j < CH; ++j) {            // CH independent loads in flight (clamped: no branch around a load)
+                                const int k = kb + j;
+                                cst[j] = (k < KMAX) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_cost, (int)colreg[k < KMAX ? k : 0], row_off_b, 0)) : 0.f;
+                            }
+#pragma unroll
+                            for (int j = 0; j < CH; ++j) {
+                                const int k = kb + j;
+                                if (k < KMAX) {
+                                    const int c = tq + k * NT;
+                                    const double vv = ((vbits >> k) & 1u) ? v[c] : 0.0;
+                                    const double r = ((minval + (double)cst[j]) - ui) - vv;
+                                    if (r < sp[j]) sp[j] = r;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) {
+                            const int k = kb + j;
+                            if (k < KMAX) {
+                                const int c = tq + k * NT;
+                                if (c < Mc && !((scbits >> k) & 1u)) {
+                                    ArgR x;
+                                    x.v = sp[j]; x.r4c = ((asgbits >> k) & 1u) ? row4col[c] : -1;
+                                    x.it = (k == 0) ? s_pos[c] : Mc - 1 - c; x.c = c;      // (S == NT: slot 0 = the columns below S)
+                                    best = (best.c < 0) ? x : argr_min(best, x);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);     // fold column by column: CH candidate records at once would spill
+                        }
+                    }
                 }
-                first = false;
+                LSA_T(2);                           // scan (thread 0's own columns)
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     ArgR y;
@@ -522,15 +596,25 @@ __global__ void __launch_bounds__(1024) lsa_topk_reg_kernel(
                 __syncthreads();
                 if ((tid & 63) == 0) sh[tid >> 6] = best;
                 __syncthreads();
+                LSA_T(3);                           // wave reduce + waiting for the slowest wave's scan
+                ArgR r;                               // the 16 wave minima: a 4-step shuffle tree in wave 0 (argr_min is a total order
+                r.v = INFINITY; r.r4c = 0; r.it = INT_MAX; r.c = -1;     // -- scan positions are unique -- so any tree gives the same record)
+                if (tid < 64) {
+                    if (tid < NT / 64) r = sh[tid];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) {
+                        ArgR y;
+                        y.v = __shfl_xor(r.v, o, 64);
+                        y.r4c = __shfl_xor(r.r4c, o, 64);
+                        y.it = __shfl_xor(r.it, o, 64);
+                        y.c = __shfl_xor(r.c, o, 64);
+                        if (y.c >= 0) r = (r.c < 0) ? y : argr_min(r, y);
+                    }
+                }
                 if (tid == 0) {
-                    ArgR r = sh[0];
-                    for (int w = 1; w < NT / 64; ++w)
-                        if (sh[w].c >= 0) r = (r.c < 0) ? sh[w] : argr_min(r, sh[w]);
-                    s_sr[i] = 1;
                     if (r.c < 0 || r.v == INFINITY) {
                         s_fail = 1; s_sink = -2; s_win = -1;
                     } else {
-                        s_minval = r.v;
                         s_win = r.c;                                   // SC[r.c] = 1: the owner sets its bit below
                         const int k = s_nvis;                          // removals so far: remaining[--n] sits at shadow slot k
                         const int idx = r.c < S ? s_pos[r.c] : Mc - 1 - r.c, last = s_rem[k];
@@ -539,30 +623,36 @@ __global__ void __launch_bounds__(1024) lsa_topk_reg_kernel(
                         s_pos[last] = idx;                             // last < S always: the tail holds low columns only
                         s_vis[k] = r.c; s_vq[k] = q < S ? q : -1; s_vlast[k] = last; s_vspc[k] = r.v;
                         s_nvis = k + 1;
-                        if (r.r4c == -1) s_sink = r.c; else { s_i = r.r4c; s_rowspc[r.r4c] = r.v; }
+                        if (r.r4c == -1) s_sink = r.c;
+                        else { s_row[nrow] = r.r4c; s_rowmin[nrow] = r.v; s_nrow = nrow + 1; }     // next scan: row4col[j], minVal
                     }
                 }
                 __syncthreads();
+                LSA_T(4);                           // thread 0's bookkeeping
                 const int win = s_win;
                 if (win >= 0 && (win & (NT - 1)) == tid) scbits |= 1u << (win >> 10);
                 if (s_sink != -1) break;
             }
             if (s_fail) break;
-            const double minval = s_minval;
-            const int nvis = s_nvis;
-            for (int i = tid; i < G; i += NT) {
-                if (i == cur) u[i] += minval;
-                else if (s_sr[i]) u[i] += minval - s_rowspc[i];        // = spc[col4row[i]]: the column row i was reached through
-            }
-            if (tid < nvis) {            // v[j] -= minVal - shortestPathCosts[j] for the scanned columns only
-                const int c = s_vis[tid];
-                v[c] -= minval - s_vspc[tid];
-            }
+            const int nvis = s_nvis, nrow = s_nrow;
+            const double minval = s_vspc[nvis - 1];                   // minVal of the search = the sink's shortest-path cost
             if (tid == 0) {
-                int j = s_sink;          // augment along the path
+                // augment along the path -- BEFORE the duals move: path[j] is re-derived from the duals the search ran on.
+                // Column j was selected as the jk-th winner, after scans 0..jk: path[j] = the first of those rows attaining
+                // min_m ((minval_m + cost[i_m][j]) - u[i_m]) - v[j]  (the stored form updates on a strict `<` only)
+                int j = s_sink;
                 while (true) {
-                    const int pw = path[j];
-                    const int i = ((pw >> 16) == stamp) ? (pw & 0xffff) : cur;
+                    int jk = 0;
+                    for (int k = 0; k < nvis; ++k) if (s_vis[k] == j) { jk = k; break; }      // every path column was visited
+                    const double vj = v[j];
+                    const size_t oj = (size_t)cols[j];
+                    double sbest = INFINITY;
+                    int i = cur;
+                    for (int m = 0; m <= jk; ++m) {
+                        const int im = s_row[m];
+                        const double r = ((s_rowmin[m] + (double)costT[(size_t)im * M + oj]) - s_u[im]) - vj;
+                        if (r < sbest) { sbest = r; i = im; }
+                    }
                     row4col[j] = i;
                     const int t = s_c4r[i];
                     s_c4r[i] = j;
@@ -571,6 +661,16 @@ __global__ void __launch_bounds__(1024) lsa_topk_reg_kernel(
                 }
             }
             __syncthreads();
+            // u[cur] += minVal; u[i] += minVal - shortestPathCosts[col4row[i]] for the other scanned rows: row s_row[m] (m >= 1)
+            // was reached through the (m-1)-th visited column, whose cost is s_vspc[m - 1]
+            if (tid < nrow) {
+                const int i = s_row[tid];
+                s_u[i] += (tid == 0) ? minval : minval - s_vspc[tid - 1];
+            }
+            if (tid < nvis) {            // v[j] -= minVal - shortestPathCosts[j] for the scanned columns only
+                const int c = s_vis[tid];
+                v[c] -= minval - s_vspc[tid];
+            }
             for (int k = 0; k < nvis; ++k) {     // owners refresh their flags: a visited column now has v != 0 and may be assigned
                 const int c = s_vis[k];
                 if ((c & (NT - 1)) == tid) {
@@ -584,11 +684,11 @@ __global__ void __launch_bounds__(1024) lsa_topk_reg_kernel(
             __syncthreads();
             if (tid < nvis) s_pos[s_vlast[tid]] = Mc - 1 - s_vlast[tid];
             __syncthreads();
+            LSA_T(5);                               // dual updates, augmentation, flag refresh, shadow restore
         }
         if (s_fail) break;
         for (int i = tid; i < G; i += NT) {
-            const int c = s_c4r[i];
-            const int j = compact ? cols[c] : c;
+            const int j = cols[s_c4r[i]];
             gt_inds[j] = i + 1;
             active[j] = 0;
         }
@@ -607,14 +707,13 @@ extern "C" int cpr_lsa_topk(const float* costT, const int* m_of, const int* g_of
     if (num_problems == 0) return CPR_OK;
     CPR_CHECK_ARG(costT && m_of && g_of && cost_off && col_off && row_off && gt_inds && ws_v && ws_spc && ws_path &&
                   ws_row4col && ws_sc && ws_active && ws_cols && ws_remaining && ws_pos && ws_u && ws_col4row && ws_sr);
-    // max_cols / max_rows: [host] upper bounds of the problems' sizes (the per-problem tables live on the device); the register-
-    // resident kernel serves max_cols <= 32768 and topk * max_rows < 65534, anything else (or max_cols <= 0 = unknown) the
-    // memory-resident one.  Bit-identical results.
+    // max_cols / max_rows: [host] upper bounds of the problems' sizes (the per-problem tables live on the device); the stateless
+    // kernel serves max_cols <= 32768, anything else (or max_cols <= 0 = unknown) the memory-resident one.  Bit-identical results.
     const bool reg_ok = max_cols > 0 && max_cols <= 32 * 1024 && max_rows > 0 && max_rows + 1 <= LSA_MAX_VIS &&
-                        (long long)topk * max_rows + 1 < 65535;
+                        (long long)max_cols * max_rows * 4 < (1ll << 31);
 #define LSA_REG(K)                                                                                                           \
     hipLaunchKernelGGL((lsa_topk_reg_kernel<K>), dim3(num_problems), dim3(1024), 0, stream, costT, m_of, g_of, cost_off,     \
-                       col_off, row_off, topk, gt_inds, ws_v, ws_path, ws_row4col, ws_active, ws_cols, ws_u, status)
+                       col_off, row_off, topk, gt_inds, ws_v, ws_row4col, ws_active, ws_cols, status)
     if (reg_ok && max_cols <= 8 * 1024) LSA_REG(8);
     else if (reg_ok && max_cols <= 16 * 1024) LSA_REG(16);
     else if (reg_ok && max_cols <= 25 * 1024) LSA_REG(25);

@@ -164,8 +164,8 @@ class P2PHead(nn.Module):
             G, Mb = gt_points[b].shape[0], props.shape[0]
             if G == 0 or Mb == 0:
                 continue
-            if Mb < G:
-                if a.topk_k == 1:
+            if Mb <= G:
+                if a.topk_k == 1 or Mb == G:      # (a square problem: one round assigns everything, in scipy's orientation)
                     # linear_sum_assignment on the (Mb, G) cost (hungarian_assigner.py:229-240): every proposal gets a
                     # distinct gt (HungarianAssignerV2.transposed_inds)
                     costs_t.append(a.cost_t(props.contiguous(), c.contiguous(), gt_points[b], gt_labels[b], img_metas[b]))

@@ -211,7 +211,7 @@ def test_register_resident_lsa_equals_the_memory_resident_kernel_and_scipy(case)
     elif case == '25600x32_k5_batch4':
         specs, k = [(160, 32), (160, 17), (160, 32), (128, 40)], 5
     elif case == 'tiny':
-        specs, k = [(2, 3), (3, 1), (1, 1), (4, 16)], 2            # fewer proposals than gts -> no round runs; 1 x 1; M == G
+        specs, k = [(2, 3), (3, 1), (1, 1), (4, 16)], 2            # one round only (4 // 3 == 1); one gt; 1 x 1; M == G
     elif case == '32768x7_k3':
         specs, k = [(None, 7)], 3                                   # the widest problem the register kernel takes
     elif case == '9000x255_k2':
@@ -232,11 +232,34 @@ def test_register_resident_lsa_equals_the_memory_resident_kernel_and_scipy(case)
             if cost is None:
                 cost = torch.rand((n_side * n_side, G), generator=g)
         costs.append(cost.t().contiguous().cuda())
-        refs.append(O.lsa_topk(cost, k))
+        if cost.shape[0] == cost.shape[1]:
+            # ops.lsa_topk's contract: the gts are the solver's rows.  scipy keeps the PROPOSALS as rows of a square matrix, so
+            # among exactly tied optima it may return another one -- HungarianAssignerV2.assign routes square problems through
+            # transposed_inds for that reason (checked below); the kernel-level reference is scipy on the transpose
+            from scipy.optimize import linear_sum_assignment
+            r, c = linear_sum_assignment(cost.t().numpy())
+            want = torch.zeros(cost.shape[0], dtype=torch.long)
+            want[torch.from_numpy(c)] = torch.from_numpy(r) + 1
+            refs.append(want)
+        else:
+            refs.append(O.lsa_topk(cost, k))
     reg, mem = _lsa_both_kernels(costs, k)
     for i, (a, b, r) in enumerate(zip(reg, mem, refs)):
         assert torch.equal(a, b), '%s[%d]: %d indices differ between the two kernels' % (case, i, int((a != b).sum()))
         assert torch.equal(a, r), '%s[%d]: %d indices differ from scipy' % (case, i, int((a != r).sum()))
+
+
+def test_square_problem_with_tied_optima_follows_scipy_orientation():
+    """As many proposals as gts and a cost matrix whose columns are identical (every assignment is optimal): the reference
+    hands scipy the (M, G) matrix, which keeps the proposals as rows for a square problem -- the assigner must return THAT
+    optimum (here the identity), through the single-image and the batched entry."""
+    ha = _ha(5)
+    pred, logits, gt, labels, shp = assigner_inputs(1334, 4, 4, 16, 1)
+    gt = gt[:1].repeat(16, 1)                       # 16 identical gts: identical cost columns
+    want, _, cost = O.hungarian_assign_v2(pred, logits, gt, labels, shp, topk_k=5, log_mode='cr')
+    assert bool((cost == cost[:, :1]).all()) and sorted(want.tolist()) == list(range(1, 17))
+    res = ha.assign(pred.cuda(), logits.cuda(), gt.cuda(), labels.cuda(), dict(img_shape=shp))
+    assert torch.equal(res.gt_inds.cpu(), want), (res.gt_inds.cpu(), want)
 
 
 def test_device_lsa_batched_problems():
