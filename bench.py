@@ -35,7 +35,7 @@ def mult_reduction(kernel_name):
     tile with 16 multiplies instead of 36, F(4x4,3x3) a 4x4 tile with 36 instead of 144; the direct kernels execute them all."""
     if 'conv_wino4_kernel' in kernel_name:
         return 4.0
-    if 'conv_wino_kernel' in kernel_name:
+    if 'conv_wino_kernel' in kernel_name or 'conv_wino32_kernel' in kernel_name:
         return 2.25
     return 1.0
 
@@ -44,7 +44,8 @@ def kernel_source_sha16(kernel_name='conv_mfma_kernel'):
     """Content hash of the source file of a conv kernel: profiles/pmc_dominant_kernel.json is stamped with it
     (tools/pmc_to_json.py), so a PMC figure measured on an older kernel is never replayed into a newer bench line."""
     import hashlib
-    fname = 'conv_wino_wgrad.hip' if 'wino_wgrad' in kernel_name else 'conv_wino.hip' if 'wino' in kernel_name else \
+    fname = 'conv_wino_wgrad.hip' if 'wino_wgrad' in kernel_name else 'conv_wino32.hip' if 'wino32' in kernel_name else \
+        'conv_wino.hip' if 'wino' in kernel_name else \
         'conv_bf16_dma.hip' if 'bf16_dma' in kernel_name else 'conv_mfma_bf16.hip' if 'bf16' in kernel_name else 'conv_mfma.hip'
     src = os.path.join(ROOT, 'pointtinybenchmark_amd', 'csrc', fname)
     return source_code_sha16(open(src).read())
@@ -175,7 +176,9 @@ class ConvProbe:
             N, H, W, _ = probe.nhwc_shape(x)
             OH, OW = pc.out_hw(H, W)
             kind, v = ops.TRACE_CONV_VARIANT[1]          # what the launcher returned through its out-parameter
-            if kind == 'wino':       # template instance of csrc/conv_wino.hip: <ABL = 0, INB8, XF>
+            if kind == 'wino32':     # csrc/conv_wino32.hip (two workgroups per CU): <XF>
+                variant = 'conv_wino32_kernel<%s>' % ('true' if v & 4 else 'false')
+            elif kind == 'wino':     # template instance of csrc/conv_wino.hip: <ABL = 0, INB8, XF>
                 # <ABL = 0, INB8, XF, TSPREAD, VAR>; the launcher picks TSPREAD = 0 for the fused-affine instances, 1 for the plain
                 # ones; VAR = 4: weights staged by LDS-DMA (WINO_VAR_DEFAULT in conv_wino.hip)
                 variant = 'conv_wino_kernel<0, %s, %s, %d, 4>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false',

@@ -96,6 +96,17 @@ int cpr_wino_pack_weights(const float* wgt, float* u, int Cin, int Cout, int Kpa
 int cpr_conv3x3_wino_fwd(const float* in, const float* u, float* out, const float* scale, const float* bias,
                          const float* in_a, const float* in_b, float* gn_part, int N, int H, int W, int Cin, int Cout,
                          int flags, int in_relu, int layout, void* stream);
+/* The two-workgroups-per-CU form of the same convolution (csrc/conv_wino32.hip, round 4): 4-wave workgroups on 8 x 16 pixel
+ * regions with 4-channel K chunks, < 80 KB of LDS each, so two are resident per CU and one's epilogue / prologue hides behind the
+ * other's MFMAs.  Same arguments as cpr_conv3x3_wino_fwd except: `u` comes from cpr_wino32_pack_weights (16 * Cin * Cout floats,
+ * chunks of 4 input channels; Cin % 8 == 0, Cin >= 16, Cout % 64 == 0), gn_part holds cpr_conv3x3_wino32_slots(H, W) slots per
+ * image (one per 8 x 16 region), a fused input affine needs Cin <= 256.  Agrees with cpr_conv3x3_wino_fwd to fp32 rounding
+ * (different accumulation order), not bit for bit. */
+int cpr_wino32_pack_weights(const float* wgt, float* u, int Cin, int Cout, int Kpad, void* stream);
+int cpr_conv3x3_wino32_slots(int H, int W);
+int cpr_conv3x3_wino32_fwd(const float* in, const float* u, float* out, const float* scale, const float* bias,
+                           const float* in_a, const float* in_b, float* gn_part, int N, int H, int W, int Cin, int Cout,
+                           int flags, int in_relu, int layout, void* stream);
 int cpr_gn_apply_b8(const float* x, const float* a, const float* b, float* y, int N, int H, int W, int C, int relu,
                     void* stream);
 

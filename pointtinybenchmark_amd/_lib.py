@@ -24,6 +24,9 @@ SIGNATURES = {
     'cpr_conv_wgrad_bf16': [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_wino_pack_weights': [_p, _p, _i, _i, _i, _p],
     'cpr_conv3x3_wino_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'cpr_wino32_pack_weights': [_p, _p, _i, _i, _i, _p],
+    'cpr_conv3x3_wino32_slots': [_i, _i],
+    'cpr_conv3x3_wino32_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_conv3x3_wino_wgrad_workspace': [_i, _i, _i, _i, _i],
     'cpr_conv3x3_wino_wgrad': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_gn_apply_b8': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -82,6 +85,7 @@ SIGNATURES = {
 # measurement build only (-DCPR_BENCH_HOOKS -> libcprhip_bench.so, tools/*.py): NOT part of the product library
 BENCH_SIGNATURES = {
     'cpr_lsa_phase_clocks': [_p, _i],
+    'cpr_wino32_set_debug': [_i, _i, _i],
     'cpr_conv_force_tile': [_i, _i],
     'cpr_conv_set_pipeline': [_i],
     'cpr_conv_set_stream': [_i],

@@ -10,7 +10,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcprhip.so')
 SOURCES = ['conv_mfma.hip', 'conv1x1_stream.hip', 'conv_mfma_bf16.hip', 'conv_bf16_dma.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad.hip', 'norm_pool.hip', 'cpr_points.hip', 'assign.hip',
-           'postproc.hip', 'backward.hip', 'preprocess.hip', 'pack.hip', 'project.hip', 'conv_wino.hip', 'conv_wino_wgrad.hip']
+           'postproc.hip', 'backward.hip', 'preprocess.hip', 'pack.hip', 'project.hip', 'conv_wino.hip', 'conv_wino32.hip', 'conv_wino_wgrad.hip']
 # Kernels whose integer / mask / index outputs are held bit-exact against the reference's CPU arithmetic restate it
 # operation by operation.  hipcc's default -ffp-contract=fast fuses a*b+c into one fma EVEN ACROSS the __fmul_rn/__fadd_rn
 # intrinsics (plain operators in the HIP headers), which changes the last bit (round 1 shipped a Hungarian cost whose
@@ -35,7 +35,7 @@ def needs_build():
 
 
 BENCH_LIB = os.path.join(CSRC, 'libcprhip_bench.so')
-HOOK_SOURCES = {'conv_mfma.hip', 'conv_wgrad.hip', 'conv_wino.hip', 'conv_mfma_bf16.hip', 'assign.hip'}     # the files that carry #ifdef CPR_BENCH_HOOKS code
+HOOK_SOURCES = {'conv_mfma.hip', 'conv_wgrad.hip', 'conv_wino.hip', 'conv_mfma_bf16.hip', 'assign.hip', 'conv_wino32.hip'}     # the files that carry #ifdef CPR_BENCH_HOOKS code
 
 
 def build(force=False, verbose=True, bench_hooks=False):

@@ -67,6 +67,7 @@ class PackedConv:
     """Conv weight repacked for the implicit-GEMM kernel: [Cout][KH][KW][Cin'] fp32, rows padded to a
     multiple of 32 floats.  Cin' = 4 for the 3-channel stem (zero 4th channel)."""
     wino = None     # transformed weights of the Winograd path, built on first use (conv3x3_wino)
+    wino32 = None   # the same for the two-workgroups-per-CU kernel (csrc/conv_wino32.hip: chunks of 4 input channels)
     ready = None    # event recorded behind the last pack kernel (weights / Winograd image); see pack_ready()
 
     def _packed(self):
@@ -169,6 +170,38 @@ def wino_eligible(pc, H, W, dtype=torch.float32):
     return fill >= WINO_MIN_FILL
 
 
+# Which fused Winograd kernel serves a 3x3 layer: '32' = the two-workgroups-per-CU form (csrc/conv_wino32.hip: 8 x 16 pixel
+# regions, 4-wave workgroups), '64' = the one-workgroup-per-CU form (csrc/conv_wino.hip: 16 x 16 regions).  The choice is a function
+# of the LAYER alone (never of the batch size: an image of a big batch must equal its single-image run bit for bit, and the two
+# kernels differ in accumulation order).  CPR_WINO_TILE=64 / 32 forces one of them everywhere it can run (A/B runs, tests).
+WINO_TILE = [os.environ.get('CPR_WINO_TILE', 'auto')]
+
+
+def wino_instance(pc, H, W, fused_affine):
+    """'32' or '64' for a Winograd-eligible layer."""
+    can32 = pc.Cin % 8 == 0 and (not fused_affine or pc.Cin <= 256)
+    if WINO_TILE[0] == '64' or not can32:
+        return '64'
+    if WINO_TILE[0] == '32':
+        return '32'
+    return WINO_AUTO(pc, H, W, fused_affine)
+
+
+def WINO_AUTO(pc, H, W, fused_affine):
+    """Measured per shape on MI355X (profiles/round4_wino32_ab.txt): the two-workgroups-per-CU kernel loses on
+    every layer of the networks at B = 64 (160x160x256: 8.9 vs 7.0 ms; 40x40x256: 0.71 vs 0.67; 80x80x128: 0.63 vs 0.54;
+    160x160x64: 0.71 vs 0.59) and wins only on launches too small to fill the chip (40x40x256 at B = 2: 0.061 vs 0.071 ms).
+    The choice may not depend on the batch size, so the one-workgroup-per-CU kernel serves every layer."""
+    return '64'
+
+
+def wino_gn_slots(pc, H, W, fused_affine):
+    """GroupNorm-statistics slots per image of the Winograd kernel that serves this layer."""
+    if wino_instance(pc, H, W, fused_affine) == '32':
+        return ((H + 7) // 8) * ((W + 15) // 16)
+    return ((H + 15) // 16) * ((W + 15) // 16)
+
+
 def is_b8(x):
     """Channel-blocked activation (N, C/8, H, W, 8): the layout Winograd layers hand to each other (csrc/conv_wino.hip)."""
     return x.dim() == 5 and x.shape[-1] == 8
@@ -178,7 +211,8 @@ def conv3x3_wino(x, pc, scale=None, bias=None, relu=False, gn_part=False, out=No
                  out_b8=False):
     """Winograd F(2x2,3x3) path of conv2d for 3x3 / stride 1 / pad 1 fp32 layers.  x: NHWC (N,H,W,Cin) or channel-blocked
     (N,Cin/8,H,W,8); out_b8=True returns the blocked form (N,Cout/8,H,W,8).  in_ab=(a,b): input read as relu?(x*a+b).
-    gn_part=True also returns one (sum, sumsq) slot per 16x16 output region: (N * ceil(H/16) * ceil(W/16), Cout, 2)."""
+    gn_part=True also returns one (sum, sumsq) slot per output region of the kernel that runs (16x16, or 8x16 for the
+    two-workgroups-per-CU form): (N * wino_gn_slots(...), Cout, 2)."""
     _check(x, ACT)
     in_b8 = is_b8(x)
     if in_b8:
@@ -187,11 +221,13 @@ def conv3x3_wino(x, pc, scale=None, bias=None, relu=False, gn_part=False, out=No
     else:
         N, H, W, Cin = x.shape
     assert x.dtype == torch.float32 and Cin == pc.Cin and pc.KH == 3 and pc.stride == 1 and pc.padding == 1
-    if pc.wino is None:     # G g G^T of the packed weights, once per PackedConv (= once per weight update)
+    inst = wino_instance(pc, H, W, in_ab is not None)
+    attr, pack_fn = ('wino32', 'cpr_wino32_pack_weights') if inst == '32' else ('wino', 'cpr_wino_pack_weights')
+    if getattr(pc, attr) is None:     # G g G^T of the packed weights, once per PackedConv (= once per weight update)
         pack_ready(pc)
         wino = torch.empty((16 * pc.Cin * pc.Cout,), device=x.device, dtype=torch.float32)
-        _lib.call('cpr_wino_pack_weights', _ptr(pc.w), _ptr(wino), pc.Cin, pc.Cout, pc.Kpad, _stream())
-        pc.wino = wino
+        _lib.call(pack_fn, _ptr(pc.w), _ptr(wino), pc.Cin, pc.Cout, pc.Kpad, _stream())
+        setattr(pc, attr, wino)
         pc._packed()
     pack_ready(pc)
     shape = (N, pc.Cout // 8, H, W, 8) if out_b8 else (N, H, W, pc.Cout)
@@ -200,16 +236,17 @@ def conv3x3_wino(x, pc, scale=None, bias=None, relu=False, gn_part=False, out=No
     assert tuple(out.shape) == shape and out.is_contiguous()
     part = None
     if gn_part:
-        part = torch.empty((N * ((H + 15) // 16) * ((W + 15) // 16), pc.Cout, 2), device=x.device, dtype=torch.float32)
+        part = torch.empty((N * wino_gn_slots(pc, H, W, in_ab is not None), pc.Cout, 2), device=x.device, dtype=torch.float32)
     a = b = None
     if in_ab is not None:
         a, b = in_ab
         assert Cin <= 512
-    _lib.call('cpr_conv3x3_wino_fwd', _ptr(x), _ptr(pc.wino), _ptr(out), _ptr(scale), _ptr(bias), _ptr(a), _ptr(b),
-              _ptr(part), N, H, W, Cin, pc.Cout, CONV_RELU if relu else 0, int(in_relu), (1 if in_b8 else 0) | (2 if out_b8 else 0),
-              _stream())
+    _lib.call('cpr_conv3x3_wino32_fwd' if inst == '32' else 'cpr_conv3x3_wino_fwd', _ptr(x), _ptr(getattr(pc, attr)), _ptr(out),
+              _ptr(scale), _ptr(bias), _ptr(a), _ptr(b), _ptr(part), N, H, W, Cin, pc.Cout, CONV_RELU if relu else 0, int(in_relu),
+              (1 if in_b8 else 0) | (2 if out_b8 else 0), _stream())
     if TRACE_CONV_VARIANT[0]:
-        TRACE_CONV_VARIANT[1] = ('wino', (1 if in_b8 else 0) | (2 if out_b8 else 0) | (4 if in_ab is not None else 0))
+        TRACE_CONV_VARIANT[1] = ('wino32' if inst == '32' else 'wino',
+                                 (1 if in_b8 else 0) | (2 if out_b8 else 0) | (4 if in_ab is not None else 0))
     return (out, part) if gn_part else out
 
 

@@ -7,6 +7,19 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=['64', '32'])
+def wino_tile(request):
+    """Every test of this file runs on both fused Winograd forward kernels: '64' = csrc/conv_wino.hip (one 8-wave workgroup per
+    CU, 16 x 16 pixel regions), '32' = csrc/conv_wino32.hip (round 4: two 4-wave workgroups per CU, 8 x 16 regions, 4-channel
+    chunks).  ops.WINO_TILE forces the instance wherever it can run."""
+    from pointtinybenchmark_amd import ops
+    keep = ops.WINO_TILE[0]
+    ops.WINO_TILE[0] = request.param
+    yield request.param
+    ops.WINO_TILE[0] = keep
+
+
 CASES = [  # N, H, W, Cin, Cout, scale/bias, relu
     (2, 32, 32, 64, 64, True, True),
     (1, 48, 40, 256, 128, False, False),     # partial regions on the right edge (40 = 2.5 x 16)
@@ -62,7 +75,8 @@ def test_wino_gn_partials():
         b = torch.randn(C, generator=g).cuda()
         pc = ops.PackedConv(w, 1, 1)
         y, part = ops.conv3x3_wino(x, pc, None, b, False, gn_part=True)
-        P = ((H + 15) // 16) * ((W + 15) // 16)
+        P = ops.wino_gn_slots(pc, H, W, False)          # 16 x 16 or 8 x 16 pixel regions, by the kernel that runs
+        assert P == (((H + 15) // 16) if ops.WINO_TILE[0] == '64' else ((H + 7) // 8)) * ((W + 15) // 16)
         assert part.shape == (N * P, C, 2)
         s = part.view(N, P, C, 2).double().sum(1)
         yy = y.double()
@@ -99,11 +113,14 @@ def _from_b8(x):
 
 
 @pytest.mark.parametrize('case', [(2, 32, 48, 64, 128), (1, 40, 24, 256, 64), (2, 16, 16, 512, 64)])
-def test_wino_blocked_layout_and_fused_affine(case):
+def test_wino_blocked_layout_and_fused_affine(case, wino_tile):
     """Channel-blocked input / output and the fused producer-GroupNorm affine (+ReLU) give the SAME bits as the NHWC
     kernel on the materialised input (the arithmetic is identical, only the addressing / where the affine runs differ)."""
     from pointtinybenchmark_amd import ops
     N, H, W, Cin, Cout = case
+    if wino_tile == '32' and Cin > 256:
+        pytest.skip('the two-workgroups-per-CU kernel keeps the affine table of <= 256 input channels (512-channel layers with a '
+                    'fused affine run the other kernel)')
     g = torch.Generator().manual_seed(Cin + W)
     x = torch.randn((N, H, W, Cin), generator=g).cuda()
     w = (torch.randn((Cout, Cin, 3, 3), generator=g) * 0.05).cuda()

@@ -26,6 +26,7 @@ ap.add_argument('--wino-sched', type=int, default=0)
 ap.add_argument('--wino-ablate', type=int, default=0)
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--pipeline', type=int, default=1)
+ap.add_argument('--w32', default='0,2,100', help='conv_wino32 debug: ablate,workgroups per CU,stagger percent')
 ap.add_argument('--bf16-dma', type=int, default=1, help='bf16 mode: 0 = keep the layer on the register-staged kernel (A/B)')
 args = ap.parse_args()
 from pointtinybenchmark_amd import _lib  # noqa: E402
@@ -34,6 +35,7 @@ _lib.call('cpr_conv_set_ablation', args.ablate)
 _lib.call('cpr_conv_set_pipeline', args.pipeline)
 _lib.call('cpr_wino_set_variant', args.wino_sched, args.wino_ablate)
 _lib.call('cpr_bf16_set_dma', args.bf16_dma)
+_lib.call('cpr_wino32_set_debug', *[int(v) for v in args.w32.split(',')])
 g = torch.Generator().manual_seed(0)
 x = torch.randn((args.batch, args.hw, args.hw, args.cin), generator=g).cuda()
 w = (torch.randn((args.cout, args.cin, args.k, args.k), generator=g) * 0.02).cuda()
