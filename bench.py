@@ -754,6 +754,36 @@ def main():
                    # rank 0's view of the last step: when each gradient bucket was final (= its reduction issued) and when the
                    # main stream held its sum, relative to the start of the backward; exposed_ms = reducer time NOT hidden
                    'reducer': _reducer_summary(trainer)}
+            # the reference's own driver sequence on the same model (Training step): BasicLocator.train_step with
+            # autograd on -> loss.backward() (autograd_bridge.py: the same HIP backward kernels behind torch.autograd.Functions) ->
+            # clip_grad_norm_(35) -> torch.optim.SGD(momentum 0.9, weight decay 1e-4).step(), one .item() sync per step as in
+            # BaseDetector._parse_losses.  N = 1 only (at N > 1 the reference wraps the model in DistributedDataParallel).
+            if world == 1:
+                try:
+                    params = [p for p in model.parameters() if p.requires_grad]
+                    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+                    data = dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
+
+                    def autograd_step():
+                        opt.zero_grad(set_to_none=True)
+                        o = model.train_step(dict(data), opt)
+                        o['loss'].backward()
+                        torch.nn.utils.clip_grad_norm_(params, 35.0)
+                        opt.step()
+                        return o
+                    autograd_step()
+                    barrier()
+                    t1 = time.perf_counter()
+                    for _ in range(args.train_steps):
+                        o = autograd_step()
+                    barrier()
+                    ta = time.perf_counter() - t1
+                    res['torch_autograd'] = {'value': args.batch * args.train_steps / ta, 'unit': 'img/s',
+                                             'ms_per_step': ta / args.train_steps * 1e3, 'loss': o['log_vars']['loss'],
+                                             'what': 'model.train_step() -> loss.backward() -> clip_grad_norm_ -> torch.optim.SGD.step(): '
+                                                     'the unmodified mmcv OptimizerHook sequence on the drop-in classes'}
+                except Exception as e:   # noqa: BLE001
+                    res['torch_autograd'] = {'error': repr(e)[:300]}
             # the same trainer in the bf16 compute mode = mixed precision (bf16 recorded forward and stride-1 data gradients,
             # fp32 weight gradients / weights / optimizer); NOT the fp32 arithmetic of the reference, reported beside it
             try:
