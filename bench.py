@@ -754,7 +754,31 @@ def main():
                    # rank 0's view of the last step: when each gradient bucket was final (= its reduction issued) and when the
                    # main stream held its sum, relative to the start of the backward; exposed_ms = reducer time NOT hidden
                    'reducer': _reducer_summary(trainer)}
-            # the reference's own driver sequence on the same model (Training step): BasicLocator.train_step with
+            # the same trainer in the bf16 compute mode = mixed precision (bf16 recorded forward and stride-1 data gradients,
+            # fp32 weight gradients / weights / optimizer); NOT the fp32 arithmetic of the reference, reported beside it
+            try:
+                model.set_compute_dtype('bf16')
+                train_step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.train_steps):
+                    tl = train_step()
+                barrier()
+                tm = time.perf_counter() - t1
+                if distributed:
+                    t = torch.tensor([tm], device='cuda', dtype=torch.float64)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    tm = float(t.item())
+                res['mixed_precision'] = {'value': args.batch * world * args.train_steps / tm, 'unit': 'img/s',
+                                          'ms_per_step': tm / args.train_steps * 1e3,
+                                          'what': 'the same step in the bf16 compute mode (bf16 recorded forward, bf16 data / weight '
+                                                  'gradients of the stride-1 layers, fp32 normalisation backward / weights / optimizer)',
+                                          'loss': float(sum(v for k, v in tl.items() if 'loss' in k))}
+            except Exception as e:   # noqa: BLE001 -- a failure of the bf16 step must not discard the fp32 result above
+                res['mixed_precision'] = {'error': repr(e)[:300]}
+            finally:
+                model.set_compute_dtype(args.dtype)
+            # LAST (torch re-binds p.grad: the native trainer cannot run on this model afterwards): the reference's own driver sequence on the same model (Training step): BasicLocator.train_step with
             # autograd on -> loss.backward() (autograd_bridge.py: the same HIP backward kernels behind torch.autograd.Functions) ->
             # clip_grad_norm_(35) -> torch.optim.SGD(momentum 0.9, weight decay 1e-4).step(), one .item() sync per step as in
             # BaseDetector._parse_losses.  N = 1 only (at N > 1 the reference wraps the model in DistributedDataParallel).
@@ -784,30 +808,6 @@ def main():
                                                      'the unmodified mmcv OptimizerHook sequence on the drop-in classes'}
                 except Exception as e:   # noqa: BLE001
                     res['torch_autograd'] = {'error': repr(e)[:300]}
-            # the same trainer in the bf16 compute mode = mixed precision (bf16 recorded forward and stride-1 data gradients,
-            # fp32 weight gradients / weights / optimizer); NOT the fp32 arithmetic of the reference, reported beside it
-            try:
-                model.set_compute_dtype('bf16')
-                train_step()
-                barrier()
-                t1 = time.perf_counter()
-                for _ in range(args.train_steps):
-                    tl = train_step()
-                barrier()
-                tm = time.perf_counter() - t1
-                if distributed:
-                    t = torch.tensor([tm], device='cuda', dtype=torch.float64)
-                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                    tm = float(t.item())
-                res['mixed_precision'] = {'value': args.batch * world * args.train_steps / tm, 'unit': 'img/s',
-                                          'ms_per_step': tm / args.train_steps * 1e3,
-                                          'what': 'the same step in the bf16 compute mode (bf16 recorded forward, bf16 data / weight '
-                                                  'gradients of the stride-1 layers, fp32 normalisation backward / weights / optimizer)',
-                                          'loss': float(sum(v for k, v in tl.items() if 'loss' in k))}
-            except Exception as e:   # noqa: BLE001 -- a failure of the bf16 step must not discard the fp32 result above
-                res['mixed_precision'] = {'error': repr(e)[:300]}
-            finally:
-                model.set_compute_dtype(args.dtype)
             return res
         except Exception as e:   # noqa: BLE001 -- reported in the JSON line
             return {'error': repr(e)[:300]}
