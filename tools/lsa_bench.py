@@ -44,7 +44,7 @@ def main():
             names = ['round set-up', 'search set-up', 'scan', 'reduce + wait', 'thread-0 bookkeeping', 'duals/augment/restore', '-', 'between rounds']
             tot = sum(buf)
             for nm, v in zip(names, buf):
-                print('   %-24s %12d clk  %5.1f %%  (%.2f ms per launch at 100 MHz s_memtime... raw)' % (nm, v, 100.0 * v / max(tot, 1), v / n / 1e5))
+                print('   %-24s %12d shader clocks over %d launches  %5.1f %%' % (nm, v, n, 100.0 * v / max(tot, 1)))
     ops.LSA_REGISTER_KERNEL[0] = True
 
 
