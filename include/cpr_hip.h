@@ -408,6 +408,8 @@ int cpr_conv_set_extra_lds(int bytes);   /* occupancy probe: dynamic LDS added t
 int cpr_wino_set_variant(int sched, int ablate); /* Winograd: sched 1 = the other placement of the patch transform (see conv_wino.hip); loop ablations */
 int cpr_bf16_set_dma(int on);            /* bf16 mode: 0 = every layer on the register-staged kernels (A/B of conv_bf16_dma.hip) */
 int cpr_wino_set_staging(int var, int tpx);      /* Winograd: staging variant (kernel template VAR) and cout tiles per XCD; -1 = the product's choice */
+int cpr_wino32_set_debug(int ablate, int wg_per_cu, int stagger_pct); /* conv_wino32.hip: loop ablations, workgroups per CU (1 / 2), stagger of the second wave of workgroups */
+int cpr_lsa_phase_clocks(long long* host_out, int reset);            /* assign.hip: shader clocks workgroup 0 of lsa_topk_reg_kernel spent per phase (8 values) */
 #endif
 
 #ifdef __cplusplus

@@ -467,3 +467,58 @@ def test_winograd_dispatch_rules_host_side():
         ops.WINOGRAD[0] = saved
     x5 = torch.zeros(2, 8, 16, 16, 8)
     assert ops.is_b8(x5) and not ops.is_b8(torch.zeros(2, 16, 16, 64))
+
+
+def test_bucket_layout_on_parameter_boundaries():
+    """training.layout_buckets: buckets end on parameter boundaries of the flat gradient buffer, close at >= min, never pass max
+    unless one parameter alone is larger, and the LAST bucket (the only reduction nothing can overlap) holds at most `tail`."""
+    import random
+    from pointtinybenchmark_amd.training import layout_buckets
+    # the R50 CPR trainer's order: head (projection, 4 x [gn, gn, 3x3 conv]), FPN, layer4 ... layer2 (element counts)
+    sizes = [256, 1, 256, 1] + [256, 256, 589824] * 5 + [256, 256, 65536, 256, 256, 131072, 256, 256, 262144, 256, 256, 524288]
+    sizes += [1048576, 2048, 2048, 2359296, 512, 512, 1048576, 512, 512] * 3 + [2097152, 2048, 2048]
+    sizes += [262144, 1024, 1024, 589824, 256, 256, 262144, 256, 256] * 6 + [524288, 1024, 1024]
+    sizes += [65536, 512, 512, 147456, 128, 128, 65536, 128, 128] * 4 + [131072, 512, 512]
+    mb = 262144
+    b = layout_buckets(sizes, 25 * mb, 4 * mb, 1 * mb)
+    ends = set()
+    acc = 0
+    for k in sizes:
+        acc += k
+        ends.add(acc)
+    assert b[0] == 0 and b[-1] == sum(sizes) and all(x < y for x, y in zip(b, b[1:]))
+    assert all(x in ends for x in b[1:]), 'bucket boundaries must be parameter boundaries'
+    lens = [y - x for x, y in zip(b, b[1:])]
+    assert lens[-1] <= 1 * mb, 'the tail bucket bounds the exposed part of the reducer'
+    assert all(n <= 25 * mb for n in lens) and all(n >= 4 * mb for n in lens[:-2]), lens
+    assert b[1] <= 3 * 589824 + 2048, 'the first bucket closes after at most two head tower layers'
+    for _ in range(300):
+        sz = [random.randint(1, 3000) for _ in range(random.randint(1, 40))]
+        mx, mn, tl = random.randint(1, 5000), random.randint(1, 3000), random.randint(1, 2000)
+        bb = layout_buckets(sz, mx, mn, tl)
+        assert bb[0] == 0 and bb[-1] == sum(sz) and all(x < y for x, y in zip(bb, bb[1:])), (sz, bb)
+        e, a = set(), 0
+        for k in sz:
+            a += k
+            e.add(a)
+        assert all(x in e for x in bb[1:])
+        assert bb[-1] - bb[-2] <= max(tl, sz[-1])
+
+
+def test_bench_config_presets_name_the_baseline_shapes():
+    """`bench.py --config cfgN` = BASELINE.json configs[N] at its own shape; explicit flags win; --dry needs no GPU."""
+    for cfg, want in (('cfg0', 'dry run'), ('cfg2', 'dry run')):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--dry', '--config', cfg, '--steps', '1'],
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-400:]
+        assert want in out.stdout
+    import importlib
+    bench = importlib.import_module('bench')
+    import argparse
+    ns = argparse.Namespace(model='cpr', depth=50, height=800, width=1344, classes=80, stride=8, radius=8, dtype='fp32')
+    assert bench.baseline_config_name(ns).startswith('configs[2]')
+    ns = argparse.Namespace(model='cpr', depth=18, height=640, width=640, classes=1, stride=4, radius=5, dtype='fp32')
+    assert bench.baseline_config_name(ns).startswith('configs[0]')
+    cfgm = bench.model_cfg(50, 80, 1, 8, 8)
+    assert cfgm['neck']['start_level'] == 1 and cfgm['bbox_head']['strides'] == [8] and cfgm['bbox_head']['num_classes'] == 80
+    assert cfgm['bbox_head']['train_pts_extractor']['pos_generator']['radius'] == 8
