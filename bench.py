@@ -717,9 +717,12 @@ def main():
         elapsed = float(t.item())
     ranks_seen, distinct_devices = world, 1
     if distributed:      # what the group really spans: every rank reports its device's identity (multi-GPU readiness check)
-        ids = [None] * torch.distributed.get_world_size()
-        torch.distributed.all_gather_object(ids, device_identity(local))
-        ranks_seen, distinct_devices = len(ids), len(set(ids))
+        try:
+            ids = [None] * torch.distributed.get_world_size()
+            torch.distributed.all_gather_object(ids, device_identity(local))
+            ranks_seen, distinct_devices = len(ids), len(set(ids))
+        except Exception:   # noqa: BLE001 -- a diagnostic field must never take the measured line down (every rank takes this path alike)
+            ranks_seen, distinct_devices = torch.distributed.get_world_size(), None
 
     def _val(v):
         if isinstance(v, (list, tuple)):
