@@ -343,6 +343,9 @@ class P2PHead(nn.Module):
             new[:, [1, 3]] += dy
         return new.view(bboxes.shape)
 
+    def aug_test(self, feats, img_metas, rescale=False):
+        return self.aug_test_bboxes(feats, img_metas, rescale=rescale)
+
     def aug_test_bboxes(self, feats, img_metas, rescale=False):
         """Test-time augmentation of the fork's tile inference (p2p_head.py:487-572): every augmentation (one image each) runs
         forward + get_bboxes (top-k, pseudo-box NMS) in ITS frame, the surviving pseudo boxes are mapped back to the original

@@ -175,9 +175,20 @@ class BasicLocator(nn.Module):
                     and isinstance(kwargs[k][0], (list, tuple)):
                 kwargs[k] = kwargs[k][0]
         if isinstance(imgs, (list, tuple)):
-            assert len(imgs) == 1, 'aug test is outside the hot path'
+            if len(imgs) > 1:          # test-time augmentation (base.py:152-157 -> single_stage.py:106-135)
+                return self.aug_test(list(imgs), list(img_metas), **kwargs)
             imgs, img_metas = imgs[0], img_metas[0]
         return self.simple_test(imgs, img_metas, **kwargs)
+
+    def extract_feats(self, imgs):
+        return [self.extract_feat(img) for img in imgs]
+
+    def aug_test(self, imgs, img_metas, rescale=False, **kwargs):
+        """T/mmdet/models/detectors/single_stage.py:106-135: one forward per augmentation (one image each), merged by the head
+        (P2PHead.aug_test_bboxes: the fork's tile / flip merge).  Returns the head's [(dets, labels)] (bbox2result is host glue)."""
+        assert hasattr(self.bbox_head, 'aug_test_bboxes'), \
+            '%s does not support test-time augmentation' % type(self.bbox_head).__name__
+        return self.bbox_head.aug_test_bboxes(self.extract_feats(imgs), img_metas, rescale=rescale)
 
     def forward(self, img, img_metas, return_loss=True, **kwargs):
         if return_loss:
