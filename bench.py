@@ -351,8 +351,8 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None, d
     in the thread count there (cgroup quota, SMT, NUMA), so the whole step is timed once at several thread counts and the
     fastest is kept and re-timed, with the backbone / neck / head towers / point stage split.
     ``hip_losses_fn(batch)``: the HIP path on the SAME sample -- the parity gate of the bench run (losses of the two paths
-    side by side).  model='p2p': backbone + neck + both P2PHead towers + the Hungarian assignment of every image (the
-    focal / SmoothL1 sums that follow are a few microseconds of host time and are not restated)."""
+    side by side).  model='p2p': backbone + neck + both P2PHead towers + Hungarian assignment + focal / SmoothL1 losses
+    (oracle.cpr_oracle.p2p_loss); the gate compares the per-batch sums of loss_cls / loss_pts."""
     from oracle import cpr_oracle as O
     from pointtinybenchmark_amd import synthetic
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -371,14 +371,9 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None, d
             if model == 'p2p':
                 cls, reg = O.p2p_head_forward(sd, feats)
                 t3 = time.perf_counter()
-                h, w = cls[0].shape[-2:]
-                anchor = O.p2p_grid_points(h, w, stride)[:, :2]
-                for b in range(batch_size):
-                    pred = anchor + reg[0][b].permute(1, 2, 0).reshape(-1, 2) * stride
-                    ctr = (batch['gt_bboxes'][b][:, :2] + batch['gt_bboxes'][b][:, 2:]) / 2
-                    O.hungarian_assign_v2(pred, cls[0][b].permute(1, 2, 0).reshape(-1, num_classes), ctr, batch['gt_labels'][b],
-                                          (height, width, 3), topk_k=5)
-                losses = {}
+                # oracle.cpr_oracle.p2p_loss: Hungarian targets + focal / SmoothL1 losses (pinned to the reference by tests/golden/p2p.npz)
+                pl, _ = O.p2p_loss(cls[0], reg[0], batch['gt_bboxes'], batch['gt_labels'], (height, width, 3), stride=stride)
+                losses = {'loss_cls': sum(pl['loss_cls']), 'loss_pts': sum(pl['loss_pts'])}
             else:
                 cls_feat, _ = O.cpr_head_forward(sd, feats)
                 t3 = time.perf_counter()
@@ -416,7 +411,7 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None, d
                       '(%.2f s/step); thread count = fastest of %s s/step out of %d logical CPUs; oracle = torch-CPU '
                       'restatement executing the reference op sequence' % (
                           len(times), batch_size, height, width, depth, num_classes, stride, radius,
-                          ', P2PHead towers + Hungarian assignment' if model == 'p2p' else '', best, dt,
+                          ', P2PHead towers + Hungarian assignment + losses' if model == 'p2p' else '', best, dt,
                           {k: round(v, 2) for k, v in trials.items()}, os.cpu_count() or 1),
                host_cpu=cpu_model, physical_cores=phys, logical_cpus=os.cpu_count() or 1,
                split_s={k: round(v, 4) for k, v in last['split'].items()})
@@ -896,10 +891,10 @@ def main():
                     model.use_graph = False
                     r = model.forward_train(b['img'].cuda(), b['img_metas'], [x.cuda() for x in b['gt_bboxes']],
                                             [x.cuda() for x in b['gt_labels']])
-                    return {k: float(v) for k, v in r.items()}
+                    return {k: float(sum(v)) if isinstance(v, (list, tuple)) else float(v) for k, v in r.items()}
             # parity gate: every fp32 CPR configuration (bf16 has its own stated tolerance, tests/test_gpu_bf16.py)
             out['cpu_baseline'] = cpu_baseline(2, args.num_gts, hip_losses_fn=hip_losses if (
-                args.model, args.dtype) == ('cpr', 'fp32') else None, depth=args.depth, height=args.height, width=args.width,
+                args.dtype == 'fp32' and args.mode != 'infer') else None, depth=args.depth, height=args.height, width=args.width,
                 num_classes=args.classes, start_level=args.start_level, stride=args.stride, radius=args.radius, model=args.model)
     # last of all, under a watchdog: if the training step (first use of the collective library at N > 1) wedges, the headline
     # line is still printed and every rank leaves

@@ -421,6 +421,52 @@ def p2p_head_forward(sd, feats, stacked_convs=4, prefix='bbox_head.'):
     return cls_outs, pts_outs
 
 
+def p2p_loss(cls_outs, pts_outs, gt_bboxes, gt_labels, img_shape, stride=4, topk_k=5, alpha=0.25, gamma=2.0,
+             beta=1.0 / 9.0, w_cls=1.0, w_reg=0.5, pts_gamma=1.0, reg_norm=1.0, point_anchor=((0., 0.),), pos_weight=1.0,
+             neg_weight=1.0, log_mode='host'):
+    """P2PHead.loss with the shipped config (p2p_head.py:172-248; T/configs2/TinyPersonV2/p2p/p2p_r50_fpns4_1x_fl_sl1_TinyPersonV2_640.py):
+    get_pred_points (:125-170, pred = anchor + point_anchor * stride + reg * gamma * stride), per image HungarianAssignerV2 ->
+    PseudoSampler -> sample_result_to_target (:308-328), then per image FocalLoss (py_sigmoid_focal_loss, losses/focal_loss.py:11-56,
+    label weights, avg_factor = positives of the whole batch) and SmoothL1Loss (losses/smooth_l1_loss.py:11-28) on
+    pred / stride / reg_norm.  cls_outs / pts_outs: (B, k*C, H, W) / (B, 2k, H, W) as the head returns them.
+    -> {'loss_cls': [B scalars], 'loss_pts': [B scalars]}, gt_inds list."""
+    import torch.nn.functional as F
+    B, kc, H, W = cls_outs.shape
+    k = len(point_anchor)
+    C = kc // k
+    anchor = p2p_grid_points(H, W, stride)[:, None, :2] + torch.tensor(point_anchor, dtype=torch.float32)[None] * stride    # (HW, k, 2)
+    reg = pts_outs.permute(0, 2, 3, 1).reshape(B, H * W, k, 2)
+    pred = (anchor[None] + reg * pts_gamma * stride).reshape(B, H * W * k, 2)
+    cls = cls_outs.permute(0, 2, 3, 1).reshape(B, H * W * k, C)
+    labels, lw, tgt, pw, inds_all = [], [], [], [], []
+    for b in range(B):
+        ctr = (gt_bboxes[b][:, :2] + gt_bboxes[b][:, 2:]) / 2
+        inds, _, _ = hungarian_assign_v2(pred[b], cls[b], ctr, gt_labels[b], img_shape, topk_k=topk_k, log_mode=log_mode)
+        pos = inds > 0
+        lab = torch.full((pred.shape[1],), C, dtype=torch.long)
+        lab[pos] = gt_labels[b][inds[pos] - 1]
+        w = torch.full((pred.shape[1],), 1.0 if neg_weight <= 0 else neg_weight)
+        w[pos] = pos_weight
+        t = torch.zeros((pred.shape[1], 2))
+        t[pos] = ctr[inds[pos] - 1]
+        ww = torch.zeros((pred.shape[1], 2))
+        ww[pos] = 1.0
+        labels.append(lab), lw.append(w), tgt.append(t), pw.append(ww), inds_all.append(inds)
+    num_pos = sum(int((w[:, 0] > 0).sum()) for w in pw)
+    loss_cls, loss_pts = [], []
+    for b in range(B):
+        target = F.one_hot(labels[b], num_classes=C + 1)[:, :C].type_as(cls)
+        ps = cls[b].sigmoid()
+        pt = (1 - ps) * target + ps * (1 - target)
+        fw = (alpha * target + (1 - alpha) * (1 - target)) * pt.pow(gamma)
+        l = F.binary_cross_entropy_with_logits(cls[b], target, reduction='none') * fw * lw[b].view(-1, 1)
+        loss_cls.append(w_cls * l.sum() / num_pos)
+        diff = torch.abs(pred[b] / stride / reg_norm - tgt[b] / stride / reg_norm)
+        sl = torch.where(diff < beta, 0.5 * diff * diff / beta, diff - 0.5 * beta) * pw[b]
+        loss_pts.append(w_reg * sl.sum() / num_pos)
+    return {'loss_cls': loss_cls, 'loss_pts': loss_pts}, inds_all
+
+
 def p2p_grid_points(h, w, stride):
     """PointGenerator.grid_points (T/mmdet/core/anchor/point_generator.py:17-25): (x*s, y*s, s), no half-stride."""
     sx = torch.arange(0., w) * stride

@@ -222,3 +222,26 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
     assert np.array_equal(torch.cat([r['not_refine'] for r in ref]).numpy(), g[p + 'not_refine'])
     np.testing.assert_allclose(torch.cat([r['refine_pts'] for r in ref]).numpy(), g[p + 'refine_pts'], rtol=1e-6, atol=1e-5)
     np.testing.assert_allclose(torch.cat([r['scores'] for r in ref]).numpy(), g[p + 'scores'], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('ci', [0, 1])
+def test_oracle_p2p_loss_matches_reference_fixture(golden_dir, ci):
+    """oracle.cpr_oracle.p2p_loss (round 4: the restatement bench.py times and gates the P2PNet line with) on the reference's OWN
+    tower outputs (tests/golden/p2p.npz, produced by the reference's P2PHead): the Hungarian targets must equal the reference's
+    bit for bit and the first image's focal / SmoothL1 losses agree to 2e-6."""
+    g = np.load(os.path.join(golden_dir, 'p2p.npz'))
+    C, hw, G, std1000 = [int(v) for v in g['p2p%d_cfg' % ci]]
+    from pointtinybenchmark_amd import synthetic
+    batch = synthetic.synthetic_batch(2, hw * 4, hw * 4, G, C, seed=300 + ci, ragged=True)
+    cls_out, pts_out = torch.from_numpy(g['p2p%d_cls_out' % ci]), torch.from_numpy(g['p2p%d_pts_out' % ci])
+    with torch.no_grad():
+        losses, inds = O.p2p_loss(cls_out, pts_out, batch['gt_bboxes'], batch['gt_labels'], (hw * 4, hw * 4, 3))
+    ref_labels = g['p2p%d_target_labels' % ci]
+    for b in range(2):
+        lab = torch.full((inds[b].shape[0],), C, dtype=torch.long)
+        pos = inds[b] > 0
+        lab[pos] = batch['gt_labels'][b][inds[b][pos] - 1]
+        assert np.array_equal(lab.numpy().astype(np.int32), ref_labels[b]), 'image %d: assignment targets differ' % b
+    for key, mine in (('loss_cls', losses['loss_cls'][0]), ('loss_pts', losses['loss_pts'][0])):
+        ref = float(g['p2p%d_%s' % (ci, key)])
+        assert abs(float(mine) - ref) <= 2e-6 * max(1.0, abs(ref)), (key, float(mine), ref)
