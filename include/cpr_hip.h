@@ -281,6 +281,10 @@ int cpr_nms_batched(const float* boxes, const float* scores, const int* labels, 
 int cpr_p2p_decode(const float* reg, const float* point_anchor, float* pred, float* anchor, int N, int H, int W, int k,
                    float stride, float gamma, void* stream);
 /* max_c sigmoid(logits[m][c]) -> out (M): the score P2PHead._get_bboxes_single ranks with (p2p_head.py:362-369) */
+/* out (N,H,W,J) = bias[j] + sum over the 3x3 taps of R[n][y+kh-1][x+kw-1][(kh*3+kw)*J + j] (taps outside the map add 0):
+ * the second half of a 3x3 / pad 1 convolution with J output channels computed as a 1x1 projection to 9 J tap responses
+ * (P2PHead's cls_out / reg_out, p2p_head.py:84-123: 1-2 output channels).  bias may be NULL. */
+int cpr_tap_sum3x3(const float* R, const float* bias, float* out, int N, int H, int W, int J, void* stream);
 int cpr_rowmax_sigmoid(const float* logits, float* out, long long M, int C, void* stream);
 /* elementwise sigmoid with the bits of torch's CPU kernel (p2p_head.py:362: the scores that order top-k and NMS) */
 int cpr_sigmoid(const float* x, float* y, long long n, void* stream);

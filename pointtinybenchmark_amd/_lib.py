@@ -55,6 +55,7 @@ SIGNATURES = {
     'cpr_nms': [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
     'cpr_topk_desc_batched': [_p, _i, _i, _i, _p, _p, _p],
     'cpr_nms_candidates_batched': [_p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p],
+    'cpr_tap_sum3x3': [_p, _p, _p, _i, _i, _i, _i, _p],
     'cpr_nms_batched': [_p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _l, _p],
     'cpr_p2p_decode': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'cpr_rowmax_sigmoid': [_p, _p, ctypes.c_longlong, _i, _p],

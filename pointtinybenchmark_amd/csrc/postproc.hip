@@ -392,6 +392,44 @@ extern "C" int cpr_p2p_decode(const float* reg, const float* point_anchor, float
     CPR_LAUNCH_STATUS();
 }
 
+// 3x3 / pad 1 convolution with a HANDFUL of output channels as a 1x1 projection + a tap sum (round 4).  P2PHead's output convs
+// (cls_out: 256 -> C k, reg_out: 256 -> 2 k; T/mmdet/models/point/dense_heads/p2p_head.py:84-105,113-123) have 1-2 output
+// channels: on the 64-cout tiles of the matrix-core conv 97 % of the multiplies meet zero padding (1.0 ms per launch at B = 16,
+// 6.5 % of the P2PNet step for two launches).  conv(x, w)[y][x][j] = sum_taps <x[y+dy][x+dx], w[j][:, tap]> -- so ONE 1x1 GEMM
+// with 9 J output rows (row tap * J + j = w[j][:, kh][kw]) gives every pixel's response to every tap, R (N,H,W,9J), and this
+// kernel adds the nine shifted responses (a tap that falls outside the map contributes 0 = the conv's zero padding) + bias.
+__global__ void tap_sum3x3_kernel(const float* __restrict__ R, const float* __restrict__ bias, float* __restrict__ out,
+                                  int N, int H, int W, int J) {
+    const long long total = (long long)N * H * W * J;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % J);
+    long long r = i / J;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    float s = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int yy = y + kh - 1;
+        if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int xx = x + kw - 1;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            s += R[(((size_t)n * H + yy) * W + xx) * (9 * J) + (kh * 3 + kw) * J + j];
+        }
+    }
+    out[i] = s + (bias ? bias[j] : 0.f);
+}
+extern "C" int cpr_tap_sum3x3(const float* R, const float* bias, float* out, int N, int H, int W, int J, hipStream_t stream) {
+    CPR_CHECK_ARG(R && out && N > 0 && H > 0 && W > 0 && J > 0);
+    const long long total = (long long)N * H * W * J;
+    hipLaunchKernelGGL(tap_sum3x3_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, stream, R, bias, out, N, H, W, J);
+    CPR_LAUNCH_STATUS();
+}
+
 // max over classes of sigmoid(logit): the per-proposal score fed to topk (p2p_head.py:362-369)
 __global__ void rowmax_sigmoid_kernel(const float* __restrict__ logits, float* __restrict__ out, long long M, int C) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;

@@ -20,6 +20,7 @@ from ..layers import ConvModule, _PackCache, conv_gn, packed_conv
 from ..registry import HEADS, build_assigner, build_sampler
 
 
+TAP_PROJECTION = [True]          # test hook: False keeps the output convs on the 3x3 matrix-core kernel (A/B, tests)
 BATCHED_POSTPROCESS = [True]     # test hook: False runs _get_bboxes_single image by image (the two must agree exactly)
 
 
@@ -88,8 +89,20 @@ class P2PHead(nn.Module):
                 rec = dict(kind='tower')
                 tape.append(rec)
             x, ab = conv_gn(self._cache, m, x, in_ab=ab, in_relu=True, materialize=False, save=rec)
-        pc = packed_conv(self._cache, out_conv)
         H, W = x.shape[1:3]
+        J = out_conv.out_channels
+        if tape is None and TAP_PROJECTION[0] and x.dtype == torch.float32 and 9 * J <= 64 and out_conv.kernel_size == (3, 3) \
+                and out_conv.padding == (1, 1) and out_conv.stride == (1, 1):
+            # forward only: a 3x3 conv with 1-2 output channels wastes 97 % of a 64-cout matrix-core tile; as a 1x1 projection to
+            # 9 J tap responses + a tap sum it is one (fused-GroupNorm) GEMM over the map and a 30 MB gather (csrc/postproc.hip)
+            pc1 = self._cache.get(('tap1x1', id(out_conv)), [out_conv.weight], lambda: ops.PackedConv(
+                out_conv.weight.detach().permute(2, 3, 0, 1).reshape(9 * J, -1)[:, :, None, None].contiguous(), 1, 0))
+            if (H * W) % 128 == 0:
+                R = ops.conv2d(x, pc1, in_ab=ab, in_relu=True)
+            else:
+                R = ops.conv2d(ops.gn_apply(x, ab[0], ab[1], relu=True), pc1)
+            return ops.tap_sum3x3(R, out_conv.bias.detach(), J)
+        pc = packed_conv(self._cache, out_conv)
         if tape is not None:
             tape.append(dict(kind='out', conv=out_conv, x=x, in_ab=ab))
         if (H * W) % 128 == 0:

@@ -719,6 +719,15 @@ def nms_batched(boxes, scores, labels, counts, iou_thr):
     return keep, num
 
 
+def tap_sum3x3(R, bias, J):
+    """R (N,H,W,9J) tap responses -> (N,H,W,J) = bias + the nine shifted responses (see csrc/postproc.hip tap_sum3x3_kernel)."""
+    N, H, W, J9 = _check(R).shape
+    assert J9 == 9 * J
+    out = torch.empty((N, H, W, J), device=R.device, dtype=torch.float32)
+    _lib.call('cpr_tap_sum3x3', _ptr(R), _ptr(bias), _ptr(out), N, H, W, J, _stream())
+    return out
+
+
 def p2p_decode(reg_nhwc, point_anchor, stride, gamma, want_anchor=False):
     """reg (N,H,W,2k) -> pred (N, H*W*k, 3) = (x, y, stride) [, anchor pts]."""
     N, H, W, C2 = _check(reg_nhwc).shape
