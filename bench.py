@@ -184,7 +184,9 @@ class ConvProbe:
                 variant = 'conv_wino_kernel<0, %s, %s, %d, 4>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false',
                                                                   0 if v & 4 else 1)
             elif kind == 'bf16':
-                variant = 'conv_bf16_dma_kernel' if v == 256256 else 'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000)
+                # conv_bf16_dma.hip reports 256256 (the <4, 2> instance) and 1128128 (<2, 1>: 128 x 128 tiles, two workgroups per CU)
+                variant = ('conv_bf16_dma_kernel<4, 2>' if v == 256256 else 'conv_bf16_dma_kernel<2, 1>' if v == 1128128 else
+                           'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000))
             elif v % 10 == 2:    # dual-source launch (conv3 + projection shortcut): <BM, BN, MODE 0, XF false, PIPE 1, ABL 0, DUAL>
                 variant = 'conv_mfma_kernel<%d, %d, 0, false, 1, 0, true>' % (v // 1000000, v // 1000 % 1000)
             elif v % 10 == 3:    # streamed 1x1 (csrc/conv1x1_stream.hip): (BM, BN) = (128, 256) K 64 / (64, 128) K 128 / (128, 64) K 256

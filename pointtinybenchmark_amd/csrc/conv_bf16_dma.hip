@@ -22,6 +22,7 @@
 // Used when Cout % 256 == 0 and Cin % 64 == 0 (the head towers, the FPN convs, the wide bottleneck convs); everything else
 // stays on conv_mfma_bf16.hip.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -47,34 +48,55 @@ struct ConvDmaParams {
     long long nt_copy;  // elements between the copies of the right operand
 };
 
-constexpr int DBM = 256, DBN = 256, DBK = 64;
-constexpr int DSTAGE = (DBM + DBN) * DBK * 2;     // bytes per stage: 64 KB
+constexpr int DBK = 64;
+// Tile instances <MI, NJ>: a wave owns MI x NJ blocks of 32 x 32, the workgroup (2 x 4 waves) 64 MI pixels x 128 NJ couts.
+//   <4, 2> = 256 x 256 (the round-3 kernel: 32 MFMAs per wave per chunk against 8 requests + 24 fragment reads, one workgroup
+//            per CU): the MFMA-bound layers -- 3x3 with K >= 1024 on maps of >= 384 tiles;
+//   <2, 1> = 128 x 128 (round 4): 8 MFMAs against 4 requests + 12 reads per chunk -- poor food for the matrix pipe, but 64 KB of
+//            LDS and 91 VGPRs = TWO workgroups per CU, and the layers it takes are not MFMA-bound: the bottleneck 1x1s move
+//            more bytes than flops (conv3 256 -> 1024 + residual on 32 768 pixels: 151 MB against 17 GFLOP), and with one
+//            workgroup per CU all 256 CUs run K loop, residual read and store phase in lock step -- HBM idles during the K loops
+//            and is the only thing working during the epilogues.  Two resident workgroups drift apart and overlap the phases;
+//            and R101's layer3 at 1024^2 B = 8 (M = 32 768: 128 tiles of 256 x 256 for 256 CUs) fills the chip.
+//   <2, 2> = 128 x 256 and <4, 1> = 256 x 128 were built and measured too (profiles/round4_bf16_tiles_and_epilogue.txt): never
+//            ahead of <2, 1>; not instantiated.
+template <int MI, int NJ> struct DmaTile {
+    static constexpr int BM = 64 * MI, BN = 128 * NJ;
+    static constexpr int NPA = MI, NPW = 2 * NJ, NP = NPA + NPW;       // 8 KB request pieces per chunk: activations, weights
+    static constexpr int NM = MI * NJ, NF = MI + NJ;                   // MFMAs / fragment reads per wave per k-step
+    static constexpr int STAGE = (BM + BN) * DBK * 2;                  // bytes per stage
+    // the chunk's pieces over three k-steps, in their LAST MFMA slots: C3 behind the barrier (k-step 3), C0 in k-step 0, C1 in k-step 1
+    static constexpr int C3 = (NP + 2) / 3, C0 = (NP - C3 + 1) / 2, C1 = NP - C3 - C0;
+    static_assert(C3 <= NM && C0 <= NM && C1 <= NM, "one request per MFMA slot at most");
+};
 
 __device__ __forceinline__ float bf16f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
 // Epilogue shared by both kernels: y = acc * scale + bias (+ residual) (ReLU) -> bf16 (cout pairs packed) or fp32; GroupNorm
 // statistics from the fp32 values, one slot per 128 pixels = per (tile, wm): a wave owns its slot's 64 channels outright.
-__device__ __forceinline__ void dma_epilogue(const ConvDmaParams& p, f32x16 (&acc)[4][2], int tm, int m0, int n0, int wm,
+template <int MI, int NJ>
+__device__ __forceinline__ void dma_epilogue(const ConvDmaParams& p, f32x16 (&acc)[MI][NJ], int tm, int m0, int n0, int wm,
                                              int wn, int lane) {
     const int l31 = lane & 31, half = lane >> 5;
+    if (p.ablate & 32) return;
     // D layout of a 32 x 32 block: col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel)
     unsigned short* out16 = reinterpret_cast<unsigned short*>(p.out);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        p.out, 0, (int)((size_t)p.M * p.Cout * (p.out_fp32 ? 4 : 2)), 0x00020000);
+        p.out, 0, (p.ablate & 16) ? 0 : (int)((size_t)p.M * p.Cout * (p.out_fp32 ? 4 : 2)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(p.residual ? p.residual : (const unsigned short*)p.out), 0,
         (int)((size_t)p.M * p.Cout * 2), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int c = n0 + wn * (NJ * 32) + j * 32 + l31;
         const bool cok = c < p.Cout;
         const int cc = cok ? c : p.Cout - 1;
         const float sc = p.scale ? p.scale[cc] : 1.f;
         const float bi = p.bias ? p.bias[cc] : 0.f;
         float gsum = 0.f, gsq = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rbase = m0 + wm * 128 + i * 32 + 4 * half;
+        for (int i = 0; i < MI; ++i) {
+            const int rbase = m0 + wm * (MI * 32) + i * 32 + 4 * half;
             const unsigned e0 = (unsigned)(rbase * p.Cout + c);
             float res[16];
             if (p.residual) {
@@ -133,7 +155,138 @@ __device__ __forceinline__ void dma_epilogue(const ConvDmaParams& p, f32x16 (&ac
     (void)out16;
 }
 
-__global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) {
+// bf16 output through LDS (round 4).  The direct epilogue above stores cout PAIRS per lane: one buffer_store_b32 moves two
+// 64-byte row segments, 128 of them (+ 128 two-byte residual loads) per wave -- measured on R101's layer3 conv3 (1x1 256 -> 1024
+// on 32 768 pixels): 0.044 ms with, 0.016 ms without the epilogue, 0.038 ms with every store dropped by the range check, i.e. the
+// INSTRUCTIONS, not the bytes (profiles/round4_bf16_epilogue_ablation.txt).  Here the fp32 results (acc * scale + bias) of half a
+// tile go to the LDS the K loop has finished with (row pitch = BN floats: a wave's D-layout write is two conflict-free 128-byte
+// runs), and the workgroup reads them back ROW-wise: lane l owns couts [4 l, 4 l + 4) of a row -- one ds_read_b128, one 8-byte
+// residual load (requested before the tile's writes, consumed behind the barrier), fp32 add + ReLU, one 8-byte store; a wave
+// instruction covers whole 512-byte (BN = 256) or 2 x 256-byte rows.  16 x fewer vector-memory instructions, every line written
+// once and whole.  Same arithmetic and rounding as the direct form (fp32 through the residual add, one RNE rounding).
+template <int MI, int NJ>
+__device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 (&acc)[MI][NJ], unsigned char* smem, int tm,
+                                                 int m0, int n0, int wm, int wn, int wave, int lane) {
+    constexpr int BN = 128 * NJ, HI = MI / 2;                  // HI pixel blocks per wave per half tile
+    constexpr int LPR = BN / 4, RPI = 64 / LPR;                // lanes per row, rows per wave instruction of the read-out
+    constexpr int HROWS = 32 * MI, PASSES = HROWS / (8 * RPI); // rows per half tile, read-out instructions per wave per half
+    static_assert(MI % 2 == 0 && HROWS * BN * 4 <= 2 * DmaTile<MI, NJ>::STAGE, "half a tile of fp32 must fit the two stages");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int l31 = lane & 31, half = lane >> 5;
+    float* tile = reinterpret_cast<float*>(smem);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (p.ablate & 16) ? 0 : (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.residual ? p.residual : (const unsigned short*)p.out), 0,
+        (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+    float sc[NJ], bi[NJ], gsum[NJ], gsq[NJ];
+    bool cok[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = n0 + wn * (NJ * 32) + j * 32 + l31;
+        cok[j] = c < p.Cout;
+        const int cc = cok[j] ? c : p.Cout - 1;
+        sc[j] = p.scale ? p.scale[cc] : 1.f;
+        bi[j] = p.bias ? p.bias[cc] : 0.f;
+        gsum[j] = 0.f;
+        gsq[j] = 0.f;
+    }
+    const bool relu_here = p.relu && !p.residual;              // with a residual the ReLU follows the add, in the read-out
+    const int rl = lane / LPR, cl = (lane % LPR) * 4;
+    __syncthreads();                                           // every wave's last fragment reads are done: the stages are free
+    // (the row arithmetic hangs on an opaque copy of the wave's first row: computed where it is used -- hoisted above the tile's
+    // LDS writes, the 2 x PASSES offsets of both halves were spilled and re-read one by one: 10 us per tile)
+    // read-out role: local row lr = wm' (32 HI) + ii 32 + rr of half h  ->  pixel m0 + wm' (32 MI) + (h HI + ii) 32 + rr
+    auto row_offset = [&](int h, int ps, int wrow) {
+        const int lr = ps * 8 * RPI + wrow;
+        const int m = m0 + (lr / (HI * 32)) * (MI * 32) + h * (HI * 32) + (lr % (HI * 32));
+        return (m < p.M && n0 + cl < p.Cout) ? (int)(((unsigned)m * (unsigned)p.Cout + (unsigned)(n0 + cl)) * 2u) : (int)0x80000000;
+    };
+    auto write_half = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+#pragma unroll
+        for (int ii = 0; ii < HI; ++ii) {
+            const int i = h * HI + ii;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float* dst = tile + (wm * (HI * 32) + ii * 32 + 4 * half) * BN + wn * (NJ * 32) + j * 32 + l31;
+                const int mb = m0 + wm * (MI * 32) + i * 32 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    float x = acc[i][j][r] * sc[j] + bi[j];
+                    if (relu_here) x = fmaxf(x, 0.f);
+                    if (p.gn_part) {
+                        const float u = (cok[j] && mb + rr < p.M) ? x : 0.f;
+                        gsum[j] += u;
+                        gsq[j] += u * u;
+                    }
+                    dst[rr * BN] = x;
+                }
+            }
+        }
+    };
+    auto read_half = [&](int h, u32x2 (&rv)[PASSES]) {
+        int wrow = wave * RPI + rl;
+        asm volatile("" : "+v"(wrow));
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int lr = ps * 8 * RPI + wrow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(tile + lr * BN + cl);
+            if (p.residual) {
+                v[0] += __uint_as_float(rv[ps][0] << 16);
+                v[1] += __uint_as_float(rv[ps][0] & 0xffff0000u);
+                v[2] += __uint_as_float(rv[ps][1] << 16);
+                v[3] += __uint_as_float(rv[ps][1] & 0xffff0000u);
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+            }
+            u32x2 pk;
+            pk[0] = __builtin_bit_cast(unsigned, bf16x2{(__bf16)v[0], (__bf16)v[1]});
+            pk[1] = __builtin_bit_cast(unsigned, bf16x2{(__bf16)v[2], (__bf16)v[3]});
+            __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, row_offset(h, ps, wrow), 0, 0);
+        }
+    };
+    u32x2 rv0[PASSES], rv1[PASSES];
+    write_half(std::integral_constant<int, 0>{});
+    // the residual of BOTH halves is requested here: the first half's accumulators have just died (their registers carry the
+    // 2 x PASSES x 8 bytes), and the second half's requests fly during the first half's read-out
+    if (p.residual) {
+        int wrow = wave * RPI + rl;
+        asm volatile("" : "+v"(wrow));
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) rv0[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, row_offset(0, ps, wrow), 0, 0);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) rv1[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, row_offset(1, ps, wrow), 0, 0);
+    }
+    __syncthreads();
+    read_half(0, rv0);
+    __syncthreads();
+    write_half(std::integral_constant<int, 1>{});
+    __syncthreads();
+    read_half(1, rv1);
+    if (p.gn_part) {            // (MI == 4 only: the launcher keeps statistics layers off the 128-pixel tile)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float a = gsum[j], b = gsq[j];
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 32, 64);
+            const int c = n0 + wn * (NJ * 32) + j * 32 + l31;
+            if (half == 0 && cok[j]) {
+                float* dst = p.gn_part + ((size_t)(tm * 2 + wm) * p.Cout + c) * 2;
+                dst[0] = a;
+                dst[1] = b;
+            }
+        }
+    }
+}
+
+template <int MI, int NJ>
+__global__ __launch_bounds__(512, (MI * NJ <= 2 ? 2 : 1)) void conv_bf16_dma_kernel(ConvDmaParams p) {
+    using T = DmaTile<MI, NJ>;
+    constexpr int DBM = T::BM, DBN = T::BN, DSTAGE = T::STAGE, NM = T::NM, NF = T::NF, NP = T::NP, NPA = T::NPA;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
 
     // XCD-aware tile order (block b runs on XCD b % 8; an XCD walks a contiguous run of tiles, cout tiles fastest)
@@ -159,16 +312,16 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- staging role: piece j (0..3) of an operand = rows 64 j + (tid >> 3), 16-byte unit (tid & 7) of the 128-byte row; the
+    // ---- staging role: piece j of an operand = rows 64 j + (tid >> 3), 16-byte unit (tid & 7) of the 128-byte row; the
     // lane fetches the k-unit (tid & 7) ^ swz, swz = (row >> 1) & 7 = (tid >> 4) & 7 for every j
     const int srow = tid >> 3;
     const int sunit = (tid & 7) ^ ((tid >> 4) & 7);
     const int ohw = p.OH * p.OW;
     const bool gemm = (p.KH == 1) & (p.KW == 1) & (p.stride == 1) & (p.pad == 0);
-    int iy0[4], ix0[4], rowoff[4];
-    bool mok[4];
+    int iy0[MI], ix0[MI], rowoff[MI];
+    bool mok[MI];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < MI; ++j) {
         const int m = m0 + srow + 64 * j;
         mok[j] = m < p.M;
         const int mm = mok[j] ? m : 0;
@@ -191,9 +344,9 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
                           (int)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000};
     const i32x4v rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32) & 0xffff,
                          (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000};
-    int woff[4];
+    int woff[2 * NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2 * NJ; ++j) {
         const int c = n0 + srow + 64 * j;
         woff[j] = c < p.Cout ? (c * p.Kpad) * 2 + sunit * 16 : (int)0x80000000;
     }
@@ -204,11 +357,11 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
     // K offset tap * Cin + c0.
     int kh = 0, kw = 0, c0 = nt ? nt_split * p.nt_chunks * DBK : 0;     // tap / channel chunk of the NEXT chunk to be requested (wave-uniform)
     int wsoff = 0;                  // byte offset of that chunk inside a weight row
-    int voffA[4];
+    int voffA[MI];
     auto refresh_rows = [&]() {
         const int tapshift = (kh * p.W + kw) * p.Cin;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MI; ++j) {
             const int iy = iy0[j] + kh, ix = ix0[j] + kw;
             const bool ok = mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             voffA[j] = ok ? (rowoff[j] + tapshift) * 2 + sunit * 16 : (int)0x80000000;
@@ -223,14 +376,14 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
                      :: "s"(lds_byte), "v"(voff), "s"(rs), "s"(soff) : "memory");
     };
     const int KT = nt ? p.nt_chunks : p.Kpad / DBK;
-    // piece z = 0..7 of chunk kt (z < 4: activations, else weights) into stage `buf`; pieces are issued in order
+    // piece z = 0..NP-1 of chunk kt (z < NPA: activations, else weights) into stage `buf`; pieces are issued in order
     auto stage_piece = [&](int kt, int buf, int z) {
         if (p.ablate & 4) return;
         const int base = lds0 + buf * DSTAGE + wave * 1024;
-        if (z < 4) {
+        if (z < NPA) {
             if (z == 0) wsoff = ((kh * p.KW + kw) * p.Cin + c0) * 2;
-            dma(rs_in, voffA[z], c0 * 2, base + z * 8192);
-            if (z == 3) {            // after the last activation piece: advance the tap / channel state to the next chunk
+            dma(rs_in, voffA[z < NPA ? z : 0], c0 * 2, base + z * 8192);
+            if (z == NPA - 1) {      // after the last activation piece: advance the tap / channel state to the next chunk
                 if (++kw == p.KW) {
                     kw = 0;
                     if (++kh == p.KH) { kh = 0; c0 += DBK; }
@@ -238,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
                 if (p.KH * p.KW > 1) refresh_rows();
             }
         } else {
-            dma(rs_w, woff[z - 4], wsoff, base + DBM * DBK * 2 + (z - 4) * 8192);
+            dma(rs_w, woff[z >= NPA ? z - NPA : 0], wsoff, base + DBM * DBK * 2 + (z - NPA) * 8192);
         }
     };
 
@@ -250,74 +403,85 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
     int koff[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) koff[kk] = l31 * 128 + (((2 * kk + half) ^ rswz) * 16);
-    const unsigned char* a_base = smem + (wm * 128) * 128;
-    const unsigned char* b_base = smem + DBM * DBK * 2 + (wn * 64) * 128;
+    const unsigned char* a_base = smem + (wm * MI * 32) * 128;
+    const unsigned char* b_base = smem + DBM * DBK * 2 + (wn * NJ * 32) * 128;
 
-    f32x16 acc[4][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 fa0[4], fb0[2], fa1[4], fb1[2];
-    // fragment piece z of a k-step: 0, 1 = the two cout blocks, 2..5 = the four pixel blocks.  MFMA q of the NEXT k-step uses
-    // pixel block q >> 1 and cout block q & 1: with the cout blocks read first every operand is requested >= 6 MFMA slots
-    // (~200 cycles of this wave, as many of its partner) before its first use
+    f32x4 fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
+    // fragment piece z of a k-step: z < NJ = the cout blocks, then the MI pixel blocks.  MFMA q of the NEXT k-step uses pixel
+    // block q / NJ and cout block q % NJ: with the cout blocks read first every operand of the 256 x 256 instance is requested
+    // >= 6 MFMA slots (~200 cycles of this wave, as many of its partner) before its first use
 #define DFRAG(FA, FB, buf, kk, z)                                                                                     \
     do {                                                                                                              \
         if (p.ablate & 8) break;                                                                                      \
-        if ((z) >= 2) FA[(z) >= 2 ? (z) - 2 : 0] = *reinterpret_cast<const f32x4*>(a_base + (buf) * DSTAGE + ((z) >= 2 ? (z) - 2 : 0) * 4096 + koff[kk]); \
-        else FB[(z) < 2 ? (z) : 0] = *reinterpret_cast<const f32x4*>(b_base + (buf) * DSTAGE + ((z) < 2 ? (z) : 0) * 4096 + koff[kk]); \
+        if ((z) >= NJ) FA[(z) >= NJ ? (z) - NJ : 0] = *reinterpret_cast<const f32x4*>(a_base + (buf) * DSTAGE + ((z) >= NJ ? (z) - NJ : 0) * 4096 + koff[kk]); \
+        else FB[(z) < NJ ? (z) : 0] = *reinterpret_cast<const f32x4*>(b_base + (buf) * DSTAGE + ((z) < NJ ? (z) : 0) * 4096 + koff[kk]); \
+    } while (0)
+    // the NF reads of a k-step over its NM MFMA slots: slot q reads piece q (NF <= NM), else pieces [q NF / NM, (q + 1) NF / NM)
+#define DFRAGS(FA, FB, buf, kk, q)                                                                    \
+    do {                                                                                              \
+        if (NF <= NM) { if ((q) < NF) DFRAG(FA, FB, buf, kk, (q) < NF ? (q) : 0); }                     \
+        else {                                                                                        \
+            _Pragma("unroll") for (int z_ = ((q) * NF) / NM; z_ < (((q) + 1) * NF) / NM; ++z_) DFRAG(FA, FB, buf, kk, z_); \
+        }                                                                                             \
     } while (0)
 #define DMFMA(FA, FB, q)                                                                              \
-    acc[(q) >> 1][(q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                 \
-        __builtin_bit_cast(bf16x8, FA[(q) >> 1]), __builtin_bit_cast(bf16x8, FB[(q) & 1]), acc[(q) >> 1][(q) & 1], 0, 0, 0)
+    acc[(q) / NJ][(q) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                \
+        __builtin_bit_cast(bf16x8, FA[(q) / NJ]), __builtin_bit_cast(bf16x8, FB[(q) % NJ]), acc[(q) / NJ][(q) % NJ], 0, 0, 0)
 
-    // prologue: chunk 0 -> stage 0 completely, the first three pieces of chunk 1 -> stage 1
+    constexpr int C3 = T::C3, C0 = T::C0, C1 = T::C1;
+    // prologue: chunk 0 -> stage 0 completely, the first C3 pieces of chunk 1 -> stage 1
 #pragma unroll
-    for (int z = 0; z < 8; ++z) stage_piece(0, 0, z);
+    for (int z = 0; z < NP; ++z) stage_piece(0, 0, z);
     if (KT > 1) {
 #pragma unroll
-        for (int z = 0; z < 3; ++z) stage_piece(1, 1, z);
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // chunk 0 has landed, chunk 1's pieces stay in flight
+        for (int z = 0; z < C3; ++z) stage_piece(1, 1, z);
+        if (C3 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // chunk 0 has landed, chunk 1's pieces stay in flight
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    static_assert(C3 == 3 || C3 == 2, "prologue wait count");
     __syncthreads();
 #pragma unroll
-    for (int z = 0; z < 6; ++z) DFRAG(fa0, fb0, 0, 0, z);
+    for (int z = 0; z < NF; ++z) DFRAG(fa0, fb0, 0, 0, z);
 
     // One chunk kt (stage buf = kt & 1).  A burst of LDS-DMA requests stalls the wave AT the requests (each costs 100+ cycles
-    // of issue when eight follow each other, against 32 cycles per MFMA), so the eight pieces of a chunk are spread over three
-    // k-steps, one piece per MFMA slot at most, in the slots that carry no (or the last) fragment read:
-    //   k-step 0: MFMAs | the fragments of k-step 1 | pieces 3, 4, 5 of chunk kt+1 -> stage buf^1 (free since the last barrier)
-    //   k-step 1: MFMAs | the fragments of k-step 2 | pieces 6, 7 of chunk kt+1
+    // of issue when eight follow each other, against 32 cycles per MFMA), so the pieces of a chunk are spread over three
+    // k-steps, one piece per MFMA slot at most, in the slots that carry no (or the last) fragment read (256 x 256: 3 + 3 + 2):
+    //   k-step 0: MFMAs | the fragments of k-step 1 | pieces C3.. of chunk kt+1 -> stage buf^1 (free since the last barrier)
+    //   k-step 1: MFMAs | the fragments of k-step 2 | the last C1 pieces of chunk kt+1
     //   k-step 2: MFMAs | the fragments of k-step 3 (the last reads of stage buf)
     //   wait: this wave's pieces of chunk kt+1 have landed; barrier: true for every wave, and all reads of stage buf are done
-    //   k-step 3: MFMAs | the first fragments of chunk kt+1 | pieces 0, 1, 2 of chunk kt+2 -> stage buf
+    //   k-step 3: MFMAs | the first fragments of chunk kt+1 | pieces 0 .. C3-1 of chunk kt+2 -> stage buf
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < KT, more2 = kt + 2 < KT;        // wave-uniform
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NM; ++q) {
             DMFMA(fa0, fb0, q);
-            if (q < 6) DFRAG(fa1, fb1, buf, 1, q);
-            if (more && q >= 5) stage_piece(kt + 1, buf ^ 1, q - 2);          // pieces 3, 4, 5
+            DFRAGS(fa1, fb1, buf, 1, q);
+            if (more && q >= NM - C0) stage_piece(kt + 1, buf ^ 1, C3 + q - (NM - C0));
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NM; ++q) {
             DMFMA(fa1, fb1, q);
-            if (q < 6) DFRAG(fa0, fb0, buf, 2, q);
-            if (more && q >= 6) stage_piece(kt + 1, buf ^ 1, q);              // pieces 6, 7
+            DFRAGS(fa0, fb0, buf, 2, q);
+            if (more && q >= NM - C1) stage_piece(kt + 1, buf ^ 1, C3 + C0 + q - (NM - C1));
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NM; ++q) {
             DMFMA(fa0, fb0, q);
-            if (q < 6) DFRAG(fa1, fb1, buf, 3, q);
+            DFRAGS(fa1, fb1, buf, 3, q);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -326,23 +490,30 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NM; ++q) {
             DMFMA(fa1, fb1, q);
-            if (q < 6 && more) DFRAG(fa0, fb0, buf ^ 1, 0, q);
-            if (more2 && q >= 5) stage_piece(kt + 2, buf, q - 5);             // pieces 0, 1, 2
+            if (more) DFRAGS(fa0, fb0, buf ^ 1, 0, q);
+            if (more2 && q >= NM - C3) stage_piece(kt + 2, buf, q - (NM - C3));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#undef DFRAGS
 #undef DFRAG
 #undef DMFMA
 
     if (nt) {   // this (split, tap)'s fp32 partial
         ConvDmaParams q = p;
         q.out = (float*)p.out + (size_t)st * p.M * p.Cout;
-        dma_epilogue(q, acc, tm, m0, n0, wm, wn, lane);
+        dma_epilogue<MI, NJ>(q, acc, tm, m0, n0, wm, wn, lane);
         return;
     }
-    dma_epilogue(p, acc, tm, m0, n0, wm, wn, lane);
+    // the 256 x 256 instance keeps the direct epilogue: its layers are MFMA-bound 3x3s whose statistics epilogue measured 12 %
+    // SLOWER through LDS (1.80 -> 2.06 ms on the head layer at B = 64; profiles/round4_bf16_tiles_and_epilogue.txt)
+    if constexpr (MI * NJ > 2) dma_epilogue<MI, NJ>(p, acc, tm, m0, n0, wm, wn, lane);
+    else {
+        if (p.out_fp32 || (p.ablate & 64)) dma_epilogue<MI, NJ>(p, acc, tm, m0, n0, wm, wn, lane);
+        else dma_epilogue_lds<MI, NJ>(p, acc, smem, tm, m0, n0, wm, wn, wave, lane);
+    }
 }
 
 // (A variant with the two wave groups staggered by half a chunk -- activation halves A_g[2] + a ring of three weight stages =
@@ -355,11 +526,13 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(ConvDmaParams p) 
 // profiles/round3_bf16_dma_kernel_development.txt.)
 
 // The launcher of conv_mfma_bf16.hip calls this for the layers that fit the tile; returns CPR_ERR_UNSUPPORTED otherwise.
+// shape: 0 = 256 x 256, 1 = 128 (pixels) x 256 (couts), 2 = 256 x 128, 3 = 128 x 128 (64 KB of LDS: two workgroups per CU).
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                          const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
-                         int ablate) {
-    if (Cout % DBN != 0 || Cin % DBK != 0 || Kpad != KH * KW * Cin) return CPR_ERR_UNSUPPORTED;
+                         int ablate, int shape) {
+    const int bm = (shape == 1 || shape == 3) ? 128 : 256, bn = (shape == 2 || shape == 3) ? 128 : 256;
+    if (Cout % bn != 0 || Cin % DBK != 0 || Kpad != KH * KW * Cin) return CPR_ERR_UNSUPPORTED;
     ConvDmaParams p;
     p.in = (const unsigned short*)in; p.wgt = (const unsigned short*)wgt; p.out = out; p.scale = scale; p.bias = bias;
     p.residual = (const unsigned short*)residual; p.gn_part = gn_part;
@@ -375,12 +548,15 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
     p.M = (int)M;
     if (gn_part && (p.OH * p.OW) % 128 != 0) return CPR_ERR_UNSUPPORTED;
     if (gn_part && M % 256 != 0) return CPR_ERR_UNSUPPORTED;      // both 128-pixel slots of every tile must exist
-    p.tilesM = (int)((M + DBM - 1) / DBM);
-    p.tilesN = Cout / DBN;
-    if (variant_out) *variant_out = 256 * 1000 + 256;
+    if (gn_part && bm != 256) return CPR_ERR_UNSUPPORTED;         // a wave of the 128-pixel tile owns half a statistics slot
+    p.tilesM = (int)((M + bm - 1) / bm);
+    p.tilesN = Cout / bn;
+    if (variant_out) *variant_out = bm * 1000 + bn + (shape == 3 ? 1000000 : 0);       // 128128 alone is the register-staged <128, 128>
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
-    hipLaunchKernelGGL(conv_bf16_dma_kernel, dim3(grid), dim3(512), 0, stream, p);
+    if (shape == 1 || shape == 2) return CPR_ERR_UNSUPPORTED;      // <2, 2> and <4, 1> were measured and dropped
+    if (shape == 3) hipLaunchKernelGGL((conv_bf16_dma_kernel<2, 1>), dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2>), dim3(grid), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }
 
@@ -389,6 +565,7 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
 // of `rs` elements, tap t = (t / k, t % k) reads copy t % k shifted by (t / k - pad) * Wp elements.  N % 256 == 0.
 int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, int N, long long rs, int k, int pad, int Wp,
                             long long copy, int splits, int chunks, hipStream_t stream) {
+    constexpr int DBM = 256, DBN = 256;
     if (N % DBN != 0 || rs % 8 != 0 || M <= 0 || splits <= 0 || splits % 8 != 0 || chunks <= 0) return CPR_ERR_UNSUPPORTED;
     if ((long long)M * rs * 2 >= (1ll << 31) || (long long)N * rs * 2 >= (1ll << 31) || rs >= (1ll << 30)) return CPR_ERR_UNSUPPORTED;
     ConvDmaParams p;
@@ -401,6 +578,6 @@ int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, in
     p.nt_taps = k * k; p.nt_k = k; p.nt_pad = pad; p.nt_Wp = Wp; p.nt_chunks = chunks; p.nt_copy = copy;
     const long long blocks = (long long)splits * p.nt_taps * p.tilesM * p.tilesN;
     if (blocks >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_bf16_dma_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }

@@ -318,18 +318,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                          const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
-                         int ablate);
+                         int ablate, int shape);
 #ifdef CPR_BENCH_HOOKS
-static int bf16_dma_on = 1, bf16_dma_ablate = 0;
+static int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0;
 extern "C" int cpr_bf16_set_dma(int on) {   // measurement build: 0 = keep every layer on the register-staged kernels (A/B);
-    CPR_CHECK_ARG(on >= 0 && on < 32);       // bits 1..4 = loop ablations of the DMA kernel (results are then WRONG)
-    bf16_dma_on = on & 1;
-    bf16_dma_ablate = on >> 1;
+    CPR_CHECK_ARG(on >= 0 && on < 2048);     // bits 1..4 = loop ablations of the DMA kernel (results are then WRONG);
+    bf16_dma_on = on & 1;                    // bits 5..7: 0 = the dispatch rule, 1 + shape = that DMA tile shape wherever it fits,
+    bf16_dma_ablate = ((on >> 1) & 15) | ((on >> 8) << 4);   //    5 = only the 256 x 256 rule of round 3
+    bf16_dma_force = (on >> 5) & 7;          // bits 8..10: epilogue (16 = stores dropped by the range check, 32 = none, 64 = the direct round-3 form)
     return CPR_OK;
 }
 #else
-constexpr int bf16_dma_on = 1, bf16_dma_ablate = 0;
+constexpr int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0;
 #endif
+
+// Which LDS-DMA tile (conv_bf16_dma.hip) a layer takes: 0 = 256 x 256, 3 = 128 x 128 (two workgroups per CU), -1 = none (the
+// register-staged kernels below).  Measured on the R101 1024^2 B = 8 and R50 640^2 B = 64 layer shapes
+// (profiles/round4_bf16_tiles_and_epilogue.txt): the big tile wins where the layer is MFMA-bound (K >= 1024) and
+// has tiles for 1.5 rounds over the CUs; everything else that fits takes the small one.  GroupNorm statistics slots are 128
+// pixels = one wave row of the big tile only.
+static int bf16_dma_shape(long long M, int Cin, int Cout, int kchunks, bool gn) {
+    if (Cin % 64 != 0 || kchunks < 1) return -1;
+    if (bf16_dma_force >= 1 && bf16_dma_force <= 4) return bf16_dma_force - 1;
+    const long long t256 = Cout % 256 == 0 ? ((M + 255) / 256) * (Cout / 256) : 0;
+    const bool big_ok = t256 >= 384 && kchunks >= 2;
+    if (bf16_dma_force == 5 || gn) return big_ok ? 0 : -1;
+    if (big_ok && kchunks >= 16) return 0;
+    if (Cout % 128 == 0 && ((M + 127) / 128) * (Cout / 128) >= 256) return 3;
+    return big_ok ? 0 : -1;
+}
 
 static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                                   const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
@@ -352,9 +369,10 @@ static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, co
     p.M = (int)M;
     if (gn_part) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
     // the wide layers with enough 256 x 256 tiles for two rounds over the CUs: LDS-DMA staged kernel (conv_bf16_dma.hip)
-    if (bf16_dma_on && Cout % 256 == 0 && Cin % 64 == 0 && Kpad / BKH >= 2 && ((M + 255) / 256) * (Cout / 256) >= 384) {
+    const int dshape = bf16_dma_on ? bf16_dma_shape(M, Cin, Cout, Kpad / BKH, gn_part != nullptr) : -1;
+    if (dshape >= 0) {
         const int rc = conv_bf16_dma_launch(in, wgt, out, scale, bias, residual, gn_part, N, H, W, Cin, Cout, KH, KW, stride,
-                                            pad, Kpad, relu, out_fp32, variant_out, stream, bf16_dma_ablate);
+                                            pad, Kpad, relu, out_fp32, variant_out, stream, bf16_dma_ablate, dshape);
         if (rc != CPR_ERR_UNSUPPORTED) return rc;
     }
     const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);

@@ -19,6 +19,7 @@ ap.add_argument('--k', type=int, default=3)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--plain', action='store_true')
 ap.add_argument('--gn-stats', action='store_true', help='plain input, GroupNorm statistics in the epilogue (the forward\'s dominant launch)')
+ap.add_argument('--res', action='store_true', help='bottleneck conv3 form: folded-BN scale / shift + residual + ReLU (with --plain)')
 ap.add_argument('--bf16', action='store_true', help='bf16 compute mode kernel (plain input, GN stats epilogue)')
 ap.add_argument('--no-wino', action='store_true', help='keep the 3x3 layer on the direct implicit GEMM')
 ap.add_argument('--b8', action='store_true', help='Winograd layer with channel-blocked input and output + fused input affine')
@@ -27,7 +28,7 @@ ap.add_argument('--wino-ablate', type=int, default=0)
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--pipeline', type=int, default=1)
 ap.add_argument('--w32', default='0,2,100', help='conv_wino32 debug: ablate,workgroups per CU,stagger percent')
-ap.add_argument('--bf16-dma', type=int, default=1, help='bf16 mode: 0 = keep the layer on the register-staged kernel (A/B)')
+ap.add_argument('--bf16-dma', type=int, default=1, help='bf16 mode: 0 = keep the layer on the register-staged kernel (A/B); + 32 * f: f = 1..3 forces DMA tile 256x256 / 128x256 / 256x128, 4 = the round-3 rule')
 args = ap.parse_args()
 from pointtinybenchmark_amd import _lib  # noqa: E402
 ops.WINOGRAD[0] = not args.no_wino
@@ -42,29 +43,41 @@ w = (torch.randn((args.cout, args.cin, args.k, args.k), generator=g) * 0.02).cud
 pc = ops.PackedConv(w, 1, args.k // 2, torch.bfloat16 if args.bf16 else torch.float32)
 if args.bf16:
     x = x.bfloat16()
-    args.gn_stats = True
+    args.gn_stats = not args.plain
 a = (torch.rand((args.batch, args.cin), generator=g) + 0.5).cuda()
 b = torch.randn((args.batch, args.cin), generator=g).cuda()
 if args.b8:
     xb = x.view(args.batch, args.hw, args.hw, args.cin // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
     run_b8 = lambda: ops.conv3x3_wino(xb, pc, gn_part=True, in_ab=(a, b), in_relu=True, out_b8=True)
+if args.res:
+    oh = args.hw
+    res_t = torch.randn((args.batch, oh, oh, args.cout), generator=g).to(x.dtype).cuda()
+    sc_t = (torch.rand(args.cout, generator=g) + 0.5).cuda()
+    bi_t = torch.randn(args.cout, generator=g).cuda()
+    plain = lambda: ops.conv2d(x, pc, scale=sc_t, bias=bi_t, residual=res_t, relu=True)
+else:
+    plain = lambda: ops.conv2d(x, pc)
 for _ in range(args.iters):
     if args.b8:
         run_b8()
     elif args.plain:
-        ops.conv2d(x, pc)
+        plain()
     elif args.gn_stats:
         ops.conv2d(x, pc, gn_part=True)
     else:
         ops.conv2d(x, pc, in_ab=(a, b), in_relu=True, gn_part=True)
 torch.cuda.synchronize()
+ops.TRACE_CONV_VARIANT[0] = True
+(run_b8 if args.b8 else plain if args.plain else (lambda: ops.conv2d(x, pc, gn_part=True)) if args.gn_stats else (lambda: None))()
+variant = ops.TRACE_CONV_VARIANT[1]
+ops.TRACE_CONV_VARIANT[0] = False
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(args.iters):
     if args.b8:
         run_b8()
     elif args.plain:
-        ops.conv2d(x, pc)
+        plain()
     elif args.gn_stats:
         ops.conv2d(x, pc, gn_part=True)
     else:
@@ -73,5 +86,5 @@ e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / args.iters
 fl = 2.0 * args.batch * args.hw * args.hw * args.cout * args.cin * args.k * args.k
-print('conv %dx%d %d->%d k%d B=%d: %.3f ms  %.1f TFLOP/s' % (args.hw, args.hw, args.cin, args.cout, args.k, args.batch,
-                                                              ms, fl / ms / 1e9))
+print('conv %dx%d %d->%d k%d B=%d: %.3f ms  %.1f TFLOP/s  variant %s' % (args.hw, args.hw, args.cin, args.cout, args.k, args.batch,
+                                                              ms, fl / ms / 1e9, variant))
