@@ -67,6 +67,10 @@ class _Block(nn.Module):
         return out
 
 
+BF16_STEM_POOL = [os.environ.get('CPR_BF16_STEM_POOL', '1') != '0']   # 0: stem conv and max-pool as two kernels
+BF16_STEM = [os.environ.get('CPR_BF16_STEM', '1') != '0']     # 0: the bf16 mode keeps its stem on the fp32 kernel (A/B, tests)
+
+
 @BACKBONES.register_module()
 class ResNet(nn.Module):
     arch_settings = {18: ('basic', (2, 2, 2, 2)), 34: ('basic', (3, 4, 6, 3)), 50: ('bottleneck', (3, 4, 6, 3)),
@@ -154,8 +158,18 @@ class ResNet(nn.Module):
         # (N,3,H,W) float image -> NHWC4; a 4-channel channels-last view (datasets.GpuImagePipeline output) is taken as is
         x = ops.from_nchw(x) if (x.shape[1] > 4 or (x.shape[1] == 4 and x.stride(1) == 1)) else ops.nchw_to_nhwc(x)
         s, b = folded_bn(c, self.bn1)
-        # bf16 compute mode: the 3-channel stem stays on the fp32 kernel and emits a bf16 map
-        x = ops.conv2d(x, packed_conv(c, self.conv1), scale=s, bias=b, relu=True, out_dtype=self.compute_dtype)
+        c1 = self.conv1
+        if self.compute_dtype == torch.bfloat16 and BF16_STEM[0] and tuple(c1.weight.shape) == (64, 3, 7, 7) and \
+                c1.stride == (2, 2) and c1.padding == (3, 3) and x.dtype == torch.float32 and x.shape[-1] == 4 and \
+                ops.stem_bf16_fits(x):
+            # bf16 compute mode: the stem on the bf16 matrix cores (csrc/stem_bf16.hip; round 4)
+            wp = c.get(('stem_bf16', id(c1)), [c1.weight], lambda: ops.stem_weight_bf16(c1.weight))
+            if BF16_STEM_POOL[0]:
+                return ops.stem7x7s2_pool_bf16(x, wp, scale=s, bias=b)       # conv + BN + ReLU + max-pool, one kernel
+            x = ops.stem7x7s2_bf16(x, wp, scale=s, bias=b, relu=True)
+        else:
+            # (other stems of the bf16 mode stay on the fp32 kernel, which then emits the bf16 map)
+            x = ops.conv2d(x, packed_conv(c, c1), scale=s, bias=b, relu=True, out_dtype=self.compute_dtype)
         return ops.maxpool3x3s2(x)
 
     def run_stage(self, i, x, tape=None):

@@ -284,7 +284,8 @@ __device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 
 }
 
 template <int MI, int NJ>
-__global__ __launch_bounds__(512, (MI * NJ <= 2 ? 2 : 1)) void conv_bf16_dma_kernel(ConvDmaParams p) {
+__global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_kernel   // (threads, waves per SIMD): 2 or 1 workgroups per CU
+(ConvDmaParams p) {
     using T = DmaTile<MI, NJ>;
     constexpr int DBM = T::BM, DBN = T::BN, DSTAGE = T::STAGE, NM = T::NM, NF = T::NF, NP = T::NP, NPA = T::NPA;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];

@@ -388,6 +388,39 @@ def bn_fold(gamma, beta, mean, var, eps, want_inv_sigma=False):
     return scale, shift, inv
 
 
+def stem_weight_bf16(weight):
+    """(64, 3, 7, 7) conv1 weight -> the (64, 224) bf16 image of csrc/stem_bf16.hip: k = (kh * 8 + kw) * 4 + c, zero at kw = 7
+    and c = 3."""
+    assert tuple(weight.shape) == (64, 3, 7, 7), tuple(weight.shape)
+    w = torch.zeros((64, 7, 8, 4), device=weight.device, dtype=torch.float32)
+    w[:, :, :7, :3] = weight.detach().float().permute(0, 2, 3, 1)
+    return w.reshape(64, 224).to(torch.bfloat16).contiguous()
+
+
+def stem_bf16_fits(x):
+    N, H, W, _ = x.shape
+    return N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1) * 64 * 2 < (1 << 31)
+
+
+def stem7x7s2_bf16(x, wpack, scale=None, bias=None, relu=True):
+    """ResNet stem of the bf16 compute mode: x (N,H,W,4) fp32 NHWC4 -> (N,OH,OW,64) bf16 = ReLU(conv7x7/2(x) * scale + bias)."""
+    N, H, W, C = _check(x).shape
+    assert C == 4 and x.dtype == torch.float32 and wpack.dtype == torch.bfloat16 and tuple(wpack.shape) == (64, 224)
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), device=x.device, dtype=torch.bfloat16)
+    _lib.call('cpr_stem7x7s2_bf16', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, int(relu), _stream())
+    return out
+
+
+def stem7x7s2_pool_bf16(x, wpack, scale=None, bias=None):
+    """stem7x7s2_bf16 (with ReLU) + maxpool3x3s2 in one kernel: x (N,H,W,4) fp32 -> (N,PH,PW,64) bf16; same bits as the pair."""
+    N, H, W, C = _check(x).shape
+    assert C == 4 and x.dtype == torch.float32 and wpack.dtype == torch.bfloat16 and tuple(wpack.shape) == (64, 224)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, (OH - 1) // 2 + 1, (OW - 1) // 2 + 1, 64), device=x.device, dtype=torch.bfloat16)
+    _lib.call('cpr_stem7x7s2_pool_bf16', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, _stream())
+    return out
+
+
 def maxpool3x3s2(x):
     N, H, W, C = _check(x, ACT).shape
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), device=x.device, dtype=x.dtype)

@@ -140,6 +140,41 @@ def test_conv2d_bf16_dma_kernel_vs_torch(case):
         np.testing.assert_allclose(s_[..., 1].numpy(), (ref * ref).sum(dim=(2, 3)).numpy(), rtol=1e-3, atol=5e-2)
 
 
+@pytest.mark.parametrize('N,H,W,seed', [(2, 64, 96, 0), (1, 61, 75, 1), (2, 224, 224, 2), (1, 7, 5, 3), (1, 130, 258, 4)])
+def test_stem_bf16_vs_torch(N, H, W, seed):
+    """csrc/stem_bf16.hip (round 4): conv 7x7 / 2 / pad 3, 3 -> 64 + folded BN + ReLU on the bf16 matrix cores against F.conv2d in
+    fp32 on the SAME bf16-rounded image and weights: |err| <= 2^-7 |ref| + 2e-3 (one bf16 rounding of the output; sums of 147
+    products in fp32), odd sizes, partial tiles and maps smaller than a tile included; and against the fp32-kernel stem that the
+    mode used before (same bar on its own bf16 output)."""
+    from pointtinybenchmark_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn((N, 3, H, W), generator=g) * 1.2
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.08
+    scale = torch.rand(64, generator=g) + 0.5
+    bias = torch.randn(64, generator=g) * 0.3
+    ref = F.conv2d(img.bfloat16().float(), w.bfloat16().float(), None, 2, 3)
+    ref = F.relu(ref * scale[None, :, None, None] + bias[None, :, None, None])
+    x = ops.nchw_to_nhwc(img.cuda())
+    assert x.shape[-1] == 4
+    out = ops.stem7x7s2_bf16(x, ops.stem_weight_bf16(w.cuda()), scale.cuda(), bias.cuda(), relu=True)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (N, ref.shape[2], ref.shape[3], 64)
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    tol = 2.0 ** -7 * ref.abs() + 2e-3
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), 'max abs err %.3e, %d/%d over tol' % (float((got - ref).abs().max()), int(bad.sum()), bad.numel())
+    old = ops.conv2d(x, ops.PackedConv(w.cuda(), 2, 3), scale=scale.cuda(), bias=bias.cuda(), relu=True, out_dtype=torch.bfloat16)
+    ref32 = F.relu(F.conv2d(img, w, None, 2, 3) * scale[None, :, None, None] + bias[None, :, None, None])
+    d = (got - old.float().permute(0, 3, 1, 2).cpu()).abs()
+    assert float(d.max()) <= 0.03 * float(ref32.abs().max()), float(d.max())      # bf16 inputs vs fp32 inputs: 8-bit operands
+    # the fused conv + BN + ReLU + max-pool kernel: the SAME bits as the two kernels one after the other
+    fused = ops.stem7x7s2_pool_bf16(x, ops.stem_weight_bf16(w.cuda()), scale.cuda(), bias.cuda())
+    pair = ops.maxpool3x3s2(out)
+    torch.cuda.synchronize()
+    assert fused.shape == pair.shape and torch.equal(fused, pair), 'fused stem + pool differs from conv -> pool: %d entries' % int(
+        (fused != pair).sum())
+
+
 def test_bf16_aux_kernels():
     from pointtinybenchmark_amd import ops
     g = torch.Generator().manual_seed(2)
