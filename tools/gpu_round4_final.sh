@@ -20,11 +20,15 @@ echo "bench exit: $?"; cut -c1-300 gpurun_out/${TAG}_bench.json; echo
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG}_b2 -- python $OLDPWD/bench.py --batch 2 --steps 20 --warmup 3 --no-cpu-baseline --no-probe --train-steps 0 --small-batch 0 --batch-sweep '' > /tmp/prof_${TAG}_b2.log 2>&1 )
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG}_cfg2 -- python $OLDPWD/bench.py --config cfg2 --steps 5 --warmup 2 --no-cpu-baseline --no-probe --train-steps 0 --small-batch 0 --batch-sweep '' > /tmp/prof_${TAG}_cfg2.log 2>&1 )
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG}_p2p -- python $OLDPWD/bench.py --config cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-probe --train-steps 0 --small-batch 0 --batch-sweep '' > /tmp/prof_${TAG}_p2p.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG}_cfg4 -- python $OLDPWD/bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline --no-probe --train-steps 0 --small-batch 0 --batch-sweep '' > /tmp/prof_${TAG}_cfg4.log 2>&1 )
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG}_train_b64 -- python $OLDPWD/bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline --no-probe > /tmp/prof_${TAG}_train.log 2>&1 )
 find /tmp/prof_${TAG} -name "*kernel_stats*" -exec cp {} gpurun_out/ \; 2>/dev/null
 # one line per BASELINE config at its own shape, each with roofline + cpu_baseline (+ parity gate where the mode is fp32 CPR)
 for m in "--config cfg0" "--config cfg2" "--config cfg3" "--config cfg3 --mode infer" "--config cfg4" "--depth 101 --size 1024 --batch 8"; do
   n=$(echo $m | tr -d ' -'); timeout 600 python bench.py $m --steps 10 --warmup 3 --batch-sweep '' --train-steps 0 2>gpurun_out/${TAG}_bench_$n.err | tail -1 > gpurun_out/${TAG}_bench_$n.json; cut -c1-220 gpurun_out/${TAG}_bench_$n.json; echo
+done
+for m in "--config cfg4 --no-probe" "--dtype bf16 --no-probe"; do
+  n=$(echo $m | tr -d ' -'); timeout 600 python bench.py $m --steps 10 --warmup 3 --no-cpu-baseline --batch-sweep '' --train-steps 0 --small-batch 0 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$n.json; cut -c1-220 gpurun_out/${TAG}_bench_$n.json; echo
 done
 timeout 600 python bench.py --mode train --batch 64 --steps 6 --warmup 2 --no-cpu-baseline --no-probe 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_modetrainbatch64.json; cut -c1-200 gpurun_out/${TAG}_bench_modetrainbatch64.json; echo
 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29621 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-probe --small-batch 0 --batch-sweep '' --train-steps 4 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_torchrun_1rank.json
