@@ -136,6 +136,11 @@ int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, v
 /* (N,H,W,C) -> dense (N,C,H,W) (export in the reference's layout) */
 int cpr_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, void* stream);
 /* nn.MaxPool2d(3, 2, 1) of the ResNet stem (resnet.py:610,637); NHWC */
+/* The ResNet stem in one kernel, exact fp32 (resnet.py:630-637): conv 7x7 / stride 2 / pad 3, 3 -> 64 + folded BatchNorm + ReLU
+ * + max-pool 3x3 / stride 2 / pad 1.  in (N,H,W,4) fp32 (4th channel ignored), wgt (64, 154) fp32 = [cout][kh][kw * 3 + c] with
+ * slot 21 of every kernel row zero, out (N, PH, PW, 64) fp32, OH = (H-1)/2+1, PH = (OH-1)/2+1. */
+int cpr_stem7x7s2_pool_f32(const float* in, const float* wgt, const float* scale, const float* bias, float* out, int N, int H,
+                           int W, void* stream);
 int cpr_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, void* stream);
 
 /* GroupNorm of mmcv ConvModule (fpn.py:124-144, cpr_head.py:990-991) as three streaming steps:

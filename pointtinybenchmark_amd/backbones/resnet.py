@@ -67,6 +67,7 @@ class _Block(nn.Module):
         return out
 
 
+F32_STEM = [os.environ.get('CPR_F32_STEM', '1') != '0']       # 0: stem conv on the implicit-GEMM kernel + separate max-pool (A/B, tests)
 BF16_STEM_POOL = [os.environ.get('CPR_BF16_STEM_POOL', '1') != '0']   # 0: stem conv and max-pool as two kernels
 BF16_STEM = [os.environ.get('CPR_BF16_STEM', '1') != '0']     # 0: the bf16 mode keeps its stem on the fp32 kernel (A/B, tests)
 
@@ -167,8 +168,13 @@ class ResNet(nn.Module):
             if BF16_STEM_POOL[0]:
                 return ops.stem7x7s2_pool_bf16(x, wp, scale=s, bias=b)       # conv + BN + ReLU + max-pool, one kernel
             x = ops.stem7x7s2_bf16(x, wp, scale=s, bias=b, relu=True)
+        elif self.compute_dtype == torch.float32 and F32_STEM[0] and tuple(c1.weight.shape) == (64, 3, 7, 7) and \
+                c1.stride == (2, 2) and c1.padding == (3, 3) and x.dtype == torch.float32 and x.shape[-1] == 4:
+            # conv + BN + ReLU + max-pool in one exact-fp32 kernel (csrc/stem_f32.hip; round 4)
+            wp = c.get(('stem_f32', id(c1)), [c1.weight], lambda: ops.stem_weight_f32(c1.weight))
+            return ops.stem7x7s2_pool_f32(x, wp, scale=s, bias=b)
         else:
-            # (other stems of the bf16 mode stay on the fp32 kernel, which then emits the bf16 map)
+            # (other stems: the implicit-GEMM kernel in its stem mode; in the bf16 mode it emits the bf16 map)
             x = ops.conv2d(x, packed_conv(c, c1), scale=s, bias=b, relu=True, out_dtype=self.compute_dtype)
         return ops.maxpool3x3s2(x)
 

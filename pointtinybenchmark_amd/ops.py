@@ -388,6 +388,26 @@ def bn_fold(gamma, beta, mean, var, eps, want_inv_sigma=False):
     return scale, shift, inv
 
 
+def stem_weight_f32(weight):
+    """(64, 3, 7, 7) conv1 weight -> the (64, 154) fp32 image of csrc/stem_f32.hip: [cout][kh][kw * 3 + c], slot 21 of every
+    kernel row zero."""
+    assert tuple(weight.shape) == (64, 3, 7, 7), tuple(weight.shape)
+    w = torch.zeros((64, 7, 22), device=weight.device, dtype=torch.float32)
+    w[:, :, :21] = weight.detach().float().permute(0, 2, 3, 1).reshape(64, 7, 21)
+    return w.reshape(64, 154).contiguous()
+
+
+def stem7x7s2_pool_f32(x, wpack, scale=None, bias=None):
+    """The whole ResNet stem in one kernel, exact fp32: x (N,H,W,4) NHWC4 -> (N,PH,PW,64) =
+    maxpool3x3s2(ReLU(conv7x7/2(x) * scale + bias))."""
+    N, H, W, C = _check(x).shape
+    assert C == 4 and x.dtype == torch.float32 and wpack.dtype == torch.float32 and tuple(wpack.shape) == (64, 154)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, (OH - 1) // 2 + 1, (OW - 1) // 2 + 1, 64), device=x.device, dtype=torch.float32)
+    _lib.call('cpr_stem7x7s2_pool_f32', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, _stream())
+    return out
+
+
 def stem_weight_bf16(weight):
     """(64, 3, 7, 7) conv1 weight -> the (64, 224) bf16 image of csrc/stem_bf16.hip: k = (kh * 8 + kw) * 4 + c, zero at kw = 7
     and c = 3."""

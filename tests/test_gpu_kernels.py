@@ -215,6 +215,33 @@ def test_maxpool(shape):
     assert torch.equal(out.permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 3, 2, 1))
 
 
+@pytest.mark.parametrize('N,H,W,seed', [(2, 64, 96, 0), (1, 61, 75, 1), (2, 224, 224, 2), (1, 7, 5, 3), (1, 130, 258, 4), (3, 33, 129, 5)])
+def test_fused_stem_vs_torch_and_the_two_kernel_path(N, H, W, seed):
+    """csrc/stem_f32.hip (round 4): conv 7x7 / 2 / pad 3 (3 -> 64) + folded BN + ReLU + max-pool 3x3 / 2 / pad 1 in one exact-fp32
+    kernel (resnet.py:630-637).  Against torch in fp64 (conv -> affine -> ReLU -> max_pool2d): <= 2e-6 of the map's max + 1e-6
+    (fp32 sums of 147 products); against the path it replaces (implicit-GEMM stem + maxpool3x3s2_kernel): <= 4e-6 of the max
+    (two fp32 summation orders).  Odd sizes, partial tiles, maps smaller than one tile, negative-heavy outputs (ReLU zeros next to the
+    pool's padding)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn((N, 3, H, W), generator=g) * 1.2
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.08
+    scale = torch.rand(64, generator=g) + 0.5
+    bias = torch.randn(64, generator=g) * 0.6 - 0.3
+    ref = F.conv2d(img.double(), w.double(), None, 2, 3)
+    ref = F.max_pool2d(F.relu(ref * scale.double()[None, :, None, None] + bias.double()[None, :, None, None]), 3, 2, 1).float()
+    x = ops.nchw_to_nhwc(img.cuda())
+    out = ops.stem7x7s2_pool_f32(x, ops.stem_weight_f32(w.cuda()), scale.cuda(), bias.cuda())
+    old = ops.maxpool3x3s2(ops.conv2d(x, ops.PackedConv(w.cuda(), 2, 3), scale=scale.cuda(), bias=bias.cuda(), relu=True))
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (N, ref.shape[2], ref.shape[3], 64) and out.shape == old.shape
+    got = out.permute(0, 3, 1, 2).cpu()
+    mx = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-6 * mx + 1e-6, float((got - ref).abs().max())
+    assert float((out - old).abs().max()) <= 4e-6 * mx + 1e-6, float((out - old).abs().max())
+    assert float((got == 0).float().mean()) > 0.001       # the ReLU really clips here
+
+
 @pytest.mark.parametrize('shape,up', [((2, 256, 20, 28), (10, 14)), ((1, 256, 25, 21), (13, 11))])
 def test_gn_apply_with_nearest_upsample_add(shape, up):
     ops = _ops()
