@@ -755,6 +755,7 @@ def main():
         try:
             trainer = make_trainer()
             train_step()
+            train_step()          # two untimed steps: the first one grows the allocator by the recorded maps of a step
             barrier()
             t1 = time.perf_counter()
             for _ in range(args.train_steps):
