@@ -60,9 +60,17 @@ constexpr int DBK = 64;
 //            and R101's layer3 at 1024^2 B = 8 (M = 32 768: 128 tiles of 256 x 256 for 256 CUs) fills the chip.
 //   <2, 2> = 128 x 256 and <4, 1> = 256 x 128 were built and measured too (profiles/round4_bf16_tiles_and_epilogue.txt): never
 //            ahead of <2, 1>; not instantiated.
-template <int MI, int NJ> struct DmaTile {
-    static constexpr int BM = 64 * MI, BN = 128 * NJ;
-    static constexpr int NPA = MI, NPW = 2 * NJ, NP = NPA + NPW;       // 8 KB request pieces per chunk: activations, weights
+//   <4, 4, 2> = 256 x 256 on FOUR waves (WN = 2 wave columns; wave = 128 x 128 = 256 accumulator registers in AGPRs, one wave per
+//            SIMD): 8 fragment reads per 16 MFMAs instead of 6 per 8, i.e. a third less LDS read traffic -- built to test whether
+//            LDS bandwidth is what holds <4, 2> at 0.42 (its reads + DMA writes are 256 KB per chunk against 262 KB of LDS
+//            cycles).  Bit-equal to <4, 2> and 10-12 % SLOWER on every shape tried: one wave per SIMD has nobody
+//            to cover its waits.  Measurement build only.
+template <int MI, int NJ, int WN = 4> struct DmaTile {
+    static constexpr int NT = 128 * WN;                                // threads: 2 wave rows x WN wave columns
+    static constexpr int RP = NT / 8;                                  // rows one request piece covers (a wave instruction = 8 rows)
+    static constexpr int PIECE = NT * 16;                              // bytes per piece
+    static constexpr int BM = 64 * MI, BN = WN * NJ * 32;
+    static constexpr int NPA = BM / RP, NPW = BN / RP, NP = NPA + NPW; // request pieces per chunk: activations, weights
     static constexpr int NM = MI * NJ, NF = MI + NJ;                   // MFMAs / fragment reads per wave per k-step
     static constexpr int STAGE = (BM + BN) * DBK * 2;                  // bytes per stage
     // the chunk's pieces over three k-steps, in their LAST MFMA slots: C3 behind the barrier (k-step 3), C0 in k-step 0, C1 in k-step 1
@@ -170,7 +178,7 @@ __device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 
     constexpr int BN = 128 * NJ, HI = MI / 2;                  // HI pixel blocks per wave per half tile
     constexpr int LPR = BN / 4, RPI = 64 / LPR;                // lanes per row, rows per wave instruction of the read-out
     constexpr int HROWS = 32 * MI, PASSES = HROWS / (8 * RPI); // rows per half tile, read-out instructions per wave per half
-    static_assert(MI % 2 == 0 && HROWS * BN * 4 <= 2 * DmaTile<MI, NJ>::STAGE, "half a tile of fp32 must fit the two stages");
+    static_assert(MI % 2 == 0 && HROWS * BN * 4 <= 2 * DmaTile<MI, NJ, 4>::STAGE, "half a tile of fp32 must fit the two stages");
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int l31 = lane & 31, half = lane >> 5;
     float* tile = reinterpret_cast<float*>(smem);
@@ -283,11 +291,12 @@ __device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 
     }
 }
 
-template <int MI, int NJ>
-__global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_kernel   // (threads, waves per SIMD): 2 or 1 workgroups per CU
+template <int MI, int NJ, int WN>
+__global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_kernel   // (threads, waves per SIMD)
 (ConvDmaParams p) {
-    using T = DmaTile<MI, NJ>;
-    constexpr int DBM = T::BM, DBN = T::BN, DSTAGE = T::STAGE, NM = T::NM, NF = T::NF, NP = T::NP, NPA = T::NPA;
+    using T = DmaTile<MI, NJ, WN>;
+    constexpr int DBM = T::BM, DBN = T::BN, DSTAGE = T::STAGE, NM = T::NM, NF = T::NF, NP = T::NP, NPA = T::NPA, NPW = T::NPW;
+    constexpr int RP = T::RP, PIECE = T::PIECE;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
 
     // XCD-aware tile order (block b runs on XCD b % 8; an XCD walks a contiguous run of tiles, cout tiles fastest)
@@ -313,17 +322,17 @@ __global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_ker
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- staging role: piece j of an operand = rows 64 j + (tid >> 3), 16-byte unit (tid & 7) of the 128-byte row; the
+    // ---- staging role: piece j of an operand = rows RP j + (tid >> 3), 16-byte unit (tid & 7) of the 128-byte row; the
     // lane fetches the k-unit (tid & 7) ^ swz, swz = (row >> 1) & 7 = (tid >> 4) & 7 for every j
     const int srow = tid >> 3;
     const int sunit = (tid & 7) ^ ((tid >> 4) & 7);
     const int ohw = p.OH * p.OW;
     const bool gemm = (p.KH == 1) & (p.KW == 1) & (p.stride == 1) & (p.pad == 0);
-    int iy0[MI], ix0[MI], rowoff[MI];
-    bool mok[MI];
+    int iy0[NPA], ix0[NPA], rowoff[NPA];
+    bool mok[NPA];
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-        const int m = m0 + srow + 64 * j;
+    for (int j = 0; j < NPA; ++j) {
+        const int m = m0 + srow + RP * j;
         mok[j] = m < p.M;
         const int mm = mok[j] ? m : 0;
         if (gemm) {
@@ -345,10 +354,10 @@ __global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_ker
                           (int)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000};
     const i32x4v rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32) & 0xffff,
                          (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000};
-    int woff[2 * NJ];
+    int woff[NPW];
 #pragma unroll
-    for (int j = 0; j < 2 * NJ; ++j) {
-        const int c = n0 + srow + 64 * j;
+    for (int j = 0; j < NPW; ++j) {
+        const int c = n0 + srow + RP * j;
         woff[j] = c < p.Cout ? (c * p.Kpad) * 2 + sunit * 16 : (int)0x80000000;
     }
     // K order: channel chunk OUTER, tap INNER.  Consecutive chunks then read the same 128-byte segments of pixels one tap
@@ -358,11 +367,11 @@ __global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_ker
     // K offset tap * Cin + c0.
     int kh = 0, kw = 0, c0 = nt ? nt_split * p.nt_chunks * DBK : 0;     // tap / channel chunk of the NEXT chunk to be requested (wave-uniform)
     int wsoff = 0;                  // byte offset of that chunk inside a weight row
-    int voffA[MI];
+    int voffA[NPA];
     auto refresh_rows = [&]() {
         const int tapshift = (kh * p.W + kw) * p.Cin;
 #pragma unroll
-        for (int j = 0; j < MI; ++j) {
+        for (int j = 0; j < NPA; ++j) {
             const int iy = iy0[j] + kh, ix = ix0[j] + kw;
             const bool ok = mok[j] & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             voffA[j] = ok ? (rowoff[j] + tapshift) * 2 + sunit * 16 : (int)0x80000000;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_ker
         const int base = lds0 + buf * DSTAGE + wave * 1024;
         if (z < NPA) {
             if (z == 0) wsoff = ((kh * p.KW + kw) * p.Cin + c0) * 2;
-            dma(rs_in, voffA[z < NPA ? z : 0], c0 * 2, base + z * 8192);
+            dma(rs_in, voffA[z < NPA ? z : 0], c0 * 2, base + z * PIECE);
             if (z == NPA - 1) {      // after the last activation piece: advance the tap / channel state to the next chunk
                 if (++kw == p.KW) {
                     kw = 0;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_ker
                 if (p.KH * p.KW > 1) refresh_rows();
             }
         } else {
-            dma(rs_w, woff[z >= NPA ? z - NPA : 0], wsoff, base + DBM * DBK * 2 + (z - NPA) * 8192);
+            dma(rs_w, woff[z >= NPA ? z - NPA : 0], wsoff, base + DBM * DBK * 2 + (z - NPA) * PIECE);
         }
     };
 
@@ -444,12 +453,10 @@ __global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_ker
     if (KT > 1) {
 #pragma unroll
         for (int z = 0; z < C3; ++z) stage_piece(1, 1, z);
-        if (C3 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // chunk 0 has landed, chunk 1's pieces stay in flight
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C3) : "memory");         // chunk 0 has landed, chunk 1's pieces stay in flight
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    static_assert(C3 == 3 || C3 == 2, "prologue wait count");
     __syncthreads();
 #pragma unroll
     for (int z = 0; z < NF; ++z) DFRAG(fa0, fb0, 0, 0, z);
@@ -508,6 +515,7 @@ __global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_ker
         dma_epilogue<MI, NJ>(q, acc, tm, m0, n0, wm, wn, lane);
         return;
     }
+    static_assert(WN == 4 || MI * NJ > 2, "the LDS epilogue is written for eight waves");
     // the 256 x 256 instance keeps the direct epilogue: its layers are MFMA-bound 3x3s whose statistics epilogue measured 12 %
     // SLOWER through LDS (1.80 -> 2.06 ms on the head layer at B = 64; profiles/round4_bf16_tiles_and_epilogue.txt)
     if constexpr (MI * NJ > 2) dma_epilogue<MI, NJ>(p, acc, tm, m0, n0, wm, wn, lane);
@@ -527,7 +535,8 @@ __global__ __launch_bounds__(512, (MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_ker
 // profiles/round3_bf16_dma_kernel_development.txt.)
 
 // The launcher of conv_mfma_bf16.hip calls this for the layers that fit the tile; returns CPR_ERR_UNSUPPORTED otherwise.
-// shape: 0 = 256 x 256, 1 = 128 (pixels) x 256 (couts), 2 = 256 x 128, 3 = 128 x 128 (64 KB of LDS: two workgroups per CU).
+// shape: 0 = 256 x 256, 1 = 128 (pixels) x 256 (couts), 2 = 256 x 128, 3 = 128 x 128 (64 KB of LDS: two workgroups per CU),
+// 4 = 256 x 256 on four waves (wave = 128 x 128).
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                          const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
@@ -552,12 +561,17 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
     if (gn_part && bm != 256) return CPR_ERR_UNSUPPORTED;         // a wave of the 128-pixel tile owns half a statistics slot
     p.tilesM = (int)((M + bm - 1) / bm);
     p.tilesN = Cout / bn;
-    if (variant_out) *variant_out = bm * 1000 + bn + (shape == 3 ? 1000000 : 0);       // 128128 alone is the register-staged <128, 128>
+    if (variant_out) *variant_out = bm * 1000 + bn + (shape == 3 ? 1000000 : shape == 4 ? 2000000 : 0);       // 128128 alone is the register-staged <128, 128>
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
     if (shape == 1 || shape == 2) return CPR_ERR_UNSUPPORTED;      // <2, 2> and <4, 1> were measured and dropped
-    if (shape == 3) hipLaunchKernelGGL((conv_bf16_dma_kernel<2, 1>), dim3(grid), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2>), dim3(grid), dim3(512), 0, stream, p);
+    if (shape == 3) hipLaunchKernelGGL((conv_bf16_dma_kernel<2, 1, 4>), dim3(grid), dim3(512), 0, stream, p);
+#ifdef CPR_BENCH_HOOKS   // measured 10-12 % slower than the eight-wave instance (profiles/round4_bf16_four_wave_tile.txt): measurement build only
+    else if (shape == 4) hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 4, 2>), dim3(grid), dim3(256), 0, stream, p);
+#else
+    else if (shape == 4) return CPR_ERR_UNSUPPORTED;
+#endif
+    else hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4>), dim3(grid), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }
 
@@ -579,6 +593,6 @@ int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, in
     p.nt_taps = k * k; p.nt_k = k; p.nt_pad = pad; p.nt_Wp = Wp; p.nt_chunks = chunks; p.nt_copy = copy;
     const long long blocks = (long long)splits * p.nt_taps * p.tilesM * p.tilesN;
     if (blocks >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }

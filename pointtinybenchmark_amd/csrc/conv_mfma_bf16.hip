@@ -324,7 +324,7 @@ static int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0;
 extern "C" int cpr_bf16_set_dma(int on) {   // measurement build: 0 = keep every layer on the register-staged kernels (A/B);
     CPR_CHECK_ARG(on >= 0 && on < 2048);     // bits 1..4 = loop ablations of the DMA kernel (results are then WRONG);
     bf16_dma_on = on & 1;                    // bits 5..7: 0 = the dispatch rule, 1 + shape = that DMA tile shape wherever it fits,
-    bf16_dma_ablate = ((on >> 1) & 15) | ((on >> 8) << 4);   //    5 = only the 256 x 256 rule of round 3
+    bf16_dma_ablate = ((on >> 1) & 15) | ((on >> 8) << 4);   //    6 = only the 256 x 256 rule of round 3
     bf16_dma_force = (on >> 5) & 7;          // bits 8..10: epilogue (16 = stores dropped by the range check, 32 = none, 64 = the direct round-3 form)
     return CPR_OK;
 }
@@ -339,10 +339,10 @@ constexpr int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0;
 // pixels = one wave row of the big tile only.
 static int bf16_dma_shape(long long M, int Cin, int Cout, int kchunks, bool gn) {
     if (Cin % 64 != 0 || kchunks < 1) return -1;
-    if (bf16_dma_force >= 1 && bf16_dma_force <= 4) return bf16_dma_force - 1;
+    if (bf16_dma_force >= 1 && bf16_dma_force <= 5) return bf16_dma_force - 1;
     const long long t256 = Cout % 256 == 0 ? ((M + 255) / 256) * (Cout / 256) : 0;
     const bool big_ok = t256 >= 384 && kchunks >= 2;
-    if (bf16_dma_force == 5 || gn) return big_ok ? 0 : -1;
+    if (bf16_dma_force == 6 || gn) return big_ok ? 0 : -1;
     if (big_ok && kchunks >= 16) return 0;
     if (Cout % 128 == 0 && ((M + 127) / 128) * (Cout / 128) >= 256) return 3;
     return big_ok ? 0 : -1;

@@ -20,6 +20,7 @@ ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--plain', action='store_true')
 ap.add_argument('--gn-stats', action='store_true', help='plain input, GroupNorm statistics in the epilogue (the forward\'s dominant launch)')
 ap.add_argument('--res', action='store_true', help='bottleneck conv3 form: folded-BN scale / shift + residual + ReLU (with --plain)')
+ap.add_argument('--check-against', type=int, default=-1, help='bf16: also run with this --bf16-dma word and require bit-equal outputs')
 ap.add_argument('--bf16', action='store_true', help='bf16 compute mode kernel (plain input, GN stats epilogue)')
 ap.add_argument('--no-wino', action='store_true', help='keep the 3x3 layer on the direct implicit GEMM')
 ap.add_argument('--b8', action='store_true', help='Winograd layer with channel-blocked input and output + fused input affine')
@@ -67,6 +68,15 @@ for _ in range(args.iters):
     else:
         ops.conv2d(x, pc, in_ab=(a, b), in_relu=True, gn_part=True)
 torch.cuda.synchronize()
+if args.check_against >= 0:
+    f = plain if args.plain else (lambda: ops.conv2d(x, pc, gn_part=True))
+    a1 = f()
+    _lib.call('cpr_bf16_set_dma', args.check_against)
+    a2 = f()
+    _lib.call('cpr_bf16_set_dma', args.bf16_dma)
+    torch.cuda.synchronize()
+    a1, a2 = (a1 if isinstance(a1, tuple) else (a1,)), (a2 if isinstance(a2, tuple) else (a2,))
+    print('bit-equal to word %d: %s' % (args.check_against, all(torch.equal(u, v) for u, v in zip(a1, a2))))
 ops.TRACE_CONV_VARIANT[0] = True
 (run_b8 if args.b8 else plain if args.plain else (lambda: ops.conv2d(x, pc, gn_part=True)) if args.gn_stats else (lambda: None))()
 variant = ops.TRACE_CONV_VARIANT[1]
