@@ -195,6 +195,89 @@ def test_ddp_wraps_the_drop_in_model_single_rank_rccl():
             assert torch.equal(p.grad, want[k]), k
 
 
+_DDP2_WORKER = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank, port, out = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+dist.init_process_group('gloo', rank=rank, world_size=2)      # two ranks on the box's one GPU: RCCL refuses that, gloo does not
+torch.cuda.set_device(0)
+from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+from oracle.gen_golden import CPR_CASES
+from pointtinybenchmark_amd import synthetic
+from tests.test_gpu_cpr_parity import build_hip_locator, to_cuda
+cfg = CPR_CASES['cpr_r18_c3_128']
+cb = to_cuda(synthetic.synthetic_batch(4, cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'], 5, True))
+sl = slice(2 * rank, 2 * rank + 2)
+m, _ = build_hip_locator(cfg)
+ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=2)
+fired = []
+def hook(state, bucket):
+    fired.append(bucket.buffer().numel())
+    return default_hooks.allreduce_hook(state, bucket)
+ddp.register_comm_hook(None, hook)
+opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4)
+logs = []
+for it in range(2):                                            # the reference's driver: forward -> _parse_losses -> backward -> clip -> step
+    opt.zero_grad()
+    losses = ddp(cb['img'][sl].contiguous(), cb['img_metas'][sl], return_loss=True, gt_bboxes=cb['gt_bboxes'][sl],
+                 gt_labels=cb['gt_labels'][sl])
+    loss, log_vars = m._parse_losses(losses)
+    loss.backward()
+    if it == 0:
+        g0 = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.requires_grad}
+    torch.nn.utils.clip_grad_norm_([p for p in m.parameters() if p.requires_grad], 35.0)
+    opt.step()
+    logs.append(log_vars['loss'])
+torch.cuda.synchronize()
+torch.save(dict(g0=g0, p={k: p.detach().cpu() for k, p in m.named_parameters() if p.requires_grad}, logs=logs, fired=fired),
+           out + '.%%d' %% rank)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_ddp_two_ranks_on_the_gpu_average_the_gradients(tmp_path):
+    """The reference's multi-GPU driver on the real kernels: torch DistributedDataParallel (MMDistributedDataParallel's base,
+    T/mmdet/apis/train.py:75-83) around BasicLocator in TWO processes -- a gloo group, since both ranks share the box's one GPU
+    -- each with its shard of a 4-image batch: ``loss.backward()`` runs the HIP backward behind the bridge's Functions, DDP's
+    hooks reduce the buckets, clip_grad_norm_ + torch.optim.SGD step.  After backward every rank must hold the MEAN of the two
+    shards' gradients (computed here by the native trainer on each shard), both ranks the same parameters after two steps."""
+    import subprocess
+    import sys
+    from pointtinybenchmark_amd.training import CprTrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'ddp2.py'
+    script.write_text(_DDP2_WORKER % dict(root=root))
+    port, out = str(30200 + os.getpid() % 300), str(tmp_path / 'res')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, out], cwd=root, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0].decode(errors='replace') for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(l[-1500:] for l in logs)
+    res = [torch.load(out + '.%d' % r) for r in range(2)]
+    cfg = CPR_CASES['cpr_r18_c3_128']
+    cb = to_cuda(synthetic.synthetic_batch(4, cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'], 5, True))
+    m, _ = build_hip_locator(cfg)
+    tr = CprTrainer(m)
+    want = {}
+    for r in range(2):
+        sl = slice(2 * r, 2 * r + 2)
+        tr.forward_backward(cb['img'][sl].contiguous(), cb['img_metas'][sl], cb['gt_bboxes'][sl], cb['gt_labels'][sl])
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            if p.requires_grad:
+                want[k] = want.get(k, 0) + p.grad.detach().cpu() * 0.5
+    assert sum(res[0]['fired']) >= sum(v.numel() for v in want.values()) and len(res[0]['fired']) >= 4, res[0]['fired'][:8]
+    for k, w in want.items():
+        for r in range(2):
+            d = float((res[r]['g0'][k] - w).abs().max())
+            assert d <= 1e-6 * max(float(w.abs().max()), 1e-6) + 1e-9, (r, k, d)
+    for k in want:
+        assert torch.equal(res[0]['p'][k], res[1]['p'][k]), k
+    assert res[0]['logs'] == res[1]['logs']                      # _parse_losses all-reduces the logged means
+
+
 def test_p2p_loss_backward_is_bit_equal_to_the_trainer():
     """The same bridge for BasicLocator(P2PHead) (configs[3]): per-image loss lists, (B, 2) upstream gradients."""
     import pointtinybenchmark_amd as P

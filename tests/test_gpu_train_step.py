@@ -304,3 +304,81 @@ def test_rccl_bucket_path_single_rank():
     # over one rank is the identity: EQUAL
     assert losses == ref_losses, (losses, ref_losses)
     assert torch.equal(p, ref_p), float((p - ref_p).abs().max())
+
+
+_TWO_RANK_WORKER = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank, port, out, reducer = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4]
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+dist.init_process_group('gloo', rank=rank, world_size=2)          # both ranks share the one GPU of the box: RCCL refuses that, gloo does not
+torch.cuda.set_device(0)
+from oracle.gen_golden import CPR_CASES
+from pointtinybenchmark_amd import synthetic
+from pointtinybenchmark_amd.training import CprTrainer
+from tests.test_gpu_cpr_parity import build_hip_locator, to_cuda
+cfg = CPR_CASES['cpr_r18_c3_128']
+batch = synthetic.synthetic_batch(4, cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'], 5, True)
+cb = to_cuda(batch)
+sl = slice(2 * rank, 2 * rank + 2)                                 # DistributedSampler-style shard: images 2r, 2r + 1
+data = dict(img=cb['img'][sl].contiguous(), img_metas=cb['img_metas'][sl], gt_bboxes=cb['gt_bboxes'][sl], gt_labels=cb['gt_labels'][sl])
+m, _ = build_hip_locator(cfg)
+tr = CprTrainer(m, lr=0.01, bucket_mb=1.0, reducer=reducer)
+losses = [float(tr.train_step(dict(data))['log_vars']['loss']) for _ in range(2)]
+torch.cuda.synchronize()
+torch.save(dict(p=tr.flat_p.cpu(), losses=losses, nb=len(tr.buckets.bounds) - 1, world=tr.buckets.world_size), out + '.%%d' %% rank)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('reducer', ['all_reduce', 'reduce_scatter'])
+def test_two_ranks_on_the_gpu_equal_the_averaged_single_process_step(tmp_path, reducer):
+    """The N > 1 training step on the real HIP kernels: two processes (gloo group -- they share the box's one GPU, which RCCL
+    refuses), each with its shard of a 4-image batch, bucketed asynchronous gradient reduction, 1 / world scale, clip + SGD.
+    Data-parallel SGD is the step on the MEAN of the ranks' gradients: one process replays both shards, averages the two
+    gradient buffers and takes the same optimizer step -- parameters after two steps must agree to fp32 rounding (the two
+    sums are (g0 + g1) / 2 either way; the log-var all-reduce gives both ranks the same mean loss)."""
+    import subprocess
+    import sys
+    from pointtinybenchmark_amd.training import CprTrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'worker.py'
+    script.write_text(_TWO_RANK_WORKER % dict(root=root))
+    port = str(29600 + os.getpid() % 300)
+    out = str(tmp_path / 'res')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, out, reducer], cwd=root, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0].decode(errors='replace') for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(l[-1500:] for l in logs)
+    res = [torch.load(out + '.%d' % r) for r in range(2)]
+    assert res[0]['world'] == 2 and res[0]['nb'] >= 3
+    assert torch.equal(res[0]['p'], res[1]['p']), 'both ranks must hold the same parameters after the reduced step'
+    assert res[0]['losses'] == res[1]['losses'], 'log_vars are all-reduced means (base.py:_parse_losses)'
+
+    # single process: both shards through the same trainer, gradients averaged by hand, same clip + SGD
+    cfg = CPR_CASES['cpr_r18_c3_128']
+    batch = synthetic.synthetic_batch(4, cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'], 5, True)
+    cb = to_cuda(batch)
+    m, _ = build_hip_locator(cfg)
+    tr = CprTrainer(m, lr=0.01, bucket_mb=1.0)
+    mean_losses = []
+    for _ in range(2):
+        gs, ls = [], []
+        for r in range(2):
+            sl = slice(2 * r, 2 * r + 2)
+            lo = tr.forward_backward(cb['img'][sl].contiguous(), cb['img_metas'][sl], cb['gt_bboxes'][sl], cb['gt_labels'][sl])
+            torch.cuda.synchronize()
+            gs.append(tr.flat_g.clone())
+            ls.append(float(m._parse_losses(lo)[1]['loss']))
+        tr.flat_g.copy_((gs[0] + gs[1]) * 0.5)
+        tr.step()
+        mean_losses.append(0.5 * (ls[0] + ls[1]))
+    torch.cuda.synchronize()
+    ref_p = tr.flat_p.cpu()
+    d = float((res[0]['p'] - ref_p).abs().max())
+    assert d <= 2e-6 * float(ref_p.abs().max()), d
+    for a, b in zip(res[0]['losses'], mean_losses):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (res[0]['losses'], mean_losses)
+
