@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); only used with --dtype bf16
+PEAK_HBM_GBS = 8000.0           # HBM3E (same guide)
 
 
 def mult_reduction(kernel_name):
@@ -199,7 +200,12 @@ class ConvProbe:
                 variant = 'conv_mfma_kernel<%d, %d, %d, %s, %d, 0, false>' % (v // 1000000, v // 1000 % 1000, v // 100 % 10,
                                                                              'true' if v // 10 % 10 else 'false', v % 10)
             kreal = pc.KH * pc.KW * (3 if pc.Cin == 4 else pc.Cin)
-            probe.records.append((variant, 2.0 * N * OH * OW * pc.Cout * kreal, s, e, probe.key(x, pc)))
+            # algorithmic HBM bytes of the launch: input map + output map (+ residual) + weights, each once
+            es = x.element_size()
+            oes = out[0].element_size() if isinstance(out, tuple) else out.element_size()
+            nbytes = (x.numel() * es + N * OH * OW * pc.Cout * oes + pc.Cout * kreal * es +
+                      (N * OH * OW * pc.Cout * es if k.get('residual') is not None else 0))
+            probe.records.append((variant, 2.0 * N * OH * OW * pc.Cout * kreal, s, e, probe.key(x, pc), float(nbytes)))
             return out
         ops.conv2d = conv2d   # callers use ``ops.conv2d(...)`` through the module object, so they see the probe
         self._orig_dual = ops.conv2d_dual
@@ -214,7 +220,8 @@ class ConvProbe:
             kind, v = ops.TRACE_CONV_VARIANT[1]
             variant = 'conv_mfma_kernel<%d, %d, 0, false, 1, 0, true>' % (v // 1000000, v // 1000 % 1000)
             flops = 2.0 * out.shape[0] * out.shape[1] * out.shape[2] * pc.Cout * (pc.KH * pc.KW * pc.Cin + pc2.Cin)
-            probe.records.append((variant, flops, s, e, ('dual',) + probe.key(x, pc)))
+            nbytes = (x.numel() + x2.numel() + out.numel()) * x.element_size() + (pc.Cout * pc.KH * pc.KW * pc.Cin + pc2.Cout * pc2.Cin) * 4.0
+            probe.records.append((variant, flops, s, e, ('dual',) + probe.key(x, pc), float(nbytes)))
             return out
         ops.conv2d_dual = conv2d_dual
 
@@ -226,14 +233,15 @@ class ConvProbe:
 
     def summary(self):
         agg = {}
-        for variant, flops, s, e, key in self.records:
-            d = agg.setdefault(variant, [0.0, 0.0, 0, set()])
+        for variant, flops, s, e, key, nbytes in self.records:
+            d = agg.setdefault(variant, [0.0, 0.0, 0, set(), 0.0])
             d[0] += flops
             d[1] += s.elapsed_time(e) * 1e-3
             d[2] += 1
             d[3].add(key)
-        return {v: dict(flops=d[0], seconds=d[1], launches=d[2], tflops=d[0] / d[1] / 1e12 if d[1] > 0 else 0.0, keys=d[3])
-                for v, d in agg.items()}
+            d[4] += nbytes
+        return {v: dict(flops=d[0], seconds=d[1], launches=d[2], tflops=d[0] / d[1] / 1e12 if d[1] > 0 else 0.0, keys=d[3],
+                        bytes=d[4]) for v, d in agg.items()}
 
 
 def hbm_probe(batch, height, width=None, stride=4, num_classes=1, radius=5):
@@ -698,7 +706,7 @@ def main():
         # 128 x 128 bf16 instance of configs[4]: ~100, whose event records cost 10 % of the step), only its heaviest shapes, at
         # most TIMED_PROBE_LAUNCHES per step; `timed_probe_time_coverage` says what share of the instance's time they are
         per_key = {}
-        for variant, _fl, s_, e_, key in full.records:
+        for variant, _fl, s_, e_, key, _nb in full.records:
             if variant == dom_name:
                 d = per_key.setdefault(key, [0.0, 0])
                 d[0] += s_.elapsed_time(e_)
@@ -867,14 +875,23 @@ def main():
             conv_f = sum(v['flops'] for v in fsum.values()) / 2
             conv_x = sum(v['flops'] / mult_reduction(k) for k, v in fsum.items()) / 2      # executed on the matrix pipe
             peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in name else PEAK_FP32_MFMA_TFLOPS
-            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                               'frac': ach / peak, 'traffic': pmc_traffic(name, args.batch), 'kernel': name,
+            hbm_gbs = dom['bytes'] / dom['seconds'] / 1e9
+            hbm_bound = hbm_gbs / PEAK_HBM_GBS > ach / peak      # (never for the fp32 Winograd / 3x3 instances; the bf16 1x1s can be)
+            out['roofline'] = {'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': hbm_gbs if hbm_bound else ach,
+                               'peak': PEAK_HBM_GBS if hbm_bound else peak, 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+                               'frac': hbm_gbs / PEAK_HBM_GBS if hbm_bound else ach / peak, 'traffic': pmc_traffic(name, args.batch), 'kernel': name,
                                'what': 'achieved = FLOPs the kernel EXECUTES on the matrix pipe per launch / HIP-event launch '
                                        'time (timed region); effective_tflops = the algorithmic 3x3-conv count '
                                        '(2*M*Cout*9*Cin) of the same launches / the same time',
                                'effective_tflops': eff, 'algorithmic_speedup': red,
                                'launches': dom['launches'],
                                'timed_probe_time_coverage': round(probe_coverage, 3),
+                               # the same launches against the HBM roof: algorithmic bytes (input + output (+ residual) + weights,
+                               # each once) / the same time; the larger of the two fractions names the binding roof
+                               'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
+                               'hbm_achieved_GBs': dom['bytes'] / dom['seconds'] / 1e9,
+                               'hbm_frac': dom['bytes'] / dom['seconds'] / 1e9 / PEAK_HBM_GBS,
+                               'mfma_frac': ach / peak,
                                'algorithmic_flops_per_launch': dom['flops'] / dom['launches'],
                                'executed_flops_per_launch': dom['flops'] / dom['launches'] / red,
                                'avg_launch_ms': dom['seconds'] / dom['launches'] * 1e3,

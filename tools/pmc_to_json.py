@@ -41,5 +41,9 @@ from bench import kernel_source_sha16  # noqa: E402
 out['source_sha16'] = kernel_source_sha16(match)      # bench.py only replays this figure for the same kernel source
 if 'bf16' in match:
     out['algorithmic_bytes_per_launch'] = batch * 160 * 160 * 256 * 2 * 2 + 256 * 2304 * 2
+if os.environ.get('ALGO_BYTES'):          # other shapes: the caller states the algorithmic bytes and the shape
+    out['algorithmic_bytes_per_launch'] = int(float(os.environ['ALGO_BYTES']))
+    out['shape'] = '%s (tools/conv_single.py %s)' % (os.environ.get('SHAPE_DESC', ''), os.environ.get('CONV_ARGS', ''))
+out['traffic_over_algorithmic'] = out['hbm_bytes_per_launch'] / out['algorithmic_bytes_per_launch']
 json.dump(out, open(os.path.join(root, 'profiles', out_name), 'w'), indent=1)
 print(json.dumps(out, indent=1))
