@@ -163,6 +163,78 @@ __device__ __forceinline__ void dma_epilogue(const ConvDmaParams& p, f32x16 (&ac
     (void)out16;
 }
 
+// Direct epilogue of the instances with TWO cout blocks per wave (<4, 2>; round 4).  The K loop of those instances lays the weight
+// rows out INTERLEAVED in LDS -- row 64 g + 32 j + l of the tile holds cout 64 g + 2 l + j (the permutation sits in the rows the DMA
+// requests, see woff in the kernel) -- so lane l of the wave holds couts 2 l (block 0) and 2 l + 1 (block 1): one dword per row
+// WITHOUT a lane exchange, all 64 lanes storing, and a wave instruction writes two whole 128-byte lines (rows m, m + 4) where the
+// shared epilogue above writes four 64-byte halves with half its lanes idle -- PMC had 96 MB written per 67 MB map on the head
+// layer (profiles/round4_pmc_bf16_big_tile.json).  Residual: one 4-byte load per row instead of two 2-byte ones; fp32 output: 8 bytes.
+template <int MI>
+__device__ __forceinline__ void dma_epilogue_pairs(const ConvDmaParams& p, f32x16 (&acc)[MI][2], int tm, int m0, int n0, int wm,
+                                                   int wn, int lane) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int l31 = lane & 31, half = lane >> 5;
+    if (p.ablate & 32) return;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (p.ablate & 16) ? 0 : (int)((size_t)p.M * p.Cout * (p.out_fp32 ? 4 : 2)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.residual ? p.residual : (const unsigned short*)p.out), 0,
+        (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+    const int c0 = n0 + wn * 64 + 2 * l31;                       // couts c0 (block 0) and c0 + 1 (block 1); Cout is even
+    const bool cok = c0 < p.Cout;
+    const int cc = cok ? c0 : p.Cout - 2;
+    const float sc0 = p.scale ? p.scale[cc] : 1.f, sc1 = p.scale ? p.scale[cc + 1] : 1.f;
+    const float bi0 = p.bias ? p.bias[cc] : 0.f, bi1 = p.bias ? p.bias[cc + 1] : 0.f;
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rbase = m0 + wm * (MI * 32) + i * 32 + 4 * half;
+        const unsigned e0 = (unsigned)(rbase * p.Cout + c0);
+        unsigned res[16];
+        if (p.residual) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                res[r] = __builtin_amdgcn_raw_buffer_load_b32(
+                    rs_res, (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            float x0 = acc[i][0][r] * sc0 + bi0 + __uint_as_float(res[r] << 16);
+            float x1 = acc[i][1][r] * sc1 + bi1 + __uint_as_float(res[r] & 0xffff0000u);
+            if (p.relu) {
+                x0 = fmaxf(x0, 0.f);
+                x1 = fmaxf(x1, 0.f);
+            }
+            if (p.gn_part) {
+                const bool ok = cok && rbase + rr < p.M;
+                const float u0 = ok ? x0 : 0.f, u1 = ok ? x1 : 0.f;
+                gs0 += u0; gq0 += u0 * u0;
+                gs1 += u1; gq1 += u1 * u1;
+            }
+            const unsigned e = e0 + (unsigned)rr * (unsigned)p.Cout;
+            if (p.out_fp32) {
+                const u32x2 v = {__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1)};
+                __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, (int)(cok ? e * 4u : 0x80000000u), 0, 0);
+            } else {
+                const bf16x2 pk = {(__bf16)x0, (__bf16)x1};
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rs_out, (int)(cok ? e * 2u : 0x80000000u), 0, 0);
+            }
+        }
+    }
+    if (p.gn_part) {
+        gs0 += __shfl_xor(gs0, 32, 64); gq0 += __shfl_xor(gq0, 32, 64);
+        gs1 += __shfl_xor(gs1, 32, 64); gq1 += __shfl_xor(gq1, 32, 64);
+        if (half == 0 && cok) {
+            const f32x4 v = {gs0, gq0, gs1, gq1};
+            *reinterpret_cast<f32x4*>(p.gn_part + ((size_t)(tm * 2 + wm) * p.Cout + c0) * 2) = v;
+        }
+    }
+}
+
 // bf16 output through LDS (round 4).  The direct epilogue above stores cout PAIRS per lane: one buffer_store_b32 moves two
 // 64-byte row segments, 128 of them (+ 128 two-byte residual loads) per wave -- measured on R101's layer3 conv3 (1x1 256 -> 1024
 // on 32 768 pixels): 0.044 ms with, 0.016 ms without the epilogue, 0.038 ms with every store dropped by the range check, i.e. the
@@ -357,7 +429,8 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
     int woff[NPW];
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-        const int c = n0 + srow + RP * j;
+        // <*, 2, 4> (two cout blocks per wave): tile row 64 g + 32 jj + l holds cout 64 g + 2 l + jj, see dma_epilogue_pairs
+        const int c = (NJ == 2 && WN == 4) ? n0 + 64 * j + 2 * (srow & 31) + (srow >> 5) : n0 + srow + RP * j;
         woff[j] = c < p.Cout ? (c * p.Kpad) * 2 + sunit * 16 : (int)0x80000000;
     }
     // K order: channel chunk OUTER, tap INNER.  Consecutive chunks then read the same 128-byte segments of pixels one tap
@@ -512,13 +585,15 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
     if (nt) {   // this (split, tap)'s fp32 partial
         ConvDmaParams q = p;
         q.out = (float*)p.out + (size_t)st * p.M * p.Cout;
-        dma_epilogue<MI, NJ>(q, acc, tm, m0, n0, wm, wn, lane);
+        if constexpr (NJ == 2 && WN == 4) dma_epilogue_pairs<MI>(q, acc, tm, m0, n0, wm, wn, lane);
+        else dma_epilogue<MI, NJ>(q, acc, tm, m0, n0, wm, wn, lane);
         return;
     }
     static_assert(WN == 4 || MI * NJ > 2, "the LDS epilogue is written for eight waves");
     // the 256 x 256 instance keeps the direct epilogue: its layers are MFMA-bound 3x3s whose statistics epilogue measured 12 %
     // SLOWER through LDS (1.80 -> 2.06 ms on the head layer at B = 64; profiles/round4_bf16_tiles_and_epilogue.txt)
-    if constexpr (MI * NJ > 2) dma_epilogue<MI, NJ>(p, acc, tm, m0, n0, wm, wn, lane);
+    if constexpr (NJ == 2 && WN == 4) dma_epilogue_pairs<MI>(p, acc, tm, m0, n0, wm, wn, lane);
+    else if constexpr (MI * NJ > 2) dma_epilogue<MI, NJ>(p, acc, tm, m0, n0, wm, wn, lane);
     else {
         if (p.out_fp32 || (p.ablate & 64)) dma_epilogue<MI, NJ>(p, acc, tm, m0, n0, wm, wn, lane);
         else dma_epilogue_lds<MI, NJ>(p, acc, smem, tm, m0, n0, wm, wn, wave, lane);

@@ -334,18 +334,18 @@ constexpr int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0;
 
 // Which LDS-DMA tile (conv_bf16_dma.hip) a layer takes: 0 = 256 x 256, 3 = 128 x 128 (two workgroups per CU), -1 = none (the
 // register-staged kernels below).  Measured on the R101 1024^2 B = 8 and R50 640^2 B = 64 layer shapes
-// (profiles/round4_bf16_tiles_and_epilogue.txt): the big tile wins where the layer is MFMA-bound (K >= 1024) and
-// has tiles for 1.5 rounds over the CUs; everything else that fits takes the small one.  GroupNorm statistics slots are 128
-// pixels = one wave row of the big tile only.
+// (profiles/round4_bf16_tiles_and_epilogue.txt, round4_bf16_pair_epilogue.txt): with its whole-line pair stores
+// the big tile wins wherever it has tiles for 1.5 rounds over the CUs; below that the small tile fills the chip.  GroupNorm
+// statistics slots are 128 pixels = one wave row of the big tile only.
 static int bf16_dma_shape(long long M, int Cin, int Cout, int kchunks, bool gn) {
     if (Cin % 64 != 0 || kchunks < 1) return -1;
     if (bf16_dma_force >= 1 && bf16_dma_force <= 5) return bf16_dma_force - 1;
     const long long t256 = Cout % 256 == 0 ? ((M + 255) / 256) * (Cout / 256) : 0;
-    const bool big_ok = t256 >= 384 && kchunks >= 2;
-    if (bf16_dma_force == 6 || gn) return big_ok ? 0 : -1;
-    if (big_ok && kchunks >= 16) return 0;
+    if (bf16_dma_force == 6) return t256 >= 384 && kchunks >= 2 ? 0 : -1;       // the round-3 rule
+    if (t256 >= 384) return 0;
+    if (gn) return -1;
     if (Cout % 128 == 0 && ((M + 127) / 128) * (Cout / 128) >= 256) return 3;
-    return big_ok ? 0 : -1;
+    return -1;
 }
 
 static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,

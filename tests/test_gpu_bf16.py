@@ -66,25 +66,25 @@ def test_conv2d_bf16_vs_torch(case):
 
 
 # shapes that reach the LDS-DMA staged kernels (csrc/conv_bf16_dma.hip; dispatch rule: bf16_dma_shape in conv_mfma_bf16.hip).
-# 256 x 256 tiles: GroupNorm layers and MFMA-bound ones (K >= 1024) with >= 384 tiles; 128 x 128 tiles, two workgroups per CU,
-# output through LDS (round 4): the rest with Cout % 128 == 0 and >= 256 tiles
+# 256 x 256 tiles (interleaved cout layout, whole-line pair stores): every layer with >= 384 such tiles; 128 x 128 tiles, two
+# workgroups per CU, output through LDS (round 4): the rest with Cout % 128 == 0 and >= 256 tiles
 BIG, SMALL = 256 * 1000 + 256, 1000000 + 128 * 1000 + 128       # the variant words conv_bf16_dma_launch reports
 DMA_CASES = [
     (8, 64, 128, 128, 256, 3, 1, 1, 'gn', BIG),                  # 3x3, borders on every side, GroupNorm statistics (two slots per tile)
-    (8, 128, 128, 128, 256, 3, 1, 1, 'bn res relu', BIG),        # K = 1152 + residual
+    (8, 128, 128, 128, 256, 3, 1, 1, 'bn res relu', BIG),        # K = 1152 + residual (4-byte pair loads)
     (10, 128, 121, 119, 256, 3, 1, 1, 'bias relu', BIG),         # ragged M: the last tile is partial
     (6, 128, 256, 192, 512, 3, 2, 1, 'bn', BIG),                 # stride 2, two cout tiles
-    (8, 1024, 128, 128, 256, 1, 1, 0, 'bias f32out', BIG),       # plain GEMM path, fp32 output (the logit-projection form)
-    (8, 128, 128, 128, 256, 1, 1, 0, 'bn res relu', SMALL),      # bottleneck conv3 form: folded BN + residual + ReLU
-    (10, 64, 121, 119, 256, 3, 1, 1, 'bias relu', SMALL),        # ragged M
-    (6, 64, 256, 192, 512, 3, 2, 1, 'bn', SMALL),                # stride 2, four cout tiles
-    (8, 256, 128, 128, 256, 1, 1, 0, 'bias f32out', SMALL),      # fp32 output: the direct epilogue
+    (8, 1024, 128, 128, 256, 1, 1, 0, 'bias f32out', BIG),       # plain GEMM path, fp32 output (8-byte pair stores)
+    (8, 128, 128, 128, 256, 1, 1, 0, 'bn res relu', BIG),        # bottleneck conv3 form, two K chunks
+    (8, 64, 128, 128, 256, 1, 1, 0, 'bn res relu', BIG),         # a single K chunk (layer1 conv3: 64 -> 256)
+    (8, 64, 96, 128, 512, 3, 1, 1, 'bias relu gn', BIG),         # statistics behind bias + ReLU, two cout tiles
     (8, 256, 64, 64, 256, 3, 1, 1, 'bn relu', SMALL),            # R101 layer3 conv2 at 1024^2 B = 8: 128 big tiles would idle half the CUs
     (8, 1024, 64, 64, 256, 1, 1, 0, 'bn res relu', SMALL),       # layer3 conv1 form, K = 1024
     (3, 64, 121, 119, 256, 3, 1, 1, 'bias res relu', SMALL),     # ragged M + residual: rows past M neither read nor written
     (8, 128, 128, 128, 128, 3, 1, 1, 'bn relu', SMALL),          # one cout tile (layer2 conv2)
     (4, 128, 256, 192, 128, 3, 2, 1, 'bn', SMALL),               # stride 2
-    (8, 64, 128, 128, 256, 1, 1, 0, 'bn res relu', SMALL),       # a single K chunk (layer1 conv3: 64 -> 256)
+    (8, 64, 128, 128, 128, 1, 1, 0, 'bn res relu', SMALL),       # a single K chunk
+    (8, 256, 100, 100, 128, 1, 1, 0, 'bias f32out', SMALL),      # fp32 output: the direct epilogue, ragged M
     (8, 512, 32, 32, 2048, 1, 1, 0, 'bn res relu', SMALL),       # layer4 conv3: 16 cout tiles
 ]
 
