@@ -383,10 +383,69 @@ __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, const
         st_bf16x4(y + i * 4, v);
     }
 }
+// The common case of the bf16 mode (C % 8 == 0, 256 % (C / 8) == 0): 16 bytes per lane, a thread keeps its channel group and walks
+// pixels, so the per-image affine sits in registers and is reloaded only when the image changes; 32-bit index arithmetic.  (The
+// generic kernel above moved 8 bytes per lane behind three 64-bit divisions and two 16-byte table loads: 1.5 TB/s, 0.8 ms = 8 %
+// of the configs[4] step over nine launches; profiles/round4_cfg4_kernel_stats.csv.)
+__global__ __launch_bounds__(256) void gn_apply_bf16_wide_kernel(const unsigned short* __restrict__ x, const float* __restrict__ a,
+                                                                 const float* __restrict__ b, const unsigned short* __restrict__ up,
+                                                                 unsigned short* __restrict__ y, int NP, int HW, int W, int C8,
+                                                                 int H, int UH, int UW, int relu) {
+    const int cg = threadIdx.x % C8, prow = threadIdx.x / C8, PP = 256 / C8;
+    const int C = C8 * 8;
+    const float sy = (float)UH / (float)H, sx = (float)UW / (float)W;
+    int ncur = -1;
+    f32x4 a0, a1, b0, b1;
+    for (int pix = blockIdx.x * PP + prow; pix < NP; pix += gridDim.x * PP) {
+        const int n = pix / HW;
+        if (n != ncur) {
+            ncur = n;
+            const float* ap = a + (size_t)n * C + cg * 8;
+            const float* bp = b + (size_t)n * C + cg * 8;
+            a0 = *reinterpret_cast<const f32x4*>(ap); a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+            b0 = *reinterpret_cast<const f32x4*>(bp); b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+        }
+        const size_t off = (size_t)pix * C + cg * 8;
+        const uint4 u = *reinterpret_cast<const uint4*>(x + off);
+        f32x4 v0 = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+        f32x4 v1 = {__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+        v0 = v0 * a0 + b0;
+        v1 = v1 * a1 + b1;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+        }
+        if (up) {
+            const int rem = pix - n * HW;
+            const int py = rem / W, px = rem - py * W;
+            const int uy = min((int)floorf(py * sy), UH - 1), ux = min((int)floorf(px * sx), UW - 1);
+            const uint4 w = *reinterpret_cast<const uint4*>(up + (((size_t)n * UH + uy) * UW + ux) * C + cg * 8);
+            v0[0] += __uint_as_float(w.x << 16); v0[1] += __uint_as_float(w.x & 0xffff0000u);
+            v0[2] += __uint_as_float(w.y << 16); v0[3] += __uint_as_float(w.y & 0xffff0000u);
+            v1[0] += __uint_as_float(w.z << 16); v1[1] += __uint_as_float(w.z & 0xffff0000u);
+            v1[2] += __uint_as_float(w.w << 16); v1[3] += __uint_as_float(w.w & 0xffff0000u);
+        }
+        uint4 o;
+        o.x = __builtin_bit_cast(unsigned, bf16x2_t{(__bf16)v0[0], (__bf16)v0[1]});
+        o.y = __builtin_bit_cast(unsigned, bf16x2_t{(__bf16)v0[2], (__bf16)v0[3]});
+        o.z = __builtin_bit_cast(unsigned, bf16x2_t{(__bf16)v1[0], (__bf16)v1[1]});
+        o.w = __builtin_bit_cast(unsigned, bf16x2_t{(__bf16)v1[2], (__bf16)v1[3]});
+        *reinterpret_cast<uint4*>(y + off) = o;
+    }
+}
 extern "C" int cpr_gn_apply_bf16(const void* x, const float* a, const float* b, const void* up, void* y, int N, int H,
                                  int W, int C, int UH, int UW, int relu, hipStream_t stream) {
     CPR_CHECK_ARG(x && a && b && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
     if (up) CPR_CHECK_ARG(UH > 0 && UW > 0);
+    const long long np = (long long)N * H * W;
+    if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 && np < (1ll << 31)) {
+        const int C8 = C / 8, PP = 256 / C8;
+        const long long blocks = cdivll(np, PP);
+        const int grid = (int)(blocks < 8192 ? blocks : 8192);
+        hipLaunchKernelGGL(gn_apply_bf16_wide_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, a, b,
+                           (const unsigned short*)up, (unsigned short*)y, (int)np, H * W, W, C8, H, UH, UW, relu);
+        CPR_LAUNCH_STATUS();
+    }
     const long long total = (long long)N * H * W * (C / 4);
     const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
     hipLaunchKernelGGL(gn_apply_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned short*)x, a, b,
