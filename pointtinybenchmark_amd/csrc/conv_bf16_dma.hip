@@ -19,8 +19,10 @@
 //     (3.5 k-steps, ~0.8 us, to land).
 // 512 threads = 8 waves: wave (wm, wn) = (wave & 1, wave >> 1) owns pixels [128 wm, +128) x couts [64 wn, +64): 4 x 2 blocks of
 // 32 x 32 = 128 accumulator registers.  One workgroup per CU (128 KB of LDS), two waves per SIMD.
-// Used when Cout % 256 == 0 and Cin % 64 == 0 (the head towers, the FPN convs, the wide bottleneck convs); everything else
-// stays on conv_mfma_bf16.hip.
+// Round 4: the kernel is a template over the wave's block grid and the wave grid (DmaTile below): the 256 x 256 instance described
+// here (<4, 2, 4>), a 128 x 128 instance with two workgroups per CU and a row-wise LDS epilogue (<2, 1, 4>) for launches that
+// cannot fill the chip with big tiles, and -- in the 256 x 256 instance -- an interleaved cout layout that lets every lane store
+// adjacent couts (dma_epilogue_pairs).  Which layer takes which instance: bf16_dma_shape in conv_mfma_bf16.hip.
 #include "common.h"
 #include <type_traits>
 
