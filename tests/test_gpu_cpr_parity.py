@@ -166,3 +166,42 @@ def test_fused_forward_train_matches_module_by_module_path():
     for k in ref:
         assert _relerr(float(fused[k]), float(ref[k])) <= 1e-5, (k, float(fused[k]), float(ref[k]))
         assert _relerr(float(streamed[k]), float(ref[k])) <= 1e-5, (k, float(streamed[k]), float(ref[k]))
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_fused_stem_kernels_and_the_two_kernel_fallback_agree_through_the_network(mode):
+    """Round 4: ResNet.stem runs conv + BN + ReLU + max-pool as one kernel (csrc/stem_f32.hip; csrc/stem_bf16.hip in the bf16
+    compute mode); ``CPR_F32_STEM=0`` / ``CPR_BF16_STEM=0`` / ``CPR_BF16_STEM_POOL=0`` (module flags here) keep the implicit-GEMM
+    stem + maxpool3x3s2.  Both paths must give the same network: stage outputs and losses within fp32 summation-order distance
+    (fp32 mode) resp. the bf16 mode's own rounding (one bf16 rounding of the stem inputs), and the bf16 fused pool the SAME bits as
+    its unfused pair."""
+    from pointtinybenchmark_amd.backbones import resnet as R
+    cfg = dict(depth=18, num_classes=2, start_level=0, stride=4, radius=5, head_std=0.3, seed=33, batch=2, height=160,
+               width=192, num_gts=5, ragged=True)
+    m, _ = build_hip_locator(cfg)
+    if mode == 'bf16':
+        m.set_compute_dtype('bf16')
+    cb = to_cuda(synthetic.synthetic_batch(2, 160, 192, 5, 2, 33, True))
+    flags = (R.F32_STEM, R.BF16_STEM, R.BF16_STEM_POOL)
+    outs = {}
+    try:
+        for name, vals in (('fused', (True, True, True)), ('pair', (True, True, False)), ('fallback', (False, False, False))):
+            for f, v in zip(flags, vals):
+                f[0] = v
+            with torch.no_grad():
+                c2 = m.backbone(cb['img'])[0].float()
+                losses = m.forward_train(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+            torch.cuda.synchronize()
+            outs[name] = (c2, {k: float(v) for k, v in losses.items()})
+    finally:
+        for f in flags:
+            f[0] = True
+    mx = float(outs['fallback'][0].abs().max())
+    tol = 2e-5 if mode == 'fp32' else 6e-2
+    d = float((outs['fused'][0] - outs['fallback'][0]).abs().max())
+    assert d <= tol * mx, (d, mx)
+    if mode == 'bf16':
+        assert torch.equal(outs['fused'][0], outs['pair'][0]), 'the fused bf16 stem + pool must equal conv -> pool bit for bit'
+    for k, v in outs['fallback'][1].items():
+        assert _relerr(outs['fused'][1][k], v) <= (1e-4 if mode == 'fp32' else 5e-2), (k, outs['fused'][1][k], v)
+
