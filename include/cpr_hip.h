@@ -118,14 +118,14 @@ int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float*
                         const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                         int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, void* stream);
 /* bf16 compute mode stem: conv 7x7 / stride 2 / pad 3, 3 -> 64 channels + folded BatchNorm + ReLU (resnet.py:630-636) on the
- * bf16 matrix cores.  in (N,H,W,4) fp32 (4th channel ignored), wgt (64, 224) bf16 with k = (kh * 8 + kw) * 4 + c (kw = 7 and
+ * bf16 matrix cores.  in: layout 0 = (N,H,W,4) fp32 (4th channel ignored), layout 1 = (N,3,H,W) fp32 planes (the NCHW network input); wgt (64, 224) bf16 with k = (kh * 8 + kw) * 4 + c (kw = 7 and
  * c = 3 zero), out (N, (H-1)/2+1, (W-1)/2+1, 64) bf16.  CPR_ERR_UNSUPPORTED when the output reaches 2 GiB. */
 int cpr_stem7x7s2_bf16(const float* in, const void* wgt, const float* scale, const float* bias, void* out, int N, int H, int W,
-                       int relu, void* stream);
+                       int relu, int layout, void* stream);
 /* The same stem with the max-pool 3x3 / stride 2 / pad 1 (resnet.py:637) fused: out (N, PH, PW, 64) bf16, PH = (OH-1)/2+1.
  * Bit-identical to cpr_stem7x7s2_bf16 (relu = 1) followed by cpr_maxpool3x3s2_bf16. */
 int cpr_stem7x7s2_pool_bf16(const float* in, const void* wgt, const float* scale, const float* bias, void* out, int N, int H,
-                            int W, void* stream);
+                            int W, int layout, void* stream);
 int cpr_maxpool3x3s2_bf16(const void* in, void* out, int N, int H, int W, int C, void* stream);
 int cpr_gn_stats_bf16(const void* x, float* part, int N, int HW, int C, int P, void* stream);
 int cpr_gn_apply_bf16(const void* x, const float* a, const float* b, const void* up, void* y, int N, int H, int W,
@@ -137,10 +137,10 @@ int cpr_nchw_to_nhwc4(const float* in, float* out, int N, int C, int H, int W, v
 int cpr_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, void* stream);
 /* nn.MaxPool2d(3, 2, 1) of the ResNet stem (resnet.py:610,637); NHWC */
 /* The ResNet stem in one kernel, exact fp32 (resnet.py:630-637): conv 7x7 / stride 2 / pad 3, 3 -> 64 + folded BatchNorm + ReLU
- * + max-pool 3x3 / stride 2 / pad 1.  in (N,H,W,4) fp32 (4th channel ignored), wgt (64, 154) fp32 = [cout][kh][kw * 3 + c] with
+ * + max-pool 3x3 / stride 2 / pad 1.  in: layout 0 = (N,H,W,4) fp32 (4th channel ignored), layout 1 = (N,3,H,W) fp32 planes; wgt (64, 154) fp32 = [cout][kh][kw * 3 + c] with
  * slot 21 of every kernel row zero, out (N, PH, PW, 64) fp32, OH = (H-1)/2+1, PH = (OH-1)/2+1. */
 int cpr_stem7x7s2_pool_f32(const float* in, const float* wgt, const float* scale, const float* bias, float* out, int N, int H,
-                           int W, void* stream);
+                           int W, int layout, void* stream);
 int cpr_maxpool3x3s2(const float* in, float* out, int N, int H, int W, int C, void* stream);
 
 /* GroupNorm of mmcv ConvModule (fpn.py:124-144, cpr_head.py:990-991) as three streaming steps:

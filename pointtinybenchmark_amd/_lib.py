@@ -31,14 +31,14 @@ SIGNATURES = {
     'cpr_conv3x3_wino_wgrad': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_gn_apply_b8': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'cpr_conv2d_fwd_bf16': [_p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p, _p],
-    'cpr_stem7x7s2_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    'cpr_stem7x7s2_pool_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'cpr_stem7x7s2_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'cpr_stem7x7s2_pool_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'cpr_maxpool3x3s2_bf16': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_gn_stats_bf16': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_gn_apply_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_nchw_to_nhwc4': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_nhwc_to_nchw': [_p, _p, _i, _i, _i, _i, _p],
-    'cpr_stem7x7s2_pool_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'cpr_stem7x7s2_pool_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'cpr_maxpool3x3s2': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_gn_stats': [_p, _p, _i, _i, _i, _i, _p],
     'cpr_gn_finalize': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],

@@ -156,25 +156,30 @@ class ResNet(nn.Module):
     def stem(self, x):
         """(N,3,H,W) image -> the NHWC map after conv1 + bn1 + ReLU + max-pool (resnet.py:630-637)."""
         c = self._cache
-        # (N,3,H,W) float image -> NHWC4; a 4-channel channels-last view (datasets.GpuImagePipeline output) is taken as is
-        x = ops.from_nchw(x) if (x.shape[1] > 4 or (x.shape[1] == 4 and x.stride(1) == 1)) else ops.nchw_to_nhwc(x)
         s, b = folded_bn(c, self.bn1)
         c1 = self.conv1
-        if self.compute_dtype == torch.bfloat16 and BF16_STEM[0] and tuple(c1.weight.shape) == (64, 3, 7, 7) and \
-                c1.stride == (2, 2) and c1.padding == (3, 3) and x.dtype == torch.float32 and x.shape[-1] == 4 and \
-                ops.stem_bf16_fits(x):
+        std7 = tuple(c1.weight.shape) == (64, 3, 7, 7) and c1.stride == (2, 2) and c1.padding == (3, 3)
+        # the fused stem kernels read the three planes of a contiguous (N,3,H,W) fp32 image themselves (no nchw_to_nhwc4 pass)
+        planar = std7 and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] == 3 and x.is_contiguous() and \
+            (F32_STEM[0] if self.compute_dtype == torch.float32 else BF16_STEM[0])
+        if not planar:
+            # (N,3,H,W) float image -> NHWC4; a 4-channel channels-last view (datasets.GpuImagePipeline output) is taken as is
+            x = ops.from_nchw(x) if (x.shape[1] > 4 or (x.shape[1] == 4 and x.stride(1) == 1)) else ops.nchw_to_nhwc(x)
+        fused_in = std7 and x.dtype == torch.float32 and (planar or x.shape[-1] == 4)
+        if self.compute_dtype == torch.bfloat16 and BF16_STEM[0] and fused_in and ops.stem_bf16_fits(x, planar):
             # bf16 compute mode: the stem on the bf16 matrix cores (csrc/stem_bf16.hip; round 4)
             wp = c.get(('stem_bf16', id(c1)), [c1.weight], lambda: ops.stem_weight_bf16(c1.weight))
             if BF16_STEM_POOL[0]:
-                return ops.stem7x7s2_pool_bf16(x, wp, scale=s, bias=b)       # conv + BN + ReLU + max-pool, one kernel
-            x = ops.stem7x7s2_bf16(x, wp, scale=s, bias=b, relu=True)
-        elif self.compute_dtype == torch.float32 and F32_STEM[0] and tuple(c1.weight.shape) == (64, 3, 7, 7) and \
-                c1.stride == (2, 2) and c1.padding == (3, 3) and x.dtype == torch.float32 and x.shape[-1] == 4:
+                return ops.stem7x7s2_pool_bf16(x, wp, scale=s, bias=b, planar=planar)       # conv + BN + ReLU + max-pool, one kernel
+            x = ops.stem7x7s2_bf16(x, wp, scale=s, bias=b, relu=True, planar=planar)
+        elif self.compute_dtype == torch.float32 and F32_STEM[0] and fused_in:
             # conv + BN + ReLU + max-pool in one exact-fp32 kernel (csrc/stem_f32.hip; round 4)
             wp = c.get(('stem_f32', id(c1)), [c1.weight], lambda: ops.stem_weight_f32(c1.weight))
-            return ops.stem7x7s2_pool_f32(x, wp, scale=s, bias=b)
+            return ops.stem7x7s2_pool_f32(x, wp, scale=s, bias=b, planar=planar)
         else:
             # (other stems: the implicit-GEMM kernel in its stem mode; in the bf16 mode it emits the bf16 map)
+            if planar:          # (a bf16-mode map too large for the bf16 stem kernel's 32-bit offsets)
+                x = ops.nchw_to_nhwc(x)
             x = ops.conv2d(x, packed_conv(c, c1), scale=s, bias=b, relu=True, out_dtype=self.compute_dtype)
         return ops.maxpool3x3s2(x)
 

@@ -26,7 +26,7 @@ struct StemParams {
     const float* scale;          // (64) folded BatchNorm, or null
     const float* bias;
     unsigned short* out;         // (N, OH, OW, 64) bf16
-    int N, H, W, OH, OW, tilesY, tilesX, relu;
+    int N, H, W, OH, OW, tilesY, tilesX, relu, layout;     // layout 0: NHWC4 input, 1: (N, 3, H, W) planes
 };
 
 constexpr int ST_TY = 16, ST_TX = 32;
@@ -56,13 +56,18 @@ __global__ __launch_bounds__(512, 4) void stem_bf16_kernel(StemParams p) {
             reinterpret_cast<const unsigned char*>(p.wgt) + (size_t)r * 448 + q * 16);
     }
     // patch: fp32 NHWC4 -> bf16, zero outside the image and in the padded column
-    const float* img = p.in + (size_t)n * p.H * p.W * 4;
+    const size_t plane = (size_t)p.H * p.W;
+    const float* img = p.in + (size_t)n * plane * (p.layout ? 3 : 4);
     for (int u = tid; u < ST_PH * ST_PW; u += 512) {
         const int py = u / ST_PW, px = u - py * ST_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (px < ST_PW - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            v = *reinterpret_cast<const f32x4*>(img + ((size_t)iy * p.W + ix) * 4);
+        {
+            const size_t o = (size_t)iy * p.W + ix;
+            if (p.layout) { v[0] = img[o]; v[1] = img[plane + o]; v[2] = img[2 * plane + o]; }
+            else v = *reinterpret_cast<const f32x4*>(img + o * 4);
+        }
         const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)0.f};
         *reinterpret_cast<bf16x4*>(patch + (size_t)u * 8) = h;
     }
@@ -141,7 +146,7 @@ struct StemPoolParams {
     const float* scale;
     const float* bias;
     unsigned short* out;         // (N, PH, PW, 64) bf16
-    int N, H, W, OH, OW, PH, PW, tilesY, tilesX;
+    int N, H, W, OH, OW, PH, PW, tilesY, tilesX, layout;
 };
 
 __global__ __launch_bounds__(512, 4) void stem_pool_bf16_kernel(StemPoolParams p) {
@@ -163,13 +168,18 @@ __global__ __launch_bounds__(512, 4) void stem_pool_bf16_kernel(StemPoolParams p
         *reinterpret_cast<f32x4*>(wl + r * ST_WROW + q * 16) = *reinterpret_cast<const f32x4*>(
             reinterpret_cast<const unsigned char*>(p.wgt) + (size_t)r * 448 + q * 16);
     }
-    const float* img = p.in + (size_t)n * p.H * p.W * 4;
+    const size_t plane = (size_t)p.H * p.W;
+    const float* img = p.in + (size_t)n * plane * (p.layout ? 3 : 4);
     for (int u = tid; u < SP_PH * SP_PW; u += 512) {
         const int py = u / SP_PW, px = u - py * SP_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (px < SP_PW - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            v = *reinterpret_cast<const f32x4*>(img + ((size_t)iy * p.W + ix) * 4);
+        {
+            const size_t o = (size_t)iy * p.W + ix;
+            if (p.layout) { v[0] = img[o]; v[1] = img[plane + o]; v[2] = img[2 * plane + o]; }
+            else v = *reinterpret_cast<const f32x4*>(img + o * 4);
+        }
         const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)0.f};
         *reinterpret_cast<bf16x4*>(patch + (size_t)u * 8) = h;
     }
@@ -269,11 +279,11 @@ __global__ __launch_bounds__(512, 4) void stem_pool_bf16_kernel(StemPoolParams p
 // in (N,H,W,4) fp32 -> out (N,PH,PW,64) bf16 = maxpool3x3/2/pad 1 (ReLU(conv7x7/2/pad 3 (in) * scale + bias)); OH = (H-1)/2+1,
 // PH = (OH-1)/2+1.
 extern "C" int cpr_stem7x7s2_pool_bf16(const float* in, const void* wgt, const float* scale, const float* bias, void* out, int N,
-                                       int H, int W, hipStream_t stream) {
-    CPR_CHECK_ARG(in && wgt && out && N > 0 && H > 0 && W > 0);
+                                       int H, int W, int layout, hipStream_t stream) {
+    CPR_CHECK_ARG(in && wgt && out && N > 0 && H > 0 && W > 0 && (layout == 0 || layout == 1));
     StemPoolParams p;
     p.in = in; p.wgt = (const unsigned short*)wgt; p.scale = scale; p.bias = bias; p.out = (unsigned short*)out;
-    p.N = N; p.H = H; p.W = W;
+    p.N = N; p.H = H; p.W = W; p.layout = layout;
     p.OH = (H - 1) / 2 + 1;
     p.OW = (W - 1) / 2 + 1;
     p.PH = (p.OH - 1) / 2 + 1;
@@ -288,11 +298,11 @@ extern "C" int cpr_stem7x7s2_pool_bf16(const float* in, const void* wgt, const f
 
 // in (N,H,W,4) fp32 -> out (N,OH,OW,64) bf16, OH = (H - 1) / 2 + 1; wgt = the (64, 224) bf16 image described above.
 extern "C" int cpr_stem7x7s2_bf16(const float* in, const void* wgt, const float* scale, const float* bias, void* out, int N,
-                                  int H, int W, int relu, hipStream_t stream) {
-    CPR_CHECK_ARG(in && wgt && out && N > 0 && H > 0 && W > 0);
+                                  int H, int W, int relu, int layout, hipStream_t stream) {
+    CPR_CHECK_ARG(in && wgt && out && N > 0 && H > 0 && W > 0 && (layout == 0 || layout == 1));
     StemParams p;
     p.in = in; p.wgt = (const unsigned short*)wgt; p.scale = scale; p.bias = bias; p.out = (unsigned short*)out;
-    p.N = N; p.H = H; p.W = W; p.relu = relu;
+    p.N = N; p.H = H; p.W = W; p.relu = relu; p.layout = layout;
     p.OH = (H - 1) / 2 + 1;
     p.OW = (W - 1) / 2 + 1;
     if ((long long)N * p.OH * p.OW * 64 * 2 >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;

@@ -28,12 +28,12 @@ constexpr int SF_CT_FLOATS = 17 * 33 * 32;                        // conv tile o
 constexpr int SF_LDS_FLOATS = SF_PATCH_FLOATS + SF_W_FLOATS > SF_CT_FLOATS ? SF_PATCH_FLOATS + SF_W_FLOATS : SF_CT_FLOATS;
 
 struct StemF32Params {
-    const float* in;       // (N, H, W, 4) fp32, 4th channel ignored
+    const float* in;       // layout 0: (N, H, W, 4) fp32, 4th channel ignored; layout 1: (N, 3, H, W) fp32 planes (NCHW)
     const float* wgt;      // (64, 154): [cout][kh][kw * 3 + c], slot 21 of every kernel row zero
     const float* scale;    // folded BatchNorm (64) or null
     const float* bias;
     float* out;            // (N, PH, PW, 64)
-    int N, H, W, OH, OW, PH, PW, tilesY, tilesX;
+    int N, H, W, OH, OW, PH, PW, tilesY, tilesX, layout;
 };
 
 __global__ __launch_bounds__(512, 4) void stem_pool_f32_kernel(StemF32Params p) {
@@ -52,13 +52,19 @@ __global__ __launch_bounds__(512, 4) void stem_pool_f32_kernel(StemF32Params p) 
 
     for (int u = tid; u < SF_W_FLOATS / 4; u += 512)              // 154 floats per row: rows are 8-byte, the image 16-byte aligned
         *reinterpret_cast<f32x4*>(wl + u * 4) = *reinterpret_cast<const f32x4*>(p.wgt + u * 4);
-    const float* img = p.in + (size_t)n * p.H * p.W * 4;
+    // (layout 1: the network input as torch hands it over, three planes -- consecutive threads read consecutive floats of a
+    // plane row; saves the nchw_to_nhwc4 pass and its 0.4 GB at 640^2 B = 64)
+    const size_t plane = (size_t)p.H * p.W;
+    const float* img = p.in + (size_t)n * plane * (p.layout ? 3 : 4);
     for (int u = tid; u < SF_PH * SF_PW; u += 512) {
         const int py = u / SF_PW, px = u - py * SF_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (px < SF_PW - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            v = *reinterpret_cast<const f32x4*>(img + ((size_t)iy * p.W + ix) * 4);
+        if (px < SF_PW - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+            const size_t o = (size_t)iy * p.W + ix;
+            if (p.layout) { v[0] = img[o]; v[1] = img[plane + o]; v[2] = img[2 * plane + o]; }
+            else v = *reinterpret_cast<const f32x4*>(img + o * 4);
+        }
         float* d = patch + u * 3;
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2];
     }
@@ -170,11 +176,11 @@ __global__ __launch_bounds__(512, 4) void stem_pool_f32_kernel(StemF32Params p) 
 // in (N,H,W,4) fp32 -> out (N,PH,PW,64) fp32 = maxpool3x3/2/pad 1 (ReLU(conv7x7/2/pad 3 (in) * scale + bias)); OH = (H-1)/2+1,
 // PH = (OH-1)/2+1; wgt = the (64, 154) image described above.
 extern "C" int cpr_stem7x7s2_pool_f32(const float* in, const float* wgt, const float* scale, const float* bias, float* out, int N,
-                                      int H, int W, hipStream_t stream) {
-    CPR_CHECK_ARG(in && wgt && out && N > 0 && H > 0 && W > 0);
+                                      int H, int W, int layout, hipStream_t stream) {
+    CPR_CHECK_ARG(in && wgt && out && N > 0 && H > 0 && W > 0 && (layout == 0 || layout == 1));
     StemF32Params p;
     p.in = in; p.wgt = wgt; p.scale = scale; p.bias = bias; p.out = out;
-    p.N = N; p.H = H; p.W = W;
+    p.N = N; p.H = H; p.W = W; p.layout = layout;
     p.OH = (H - 1) / 2 + 1;
     p.OW = (W - 1) / 2 + 1;
     p.PH = (p.OH - 1) / 2 + 1;

@@ -397,14 +397,14 @@ def stem_weight_f32(weight):
     return w.reshape(64, 154).contiguous()
 
 
-def stem7x7s2_pool_f32(x, wpack, scale=None, bias=None):
-    """The whole ResNet stem in one kernel, exact fp32: x (N,H,W,4) NHWC4 -> (N,PH,PW,64) =
+def stem7x7s2_pool_f32(x, wpack, scale=None, bias=None, planar=None):
+    """The whole ResNet stem in one kernel, exact fp32: x (N,H,W,4) NHWC4 or the (N,3,H,W) network input -> (N,PH,PW,64) =
     maxpool3x3s2(ReLU(conv7x7/2(x) * scale + bias))."""
-    N, H, W, C = _check(x).shape
-    assert C == 4 and x.dtype == torch.float32 and wpack.dtype == torch.float32 and tuple(wpack.shape) == (64, 154)
+    N, H, W, layout = _stem_input(_check(x), planar)
+    assert wpack.dtype == torch.float32 and tuple(wpack.shape) == (64, 154)
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((N, (OH - 1) // 2 + 1, (OW - 1) // 2 + 1, 64), device=x.device, dtype=torch.float32)
-    _lib.call('cpr_stem7x7s2_pool_f32', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, _stream())
+    _lib.call('cpr_stem7x7s2_pool_f32', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, layout, _stream())
     return out
 
 
@@ -417,27 +417,42 @@ def stem_weight_bf16(weight):
     return w.reshape(64, 224).to(torch.bfloat16).contiguous()
 
 
-def stem_bf16_fits(x):
-    N, H, W, _ = x.shape
+def _stem_input(x, planar=None):
+    """(N, H, W, layout) of a stem input: NHWC4 (N,H,W,4) -> layout 0, the NCHW network input (N,3,H,W) -> layout 1.
+    planar: say which one it is (a (N,3,W,4) tensor reads both ways); None = by shape, NHWC4 first."""
+    assert x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()
+    if planar is None:
+        planar = x.shape[-1] != 4
+    if not planar:
+        assert x.shape[-1] == 4, tuple(x.shape)
+        return x.shape[0], x.shape[1], x.shape[2], 0
+    assert x.shape[1] == 3, tuple(x.shape)
+    return x.shape[0], x.shape[2], x.shape[3], 1
+
+
+def stem_bf16_fits(x, planar=None):
+    N, H, W, _ = _stem_input(x, planar)
     return N * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1) * 64 * 2 < (1 << 31)
 
 
-def stem7x7s2_bf16(x, wpack, scale=None, bias=None, relu=True):
-    """ResNet stem of the bf16 compute mode: x (N,H,W,4) fp32 NHWC4 -> (N,OH,OW,64) bf16 = ReLU(conv7x7/2(x) * scale + bias)."""
-    N, H, W, C = _check(x).shape
-    assert C == 4 and x.dtype == torch.float32 and wpack.dtype == torch.bfloat16 and tuple(wpack.shape) == (64, 224)
+def stem7x7s2_bf16(x, wpack, scale=None, bias=None, relu=True, planar=None):
+    """ResNet stem of the bf16 compute mode: x (N,H,W,4) fp32 NHWC4 or (N,3,H,W) fp32 -> (N,OH,OW,64) bf16 =
+    ReLU(conv7x7/2(x) * scale + bias)."""
+    N, H, W, layout = _stem_input(_check(x), planar)
+    assert wpack.dtype == torch.bfloat16 and tuple(wpack.shape) == (64, 224)
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), device=x.device, dtype=torch.bfloat16)
-    _lib.call('cpr_stem7x7s2_bf16', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, int(relu), _stream())
+    _lib.call('cpr_stem7x7s2_bf16', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, int(relu), layout, _stream())
     return out
 
 
-def stem7x7s2_pool_bf16(x, wpack, scale=None, bias=None):
-    """stem7x7s2_bf16 (with ReLU) + maxpool3x3s2 in one kernel: x (N,H,W,4) fp32 -> (N,PH,PW,64) bf16; same bits as the pair."""
-    N, H, W, C = _check(x).shape
-    assert C == 4 and x.dtype == torch.float32 and wpack.dtype == torch.bfloat16 and tuple(wpack.shape) == (64, 224)
+def stem7x7s2_pool_bf16(x, wpack, scale=None, bias=None, planar=None):
+    """stem7x7s2_bf16 (with ReLU) + maxpool3x3s2 in one kernel: x (N,H,W,4) or (N,3,H,W) fp32 -> (N,PH,PW,64) bf16; same bits as
+    the pair."""
+    N, H, W, layout = _stem_input(_check(x), planar)
+    assert wpack.dtype == torch.bfloat16 and tuple(wpack.shape) == (64, 224)
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((N, (OH - 1) // 2 + 1, (OW - 1) // 2 + 1, 64), device=x.device, dtype=torch.bfloat16)
-    _lib.call('cpr_stem7x7s2_pool_bf16', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, _stream())
+    _lib.call('cpr_stem7x7s2_pool_bf16', _ptr(x), _ptr(wpack), _ptr(scale), _ptr(bias), _ptr(out), N, H, W, layout, _stream())
     return out
 
 

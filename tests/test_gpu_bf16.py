@@ -173,6 +173,10 @@ def test_stem_bf16_vs_torch(N, H, W, seed):
     torch.cuda.synchronize()
     assert fused.shape == pair.shape and torch.equal(fused, pair), 'fused stem + pool differs from conv -> pool: %d entries' % int(
         (fused != pair).sum())
+    # the (N,3,H,W) network input read plane by plane: the same bits from both kernels
+    wq = ops.stem_weight_bf16(w.cuda())
+    assert torch.equal(ops.stem7x7s2_pool_bf16(img.cuda().contiguous(), wq, scale.cuda(), bias.cuda(), planar=True), fused)
+    assert torch.equal(ops.stem7x7s2_bf16(img.cuda().contiguous(), wq, scale.cuda(), bias.cuda(), relu=True, planar=True), out)
 
 
 def test_bf16_aux_kernels():

@@ -240,6 +240,9 @@ def test_fused_stem_vs_torch_and_the_two_kernel_path(N, H, W, seed):
     assert float((got - ref).abs().max()) <= 2e-6 * mx + 1e-6, float((got - ref).abs().max())
     assert float((out - old).abs().max()) <= 4e-6 * mx + 1e-6, float((out - old).abs().max())
     assert float((got == 0).float().mean()) > 0.001       # the ReLU really clips here
+    # the (N,3,H,W) network input read plane by plane (no nchw_to_nhwc4 pass): the same bits
+    planar = ops.stem7x7s2_pool_f32(img.cuda().contiguous(), ops.stem_weight_f32(w.cuda()), scale.cuda(), bias.cuda(), planar=True)
+    assert torch.equal(planar, out)
 
 
 @pytest.mark.parametrize('shape,up', [((2, 256, 20, 28), (10, 14)), ((1, 256, 25, 21), (13, 11))])
