@@ -281,8 +281,8 @@ def hbm_probe(batch, height, width=None, stride=4, num_classes=1, radius=5):
     cases = [
         ('gn_apply_kernel (GroupNorm apply + ReLU, head map)', len(xs), lambda i: ops.gn_apply(xs[i][0], a, b, relu=True), 2 * nb),
         ('gn_stats_kernel (statistics pass)', len(xs), lambda i: ops.gn_stats(xs[i][0]), nb),
-        ('maxpool3x3s2_kernel (stem)', len(stems), lambda i: ops.maxpool3x3s2(stems[i]), stems[0].numel() * 4 * 1.25),
-        ('nchw_to_nhwc4_kernel (network input)', len(imgs), lambda i: ops.nchw_to_nhwc(imgs[i]), imgs[0].numel() * 4 * (1 + 4 / 3)),
+        ('maxpool3x3s2_kernel (stem; only on the two-kernel fallback since the fused stem of round 4)', len(stems), lambda i: ops.maxpool3x3s2(stems[i]), stems[0].numel() * 4 * 1.25),
+        ('nchw_to_nhwc4_kernel (network input; only on the two-kernel stem fallback since round 4)', len(imgs), lambda i: ops.nchw_to_nhwc(imgs[i]), imgs[0].numel() * 4 * (1 + 4 / 3)),
         ('preprocess_u8_kernel (uint8 HWC -> normalised NHWC4)', len(u8s),
          lambda i: pipe._launch(u8s[i], None, pre_outs[i], batch, height, width, height, width), u8s[0].numel() + pre_outs[0].numel() * 4),
         ('gn_bwd (stats + apply passes of the GroupNorm backward)', len(x2),
