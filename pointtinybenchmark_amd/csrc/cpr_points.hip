@@ -450,6 +450,75 @@ __global__ void mil_bag_kernel(const float* __restrict__ logits, int J, int ins_
     }
 }
 
+// The same bag loss with the classes of a bag spread over the waves of a workgroup (round 4; C >= 8, e.g. the 80-class COCO
+// form of BASELINE.json configs[2]): mil_bag_kernel walks the classes one after the other, three strided passes over the bag per
+// class -- 391 us for 256 bags x 80 classes (2.4 % of the configs[2] step) on 256 waves.  Here workgroup = one bag, wave w takes
+// classes w, w + NW, ...; every per-class quantity is computed by the SAME code (lanes over the bag's points, the same wave
+// reductions), parked in LDS, and lane 0 of wave 0 then adds the terms and scans for the best class in ascending class order --
+// the order mil_bag_kernel uses: bit-identical outputs.
+constexpr int MIL_NW = 8, MIL_MAXT = 512;
+__global__ __launch_bounds__(64 * MIL_NW) void mil_bag_cls_kernel(
+    const float* __restrict__ logits, int J, int ins_off, const unsigned char* __restrict__ valid, const int* __restrict__ labels,
+    const float* __restrict__ gt_weight, float* __restrict__ bag, int G, int bag_stride, int bag_off, int K, int ctr_off,
+    int ctr_stride, int ctr_count, int ctr_mod, int C, float eps, int ptype, float norm_p, int binary_ins) {
+    __shared__ float s_p[MIL_MAXT];          // p of (class, branch)
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t full = (size_t)g * bag_stride;
+    const float* L = logits + (full + bag_off) * J;
+    const unsigned char* V = valid + full + bag_off;
+    const int label = labels[g];
+    const float wg = gt_weight ? gt_weight[g] : 1.f;
+    float nvalid = 0.f;
+    for (int k = lane; k < K; k += 64) nvalid += V[k] ? 1.f : 0.f;
+    nvalid = wave_sum(nvalid);
+    const float lw = (nvalid * wg > 0.f) ? 1.f : 0.f;
+    const int nj = binary_ins ? 2 : 1;
+    for (int c = wave; c < C; c += MIL_NW) {
+        for (int j = 0; j < nj; ++j) {
+            const int ic = ins_off + c * nj + j;
+            float m = -INFINITY;
+            for (int k = lane; k < K; k += 64) m = fmaxf(m, L[(size_t)k * J + ic]);
+            m = wave_max(m);
+            float se = 0.f;
+            for (int k = lane; k < K; k += 64) se += expf(L[(size_t)k * J + ic] - m);
+            se = wave_sum(se);
+            float sv = 0.f, sp = 0.f;
+            for (int k = lane; k < K; k += 64) {
+                const float pi = expf(L[(size_t)k * J + ic] - m) / se * (V[k] ? wg : 0.f);
+                sv += pi;
+                sp += bag_prob(L + (size_t)k * J, C, c, ptype, norm_p) * pi;
+            }
+            sv = wave_sum(sv);
+            sp = wave_sum(sp);
+            if (lane == 0) s_p[c * nj + j] = sp / fmaxf(sv, 1e-12f);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float gloss = 0.f, gcount = 0.f;
+        if (ctr_count > 0 && (g % ctr_mod) == 0) {
+            for (int j = 0; j < ctr_count; ++j) {
+                const size_t e = full + ctr_off + (size_t)j * ctr_stride;
+                const float gtv = valid[e] ? wg : 0.f;
+                for (int c = 0; c < C; ++c)
+                    gloss += gfocal_term(bag_prob(logits + e * J, C, c, ptype, norm_p), (c == label) ? 1.f : 0.f, eps) * gtv;
+                gcount += gtv > 0.f ? 1.f : 0.f;
+            }
+        }
+        float loss = 0.f, best = -INFINITY;
+        int best_c = 0;
+        for (int c = 0; c < C; ++c)
+            for (int j = 0; j < nj; ++j) {
+                const float pv = s_p[c * nj + j];
+                if (j == 0 && pv > best) { best = pv; best_c = c; }
+                loss += gfocal_term(pv, (j == 0 && c == label) ? 1.f : 0.f, eps) * lw;
+            }
+        float* o = bag + (size_t)g * 5;
+        o[0] = loss; o[1] = gloss; o[2] = lw; o[3] = gcount; o[4] = (best_c == label) ? 1.f : 0.f;
+    }
+}
+
 // out[0..4] = {gt_loss, pos_loss, bag_acc, neg_loss, num_sample}  (cpr_head.py:1180-1184,1216-1228).  The negative loss
 // is averaged over the LAST num_pos the reference computed: the MIL num_sample, or the gt count when with_mil_loss is off.
 __global__ void loss_finalize_kernel(const float* __restrict__ bag, int G, const double* __restrict__ neg_partial,
@@ -489,9 +558,15 @@ extern "C" int cpr_mil_loss(const float* logits, int J, int ins_off, const unsig
     CPR_CHECK_ARG(J >= ins_off + C * (binary_ins ? 2 : 1) && logits && valid && labels && bag_ws && out5);
     CPR_CHECK_ARG(ctr_count == 0 || (ctr_off >= 0 && ctr_off + (ctr_count - 1) * ctr_stride < bag_stride));
     CPR_CHECK_ARG(prob_type >= 0 && prob_type <= 3 && norm_p > 0.f && (n_partial == 0 || neg_partial));
-    hipLaunchKernelGGL(mil_bag_kernel, dim3(cdiv(G, 4)), dim3(256), 0, stream, logits, J, ins_off, valid, labels,
-                       gt_weight, bag_ws, G, bag_stride, bag_off, K, ctr_off, ctr_stride, ctr_count, ctr_mod, C, eps,
-                       prob_type, norm_p, binary_ins, allpos);
+    const int terms = C * (binary_ins ? 2 : 1);
+    if (!allpos && terms >= MIL_NW && terms <= MIL_MAXT)       // many classes: one workgroup per bag, classes over its waves
+        hipLaunchKernelGGL(mil_bag_cls_kernel, dim3(G), dim3(64 * MIL_NW), 0, stream, logits, J, ins_off, valid, labels, gt_weight,
+                           bag_ws, G, bag_stride, bag_off, K, ctr_off, ctr_stride, ctr_count, ctr_mod, C, eps, prob_type, norm_p,
+                           binary_ins);
+    else
+        hipLaunchKernelGGL(mil_bag_kernel, dim3(cdiv(G, 4)), dim3(256), 0, stream, logits, J, ins_off, valid, labels,
+                           gt_weight, bag_ws, G, bag_stride, bag_off, K, ctr_off, ctr_stride, ctr_count, ctr_mod, C, eps,
+                           prob_type, norm_p, binary_ins, allpos);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, bag_ws, G, neg_partial, n_partial, w_mil,
                        w_gt, w_neg, allpos ? (float)G * (float)K : (float)G, neg_from_gt, out5);
     CPR_LAUNCH_STATUS();
