@@ -110,7 +110,9 @@ CPR_CASES = {
 }
 
 
-GRAD_CASES = ('cpr_r18_c3_128', 'cpr_r50_c1_160_spread')
+# round 5: + the configs[2] family (80 classes, start_level 1, stride 8, radius 8) -- the config whose BASELINE line is the
+# gradient all-reduce
+GRAD_CASES = ('cpr_r18_c3_128', 'cpr_r50_c1_160_spread', 'cpr_r50_c80_s8_r8')
 
 
 def grad_sample_index(numel, k=256):

@@ -49,7 +49,8 @@ class Bridge:
         if engine is None:
             two = os.environ.get('CPR_TRAIN_STREAMS', '2') != '1'
             engine = (P2PBackwardEngine if type(head).__name__ == 'P2PHead' else BackwardEngine)(model, two_streams=two)
-            engine._sink = {}
+        if getattr(engine, '_sink', None) is None:
+            engine._sink = {}           # gradients go to fresh tensors handed to torch (any engine, also a caller's own)
         self.engine = engine
         bb, neck = model.backbone, model.neck
         self.stage_params = [[p for p in getattr(bb, name).parameters() if p.requires_grad] for name in bb.res_layers]

@@ -3,7 +3,10 @@
 mmcv.ops.nms.batched_nms does in the un-vendored mmcv-full) out of the 64x64 bitmask kernels; both in csrc/postproc.hip."""
 import torch
 
-from .. import ops
+from .. import _lib, ops
+
+NMS_SLAB_MAX = 16384                 # candidates per image the NMS kernels take (csrc/postproc.hip: 256 mask words in LDS)
+NMS_MASK_BYTES_MAX = 256 << 20       # worst-case pair-mask workspace above which the slabs are sized by the actual counts
 
 
 def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None, return_inds=False):
@@ -33,8 +36,20 @@ def multiclass_nms_batched(multi_bboxes, multi_scores, score_thr, nms_cfg, max_n
     B = multi_scores.shape[0]
     boxes, scores, labels, _, cnt = ops.nms_candidates_batched(multi_bboxes.float().contiguous(),
                                                                multi_scores.float().contiguous(), score_thr)
-    keep, num = ops.nms_batched(boxes, scores, labels, cnt, iou_thr)
     cap = scores.shape[1]
+    if cap > NMS_SLAB_MAX or B * cap * ((cap + 63) // 64) * 8 > NMS_MASK_BYTES_MAX:
+        # many classes (DOTA: 15 x nms_pre 2000 = 30 000 slots, COCO: 80 x 1000 = 80 000): the slab CAPACITY n * C is far above
+        # what the NMS kernels take (16 384 candidates, the limit of the per-image path too) and its worst-case pair mask would
+        # be hundreds of MB per image, while the candidates that pass score_thr are a few thousand.  One extra host read of the
+        # candidate counts sizes the NMS slabs by the largest actual count instead.
+        kmax = int(cnt.max().item())
+        if kmax > NMS_SLAB_MAX:
+            raise _lib.CprHipError('multiclass_nms: %d candidates above score_thr in one image (the NMS kernels take %d)'
+                                   % (kmax, NMS_SLAB_MAX))
+        kk = max(kmax, 1)
+        boxes, scores, labels = boxes[:, :kk].contiguous(), scores[:, :kk].contiguous(), labels[:, :kk].contiguous()
+        cap = kk
+    keep, num = ops.nms_batched(boxes, scores, labels, cnt, iou_thr)
     # gather in keep order on the whole slabs (entries past num_keep[b] are garbage indices: clamp, they are sliced away below)
     kc = keep.clamp_(0, max(cap - 1, 0))
     dets = torch.cat([torch.gather(boxes, 1, kc[..., None].expand(-1, -1, 4)), torch.gather(scores, 1, kc)[..., None]], dim=-1)

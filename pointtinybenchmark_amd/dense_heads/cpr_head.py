@@ -104,8 +104,16 @@ class _Extractor:
     def offsets(self, stride, device):
         key = (stride, str(device))
         if key not in self._off:
-            self._off[key] = circle_offsets(self.pos_radius, stride, **self.pos_kw).to(device)
+            off = circle_offsets(self.pos_radius, stride, **self.pos_kw)
+            # how far (in grid cells, rounded up) a bag point can lie from its centre: read off the offsets themselves, so a
+            # non-integer radius or any start_angle sizes the backward's gather window correctly (ops.cpr_loss_bwd)
+            self._off[('cells', stride)] = int(math.ceil(float(off.abs().max()) / stride)) if off.numel() else 0
+            self._off[key] = off.to(device)
         return self._off[key]
+
+    def window_radius_cells(self, stride, device):
+        self.offsets(stride, device)
+        return self._off[('cells', stride)]
 
 
 def cat_rows(tensors):
@@ -485,7 +493,8 @@ class CPRHead(nn.Module):
             out, bag_ws = out
             save.update(feat=feat, ab=ab, lmap=lmap, neg_mask=neg_mask, out5=out, bag_logits=bag_logits, valid=valid,
                         labels=labels, gt_weight=w, bag_ws=bag_ws, centers=gts.points, gt_img=gts.gt_img,
-                        offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride, radius_cells=ex.pos_radius)
+                        offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride,
+                        radius_cells=ex.window_radius_cells(stride, dev))
         return self._loss_dict(out)
 
     def _loss_dict(self, out):

@@ -6,6 +6,7 @@ Activations are NHWC fp32 (see csrc/conv_mfma.hip for why).  ``as_nchw`` / ``fro
 NCHW-shaped (channels_last-strided) tensors, which is what crosses the reference's module boundaries.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -1062,7 +1063,7 @@ def cpr_loss_bwd(lmap, neg_mask, out5, bag_logits, valid, labels, bag_ws, center
     dmap = torch.empty((N, H, W, Jd), device=lmap.device, dtype=torch.float32)
     dbag = torch.empty((G, K, J), device=lmap.device, dtype=torch.float32)
     assert radius_cells is not None and radius_cells >= 0, 'the bag radius (in cells) sizes the gather window'
-    win = 2 * int(radius_cells) + 3
+    win = 2 * int(math.ceil(radius_cells)) + 3      # taps of a bag span floor(c - r) .. floor(c + r) + 1
     win_ws = torch.empty((G, win, win, J), device=lmap.device, dtype=torch.float32)
     win_org = torch.empty((G, 2), device=lmap.device, dtype=torch.int32)
     _lib.call('cpr_loss_bwd', _ptr(lmap), _ptr(neg_mask), _ptr(out5), _ptr(bag_logits), _ptr(valid), _ptr(labels),

@@ -16,3 +16,12 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+def free_port():
+    """A TCP port the OS just handed out on 127.0.0.1 (pid-derived ports collided with sockets in TIME_WAIT / other jobs on a
+    shared box and made the two-rank tests flaky)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]

@@ -11,6 +11,8 @@ import warnings
 
 import numpy as np
 import pytest
+
+from tests.conftest import free_port
 import torch
 
 from oracle.gen_golden import CPR_CASES
@@ -65,7 +67,7 @@ def test_loss_backward_is_bit_equal_to_the_trainer(name):
         out['loss'].backward()
 
 
-@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread', 'cpr_r50_c80_s8_r8'])
 def test_loss_backward_matches_reference_autograd_golden(name):
     """The same bar tests/test_gpu_train_step.py holds the trainer to, on loss.backward(): total loss 1e-4, per-tensor norm
     2e-3 and strided samples 2e-3 against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_grads_*)."""
@@ -171,7 +173,7 @@ def test_ddp_wraps_the_drop_in_model_single_rank_rccl():
     data = _data(cfg)
     want, _ = _trainer_grads(cfg, data)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', str(29900 + os.getpid() % 500))
+    os.environ.setdefault('MASTER_PORT', str(free_port()))
     dist.init_process_group('nccl', rank=0, world_size=1)
     try:
         m, _ = build_hip_locator(cfg)
@@ -250,7 +252,7 @@ def test_ddp_two_ranks_on_the_gpu_average_the_gradients(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'ddp2.py'
     script.write_text(_DDP2_WORKER % dict(root=root))
-    port, out = str(30200 + os.getpid() % 300), str(tmp_path / 'res')
+    port, out = str(free_port()), str(tmp_path / 'res')
     procs = [subprocess.Popen([sys.executable, str(script), str(r), port, out], cwd=root, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     logs = [p.communicate(timeout=600)[0].decode(errors='replace') for p in procs]

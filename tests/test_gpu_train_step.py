@@ -4,6 +4,8 @@ L2 error of 2e-3 per parameter tensor (fp32 accumulation orders differ across ~5
 import os
 
 import pytest
+
+from tests.conftest import free_port
 import torch
 
 from oracle import cpr_oracle as O
@@ -192,7 +194,7 @@ def test_two_stream_step_is_bit_repeatable_under_allocator_pressure(mode):
             mode, rep, int((tr.flat_g != g0).sum()), float((tr.flat_g - g0).abs().max()))
 
 
-@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread', 'cpr_r50_c80_s8_r8'])
 def test_backward_matches_reference_autograd_golden(name):
     """HIP gradients against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_grads_*.npz, produced
     in the build container by oracle.gen_golden): total loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the
@@ -283,7 +285,7 @@ def test_rccl_bucket_path_single_rank():
     ref_losses, ref_p, _, tl0 = run(False)
     assert tl0 is None                      # no process group: nothing is issued, nothing is timed
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
+    os.environ.setdefault('MASTER_PORT', str(free_port()))
     dist.init_process_group('nccl', rank=0, world_size=1)
     try:
         losses, p, nb, tl = run(True)
@@ -346,7 +348,7 @@ def test_two_ranks_on_the_gpu_equal_the_averaged_single_process_step(tmp_path, r
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'worker.py'
     script.write_text(_TWO_RANK_WORKER % dict(root=root))
-    port = str(29600 + os.getpid() % 300)
+    port = str(free_port())
     out = str(tmp_path / 'res')
     procs = [subprocess.Popen([sys.executable, str(script), str(r), port, out, reducer], cwd=root, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]

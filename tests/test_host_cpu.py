@@ -6,6 +6,8 @@ import subprocess
 import sys
 
 import pytest
+
+from tests.conftest import free_port
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -127,7 +129,7 @@ dist.barrier(); dist.destroy_process_group(); print('rank', rank, 'ok')
 def test_two_rank_gloo_log_var_reduction(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER % ROOT)
-    port = str(29500 + os.getpid() % 2000)
+    port = str(free_port())
     procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
@@ -161,7 +163,7 @@ def test_two_rank_gloo_gradient_buckets(tmp_path):
     """The bucketed reducer of the training step (training.GradBuckets) under gloo, world_size 2."""
     script = tmp_path / 'bworker.py'
     script.write_text(_BUCKET_WORKER % ROOT)
-    port = str(31500 + os.getpid() % 2000)
+    port = str(free_port())
     procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
@@ -198,7 +200,7 @@ def test_two_rank_gloo_reduce_scatter_reducer_equals_all_reduce(tmp_path):
     all-reduce reducer's sums bit for bit on two ranks."""
     script = tmp_path / 'rsworker.py'
     script.write_text(_RS_WORKER % ROOT)
-    port = str(33500 + os.getpid() % 2000)
+    port = str(free_port())
     procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
@@ -340,7 +342,7 @@ def test_two_rank_gloo_ddp_drives_the_autograd_bridge(tmp_path):
     needs a GPU, so the segment API is served by a closed-form CPU stand-in; the Functions, the graph and DDP are real."""
     script = tmp_path / 'ddpworker.py'
     script.write_text(_DDP_WORKER % ROOT)
-    port = str(35500 + os.getpid() % 2000)
+    port = str(free_port())
     procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
@@ -407,7 +409,7 @@ def test_two_rank_gloo_trainer_broadcasts_initial_state(tmp_path):
     buffers (only gradients are averaged afterwards).  Also: the re-binding guard and the cloning state_dict()."""
     script = tmp_path / 'sworker.py'
     script.write_text(_SYNC_WORKER % ROOT)
-    port = str(33500 + os.getpid() % 2000)
+    port = str(free_port())
     procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]

@@ -89,7 +89,7 @@ def test_hungarian_v2_matches_reference_fixture(golden_dir, case):
     assert int((inds > 0).sum()) == min(k, (n_side * n_side) // G) * G
 
 
-@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread', 'cpr_r50_c80_s8_r8'])
 def test_oracle_autograd_matches_reference_autograd(golden_dir, name):
     """Pins the ORACLE's backward: torch autograd over oracle/cpr_oracle.py against loss.backward() through the reference's
     own modules (fixtures from oracle.gen_golden.run_reference_cpr_grads): per-tensor norm, sum and strided samples."""
