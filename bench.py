@@ -188,8 +188,9 @@ class ConvProbe:
                 variant = 'conv_wino_kernel<0, %s, %s, %d, 4>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false',
                                                                   0 if v & 4 else 1)
             elif kind == 'bf16':
-                # conv_bf16_dma.hip reports 256256 (the <4, 2> instance) and 1128128 (<2, 1>: 128 x 128 tiles, two workgroups per CU)
-                variant = ('conv_bf16_dma_kernel<4, 2>' if v == 256256 else 'conv_bf16_dma_kernel<2, 1>' if v == 1128128 else
+                # conv_bf16_dma.hip reports 256256 (the <MI 4, NJ 2, WN 4> instance, as rocprof prints it) and 1128128 (<2, 1, 4>: 128 x 128
+                # tiles, two workgroups per CU)
+                variant = ('conv_bf16_dma_kernel<4, 2, 4>' if v == 256256 else 'conv_bf16_dma_kernel<2, 1, 4>' if v == 1128128 else
                            'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000))
             elif v % 10 == 2:    # dual-source launch (conv3 + projection shortcut): <BM, BN, MODE 0, XF false, PIPE 1, ABL 0, DUAL>
                 variant = 'conv_mfma_kernel<%d, %d, 0, false, 1, 0, true>' % (v // 1000000, v // 1000 % 1000)
@@ -358,18 +359,23 @@ def host_cpu_info():
 
 
 def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None, depth=50, height=640, width=640,
-                 num_classes=1, start_level=0, stride=4, radius=5, model='cpr'):
+                 num_classes=1, start_level=0, stride=4, radius=5, model='cpr', gate_fn=None, ctx_out=None, sd=None):
     """The CPU oracle on this box's host cores: same synthetic workload (same depth / size / classes / stride / radius as the
     timed configuration), bounded sample.  The box reports 256 logical CPUs but torch/oneDNN throughput is far from monotone
     in the thread count there (cgroup quota, SMT, NUMA), so the whole step is timed once at several thread counts and the
     fastest is kept and re-timed, with the backbone / neck / head towers / point stage split.
     ``hip_losses_fn(batch)``: the HIP path on the SAME sample -- the parity gate of the bench run (losses of the two paths
     side by side).  model='p2p': backbone + neck + both P2PHead towers + Hungarian assignment + focal / SmoothL1 losses
-    (oracle.cpr_oracle.p2p_loss); the gate compares the per-batch sums of loss_cls / loss_pts."""
+    (oracle.cpr_oracle.p2p_loss); the gate compares the per-batch sums of loss_cls / loss_pts.
+    ``gate_fn(ctx)``: a mode-specific gate (bf16 / inference: see main) on the same sample, ctx = {sd, batch, losses, feat,
+    cls, reg} of the oracle's last step; its dict becomes ``parity_gate``.  ``ctx_out``: a dict that receives ctx (the
+    training-step gate re-uses the sample).  ``sd``: the weights to run (default: the seeded synthetic initialisation; the
+    training mode passes the model's CURRENT state so the two sides stay on the same weights after optimizer steps)."""
     from oracle import cpr_oracle as O
     from pointtinybenchmark_amd import synthetic
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    sd = synthetic.locator_state_dict(depth, num_classes, start_level, model, 0, **({'head_std': 0.05} if model == 'p2p' else {}))
+    if sd is None:
+        sd = synthetic.locator_state_dict(depth, num_classes, start_level, model, 0, **({'head_std': 0.05} if model == 'p2p' else {}))
     batch = synthetic.synthetic_batch(batch_size, height, width, num_gts, num_classes, 0)
     last = {}
 
@@ -383,12 +389,14 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None, d
             t2 = time.perf_counter()
             if model == 'p2p':
                 cls, reg = O.p2p_head_forward(sd, feats)
+                last.update(cls=cls[0], reg=reg[0])
                 t3 = time.perf_counter()
                 # oracle.cpr_oracle.p2p_loss: Hungarian targets + focal / SmoothL1 losses (pinned to the reference by tests/golden/p2p.npz)
                 pl, _ = O.p2p_loss(cls[0], reg[0], batch['gt_bboxes'], batch['gt_labels'], (height, width, 3), stride=stride)
                 losses = {'loss_cls': sum(pl['loss_cls']), 'loss_pts': sum(pl['loss_pts'])}
             else:
                 cls_feat, _ = O.cpr_head_forward(sd, feats)
+                last.update(feat=cls_feat[0])
                 t3 = time.perf_counter()
                 losses, _ = O.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], stride, radius,
                                        num_classes)
@@ -428,7 +436,15 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None, d
                           {k: round(v, 2) for k, v in trials.items()}, os.cpu_count() or 1),
                host_cpu=cpu_model, physical_cores=phys, logical_cpus=os.cpu_count() or 1,
                split_s={k: round(v, 4) for k, v in last['split'].items()})
-    if hip_losses_fn is not None:          # parity gate: the HIP path on the very sample the oracle was timed on
+    ctx = dict(sd=sd, batch=batch, losses=last['losses'], feat=last.get('feat'), cls=last.get('cls'), reg=last.get('reg'))
+    if ctx_out is not None:
+        ctx_out.update(ctx)
+    if gate_fn is not None:
+        try:
+            out['parity_gate'] = gate_fn(ctx)
+        except Exception as e:   # noqa: BLE001
+            out['parity_gate'] = dict(error=repr(e)[:300])
+    elif hip_losses_fn is not None:          # parity gate: the HIP path on the very sample the oracle was timed on
         try:
             hip = hip_losses_fn(batch)
             rel = {k: abs(hip[k] - v) / max(abs(v), 1e-12) for k, v in last['losses'].items() if k in hip}
@@ -437,6 +453,91 @@ def cpu_baseline(batch_size, num_gts, seconds_budget=30.0, hip_losses_fn=None, d
         except Exception as e:   # noqa: BLE001
             out['parity_gate'] = dict(error=repr(e)[:200])
     return out
+
+
+def grad_report(got, ref):
+    """got / ref: name -> gradient tensor.  Per-tensor relative L2 (worst first), relative error of the global gradient norm,
+    cosine over all parameters, and the error on a strided sample of entries (oracle.gen_golden.grad_sample_index: the
+    indices the reference-autograd fixtures hold).  Shared by tests/test_gpu_fullsize_grads.py and the bench gates."""
+    from oracle.gen_golden import grad_sample_index
+    rows, g2, r2, dot = [], 0.0, 0.0, 0.0
+    gmax = max(float(r.abs().max()) for r in ref.values())
+    for k, r in ref.items():
+        g = got[k].detach().double().flatten().cpu()
+        r = r.detach().double().flatten().cpu()
+        g2 += float(g.pow(2).sum())
+        r2 += float(r.pow(2).sum())
+        dot += float((g * r).sum())
+        idx = torch.from_numpy(grad_sample_index(r.numel()))
+        rows.append(dict(key=k, rel_l2=float((g - r).norm() / max(float(r.norm()), 1e-30)), ref_max=float(r.abs().max()),
+                         sample_err=float((g[idx] - r[idx]).abs().max()), nil=bool(float(r.abs().max()) <= 1e-6 * gmax)))
+    rows.sort(key=lambda d: -d['rel_l2'])
+    return dict(rows=rows, norm_rel=abs(g2 ** 0.5 - r2 ** 0.5) / max(r2 ** 0.5, 1e-30), ref_norm=r2 ** 0.5, gmax=gmax,
+                cosine=dot / max((g2 * r2) ** 0.5, 1e-300))
+
+
+def oracle_step_grads(args, sd, batch, trainable):
+    """loss.backward() of the reference's training step as torch autograd over the CPU oracle (plain differentiable torch,
+    pinned to the reference's own autograd by tests/golden/cpr_grads_*.npz / p2p_grads.npz) -> (total loss, name -> grad)."""
+    from oracle import cpr_oracle as O
+    sd = {k: v.detach().clone() for k, v in sd.items()}
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else 8)))
+    if args.model == 'p2p':
+        feats = O.fpn_forward(sd, O.resnet_forward(sd, batch['img'], args.depth), args.start_level, 1)
+        cls, reg = O.p2p_head_forward(sd, feats)
+        pl, _ = O.p2p_loss(cls[0], reg[0], batch['gt_bboxes'], batch['gt_labels'], (args.height, args.width, 3), stride=args.stride)
+        total = sum(pl['loss_cls']) + sum(pl['loss_pts'])
+    else:
+        losses, _, _ = O.locator_forward_train(sd, batch, args.depth, args.start_level, args.stride, args.radius, args.classes)
+        total = sum(v for k, v in losses.items() if 'loss' in k)
+    total.backward()
+    return float(total.detach()), {k: sd[k].grad for k in trainable}
+
+
+def train_parity_gate(trainer, model, args, batch, ref=None):
+    """The training step's gradients on the B=2 sample of the cpu_baseline leg, HIP (CprTrainer.forward_backward with the model's
+    CURRENT weights and compute mode) against the oracle's autograd.  fp32 bars: per-tensor relative L2 <= 2e-3 (tensors whose
+    gradient is numerically nil excepted), global norm <= 1e-4, total loss <= 5e-4.  Mixed precision (bf16 compute mode) bars:
+    cosine over all parameters >= 0.99, per-tensor relative L2 <= 0.25, loss <= 3e-2 (tests/test_gpu_train_step.py).  P2PNet:
+    3e-2 per tensor (an fp32 ReLU flip on the few dozen positives moves a whole regression-tower tensor: tests/test_gpu_p2p.py),
+    global norm 1e-3.  ``ref``: (total, grads) of a previous call on the same weights (re-used for the mixed-precision gate)."""
+    t0 = time.perf_counter()
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    if ref is None:
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        ref = oracle_step_grads(args, sd, batch, trainable)
+    t_oracle = time.perf_counter() - t0
+    losses = trainer.forward_backward(batch['img'].cuda(), batch['img_metas'], [x.cuda() for x in batch['gt_bboxes']],
+                                      [x.cuda() for x in batch['gt_labels']])
+    trainer.buckets.finish()            # (a 1-rank group under torchrun: the buckets' sums are the gradients themselves)
+    torch.cuda.synchronize()
+    total = 0.0
+    for k, v in losses.items():
+        if 'loss' in k:
+            total += float(sum(v)) if isinstance(v, (list, tuple)) else float(v)
+    got = {k: p.grad for k, p in model.named_parameters() if p.requires_grad}
+    rep = grad_report(got, ref[1])
+    mixed = model.backbone.compute_dtype == torch.bfloat16
+    live = [d for d in rep['rows'] if not d['nil']]
+    worst = max((d['rel_l2'] for d in live), default=0.0)
+    loss_rel = abs(total - ref[0]) / max(abs(ref[0]), 1e-12)
+    if mixed:
+        bars = dict(cosine_min=0.99, per_tensor_rel_l2=0.25, loss_rel=3e-2)
+        ok = rep['cosine'] >= 0.99 and worst <= 0.25 and loss_rel <= 3e-2
+    elif args.model == 'p2p':
+        bars = dict(per_tensor_rel_l2=3e-2, global_norm_rel=1e-3, loss_rel=5e-4)
+        ok = worst <= 3e-2 and rep['norm_rel'] <= 1e-3 and loss_rel <= 5e-4
+    else:
+        bars = dict(per_tensor_rel_l2=2e-3, global_norm_rel=1e-4, loss_rel=5e-4)
+        ok = worst <= 2e-3 and rep['norm_rel'] <= 1e-4 and loss_rel <= 5e-4
+    return dict(what='gradients of the HIP training step vs torch autograd over the CPU oracle, B=%d sample of the cpu_baseline leg, '
+                     'current weights' % len(batch['img_metas']),
+                tensors=len(rep['rows']), max_rel_l2=worst, worst=[(d['key'], round(d['rel_l2'], 6)) for d in live[:3]],
+                global_norm_rel=rep['norm_rel'], cosine=rep['cosine'], oracle_grad_norm=rep['ref_norm'],
+                loss_rel=loss_rel, hip_loss=total, oracle_loss=ref[0], bars=bars, passed=bool(ok),
+                oracle_seconds=round(t_oracle, 2)), ref
 
 
 def measure_small_batch(model, b, size, num_gts, steps=30, graph_too=True, width=None, num_classes=1):
@@ -670,7 +771,7 @@ def main():
         return cls(model, lr=1e-3 if args.model == 'cpr' else 1e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0,
                           two_streams=os.environ.get('CPR_TRAIN_STREAMS', '2') != '1',
                           force_collectives=distributed and world == 1,
-                          **({} if args.model == 'p2p' else dict(reducer=args.reducer, reducer_timing=distributed)))
+                          reducer=args.reducer, reducer_timing=distributed)
 
     def train_step():
         losses = trainer.forward_backward(img, metas, gtb, gtl)
@@ -782,6 +883,19 @@ def main():
                    # rank 0's view of the last step: when each gradient bucket was final (= its reduction issued) and when the
                    # main stream held its sum, relative to the start of the backward; exposed_ms = reducer time NOT hidden
                    'reducer': _reducer_summary(trainer)}
+            grad_ref = None
+            if world == 1 and sample_ctx.get('batch') is not None:      # (cpu_baseline leg only: the oracle is the checker)
+                try:
+                    res['parity_gate'], grad_ref = train_parity_gate(trainer, model, args, sample_ctx['batch'])
+                    model.set_compute_dtype('bf16')        # same weights (no step in between): the oracle gradients are re-used
+                    mixed_gate, _ = train_parity_gate(trainer, model, args, sample_ctx['batch'], ref=grad_ref)
+                except Exception as e:   # noqa: BLE001
+                    res.setdefault('parity_gate', dict(error=repr(e)[:300]))
+                    mixed_gate = dict(error=repr(e)[:300])
+                finally:
+                    model.set_compute_dtype(args.dtype)
+            else:
+                mixed_gate = None
             # the same trainer in the bf16 compute mode = mixed precision (bf16 recorded forward and stride-1 data gradients,
             # fp32 weight gradients / weights / optimizer); NOT the fp32 arithmetic of the reference, reported beside it
             try:
@@ -802,6 +916,8 @@ def main():
                                           'what': 'the same step in the bf16 compute mode (bf16 recorded forward, bf16 data / weight '
                                                   'gradients of the stride-1 layers, fp32 normalisation backward / weights / optimizer)',
                                           'loss': float(sum(v for k, v in tl.items() if 'loss' in k))}
+                if mixed_gate is not None:
+                    res['mixed_precision']['parity_gate'] = mixed_gate
             except Exception as e:   # noqa: BLE001 -- a failure of the bf16 step must not discard the fp32 result above
                 res['mixed_precision'] = {'error': repr(e)[:300]}
             finally:
@@ -841,6 +957,7 @@ def main():
             return {'error': repr(e)[:300]}
 
     out = None
+    sample_ctx = {}      # the B=2 sample (weights, batch, oracle outputs) of the cpu_baseline leg, re-used by the training-step gate
     if rank == 0:
         total_imgs = args.batch * world * args.steps
         out = {
@@ -932,10 +1049,74 @@ def main():
                     r = model.forward_train(b['img'].cuda(), b['img_metas'], [x.cuda() for x in b['gt_bboxes']],
                                             [x.cuda() for x in b['gt_labels']])
                     return {k: float(sum(v)) if isinstance(v, (list, tuple)) else float(v) for k, v in r.items()}
-            # parity gate: every fp32 CPR configuration (bf16 has its own stated tolerance, tests/test_gpu_bf16.py)
-            out['cpu_baseline'] = cpu_baseline(2, args.num_gts, hip_losses_fn=hip_losses if (
-                args.dtype == 'fp32' and args.mode != 'infer') else None, depth=args.depth, height=args.height, width=args.width,
-                num_classes=args.classes, start_level=args.start_level, stride=args.stride, radius=args.radius, model=args.model)
+
+            def bf16_gate(ctx):
+                """bf16 compute mode against the fp32 oracle at the stated bars (the mode's arithmetic is NOT the reference's):
+                losses 3e-2; the head feature map |err| <= 8e-2 max, 1e-2 mean (of the map's max: tests/test_gpu_bf16.py) and --
+                what those two cannot see, a mis-indexed tile on a small share of the pixels -- relative L2 <= 3e-2 and at most
+                1e-4 of the entries further than 0.1 * max|ref| from the oracle."""
+                b = ctx['batch']
+                hip = hip_losses(b)
+                rel = {k: abs(hip[k] - v) / max(abs(v), 1e-3) for k, v in ctx['losses'].items() if k in hip and 'loss' in k}
+                with torch.no_grad():
+                    cls_feat, _ = model.bbox_head(model.neck(model.backbone(b['img'].cuda())))
+                    f = cls_feat[0].float().cpu()
+                ref = ctx['feat']
+                err = (f - ref).abs()
+                scale = max(1.0, float(ref.abs().max()))
+                st = dict(max_abs_over_scale=float(err.max()) / scale, mean_abs_over_scale=float(err.mean()) / scale,
+                          rel_l2=float((f - ref).norm() / ref.norm()), outlier_frac=float((err > 0.1 * scale).float().mean()))
+                bars = dict(loss_rel=3e-2, max_abs_over_scale=8e-2, mean_abs_over_scale=1e-2, rel_l2=3e-2, outlier_frac=1e-4)
+                ok = max(rel.values()) <= 3e-2 and all(st[k] <= bars[k] for k in st)
+                return dict(what='bf16 compute mode vs the fp32 CPU oracle on the B=2 sample: losses and the head feature map',
+                            oracle_losses=ctx['losses'], hip_losses=hip, max_rel_err=max(rel.values()), cls_feat=st, bars=bars,
+                            passed=bool(ok))
+
+            def infer_gate(ctx):
+                """P2PNet inference (forward + top-k + pseudo-box NMS) against the oracle's p2p_get_points_single on the oracle's
+                own tower outputs, B=2 sample: detection counts per image (|diff| <= max(2, 1 %)) and, detection by detection, a
+                partner within 0.01 px and 1e-4 in score for >= 99 % of the HIP detections (the towers agree to ~1e-5, so a
+                candidate at the score threshold or an IoU at the NMS threshold may fall the other way)."""
+                from oracle import cpr_oracle as O
+                b = ctx['batch']
+                with torch.no_grad():
+                    res = model.simple_test(b['img'].cuda(), b['img_metas'])
+                B, C, H, W = ctx['cls'].shape
+                anchor = O.p2p_grid_points(H, W, args.stride)[:, :2]
+                rows = []
+                for i in range(B):
+                    cls_i = ctx['cls'][i].permute(1, 2, 0).reshape(H * W, C)
+                    pred_i = anchor + ctx['reg'][i].permute(1, 2, 0).reshape(H * W, 2) * args.stride
+                    dets, labels, _, _ = O.p2p_get_points_single(cls_i, pred_i, None, (args.height, args.width, 3))
+                    got = res[i][0].cpu()
+                    gc = torch.stack([(got[:, 0] + got[:, 2]) * 0.5, (got[:, 1] + got[:, 3]) * 0.5], -1)
+                    matched = 1.0
+                    if len(got) and len(dets):
+                        d = torch.cdist(gc.double(), dets[:, :2].double())
+                        ds = (got[:, 4][:, None] - dets[:, 2][None]).abs()
+                        matched = float(((d <= 1e-2) & (ds <= 1e-4)).any(dim=1).float().mean())
+                    rows.append(dict(hip_dets=int(len(got)), oracle_dets=int(len(dets)), matched_frac=matched))
+                ok = all(abs(r['hip_dets'] - r['oracle_dets']) <= max(2, 0.01 * r['oracle_dets']) and r['matched_frac'] >= 0.99
+                         for r in rows)
+                return dict(what='P2PNet detections vs the oracle (p2p_get_points_single on the oracle towers), B=2 sample',
+                            images=rows, bars=dict(count_diff='max(2, 1 %)', matched_frac_min=0.99, match='0.01 px, 1e-4 score'),
+                            passed=bool(ok))
+            gate_fn = infer_gate if args.mode == 'infer' else bf16_gate if (args.dtype == 'bf16' and args.model == 'cpr') else None
+            # parity gate: fp32 -> losses at 5e-4; bf16 -> losses + head feature map at the bf16 bars; inference -> detections
+            out['cpu_baseline'] = cpu_baseline(2, args.num_gts, hip_losses_fn=hip_losses if args.dtype == 'fp32' else None,
+                                               depth=args.depth, height=args.height, width=args.width,
+                                               num_classes=args.classes, start_level=args.start_level, stride=args.stride,
+                                               radius=args.radius, model=args.model, gate_fn=gate_fn, ctx_out=sample_ctx,
+                                               sd={k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+            if trainer is not None:        # --mode train: the timed step's own gate + where its gradient buckets landed
+                ts = {'reducer': _reducer_summary(trainer), 'grad_norm': trainer.grad_norm()}
+                try:
+                    ts['parity_gate'], _ = train_parity_gate(trainer, model, args, sample_ctx['batch'])
+                except Exception as e:   # noqa: BLE001
+                    ts['parity_gate'] = dict(error=repr(e)[:300])
+                out['train_step'] = ts
+        elif trainer is not None and rank == 0:
+            out['train_step'] = {'reducer': _reducer_summary(trainer), 'grad_norm': trainer.grad_norm() if world == 1 else None}
     # last of all, under a watchdog: if the training step (first use of the collective library at N > 1) wedges, the headline
     # line is still printed and every rank leaves
     import threading

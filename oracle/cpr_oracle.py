@@ -441,7 +441,9 @@ def p2p_loss(cls_outs, pts_outs, gt_bboxes, gt_labels, img_shape, stride=4, topk
     labels, lw, tgt, pw, inds_all = [], [], [], [], []
     for b in range(B):
         ctr = (gt_bboxes[b][:, :2] + gt_bboxes[b][:, 2:]) / 2
-        inds, _, _ = hungarian_assign_v2(pred[b], cls[b], ctr, gt_labels[b], img_shape, topk_k=topk_k, log_mode=log_mode)
+        # the assignment carries no gradient (the reference builds its cost from detached tensors: hungarian_assigner.py:214-236)
+        inds, _, _ = hungarian_assign_v2(pred[b].detach(), cls[b].detach(), ctr, gt_labels[b], img_shape, topk_k=topk_k,
+                                         log_mode=log_mode)
         pos = inds > 0
         lab = torch.full((pred.shape[1],), C, dtype=torch.long)
         lab[pos] = gt_labels[b][inds[pos] - 1]

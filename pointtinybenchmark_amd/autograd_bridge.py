@@ -18,8 +18,10 @@ the neck and backbone still compute, as with the trainer's own buckets.  The ari
 ``p.grad`` after ``loss.backward()`` is BIT-equal to ``CprTrainer.forward_backward``'s (tests/test_gpu_autograd.py), which is
 pinned to ``loss.backward()`` through the reference's own modules by tests/golden/cpr_grads_*.npz.
 
-fp32 compute mode, the shipped configs' head options (``CPRHead.train_step_supported``), one FPN output level, a frozen stem.
-Anything else keeps the forward-only path and warns once (the bf16 compute mode trains through ``training.CprTrainer``)."""
+Both compute modes (round 5: the bf16 mode = mixed precision, the reference analogue being mmcv's ``Fp16OptimizerHook`` around an
+unmodified ``loss.backward()``, T/mmdet/apis/train.py:116-119 -- see ``Bridge.carrier`` for how bf16 maps cross the Function
+boundaries), the shipped configs' head options (``CPRHead.train_step_supported``), one FPN output level, a frozen stem.  Anything
+else keeps the forward-only path and warns once."""
 import os
 import warnings
 
@@ -53,10 +55,29 @@ class Bridge:
             engine._sink = {}           # gradients go to fresh tensors handed to torch (any engine, also a caller's own)
         self.engine = engine
         bb, neck = model.backbone, model.neck
+        self._maps = {}         # bf16 compute mode: data_ptr of an fp32 carrier -> the bf16 map it stands for (see carrier())
         self.stage_params = [[p for p in getattr(bb, name).parameters() if p.requires_grad] for name in bb.res_layers]
         self.lateral_params = [p for cm in neck.lateral_convs for p in cm.parameters() if p.requires_grad]
         self.head_params = [p for p in list(neck.fpn_convs[0].parameters()) + list(head.parameters()) if p.requires_grad]
         self.signature = signature(model)
+
+
+    # ---- mixed precision (bf16 compute mode) behind the same Functions.  The recorded maps are bf16, the gradients the backward
+    # kernels hand from segment to segment are fp32 -- and autograd casts a gradient to the dtype of the output it belongs to, so
+    # a bf16 map cannot be a Function output without rounding every boundary gradient to 8 bits.  The boundary therefore carries
+    # an fp32 STAND-IN of the map's shape (all strides 0: one element of storage, never read or written); the Functions look
+    # the real map up here.  fp32 maps pass through unchanged.
+    def carrier(self, real):
+        if real.dtype == torch.float32:
+            return real
+        ph = torch.empty_strided(tuple(real.shape), (0,) * real.dim(), dtype=torch.float32, device=real.device)
+        self._maps[ph.data_ptr()] = real
+        return ph
+
+    def real(self, t):
+        if t.dtype == torch.float32 and self._maps and t.dim() > 0 and all(s == 0 for s in t.stride()):
+            return self._maps.get(t.data_ptr(), t)
+        return t
 
 
 def signature(model):
@@ -68,8 +89,8 @@ def unsupported_reason(model, gt_bboxes=None, gt_labels=None):
     bb, neck, head = model.backbone, model.neck, model.bbox_head
     if neck is None or type(neck).__name__ != 'FPN' or len(neck.fpn_convs) != 1:
         return 'needs an FPN neck with num_outs == 1 (every shipped CPR / P2P config)'
-    if bb.compute_dtype != torch.float32:
-        return 'the bf16 compute mode trains through training.CprTrainer (mixed precision), not through torch autograd'
+    if bb.compute_dtype != torch.float32 and type(head).__name__ != 'CPRHead':
+        return 'the mixed-precision step (bf16 compute mode) covers the CPR locator; P2PNet trains in fp32'
     if any(p.requires_grad for m in (bb.conv1, bb.bn1) for p in m.parameters()):
         return 'a trainable stem (frozen_stages < 0) has no backward rule'
     if tuple(bb.out_indices) != tuple(range(len(bb.res_layers))):
@@ -125,7 +146,8 @@ class _StageFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bridge, stage, x, *params):
-        out, tape = bridge.engine.forward_stage(stage, x)
+        out, tape = bridge.engine.forward_stage(stage, bridge.real(x))
+        out = bridge.carrier(out)
         if tape and isinstance(tape[-1], dict) and tape[-1].get('out') is out:
             tape[-1]['out'] = out.detach()
         ctx.bridge, ctx.tape, ctx.params = bridge, tape, params
@@ -149,9 +171,9 @@ class _LateralsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bridge, n_in, *args):
         xs, params = args[:n_in], args[n_in:]
-        lat0, recs = bridge.engine.forward_laterals(xs)
+        lat0, recs = bridge.engine.forward_laterals([bridge.real(x) for x in xs])
         ctx.bridge, ctx.recs, ctx.params, ctx.n_in = bridge, recs, params, n_in
-        return lat0
+        return bridge.carrier(lat0)
 
     @staticmethod
     @once_differentiable
@@ -174,8 +196,8 @@ class _HeadLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bridge, lat0, pack, *params):
         eng = bridge.engine
-        out, state = eng.forward_head_loss(lat0, pack.img_metas, pack.gt_bboxes, pack.gt_labels, pack.gt_bboxes_ignore,
-                                           pack.gt_true_bboxes)
+        out, state = eng.forward_head_loss(bridge.real(lat0), pack.img_metas, pack.gt_bboxes, pack.gt_labels,
+                                           pack.gt_bboxes_ignore, pack.gt_true_bboxes)
         saved = state[1] if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict) else None
         if saved is not None and saved.get(eng.loss_vector_key) is out:
             saved[eng.loss_vector_key] = out.detach()
@@ -203,6 +225,7 @@ def forward_train(model, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=
     eng = bridge.engine
     eng.begin_step()
     eng._sink.clear()
+    bridge._maps.clear()
     bb, neck = model.backbone, model.neck
     with torch.no_grad():
         x = bb.stem(img)
@@ -213,11 +236,12 @@ def forward_train(model, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=
             x = _StageFn.apply(bridge, i, x, *params)
         else:
             with torch.no_grad():
-                x = bb.run_stage(i, x)
+                x = bb.run_stage(i, bridge.real(x))
         feats.append(x)
     assert len(feats) == len(neck.in_channels)
     xs = feats[neck.start_level:neck.start_level + len(neck.lateral_convs)]
     lat0 = _LateralsFn.apply(bridge, len(xs), *xs, *bridge.lateral_params)
     pack = _GtPack(img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_true_bboxes)
     out = _HeadLossFn.apply(bridge, lat0, pack, *bridge.head_params)
+    bridge._maps.clear()          # every forward consumer has run; the backward reads the tapes
     return eng.loss_dict(out)

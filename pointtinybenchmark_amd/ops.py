@@ -188,12 +188,19 @@ def wino_instance(pc, H, W, fused_affine):
     return WINO_AUTO(pc, H, W, fused_affine)
 
 
+WINO32_MAX_PIXELS = 40 * 40
+
+
 def WINO_AUTO(pc, H, W, fused_affine):
-    """Measured per shape on MI355X (profiles/round4_wino32_ab.txt): the two-workgroups-per-CU kernel loses on
-    every layer of the networks at B = 64 (160x160x256: 8.9 vs 7.0 ms; 40x40x256: 0.71 vs 0.67; 80x80x128: 0.63 vs 0.54;
-    160x160x64: 0.71 vs 0.59) and wins only on launches too small to fill the chip (40x40x256 at B = 2: 0.061 vs 0.071 ms).
-    The choice may not depend on the batch size, so the one-workgroup-per-CU kernel serves every layer."""
-    return '64'
+    """Keyed on the LAYER GEOMETRY alone (never on the batch size: an image of a big batch must equal its single-image run bit
+    for bit, and the two kernels differ in accumulation order).  Measured per shape on MI355X (profiles/round4_wino32_ab.txt,
+    DESIGN.md 4.1d): the two-workgroups-per-CU kernel loses on the large maps at every batch (160x160x256: 8.9 vs 7.0 ms at
+    B = 64, 0.359 vs 0.319 at B = 2; 80x80x128: 0.63 vs 0.54; 160x160x64: 0.71 vs 0.59) and wins where one image brings fewer
+    16 x 16 regions than a tenth of the chip: 40x40x256 at the reference's batch of 2 runs 0.061 vs 0.071 ms (B = 2: 18 regions of
+    16 x 16 per image against 30 of 8 x 16), at B = 64 it costs 0.709 vs 0.672 ms.  Maps of at most 40 x 40 pixels (layer3 of
+    a 640 x 640 input) therefore take the 8 x 16-region kernel at every batch: -14 % on those layers at B = 2, +5 % at B = 64
+    (0.3 % of that step)."""
+    return '32' if H * W <= WINO32_MAX_PIXELS else '64'
 
 
 def wino_gn_slots(pc, H, W, fused_affine):

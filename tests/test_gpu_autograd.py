@@ -67,6 +67,39 @@ def test_loss_backward_is_bit_equal_to_the_trainer(name):
         out['loss'].backward()
 
 
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
+def test_mixed_precision_loss_backward_is_bit_equal_to_the_trainer(name):
+    """bf16 compute mode through the bridge (round 5; the reference analogue is Fp16OptimizerHook around an unmodified
+    loss.backward(), T/mmdet/apis/train.py:116-119): bf16 recorded maps cross the Function boundaries behind fp32 carriers, the
+    boundary gradients stay fp32 -- so every .grad must equal the mixed-precision CprTrainer's bit for bit, and the logged losses
+    must be the same floats."""
+    from pointtinybenchmark_amd.training import CprTrainer
+    cfg = CPR_CASES[name]
+    data = _data(cfg)
+    m, _ = build_hip_locator(cfg)
+    m.set_compute_dtype('bf16')
+    tr = CprTrainer(m)
+    losses = tr.forward_backward(**data)
+    torch.cuda.synchronize()
+    want = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad}
+    want_losses = {k: float(v) for k, v in losses.items()}
+    m2, _ = build_hip_locator(cfg)
+    m2.set_compute_dtype('bf16')
+    out = m2.train_step(dict(data), optimizer=None)
+    assert out['loss'].requires_grad and out['loss'].grad_fn is not None, 'the bf16 mode must return a differentiable loss too'
+    for k, v in want_losses.items():
+        assert out['log_vars'][k] == v, (k, out['log_vars'][k], v)
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    for k, p in m2.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and p.grad.dtype == torch.float32, k
+            assert torch.equal(p.grad, want[k]), '%s: max abs diff %.3e (|g| max %.3e)' % (
+                k, float((p.grad - want[k]).abs().max()), float(want[k].abs().max()))
+        else:
+            assert p.grad is None, k
+
+
 @pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread', 'cpr_r50_c80_s8_r8'])
 def test_loss_backward_matches_reference_autograd_golden(name):
     """The same bar tests/test_gpu_train_step.py holds the trainer to, on loss.backward(): total loss 1e-4, per-tensor norm
@@ -312,13 +345,15 @@ def test_p2p_loss_backward_is_bit_equal_to_the_trainer():
 
 
 def test_unsupported_options_keep_the_forward_only_path_and_say_so():
-    """bf16 compute mode (trained through CprTrainer's mixed-precision step): with autograd on, forward_train still returns
-    the losses, without a graph, and warns once; under no_grad nothing warns."""
+    """A head option without a hand-written backward (softmax class probabilities): with autograd on, forward_train still
+    returns the losses, without a graph, and warns once; under no_grad nothing warns.  (The bf16 compute mode, which this
+    test used until round 4, now trains through the bridge: test_mixed_precision_loss_backward_is_bit_equal_to_the_trainer.)"""
     from pointtinybenchmark_amd import autograd_bridge
     cfg = CPR_CASES['cpr_r18_c3_128']
     data = _data(cfg)
     m, _ = build_hip_locator(cfg)
-    m.set_compute_dtype('bf16')
+    m.bbox_head.prob_type = 'softmax'
+    assert not m.bbox_head.train_step_supported()
     autograd_bridge._WARNED.clear()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
@@ -328,7 +363,7 @@ def test_unsupported_options_keep_the_forward_only_path_and_say_so():
             m.forward_train(**data)
     assert not any(v.requires_grad for v in losses.values())
     msgs = [str(x.message) for x in w if 'WITHOUT a graph' in str(x.message)]
-    assert len(msgs) == 1 and 'bf16' in msgs[0], msgs
+    assert len(msgs) == 1 and 'option set' in msgs[0], msgs
 
 
 def test_backward_releases_the_recorded_maps():

@@ -19,7 +19,7 @@ import pytest
 import torch
 
 from oracle import cpr_oracle as O
-from oracle.gen_golden import grad_sample_index
+from bench import grad_report          # the same report the bench's train_step parity gate prints
 from pointtinybenchmark_amd import synthetic
 from tests.test_gpu_cpr_parity import build_hip_locator, to_cuda
 
@@ -34,23 +34,6 @@ FULL = {
     'r50_800x1344_c80_b2': dict(depth=50, num_classes=80, start_level=1, stride=8, radius=8, head_std=0.3, seed=41, batch=2,
                                 height=800, width=1344, num_gts=24),
 }
-
-
-def grad_report(got, ref):
-    """got / ref: name -> gradient tensor.  Per-tensor relative L2, the global-norm relative error and the strided-sample
-    error; shared with bench.py's train_step parity gate (same numbers in the JSON line)."""
-    rows, g2, r2 = [], 0.0, 0.0
-    gmax = max(float(r.abs().max()) for r in ref.values())
-    for k, r in ref.items():
-        g = got[k].detach().double().flatten().cpu()
-        r = r.detach().double().flatten().cpu()
-        g2 += float(g.pow(2).sum())
-        r2 += float(r.pow(2).sum())
-        idx = torch.from_numpy(grad_sample_index(r.numel()))
-        rows.append(dict(key=k, rel_l2=float((g - r).norm() / max(float(r.norm()), 1e-30)), ref_max=float(r.abs().max()),
-                         sample_err=float((g[idx] - r[idx]).abs().max()), nil=bool(float(r.abs().max()) <= 1e-6 * gmax)))
-    rows.sort(key=lambda d: -d['rel_l2'])
-    return dict(rows=rows, norm_rel=abs(g2 ** 0.5 - r2 ** 0.5) / max(r2 ** 0.5, 1e-30), ref_norm=r2 ** 0.5, gmax=gmax)
 
 
 def oracle_grads(cfg, sd, batch, trainable):
