@@ -113,8 +113,11 @@ int cpr_gn_apply_b8(const float* x, const float* a, const float* b, float* y, in
 /* bf16 compute mode (BASELINE.json configs[4]): bf16 activations / weights / residual, fp32 accumulate
  * (v_mfma_f32_32x32x16_bf16), K chunks of 64 (Cin % 64 == 0, Kpad == KH*KW*Cin), output bf16 or fp32 (out_fp32).
  * No fused producer-GroupNorm input; GroupNorm statistics come from the fp32 accumulators.
- * variant_out [host, may be NULL]: bm*1000 + bn of the launched instance. */
-int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+ * variant_out [host, may be NULL]: bm*1000 + bn of the launched instance.
+ * wgt_frag [may be NULL; Cout % 256 == 0 only]: a second image of the same weights in MFMA-fragment order,
+ * [cout / 64][k / 16][j = 0, 1][lane = l + 32 h][8] = wgt[64 g + 2 l + j][16 ks + 8 h .. + 8]; with it the 256 x 256 tile's launches
+ * take the instance that loads the weight operand straight into registers (conv_bf16_dma_kernel<4, 2, 4, true>). */
+int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, const void* wgt_frag, void* out, const float* scale, const float* bias,
                         const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                         int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, void* stream);
 /* bf16 compute mode stem: conv 7x7 / stride 2 / pad 3, 3 -> 64 channels + folded BatchNorm + ReLU (resnet.py:630-636) on the
@@ -425,6 +428,7 @@ int cpr_wgrad_set_ablation(int mode);    /* same for the weight-gradient kernel 
 int cpr_conv_set_extra_lds(int bytes);   /* occupancy probe: dynamic LDS added to every direct-conv launch */
 int cpr_wino_set_variant(int sched, int ablate); /* Winograd: sched 1 = the other placement of the patch transform (see conv_wino.hip); loop ablations */
 int cpr_bf16_set_dma(int on);            /* bf16 mode: 0 = every layer on the register-staged kernels (A/B of conv_bf16_dma.hip) */
+int cpr_bf16_set_wfrag(int on);          /* bf16 mode: 0 = ignore wgt_frag (A/B of the weights-direct-to-registers instance) */
 int cpr_wino_set_staging(int var, int tpx);      /* Winograd: staging variant (kernel template VAR) and cout tiles per XCD; -1 = the product's choice */
 int cpr_wino32_set_debug(int ablate, int wg_per_cu, int stagger_pct); /* conv_wino32.hip: loop ablations, workgroups per CU (1 / 2), stagger of the second wave of workgroups */
 int cpr_lsa_phase_clocks(long long* host_out, int reset);            /* assign.hip: shader clocks workgroup 0 of lsa_topk_reg_kernel spent per phase (8 values) */

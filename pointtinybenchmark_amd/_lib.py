@@ -30,7 +30,7 @@ SIGNATURES = {
     'cpr_conv3x3_wino_wgrad_workspace': [_i, _i, _i, _i, _i],
     'cpr_conv3x3_wino_wgrad': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_gn_apply_b8': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    'cpr_conv2d_fwd_bf16': [_p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p, _p],
+    'cpr_conv2d_fwd_bf16': [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p, _p],
     'cpr_stem7x7s2_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'cpr_stem7x7s2_pool_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'cpr_maxpool3x3s2_bf16': [_p, _p, _i, _i, _i, _i, _p],
@@ -99,6 +99,7 @@ BENCH_SIGNATURES = {
     'cpr_wino_set_staging': [_i, _i],
     'cpr_conv_set_extra_lds': [_i],
     'cpr_bf16_set_dma': [_i],
+    'cpr_bf16_set_wfrag': [_i],
 }
 BENCH_LIB_PATH = os.path.join(_HERE, 'csrc', 'libcprhip_bench.so')
 

@@ -33,6 +33,7 @@ typedef int i32x4v __attribute__((ext_vector_type(4)));
 struct ConvDmaParams {
     const unsigned short* in;
     const unsigned short* wgt;
+    const unsigned short* wfrag;   // BD instances: the weights in MFMA-fragment order (see conv_bf16_dma_kernel<.., BD = true>), else null
     void* out;
     const float* scale;
     const float* bias;
@@ -67,14 +68,14 @@ constexpr int DBK = 64;
 //            LDS bandwidth is what holds <4, 2> at 0.42 (its reads + DMA writes are 256 KB per chunk against 262 KB of LDS
 //            cycles).  Bit-equal to <4, 2> and 10-12 % SLOWER on every shape tried: one wave per SIMD has nobody
 //            to cover its waits.  Measurement build only.
-template <int MI, int NJ, int WN = 4> struct DmaTile {
+template <int MI, int NJ, int WN = 4, bool BD = false> struct DmaTile {
     static constexpr int NT = 128 * WN;                                // threads: 2 wave rows x WN wave columns
     static constexpr int RP = NT / 8;                                  // rows one request piece covers (a wave instruction = 8 rows)
     static constexpr int PIECE = NT * 16;                              // bytes per piece
     static constexpr int BM = 64 * MI, BN = WN * NJ * 32;
-    static constexpr int NPA = BM / RP, NPW = BN / RP, NP = NPA + NPW; // request pieces per chunk: activations, weights
-    static constexpr int NM = MI * NJ, NF = MI + NJ;                   // MFMAs / fragment reads per wave per k-step
-    static constexpr int STAGE = (BM + BN) * DBK * 2;                  // bytes per stage
+    static constexpr int NPA = BM / RP, NPW = BD ? 0 : BN / RP, NP = NPA + NPW; // request pieces per chunk: activations, weights (BD: none)
+    static constexpr int NM = MI * NJ, NF = BD ? MI : MI + NJ;         // MFMAs / LDS fragment reads per wave per k-step
+    static constexpr int STAGE = (BM + (BD ? 0 : BN)) * DBK * 2;       // bytes per stage
     // the chunk's pieces over three k-steps, in their LAST MFMA slots: C3 behind the barrier (k-step 3), C0 in k-step 0, C1 in k-step 1
     static constexpr int C3 = (NP + 2) / 3, C0 = (NP - C3 + 1) / 2, C1 = NP - C3 - C0;
     static_assert(C3 <= NM && C0 <= NM && C1 <= NM, "one request per MFMA slot at most");
@@ -365,10 +366,21 @@ __device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 
     }
 }
 
-template <int MI, int NJ, int WN>
+// BD = true (round 5, <4, 2, 4, true> only): the WEIGHT operand goes global -> VGPR directly, only the activations go through LDS.
+// The host hands over a second image of the weights in fragment order -- wfrag[g = cout / 64][ks = k / 16][j][lane][8]: lane
+// (l31 + 32 half) of block j holds k = 16 ks + 8 half .. + 8 of cout 64 g + 2 l31 + j (the interleaved cout layout of
+// dma_epilogue_pairs), i.e. exactly the 16 bytes that lane feeds to the MFMA -- so a wave's B operand of one k-step is two
+// coalesced 1 KB loads with no LDS round trip.  Per chunk a wave then issues 4 LDS-DMA requests + 8 register loads (before: 8
+// requests) and 16 ds_read_b128 (before: 24); the stages shrink to 32 KB.  The register loads are inline asm like the DMA
+// requests (the compiler would otherwise count its own loads against a vmcnt that also holds the DMA requests it cannot see and
+// drain them with every wait): four k-steps of B fragments live in a ring of 32 registers, slot kk is re-requested for the NEXT
+// chunk one k-step after the MFMAs of k-step kk have been issued, and the loop's two waits (the barrier's vmcnt(0), one counted
+// wait in front of k-step 2) cover them.
+template <int MI, int NJ, int WN, bool BD = false>
 __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_kernel   // (threads, waves per SIMD)
 (ConvDmaParams p) {
-    using T = DmaTile<MI, NJ, WN>;
+    static_assert(!BD || (MI == 4 && NJ == 2 && WN == 4), "weights direct to registers: the 256 x 256 eight-wave instance");
+    using T = DmaTile<MI, NJ, WN, BD>;
     constexpr int DBM = T::BM, DBN = T::BN, DSTAGE = T::STAGE, NM = T::NM, NF = T::NF, NP = T::NP, NPA = T::NPA, NPW = T::NPW;
     constexpr int RP = T::RP, PIECE = T::PIECE;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
                           (int)((size_t)p.N * p.H * p.W * p.Cin * 2), 0x00020000};
     const i32x4v rs_w = {(int)(unsigned)w_addr, (int)(unsigned)(w_addr >> 32) & 0xffff,
                          (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000};
-    int woff[NPW];
+    int woff[NPW > 0 ? NPW : 1];
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
         // <*, 2, 4> (two cout blocks per wave): tile row 64 g + 32 jj + l holds cout 64 g + 2 l + jj, see dma_epilogue_pairs
@@ -490,6 +502,26 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
     for (int kk = 0; kk < 4; ++kk) koff[kk] = l31 * 128 + (((2 * kk + half) ^ rswz) * 16);
     const unsigned char* a_base = smem + (wm * MI * 32) * 128;
     const unsigned char* b_base = smem + DBM * DBK * 2 + (wn * NJ * 32) * 128;
+    // BD: the B fragments of the four k-steps of a chunk, requested straight from the fragment-order image.  One request =
+    // buffer_load_dwordx4 of 1 KB: wave-uniform byte offset of (cout group, k-step) in an SGPR + lane * 16 (+ 1 KB for block 1)
+    f32x4 fbr[BD ? 4 : 1][NJ];
+    const size_t wf_addr = (size_t)p.wfrag;
+    const i32x4v rs_wf = {(int)(unsigned)wf_addr, (int)(unsigned)(wf_addr >> 32) & 0xffff,
+                          (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000};
+    const int wf_lane = lane * 16;
+    const int wf_group = BD ? ((n0 >> 6) + wn) * (p.Kpad >> 4) * 2048 : 0;          // byte offset of this wave's 64-cout group
+    int bkh = 0, bkw = 0, bc0 = 0;            // tap / channel chunk of the NEXT chunk whose B fragments are requested (wave-uniform)
+    int bks = 0;                              // byte offset of that chunk's first k-step inside the group: (K offset / 16) * 2048
+    auto b_advance = [&]() {                  // the K order of the activations: channel chunk outer, tap inner
+        if (++bkw == p.KW) {
+            bkw = 0;
+            if (++bkh == p.KH) { bkh = 0; bc0 += DBK; }
+        }
+        bks = (((bkh * p.KW + bkw) * p.Cin + bc0) >> 4) * 2048;
+    };
+#define BLOAD_AT(kk, off)                                                                                             \
+    asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:0\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024" \
+                 : "=&v"(fbr[kk][0]), "=&v"(fbr[kk][1]) : "v"(wf_lane), "s"(rs_wf), "s"(wf_group + (off) + (kk) * 2048) : "memory")
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -503,11 +535,12 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
     // fragment piece z of a k-step: z < NJ = the cout blocks, then the MI pixel blocks.  MFMA q of the NEXT k-step uses pixel
     // block q / NJ and cout block q % NJ: with the cout blocks read first every operand of the 256 x 256 instance is requested
     // >= 6 MFMA slots (~200 cycles of this wave, as many of its partner) before its first use
+    constexpr int NJR = BD ? 0 : NJ;        // cout-block fragments read from LDS (BD: none, they come from global memory)
 #define DFRAG(FA, FB, buf, kk, z)                                                                                     \
     do {                                                                                                              \
         if (p.ablate & 8) break;                                                                                      \
-        if ((z) >= NJ) FA[(z) >= NJ ? (z) - NJ : 0] = *reinterpret_cast<const f32x4*>(a_base + (buf) * DSTAGE + ((z) >= NJ ? (z) - NJ : 0) * 4096 + koff[kk]); \
-        else FB[(z) < NJ ? (z) : 0] = *reinterpret_cast<const f32x4*>(b_base + (buf) * DSTAGE + ((z) < NJ ? (z) : 0) * 4096 + koff[kk]); \
+        if ((z) >= NJR) FA[(z) >= NJR ? (z) - NJR : 0] = *reinterpret_cast<const f32x4*>(a_base + (buf) * DSTAGE + ((z) >= NJR ? (z) - NJR : 0) * 4096 + koff[kk]); \
+        else FB[(z) < NJR ? (z) : 0] = *reinterpret_cast<const f32x4*>(b_base + (buf) * DSTAGE + ((z) < NJR ? (z) : 0) * 4096 + koff[kk]); \
     } while (0)
     // the NF reads of a k-step over its NM MFMA slots: slot q reads piece q (NF <= NM), else pieces [q NF / NM, (q + 1) NF / NM)
 #define DFRAGS(FA, FB, buf, kk, q)                                                                    \
@@ -522,6 +555,76 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
         __builtin_bit_cast(bf16x8, FA[(q) / NJ]), __builtin_bit_cast(bf16x8, FB[(q) % NJ]), acc[(q) / NJ][(q) % NJ], 0, 0, 0)
 
     constexpr int C3 = T::C3, C0 = T::C0, C1 = T::C1;
+    if constexpr (BD) {
+        // Weights direct to registers.  EVERY request of the schedule is issued in every chunk -- past the last chunk the
+        // offsets run into the next cout group / out of the buffer range (zeros) and land in a stage / a ring slot nobody reads
+        // again -- so the number of requests between any two points of the loop is a constant and the waits can be counted:
+        //   per chunk   k-step 0: B3 (this chunk, 2 loads) .. P2 | k-step 1: B0' (next chunk) .. P3 | k-step 2: B1' |
+        //               wait + barrier | k-step 3: B2' .. P0'', P1'' (the chunk after next -> the stage just freed)
+        //   before k-step 1: B1 landed = vmcnt(7) (B2 B2 P0 P1 B3 B3 P2 younger); before k-step 2: B2 landed = vmcnt(8);
+        //   barrier: P3 and everything older (B3, B0') landed = vmcnt(2) (B1' B1' younger).  A request has three k-steps to land.
+        static_assert(NPA == 4 && C3 == 2 && C0 == 1 && C1 == 1, "the counted waits below are written for four activation pieces");
+#pragma unroll
+        for (int z = 0; z < NP; ++z) stage_piece(0, 0, z);
+        BLOAD_AT(0, 0); BLOAD_AT(1, 0); BLOAD_AT(2, 0);
+        int bks_cur = bks;
+        b_advance();
+#pragma unroll
+        for (int z = 0; z < C3; ++z) stage_piece(1, 1, z);
+        asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(fbr[0][0]), "+v"(fbr[0][1]), "+v"(fbr[1][0]), "+v"(fbr[1][1]), "+v"(fbr[2][0]),
+                     "+v"(fbr[2][1]) : [n] "n"(C3) : "memory");
+        __syncthreads();
+#pragma unroll
+        for (int z = 0; z < NF; ++z) DFRAG(fa0, fb0, 0, 0, z);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                DMFMA(fa0, fbr[0], q);
+                DFRAGS(fa1, fb1, buf, 1, q);
+                if (q == 0) BLOAD_AT(3, bks_cur);
+                if (q >= NM - C0) stage_piece(kt + 1, buf ^ 1, C3 + q - (NM - C0));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(7)" : "+v"(fbr[1][0]), "+v"(fbr[1][1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                DMFMA(fa1, fbr[1], q);
+                DFRAGS(fa0, fb0, buf, 2, q);
+                if (q == 0) BLOAD_AT(0, bks);
+                if (q >= NM - C1) stage_piece(kt + 1, buf ^ 1, C3 + C0 + q - (NM - C1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(fbr[2][0]), "+v"(fbr[2][1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                DMFMA(fa0, fbr[2], q);
+                DFRAGS(fa1, fb1, buf, 3, q);
+                if (q == 0) BLOAD_AT(1, bks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(2)" : "+v"(fbr[3][0]), "+v"(fbr[3][1]), "+v"(fbr[0][0]), "+v"(fbr[0][1]) :: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                DMFMA(fa1, fbr[3], q);
+                DFRAGS(fa0, fb0, buf ^ 1, 0, q);
+                if (q == 0) BLOAD_AT(2, bks);
+                if (q >= NM - C3) stage_piece(kt + 2, buf, q - (NM - C3));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bks_cur = bks;
+            b_advance();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the requests past the last chunk must land before the LDS is released
+        dma_epilogue_pairs<MI>(p, acc, tm, m0, n0, wm, wn, lane);
+        return;
+    }
     // prologue: chunk 0 -> stage 0 completely, the first C3 pieces of chunk 1 -> stage 1
 #pragma unroll
     for (int z = 0; z < NP; ++z) stage_piece(0, 0, z);
@@ -583,6 +686,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
 #undef DFRAGS
 #undef DFRAG
 #undef DMFMA
+#undef BLOAD_AT
 
     if (nt) {   // this (split, tap)'s fp32 partial
         ConvDmaParams q = p;
@@ -617,11 +721,12 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                          const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
-                         int ablate, int shape) {
+                         int ablate, int shape, const void* wfrag) {
     const int bm = (shape == 1 || shape == 3) ? 128 : 256, bn = (shape == 2 || shape == 3) ? 128 : 256;
     if (Cout % bn != 0 || Cin % DBK != 0 || Kpad != KH * KW * Cin) return CPR_ERR_UNSUPPORTED;
     ConvDmaParams p;
     p.in = (const unsigned short*)in; p.wgt = (const unsigned short*)wgt; p.out = out; p.scale = scale; p.bias = bias;
+    p.wfrag = (const unsigned short*)wfrag;
     p.residual = (const unsigned short*)residual; p.gn_part = gn_part;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.Kpad = Kpad; p.relu = relu; p.out_fp32 = out_fp32; p.ablate = ablate;
@@ -638,7 +743,8 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
     if (gn_part && bm != 256) return CPR_ERR_UNSUPPORTED;         // a wave of the 128-pixel tile owns half a statistics slot
     p.tilesM = (int)((M + bm - 1) / bm);
     p.tilesN = Cout / bn;
-    if (variant_out) *variant_out = bm * 1000 + bn + (shape == 3 ? 1000000 : shape == 4 ? 2000000 : 0);       // 128128 alone is the register-staged <128, 128>
+    const bool bd = shape == 0 && wfrag != nullptr;      // the 256 x 256 instance with the weights direct to registers
+    if (variant_out) *variant_out = bm * 1000 + bn + (shape == 3 ? 1000000 : shape == 4 ? 2000000 : bd ? 3000000 : 0);       // 128128 alone is the register-staged <128, 128>
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
     if (shape == 1 || shape == 2) return CPR_ERR_UNSUPPORTED;      // <2, 2> and <4, 1> were measured and dropped
@@ -648,6 +754,7 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
 #else
     else if (shape == 4) return CPR_ERR_UNSUPPORTED;
 #endif
+    else if (bd) hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4, true>), dim3(grid), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4>), dim3(grid), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }
@@ -661,7 +768,7 @@ int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, in
     if (N % DBN != 0 || rs % 8 != 0 || M <= 0 || splits <= 0 || splits % 8 != 0 || chunks <= 0) return CPR_ERR_UNSUPPORTED;
     if ((long long)M * rs * 2 >= (1ll << 31) || (long long)N * rs * 2 >= (1ll << 31) || rs >= (1ll << 30)) return CPR_ERR_UNSUPPORTED;
     ConvDmaParams p;
-    p.in = (const unsigned short*)a; p.wgt = (const unsigned short*)b; p.out = part; p.scale = nullptr; p.bias = nullptr;
+    p.in = (const unsigned short*)a; p.wgt = (const unsigned short*)b; p.wfrag = nullptr; p.out = part; p.scale = nullptr; p.bias = nullptr;
     p.residual = nullptr; p.gn_part = nullptr;
     p.N = 1; p.H = 1; p.W = M; p.Cin = (int)rs; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.Kpad = (int)rs; p.relu = 0; p.out_fp32 = 1; p.ablate = 0;

@@ -318,9 +318,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                          const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
-                         int ablate, int shape);
+                         int ablate, int shape, const void* wfrag);
 #ifdef CPR_BENCH_HOOKS
-static int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0;
+static int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0, bf16_wfrag_on = 1;
+extern "C" int cpr_bf16_set_wfrag(int on) {  // measurement build: 0 = ignore the fragment-order weight image (A/B of the round-5 instance)
+    bf16_wfrag_on = on != 0;
+    return CPR_OK;
+}
 extern "C" int cpr_bf16_set_dma(int on) {   // measurement build: 0 = keep every layer on the register-staged kernels (A/B);
     CPR_CHECK_ARG(on >= 0 && on < 2048);     // bits 1..4 = loop ablations of the DMA kernel (results are then WRONG);
     bf16_dma_on = on & 1;                    // bits 5..7: 0 = the dispatch rule, 1 + shape = that DMA tile shape wherever it fits,
@@ -329,7 +333,7 @@ extern "C" int cpr_bf16_set_dma(int on) {   // measurement build: 0 = keep every
     return CPR_OK;
 }
 #else
-constexpr int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0;
+constexpr int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0, bf16_wfrag_on = 1;
 #endif
 
 // Which LDS-DMA tile (conv_bf16_dma.hip) a layer takes: 0 = 256 x 256, 3 = 128 x 128 (two workgroups per CU), -1 = none (the
@@ -348,7 +352,7 @@ static int bf16_dma_shape(long long M, int Cin, int Cout, int kchunks, bool gn) 
     return -1;
 }
 
-static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, const void* wfrag, void* out, const float* scale, const float* bias,
                                   const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
                                   int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream) {
     CPR_CHECK_ARG(in && wgt && out);
@@ -372,7 +376,8 @@ static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, co
     const int dshape = bf16_dma_on ? bf16_dma_shape(M, Cin, Cout, Kpad / BKH, gn_part != nullptr) : -1;
     if (dshape >= 0) {
         const int rc = conv_bf16_dma_launch(in, wgt, out, scale, bias, residual, gn_part, N, H, W, Cin, Cout, KH, KW, stride,
-                                            pad, Kpad, relu, out_fp32, variant_out, stream, bf16_dma_ablate, dshape);
+                                            pad, Kpad, relu, out_fp32, variant_out, stream, bf16_dma_ablate, dshape,
+                                            bf16_wfrag_on ? wfrag : nullptr);
         if (rc != CPR_ERR_UNSUPPORTED) return rc;
     }
     const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
@@ -389,7 +394,7 @@ static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, void* out, co
 }
 
 // >= 2 GiB maps: balanced chunks of whole images (see cpr_images_per_launch)
-extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
+extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, const void* wgt_frag, void* out, const float* scale, const float* bias,
                                    const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
                                    int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream) {
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
@@ -401,7 +406,7 @@ extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, void* out, c
     for (int n0 = 0; n0 < N; n0 += per) {
         const int n = N - n0 < per ? N - n0 : per;
         const size_t rows = (size_t)n0 * OH * OW;
-        const int rc = conv2d_fwd_bf16_launch((const char*)in + (size_t)n0 * H * W * Cin * 2, wgt, (char*)out + rows * Cout * oe,
+        const int rc = conv2d_fwd_bf16_launch((const char*)in + (size_t)n0 * H * W * Cin * 2, wgt, wgt_frag, (char*)out + rows * Cout * oe,
                                               scale, bias, residual ? (const char*)residual + rows * Cout * 2 : nullptr,
                                               gn_part ? gn_part + rows / 128 * Cout * 2 : nullptr, n, H, W, Cin, Cout, KH, KW,
                                               stride, pad, Kpad, relu, out_fp32, n0 == 0 ? variant_out : nullptr, stream);

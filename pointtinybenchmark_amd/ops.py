@@ -67,6 +67,7 @@ def nhwc_to_nchw_dense(x_nhwc):
 class PackedConv:
     """Conv weight repacked for the implicit-GEMM kernel: [Cout][KH][KW][Cin'] fp32, rows padded to a
     multiple of 32 floats.  Cin' = 4 for the 3-channel stem (zero 4th channel)."""
+    wfrag = None    # bf16: the weights in MFMA-fragment order (frag_image), built on first use for Cout % 256 == 0
     wino = None     # transformed weights of the Winograd path, built on first use (conv3x3_wino)
     wino32 = None   # the same for the two-workgroups-per-CU kernel (csrc/conv_wino32.hip: chunks of 4 input channels)
     ready = None    # event recorded behind the last pack kernel (weights / Winograd image); see pack_ready()
@@ -112,6 +113,18 @@ class PackedConv:
         packed[:, :K] = wp.reshape(Cout, K)
         self.w = packed.contiguous()
 
+    def frag_image(self):
+        """bf16 weights in the fragment order of conv_bf16_dma_kernel<4, 2, 4, true> (include/cpr_hip.h, cpr_conv2d_fwd_bf16):
+        [cout / 64][k / 16][j][lane = l + 32 h][8] = w[64 g + 2 l + j][16 ks + 8 h .. + 8] -- the 16 bytes lane (l, h) of cout block j
+        feeds to one MFMA, so a wave's weight operand of a k-step is two coalesced 1 KB loads.  None when the layer cannot take
+        the 256 x 256 tile (Cout % 256, K % 64)."""
+        if self.dtype != torch.bfloat16 or self.Cout % 256 != 0 or self.Kpad % 64 != 0 or not WFRAG[0]:
+            return None
+        if self.wfrag is None:
+            G, KS = self.Cout // 64, self.Kpad // 16
+            self.wfrag = self.w.view(G, 32, 2, KS, 2, 8).permute(0, 3, 2, 4, 1, 5).contiguous()
+        return self.wfrag
+
     @classmethod
     def for_dgrad(cls, weight, padding, scale=None, pad_override=None):
         """Weights of the stride-1 conv over dy that yields the data gradient: in/out channels swapped, taps flipped,
@@ -141,6 +154,9 @@ class PackedConv:
 
 
 CONV_RELU, CONV_OUT_BF16, CONV_RES_MASK, CONV_COLSUM = 1, 2, 4, 8      # include/cpr_hip.h CPR_CONV_*
+# bf16 mode: hand the fragment-order weight image to the conv launcher (the 256 x 256 tile then loads its weight operand
+# straight into registers, csrc/conv_bf16_dma.hip BD instance).  CPR_BF16_WFRAG=0 keeps both operands on the LDS-DMA path (A/B).
+WFRAG = [os.environ.get('CPR_BF16_WFRAG', '1') != '0']
 # profilers (bench.py) set [0] = True; the template instance of the last conv launch is then left in [1] as
 # (kind, code).  Host-side, single-threaded bookkeeping of a value the C ABI returns through an out-parameter.
 TRACE_CONV_VARIANT = [False, None]
@@ -304,7 +320,7 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     if x.dtype == torch.bfloat16:
         assert not (res_mask or colsum), 'backward helpers are fp32'
         assert in_ab is None, 'the bf16 kernel does not fuse the producer GroupNorm (materialise with gn_apply)'
-        _lib.call('cpr_conv2d_fwd_bf16', _ptr(x), _ptr(pc.w), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
+        _lib.call('cpr_conv2d_fwd_bf16', _ptr(x), _ptr(pc.w), _ptr(pc.frag_image()), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
                   _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding, pc.Kpad, int(relu),
                   int(odt == torch.float32), vref, _stream())
         if variant is not None:

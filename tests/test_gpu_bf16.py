@@ -68,7 +68,10 @@ def test_conv2d_bf16_vs_torch(case):
 # shapes that reach the LDS-DMA staged kernels (csrc/conv_bf16_dma.hip; dispatch rule: bf16_dma_shape in conv_mfma_bf16.hip).
 # 256 x 256 tiles (interleaved cout layout, whole-line pair stores): every layer with >= 384 such tiles; 128 x 128 tiles, two
 # workgroups per CU, output through LDS (round 4): the rest with Cout % 128 == 0 and >= 256 tiles
-BIG, SMALL = 256 * 1000 + 256, 1000000 + 128 * 1000 + 128       # the variant words conv_bf16_dma_launch reports
+# the variant words conv_bf16_dma_launch reports.  BIG = the 256 x 256 tile with the weights loaded straight into registers from the
+# fragment-order image (round 5, conv_bf16_dma_kernel<4, 2, 4, true>); BIG_LDS = the same tile with both operands through LDS-DMA
+# (ops.WFRAG[0] = False) -- identical MFMA sequence on identical operands, so the two must agree BIT for bit
+BIG, BIG_LDS, SMALL = 3000000 + 256 * 1000 + 256, 256 * 1000 + 256, 1000000 + 128 * 1000 + 128
 DMA_CASES = [
     (8, 64, 128, 128, 256, 3, 1, 1, 'gn', BIG),                  # 3x3, borders on every side, GroupNorm statistics (two slots per tile)
     (8, 128, 128, 128, 256, 3, 1, 1, 'bn res relu', BIG),        # K = 1152 + residual (4-byte pair loads)
@@ -95,7 +98,7 @@ def test_conv2d_bf16_dma_kernel_vs_torch(case):
     instance is asserted through the variant word)."""
     from pointtinybenchmark_amd import ops
     N, Cin, H, W, Cout, k, stride, pad, flags = case[:9]
-    want = case[9] if len(case) > 9 else 256 * 1000 + 256
+    want = case[9] if len(case) > 9 else BIG
     g = torch.Generator().manual_seed(sum(case[:8]))
     x = torch.randn((N, Cin, H, W), generator=g).bfloat16()
     w = (torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5).bfloat16()
@@ -126,6 +129,19 @@ def test_conv2d_bf16_dma_kernel_vs_torch(case):
     finally:
         ops.TRACE_CONV_VARIANT[0] = False
     assert variant == ('bf16', want), 'this shape must run the LDS-DMA staged instance %d, got %r' % (want, variant)
+    if want == BIG:         # the same launch with both operands staged through LDS: bit-equal outputs and statistics
+        ops.WFRAG[0], ops.TRACE_CONV_VARIANT[0] = False, True
+        try:
+            out2 = ops.conv2d(xin, pc, scale=None if scale is None else scale.cuda(), bias=None if bias is None else bias.cuda(),
+                              residual=None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda(), relu='relu' in flags,
+                              gn_part='gn' in flags, out_dtype=torch.float32 if f32out else None)
+            variant2 = ops.TRACE_CONV_VARIANT[1]
+        finally:
+            ops.WFRAG[0], ops.TRACE_CONV_VARIANT[0] = True, False
+        assert variant2 == ('bf16', BIG_LDS), variant2
+        for u, v in zip(out if isinstance(out, tuple) else (out,), out2 if isinstance(out2, tuple) else (out2,)):
+            assert torch.equal(u, v), 'weights-direct-to-registers instance differs from the LDS-staged one: max abs %.3e' % float(
+                (u.float() - v.float()).abs().max())
     part = None
     if 'gn' in flags:
         out, part = out

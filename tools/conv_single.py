@@ -29,6 +29,7 @@ ap.add_argument('--wino-ablate', type=int, default=0)
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--pipeline', type=int, default=1)
 ap.add_argument('--w32', default='0,2,100', help='conv_wino32 debug: ablate,workgroups per CU,stagger percent')
+ap.add_argument('--wfrag', type=int, default=1, help='bf16 mode: 0 = ignore the fragment-order weight image (the 256 x 256 tile then stages both operands through LDS: A/B of the round-5 instance)')
 ap.add_argument('--bf16-dma', type=int, default=1, help='bf16 mode: 0 = keep the layer on the register-staged kernel (A/B); + 32 * f: f = 1..3 forces DMA tile 256x256 / 128x256 / 256x128, 4 = the round-3 rule')
 args = ap.parse_args()
 from pointtinybenchmark_amd import _lib  # noqa: E402
@@ -37,6 +38,7 @@ _lib.call('cpr_conv_set_ablation', args.ablate)
 _lib.call('cpr_conv_set_pipeline', args.pipeline)
 _lib.call('cpr_wino_set_variant', args.wino_sched, args.wino_ablate)
 _lib.call('cpr_bf16_set_dma', args.bf16_dma)
+_lib.call('cpr_bf16_set_wfrag', args.wfrag)
 _lib.call('cpr_wino32_set_debug', *[int(v) for v in args.w32.split(',')])
 g = torch.Generator().manual_seed(0)
 x = torch.randn((args.batch, args.hw, args.hw, args.cin), generator=g).cuda()
@@ -72,11 +74,13 @@ if args.check_against >= 0:
     f = plain if args.plain else (lambda: ops.conv2d(x, pc, gn_part=True))
     a1 = f()
     _lib.call('cpr_bf16_set_dma', args.check_against)
+    _lib.call('cpr_bf16_set_wfrag', 0)
     a2 = f()
     _lib.call('cpr_bf16_set_dma', args.bf16_dma)
+    _lib.call('cpr_bf16_set_wfrag', args.wfrag)
     torch.cuda.synchronize()
     a1, a2 = (a1 if isinstance(a1, tuple) else (a1,)), (a2 if isinstance(a2, tuple) else (a2,))
-    print('bit-equal to word %d: %s' % (args.check_against, all(torch.equal(u, v) for u, v in zip(a1, a2))))
+    print('bit-equal to word %d without the fragment image: %s' % (args.check_against, all(torch.equal(u, v) for u, v in zip(a1, a2))))
 ops.TRACE_CONV_VARIANT[0] = True
 (run_b8 if args.b8 else plain if args.plain else (lambda: ops.conv2d(x, pc, gn_part=True)) if args.gn_stats else (lambda: None))()
 variant = ops.TRACE_CONV_VARIANT[1]
