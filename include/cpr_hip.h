@@ -376,6 +376,13 @@ int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* 
                  const float* centers, const int* gt_img, const float* offsets, float* dbag_ws, float* dmap, float* win_ws,
                  int* win_org, int win, int N, int H, int W, int J, int Jd, int ins_off, int G, int K, int C, float stride,
                  float eps, float w_mil, float w_gt, float w_neg, const float* upstream, void* stream);
+/* win == 0 in cpr_loss_bwd: the bag logits were NOT sampled from the logit map (CPRHead num_cls_fcs > 0 samples the features and
+ * runs them through the FC stack, cpr_head.py:1055-1059) -- dmap then holds the negative-grid term alone and dbag_ws (G,K,J) is
+ * the gradient wrt the bag logits.  cpr_bag_gather_bwd is the gather stage on its own: dsample (G,K,J), the gradient wrt the
+ * bilinear samples of a (N,H,W,.) map, is ADDED onto dmap (N,H,W,Jd) through bag_sample's taps (same windows, same order). */
+int cpr_bag_gather_bwd(const float* dsample, int J, const float* centers, const int* gt_img, const float* offsets,
+                       float* win_ws, int* win_org, int win, float* dmap, int N, int H, int W, int Jd, int G, int K,
+                       float stride, void* stream);
 /* OIHW fp32 master weights -> the conv kernels' layout [rows][KH][KW][cols'] (row stride Kpad, zero padded).
  * transpose 0: forward pack (rows = O).  transpose 1: data-gradient pack (rows = I, taps flipped, optional per-O scale =
  * the folded BatchNorm scale of the forward conv).  colsp = padded column count (4 for <= 4 channels). */

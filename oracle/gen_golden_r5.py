@@ -1,0 +1,71 @@
+"""Round-5 fixtures from the REFERENCE's own classes (build container only).  TEST INFRASTRUCTURE ONLY.
+
+  python -m oracle.gen_golden_r5
+
+  tests/golden/cpr_option_grads.npz   loss.backward() through the reference's own ResNet / FPN / CPRHead (torch autograd on CPU)
+                                      for the CPRHead options that gained a hand-written backward in round 5
+                                      (oracle.gen_golden_r2 option cases): num_refine = 2 inputs under the default bag policy
+                                      (T/mmdet/models/point/dense_heads/cpr_head.py:1159-1211), ins_share_head_feat=False
+                                      (a second tower, cpr_head.py:992-1008,1037-1040,1061-1070), and both together with FC layers
+                                      between the sampled features and the classifiers (num_cls_fcs > 0, cpr_head.py:999-1005,
+                                      1055-1059).  Per case and trainable tensor: L2 norm, sum, a strided sample
+                                      (oracle.gen_golden.grad_sample_index) -- the format of cpr_grads_*.npz.
+Inputs and weights come from ``pointtinybenchmark_amd.synthetic`` (seeded, regenerated at test time)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import ref_loader  # noqa: E402
+from oracle.gen_golden import GOLDEN, grad_sample_index  # noqa: E402
+from oracle.gen_golden_r2 import build_reference, option_cfg  # noqa: E402
+
+OPTION_GRAD_CASES = ('r2_independent', 'ins_tower', 'ins_tower_fc')
+
+
+def run_reference_option_grads(R, name):
+    cfg = option_cfg(name)
+    torch.manual_seed(0)
+    backbone, neck, head, batch = build_reference(R, cfg)
+    cls_feat, ins_feat = head(neck(backbone(batch['img'])))
+    losses = head.loss(cls_feat, ins_feat, batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'])
+    total = sum(v.mean() for k, v in losses.items() if 'loss' in k)          # BaseDetector._parse_losses (base.py:179-212)
+    total.backward()
+    out = {name + ':total_loss': np.float64(float(total))}
+    n = 0
+    for prefix, mod in (('backbone.', backbone), ('neck.', neck), ('bbox_head.', head)):
+        for pname, prm in mod.named_parameters():
+            if not prm.requires_grad:
+                continue
+            if prm.grad is None:          # a parameter the option leaves without gradient (find_unused_parameters semantics)
+                out['%s:unused:%s%s' % (name, prefix, pname)] = np.array(True)
+                continue
+            g = prm.grad.detach().double().flatten()
+            key = prefix + pname
+            out['%s:norm:%s' % (name, key)] = np.float64(float(g.norm()))
+            out['%s:sum:%s' % (name, key)] = np.float64(float(g.sum()))
+            out['%s:sample:%s' % (name, key)] = g[torch.from_numpy(grad_sample_index(g.numel()))].numpy().astype(np.float32)
+            n += 1
+    out[name + ':num_tensors'] = np.int64(n)
+    return out
+
+
+def main():
+    assert ref_loader.available(), 'needs /root/reference'
+    torch.set_num_threads(8)
+    R = ref_loader.load()
+    out = {}
+    for name in OPTION_GRAD_CASES:
+        o = run_reference_option_grads(R, name)
+        out.update(o)
+        print('option grads', name, 'tensors', int(o[name + ':num_tensors']), 'loss', float(o[name + ':total_loss']),
+              'unused', [k.split(':', 2)[2] for k in o if ':unused:' in k])
+    np.savez_compressed(os.path.join(GOLDEN, 'cpr_option_grads.npz'), **out)
+
+
+if __name__ == '__main__':
+    main()

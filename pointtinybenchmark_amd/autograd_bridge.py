@@ -100,13 +100,16 @@ def unsupported_reason(model, gt_bboxes=None, gt_labels=None):
             return 'stage %s is partly frozen' % name
     kind = type(head).__name__
     if kind == 'CPRHead':
-        if not head.train_step_supported():
-            return 'this CPRHead option set has no hand-written backward (CPRHead.train_step_supported)'
+        R = 1
+        if gt_bboxes is not None and gt_labels is not None and len(gt_labels) and len(gt_labels[0]):
+            R = max(1, int(gt_bboxes[0].shape[0]) // int(len(gt_labels[0])))     # (every image brings num_gts * R boxes: the head asserts)
+        if not head.train_step_supported(R):
+            return 'this CPRHead option set has no hand-written backward (CPRHead.train_step_supported)' if R == 1 else \
+                'num_refine > 1 inputs train under refine_bag_policy=independent_with_gt_bag / gt_loss_type=gt_refine only'
         if not head.loss_cfg.get('with_neg', True):
             return 'with_neg=False is not on the training path'
-        if gt_bboxes is not None and gt_labels is not None and len(gt_labels) and \
-                gt_bboxes[0].shape[0] != len(gt_labels[0]):
-            return 'num_refine > 1 inputs have no hand-written backward'
+        if head.num_cls_fcs > 0 and bb.compute_dtype != torch.float32:
+            return 'num_cls_fcs > 0 trains in the fp32 compute mode (the FC backward reads fp32 activations)'
     elif kind == 'P2PHead':
         if head.num_points != 1 or not getattr(head, 'train_cfg', None):
             return 'P2PHead trains with one point per cell and a train_cfg (the shipped P2P configs)'

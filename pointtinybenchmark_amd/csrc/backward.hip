@@ -647,7 +647,7 @@ extern "C" int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, co
                             int N, int H, int W, int J, int Jd, int ins_off, int G, int K, int C, float stride, float eps,
                             float w_mil, float w_gt, float w_neg, const float* upstream, hipStream_t stream) {
     CPR_CHECK_ARG(lmap && neg_mask && out5 && bag_logits && valid && labels && bag_ws && centers && gt_img && dbag_ws && dmap);
-    CPR_CHECK_ARG(win_ws && win_org && win >= 3 && (size_t)K * 16 <= 60000);
+    CPR_CHECK_ARG(win == 0 || (win_ws && win_org && win >= 3 && (size_t)K * 16 <= 60000));
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && G > 0 && K > 0 && C > 0 && J >= ins_off + C && Jd >= J && (K == 1 || offsets));
     const long long NP = (long long)N * H * W;
     const int grid = (int)(cdivll(NP * Jd, 256) < 32768 ? cdivll(NP * Jd, 256) : 32768);
@@ -655,7 +655,24 @@ extern "C" int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, co
                        eps, w_neg, upstream);
     hipLaunchKernelGGL(bag_loss_bwd_kernel, dim3(cdiv(G, 4)), dim3(256), 0, stream, bag_logits, J, ins_off, valid, labels,
                        gt_weight, bag_ws, dbag_ws, G, K, C, eps, w_mil, w_gt, upstream);
+    if (win == 0) { CPR_LAUNCH_STATUS(); }     // the bag logits were not sampled from the map (num_cls_fcs > 0): dbag_ws is the result
     hipLaunchKernelGGL(bag_window_kernel, dim3(G), dim3(256), (size_t)K * 16, stream, dbag_ws, J, centers, offsets, win_ws,
+                       win_org, win, K, H, W, stride);
+    hipLaunchKernelGGL(bag_window_add_kernel, dim3(N), dim3(win * win * J >= 4096 ? 1024 : 256), 0, stream, win_ws, win_org,
+                       win, J, gt_img, dmap, Jd, G, H, W);
+    CPR_LAUNCH_STATUS();
+}
+
+// The gather stage alone: dsample (G, K, J) -- the gradient wrt the bilinear samples bag_sample took from a (N, H, W, .) map --
+// is ADDED onto dmap (N, H, W, Jd) through the same taps (bag_window_kernel + bag_window_add_kernel: deterministic, gt order).
+// CPRHead with num_cls_fcs > 0 samples the 256-channel FEATURES (the ReLUs of the FC stack do not commute with the interpolation,
+// cpr_head.py:1055-1059), so its bag gradient reaches the feature map here instead of through the logit map.
+extern "C" int cpr_bag_gather_bwd(const float* dsample, int J, const float* centers, const int* gt_img, const float* offsets,
+                                  float* win_ws, int* win_org, int win, float* dmap, int N, int H, int W, int Jd, int G, int K,
+                                  float stride, hipStream_t stream) {
+    CPR_CHECK_ARG(dsample && centers && gt_img && win_ws && win_org && dmap && win >= 3 && (size_t)K * 16 <= 60000);
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && G > 0 && K > 0 && J > 0 && Jd >= J && (K == 1 || offsets));
+    hipLaunchKernelGGL(bag_window_kernel, dim3(G), dim3(256), (size_t)K * 16, stream, dsample, J, centers, offsets, win_ws,
                        win_org, win, K, H, W, stride);
     hipLaunchKernelGGL(bag_window_add_kernel, dim3(N), dim3(win * win * J >= 4096 ? 1024 : 256), 0, stream, win_ws, win_org,
                        win, J, gt_img, dmap, Jd, G, H, W);

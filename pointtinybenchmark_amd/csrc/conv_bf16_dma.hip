@@ -41,7 +41,8 @@ struct ConvDmaParams {
     float* gn_part;
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, out_fp32;
     int tilesM, tilesN;
-    int ablate;     // measurement builds only (results are then WRONG): 1 no wait for the DMA, 2 no barrier, 4 no DMA requests, 8 no fragment reads
+    int ablate;     // measurement builds only (results are then WRONG): 1 no wait for the DMA, 2 no barrier, 4 no DMA requests, 8 no fragment reads,
+                    // 16 / 32 / 64 epilogue forms, 128 no weight-fragment loads (BD instance)
     // NT-GEMM mode (the bf16 weight gradient, csrc/conv_wgrad_bf16.hip): out[split][tap][m][n] = sum over the split's K range of
     // in[m][k] * wgt_tap[n][k], both operands rows of Kpad (= Cin) elements.  Tiles = splits x taps x tilesM x tilesN.
     int nt_taps;        // 0 = convolution mode
@@ -520,8 +521,11 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
         bks = (((bkh * p.KW + bkw) * p.Cin + bc0) >> 4) * 2048;
     };
 #define BLOAD_AT(kk, off)                                                                                             \
-    asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:0\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024" \
-                 : "=&v"(fbr[kk][0]), "=&v"(fbr[kk][1]) : "v"(wf_lane), "s"(rs_wf), "s"(wf_group + (off) + (kk) * 2048) : "memory")
+    do {                                                                                                              \
+        if (p.ablate & 128) break;                                                                                    \
+        asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:0\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024" \
+                     : "=&v"(fbr[kk][0]), "=&v"(fbr[kk][1]) : "v"(wf_lane), "s"(rs_wf), "s"(wf_group + (off) + (kk) * 2048) : "memory"); \
+    } while (0)
 
     f32x16 acc[MI][NJ];
 #pragma unroll

@@ -219,11 +219,18 @@ class CPRHead(nn.Module):
         self._thr = {}
         self.init_weights()
 
-    def train_step_supported(self):
-        """The hand-written backward (training.CprTrainer) covers the shipped configs' options."""
+    def train_step_supported(self, num_refine=1):
+        """The hand-written backward (training.BackwardEngine) covers the shipped configs' options and, since round 5, a separate
+        instance tower (``ins_share_head_feat=False``, cpr_head.py:992-1008,1037), FC layers between the sampled features and the
+        classifiers (``num_cls_fcs > 0``, cpr_head.py:999-1005,1055-1059) and num_refine > 1 inputs under the default
+        ``refine_bag_policy='independent_with_gt_bag'`` / ``gt_loss_type='gt_refine'`` (cpr_head.py:1159-1211: every refine point
+        is a bag of its own with its own annotated-point term -- the R = 1 loss over G * R bags)."""
+        if num_refine > 1 and (self.loss_cfg.get('refine_bag_policy', 'independent_with_gt_bag') != 'independent_with_gt_bag' or
+                               self.loss_cfg.get('gt_loss_type', 'gt_refine') != 'gt_refine'):
+            return False
         return (self.prob_type == 'sigmoid' and not self.binary_ins and not self.loss_mil.allpos and
-                self.num_cls_fcs == 0 and not self.train_pts_extractor.pos_is_grid and self.ins_share_head_feat and
-                not self.out_bg_cls and not self.train_pts_extractor.align_corners)
+                not self.train_pts_extractor.pos_is_grid and not self.out_bg_cls and
+                not self.train_pts_extractor.align_corners)
 
     # ------------------------------------------------------------------ init (cpr_head.py:939-948)
     def init_weights(self):
@@ -289,21 +296,27 @@ class CPRHead(nn.Module):
         raw0, ab0 = lazy_feats[0]
         ins = None
         if not self.ins_share_head_feat:        # the instance tower reads the neck output first (the cls tower may consume it)
-            assert tape is None, 'the training step is built for ins_share_head_feat=True'
-            ins = [self._tower(raw0, ab0, in_relu=False, convs=self.ins_convs)]
+            ins_tape = [] if tape is not None else None          # training: the second tower is recorded like the first
+            ins = [self._tower(raw0, ab0, in_relu=False, convs=self.ins_convs, tape=ins_tape)]
+            if save is not None:
+                save['ins_tape'] = ins_tape
         raw, ab = self._tower(raw0, ab0, in_relu=False, tape=tape, own_input=True)
         return self.loss([(raw, ab)], ins, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore,
                          gt_true_bboxes=gt_true_bboxes, save=save)
 
     # ------------------------------------------------------------------ shared extraction
-    def _fc_stack(self, rows_nhwc, ins=False):
+    def _fc_stack(self, rows_nhwc, ins=False, acts=None):
         """get_pts_outs.forward_with_fc (cpr_head.py:1055-1059): relu(fc_i(.)) as 1x1 convs over an NHWC block of rows
-        (ins: the instance tower's ``ins_fcs``)."""
+        (ins: the instance tower's ``ins_fcs``).  acts (list, training): receives the input and every layer's output."""
         x = rows_nhwc
+        if acts is not None:
+            acts.append(x)
         for i, fc in enumerate(self.ins_fcs if ins else self.cls_fcs):
             pc, bias = self._cache.get(('fc', ins, i, x.dtype), [fc.weight, fc.bias], lambda fc=fc, x=x: (
                 ops.PackedConv(fc.weight.detach()[:, :, None, None], 1, 0, x.dtype), fc.bias.detach().float().contiguous()))
             x = ops.conv2d(x, pc, bias=bias, relu=True)
+            if acts is not None:
+                acts.append(x)
         return x
 
     def _proj(self, dt, part=None):
@@ -318,7 +331,7 @@ class CPRHead(nn.Module):
         srcs = [self.cls_out.weight, self.cls_out.bias, self.ins_out.weight, self.ins_out.bias]
         return self._cache.get(('proj', dt, part), srcs, make)
 
-    def _logit_map(self, feat_nhwc, in_ab=None, part=None):
+    def _logit_map(self, feat_nhwc, in_ab=None, part=None, acts=None):
         """(N,H,W,256) -> (N,H,W,J) with J = [cls(C) ++ ins(C, or 2C with binary_ins)] (or C when features and classifier are
         shared; part='cls' / 'ins': that classifier's logits alone, through its own FC stack).
         in_ab: the input is the raw last-layer conv output and (a, b) its GroupNorm affine (+ReLU), applied on load.
@@ -327,7 +340,7 @@ class CPRHead(nn.Module):
         dt = feat_nhwc.dtype
         if self.num_cls_fcs > 0:
             assert in_ab is None
-            feat_nhwc = self._fc_stack(feat_nhwc, ins=(part == 'ins' and not self.ins_share_head_feat))
+            feat_nhwc = self._fc_stack(feat_nhwc, ins=(part == 'ins' and not self.ins_share_head_feat), acts=acts)
 
         pc, bias, w_rows = self._proj(dt, part)
         if in_ab is not None and ((feat_nhwc.shape[1] * feat_nhwc.shape[2]) % 128 != 0 or dt != torch.float32):
@@ -340,12 +353,14 @@ class CPRHead(nn.Module):
                 return out
         return ops.conv2d(feat_nhwc, pc, bias=bias, in_ab=in_ab, in_relu=True, out_dtype=torch.float32)
 
-    def _lmap_all(self, feat, ab=None, ifeat=None, iab=None):
+    def _lmap_all(self, feat, ab=None, ifeat=None, iab=None, acts=None):
         """The logit map the loss reads: [cls ++ ins] channels.  Two towers (ins_share_head_feat=False): the class logits
-        come from the class tower's map, the instance logits from the instance tower's (cpr_head.py:1061-1070)."""
+        come from the class tower's map, the instance logits from the instance tower's (cpr_head.py:1061-1070).
+        acts (dict, training with num_cls_fcs > 0): acts['map'] receives the FC activations of the class path over the map."""
+        rec = None if acts is None else acts.setdefault('map', [])
         if self.ins_share_head_feat:
-            return self._logit_map(feat, ab)
-        return torch.cat([self._logit_map(feat, ab, 'cls'), self._logit_map(ifeat, iab, 'ins')], dim=-1).contiguous()
+            return self._logit_map(feat, ab, acts=rec)
+        return torch.cat([self._logit_map(feat, ab, 'cls', acts=rec), self._logit_map(ifeat, iab, 'ins')], dim=-1).contiguous()
 
     def _sample(self, ex, src, gts, stride, pad):
         """The positive generator on one map: bag points, validity, samples and the bag view.  pad: what a slot / tap without
@@ -365,7 +380,7 @@ class CPRHead(nn.Module):
                                          align_corners=ex.align_corners, pad_value=pad if ex.align_corners else None)
         return pts, valid, out, (gts.R, pts.shape[1])
 
-    def _bags(self, ex, feat, lmap, gts, stride, ifeat=None, part=None):
+    def _bags(self, ex, feat, lmap, gts, stride, ifeat=None, part=None, acts=None):
         """Bag points (E,2), validity (E) and bag logits (E,J) of the positive generator, E = G * entries-per-gt, plus
         the bag view (sub_bags per gt, entries per sub-bag).  num_cls_fcs == 0: Linear commutes with bilinear sampling, so
         the logits are sampled from the projected map ``lmap``.  Otherwise the 256-channel features are sampled and run
@@ -379,15 +394,20 @@ class CPRHead(nn.Module):
                     torch.cat([self._proj(lmap.dtype, 'cls')[1], self._proj(lmap.dtype, 'ins')[1]])
             pts, valid, out, view = self._sample(ex, lmap, gts, stride, pad)
         else:
+            # acts (dict, training): the sampled features and the FC activations of each path ('bag': shared features;
+            # 'bag_cls' / 'bag_ins': the two towers)
             pts, valid, out, view = self._sample(ex, feat, gts, stride, None)
             E, K, Cf = out.shape
             if self.ins_share_head_feat:
-                out = self._logit_map(out.view(1, E * K, 1, Cf), part=part).view(E, K, -1)
+                out = self._logit_map(out.view(1, E * K, 1, Cf), part=part,
+                                      acts=None if acts is None else acts.setdefault('bag', [])).view(E, K, -1)
             else:
-                parts = [self._logit_map(out.view(1, E * K, 1, Cf), part='cls').view(E, K, -1)]
+                parts = [self._logit_map(out.view(1, E * K, 1, Cf), part='cls',
+                                         acts=None if acts is None else acts.setdefault('bag_cls', [])).view(E, K, -1)]
                 if part is None:
                     _, _, iout, _ = self._sample(ex, ifeat, gts, stride, None)
-                    parts.append(self._logit_map(iout.view(1, E * K, 1, Cf), part='ins').view(E, K, -1))
+                    parts.append(self._logit_map(iout.view(1, E * K, 1, Cf), part='ins',
+                                                 acts=None if acts is None else acts.setdefault('bag_ins', [])).view(E, K, -1))
                 out = torch.cat(parts, dim=-1).contiguous()
         G = gts.G
         return pts.view(G, -1, 2), valid.view(G, -1), out.view(G, -1, out.shape[-1]), view
@@ -460,16 +480,17 @@ class CPRHead(nn.Module):
         if not self.ins_share_head_feat:
             ifeat, iab = unpack(ins_feat[0])
         dev = feat.device
+        fc_acts = None
         if self.num_cls_fcs > 0:                          # the FC path samples the normalised, activated features
-            assert save is None, 'the training step is built for num_cls_fcs == 0'
-            if ab is not None:
+            if ab is not None:                            # (out of place: in training the raw map is on the tape)
                 feat, ab = ops.gn_apply(feat, ab[0], ab[1], relu=True), None
             if iab is not None:
                 ifeat, iab = ops.gn_apply(ifeat, iab[0], iab[1], relu=True), None
+            fc_acts = {} if save is not None else None    # training: the FC activations of the map and bag paths (round 5)
         if lmap is None:                            # (a caller that replays a hipGraph hands the projected map over)
-            lmap = self._lmap_all(feat, ab, ifeat, iab)
+            lmap = self._lmap_all(feat, ab, ifeat, iab, acts=fc_acts)
         gts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev)
-        _, valid, bag_logits, view = self._bags(ex, feat, lmap, gts, stride, ifeat=ifeat)
+        _, valid, bag_logits, view = self._bags(ex, feat, lmap, gts, stride, ifeat=ifeat, acts=fc_acts)
         cfg = self.loss_cfg
         with_mil, with_gt, with_neg = cfg.get('with_mil_loss', True), cfg.get('with_gt_loss', False), cfg.get('with_neg', True)
         assert with_mil or with_gt, 'loss0 needs num_pos from the MIL or the gt loss (cpr_head.py:1180,1213,1227)'
@@ -488,13 +509,17 @@ class CPRHead(nn.Module):
                                            want_bag_ws=save is not None, bags=bags, centres=centres,
                                            prob_type=self.prob_type, norm_p=self.norm_p, neg_from_gt=not with_mil)
         if save is not None:
-            assert self.train_step_supported() and gts.R == 1, \
-                'the hand-written backward covers the shipped configs (sigmoid, MILLoss, circle bags, num_refine = 1)'
+            assert self.train_step_supported(gts.R), \
+                'the hand-written backward covers sigmoid / MILLoss / circle bags (CPRHead.train_step_supported)'
             out, bag_ws = out
-            save.update(feat=feat, ab=ab, lmap=lmap, neg_mask=neg_mask, out5=out, bag_logits=bag_logits, valid=valid,
-                        labels=labels, gt_weight=w, bag_ws=bag_ws, centers=gts.points, gt_img=gts.gt_img,
+            # one row per BAG: with num_refine = R > 1 (independent bags) the (G, R * Kv) layout is (G * R, Kv) in memory, every
+            # refine point a bag around its own centre (gts.points is gt-major, pt_img ascends)
+            nb, Kv = bags[0], view[1]
+            save.update(feat=feat, ab=ab, ifeat=ifeat, iab=iab, lmap=lmap, neg_mask=neg_mask, out5=out,
+                        bag_logits=bag_logits.view(nb, Kv, -1), valid=valid.view(nb, Kv),
+                        labels=labels, gt_weight=w, bag_ws=bag_ws, centers=gts.points, gt_img=gts.pt_img,
                         offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride,
-                        radius_cells=ex.window_radius_cells(stride, dev))
+                        radius_cells=ex.window_radius_cells(stride, dev), fc=fc_acts)
         return self._loss_dict(out)
 
     def _loss_dict(self, out):

@@ -1074,7 +1074,7 @@ def axpby(y, x, alpha=1.0, beta=1.0):
 
 
 def cpr_loss_bwd(lmap, neg_mask, out5, bag_logits, valid, labels, bag_ws, centers, gt_img, offsets, ins_off, num_classes,
-                 stride, w_mil, w_gt, w_neg, Jd, gt_weight=None, eps=1e-6, upstream=None, radius_cells=None):
+                 stride, w_mil, w_gt, w_neg, Jd, gt_weight=None, eps=1e-6, upstream=None, radius_cells=None, gather=True):
     """-> dmap (N,H,W,Jd): gradient of gt_loss + pos_loss + neg_loss wrt the logit map (channels >= J are zero).
     radius_cells: the bag radius in grid cells (every offset lies within radius_cells * stride of its centre): the taps of a
     bag are gathered in a (2 * radius_cells + 3)^2 window -- deterministic, no float atomics.  gt_img must ascend.
@@ -1085,15 +1085,31 @@ def cpr_loss_bwd(lmap, neg_mask, out5, bag_logits, valid, labels, bag_ws, center
     G, K, _ = bag_logits.shape
     dmap = torch.empty((N, H, W, Jd), device=lmap.device, dtype=torch.float32)
     dbag = torch.empty((G, K, J), device=lmap.device, dtype=torch.float32)
-    assert radius_cells is not None and radius_cells >= 0, 'the bag radius (in cells) sizes the gather window'
-    win = 2 * int(math.ceil(radius_cells)) + 3      # taps of a bag span floor(c - r) .. floor(c + r) + 1
-    win_ws = torch.empty((G, win, win, J), device=lmap.device, dtype=torch.float32)
-    win_org = torch.empty((G, 2), device=lmap.device, dtype=torch.int32)
+    if gather:
+        assert radius_cells is not None and radius_cells >= 0, 'the bag radius (in cells) sizes the gather window'
+        win = 2 * int(math.ceil(radius_cells)) + 3      # taps of a bag span floor(c - r) .. floor(c + r) + 1
+        win_ws = torch.empty((G, win, win, J), device=lmap.device, dtype=torch.float32)
+        win_org = torch.empty((G, 2), device=lmap.device, dtype=torch.int32)
+    else:     # the bag logits were not sampled from ``lmap`` (num_cls_fcs > 0): dmap = the negative-grid term, dbag is returned as is
+        win, win_ws, win_org = 0, None, None
     _lib.call('cpr_loss_bwd', _ptr(lmap), _ptr(neg_mask), _ptr(out5), _ptr(bag_logits), _ptr(valid), _ptr(labels),
               _ptr(gt_weight), _ptr(bag_ws), _ptr(centers), _ptr(gt_img), _ptr(offsets), _ptr(dbag), _ptr(dmap), _ptr(win_ws),
               _ptr(win_org), win, N, H, W, J, Jd, ins_off, G, K, num_classes, float(stride), float(eps), float(w_mil),
               float(w_gt), float(w_neg), _ptr(upstream), _stream())
     return dmap, dbag
+
+
+def bag_gather_bwd(dsample, centers, gt_img, offsets, dmap, stride, radius_cells):
+    """dsample (G,K,J): gradient wrt the bilinear samples ``bag_sample`` took from a (N,H,W,J') map, J <= J'; ADDED onto dmap
+    (N,H,W,J') through the same taps (deterministic: per-bag windows, per-image gt order).  gt_img must ascend."""
+    G, K, J = _check(dsample).shape
+    N, H, W, Jd = _check(dmap).shape
+    win = 2 * int(math.ceil(radius_cells)) + 3
+    win_ws = torch.empty((G, win, win, J), device=dmap.device, dtype=torch.float32)
+    win_org = torch.empty((G, 2), device=dmap.device, dtype=torch.int32)
+    _lib.call('cpr_bag_gather_bwd', _ptr(dsample), J, _ptr(centers), _ptr(gt_img), _ptr(offsets), _ptr(win_ws), _ptr(win_org), win,
+              _ptr(dmap), N, H, W, Jd, G, K, float(stride), _stream())
+    return dmap
 
 
 def p2p_loss_bwd(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, beta, pos_w, neg_w, reg_norm, w_cls,

@@ -393,10 +393,15 @@ class BackwardEngine:
         w_gt = cfg.get('gt_loss_weight', 1.0) if cfg.get('with_gt_loss', False) else 0.0
         w_neg = cfg.get('neg_loss_weight', 1.0) if cfg.get('with_neg', True) else 0.0
         assert s['neg_mask'] is not None, 'with_neg=False is not on the training path'
-        dmap, _ = ops.cpr_loss_bwd(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
-                                   s['bag_ws'], s['centers'], s['gt_img'], s['offsets'], s['ins_off'], C, s['stride'],
-                                   w_mil, w_gt, w_neg, Jd, gt_weight=s['gt_weight'], eps=head.loss_mil.eps,
-                                   upstream=upstream, radius_cells=s['radius_cells'])
+        fc = head.num_cls_fcs > 0
+        dmap, dbag = ops.cpr_loss_bwd(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
+                                      s['bag_ws'], s['centers'], s['gt_img'], s['offsets'], s['ins_off'], C, s['stride'],
+                                      w_mil, w_gt, w_neg, Jd, gt_weight=s['gt_weight'], eps=head.loss_mil.eps,
+                                      upstream=upstream, radius_cells=s['radius_cells'], gather=not fc)
+        if fc:
+            return self._backward_head_fc(head, s, dmap, dbag, J, Jd)
+        if not head.ins_share_head_feat:
+            return self._backward_head_two_towers(head, s, dmap, J, Jd)
         # ---- logit projection (cls_out ++ ins_out as one 1x1 conv over the un-normalised last tower layer)
         shared = head.ins_share_head_classifier
         wcat = head.cls_out.weight if shared else torch.cat([head.cls_out.weight, head.ins_out.weight], 0)
@@ -415,6 +420,111 @@ class BackwardEngine:
         for rec in reversed(head_tape):
             dz = self._gn_conv_backward(rec, dz, relu=True, need_dx=True)
             self._done(rec['module'].conv.weight)
+        return dz
+
+    def _backward_head_two_towers(self, head, s, dmap, J, Jd):
+        """ins_share_head_feat=False (cpr_head.py:992-1008,1037-1040,1061-1070): the class logits (channels [0, C) of the map the
+        loss reads) are cls_out over the class tower's last layer, the instance logits (channels [C, 2C)) ins_out over the instance
+        tower's.  Each projection is a 1x1 conv whose padded weight holds its classifier's rows and zeros elsewhere, so the shared
+        gradient map feeds both weight / data gradients unchanged; the towers' gradients meet at the FPN output."""
+        C = head.num_cls_out
+        assert J == 2 * C, 'two towers: [cls ++ ins] logits'
+        _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
+        same = head.ins_out is head.cls_out                      # ins_share_head_classifier on two towers: one Linear, two inputs
+        dz, first = None, True
+        for name, lo, mod, feat, ab, tape in (('cls', 0, head.cls_out, s['feat'], s['ab'], s['tape']),
+                                              ('ins', C, head.ins_out, s['ifeat'], s['iab'], s['ins_tape'])):
+            wpad = torch.zeros((Jd, mod.weight.shape[1], 1, 1), device=dmap.device, dtype=torch.float32)
+            wpad[lo:lo + C, :, 0, 0] = mod.weight.detach()
+            gw = ops.conv2d_wgrad(dmap, self._f32(feat), wpad.shape, 1, 0, in_ab=ab, in_relu=True)
+            if same and not first:
+                self._g(mod.weight).add_(gw[lo:lo + C, :, 0, 0])
+                self._g(mod.bias).add_(gb[lo:lo + C])
+            else:
+                self._g(mod.weight).copy_(gw[lo:lo + C, :, 0, 0])
+                self._g(mod.bias).copy_(gb[lo:lo + C])
+            first = False
+            if name == 'ins':
+                self._done(head.ins_out.bias)
+            d = ops.conv2d_dgrad(dmap, ops.dgrad_pack(wpad, 1, 0), (dmap.shape[1], dmap.shape[2]))
+            for rec in reversed(tape):
+                d = self._gn_conv_backward(rec, d, relu=True, need_dx=True)
+                if name == 'ins':
+                    self._done(rec['module'].conv.weight)
+            dz = d if dz is None else ops.axpby(dz, d, 1.0, 1.0)
+        return dz
+
+    # ------------------------------------------------------------------ CPRHead with FC layers (num_cls_fcs > 0)
+    def _fc_chain_backward(self, dlogit, acts, fcs, rows, touched):
+        """Backward of [relu(fc_i(.))]* -> classifier rows over an NHWC block.  dlogit (N,H,W,Jd): gradient wrt the Jd-padded
+        logits; acts = [x0, x1 .. xn] (input and every FC output); fcs: the nn.Linear layers; rows: [(classifier module, first
+        logit channel)] -- the classifiers that read x_n, placed at their channels of the padded projection (other channels of
+        dlogit meet zero rows).  Parameter gradients are written on first touch and accumulated after (``touched``: ids).
+        Returns the gradient wrt x0."""
+        def put(p, g):
+            if id(p) in touched:
+                self._g(p).add_(g)
+            else:
+                self._g(p).copy_(g)
+                touched.add(id(p))
+        Jd = dlogit.shape[-1]
+        xn = acts[-1]
+        hw = (xn.shape[1], xn.shape[2])
+        wpad = torch.zeros((Jd, xn.shape[-1], 1, 1), device=dlogit.device, dtype=torch.float32)
+        for mod, lo in rows:
+            wpad[lo:lo + mod.weight.shape[0], :, 0, 0] = mod.weight.detach()
+        gw = ops.conv2d_wgrad(dlogit, xn, wpad.shape, 1, 0)
+        _, gb = ops.relu_bwd_colsum(dlogit, None, want_g=False)
+        for mod, lo in rows:
+            n = mod.weight.shape[0]
+            put(mod.weight, gw[lo:lo + n, :, 0, 0])
+            put(mod.bias, gb[lo:lo + n])
+        # x_n is a ReLU output (n >= 1 FC layers): the data gradient comes back through that ReLU in the conv epilogue
+        d = ops.conv2d_dgrad(dlogit, ops.dgrad_pack(wpad, 1, 0), hw, mask=xn)
+        for i in range(len(fcs) - 1, -1, -1):
+            fc, x = fcs[i], acts[i]
+            w4 = fc.weight.detach()[:, :, None, None]
+            put(fc.weight, ops.conv2d_wgrad(d, x, tuple(w4.shape), 1, 0)[:, :, 0, 0])
+            put(fc.bias, ops.relu_bwd_colsum(d, None, want_g=False)[1])
+            d = ops.conv2d_dgrad(d, ops.dgrad_pack(w4, 1, 0), hw, mask=x if i > 0 else None)
+        return d
+
+    def _backward_head_fc(self, head, s, dmap, dbag, J, Jd):
+        """num_cls_fcs > 0 (cpr_head.py:999-1005,1055-1072): the classifiers read relu(fc(.)) of the normalised, activated tower
+        output -- over the whole map for the negative-grid term (class path only: the instance logits of the map enter no loss),
+        and over the bilinear SAMPLES of the features for the bags (the ReLUs do not commute with the interpolation, so the bag
+        gradient reaches the feature map through the samples' taps, not through the logit map).  One chain per (path, tower);
+        the FC / classifier gradients of the map and bag paths add up."""
+        assert s['feat'].dtype == torch.float32, 'num_cls_fcs > 0 trains in the fp32 compute mode'
+        C = head.num_cls_out
+        acts, touched = s['fc'], set()
+        G, K, _ = s['bag_logits'].shape
+        dl_bag = torch.zeros((1, G * K, 1, Jd), device=dmap.device, dtype=torch.float32)
+        dl_bag[0, :, 0, :J] = dbag.reshape(G * K, J)
+        two = not head.ins_share_head_feat
+        if two:
+            towers = [('cls', s['feat'], s['tape'], list(head.cls_fcs), [(head.cls_out, 0)], acts['map'], acts['bag_cls']),
+                      ('ins', s['ifeat'], s['ins_tape'], list(head.ins_fcs), [(head.ins_out, C)], None, acts['bag_ins'])]
+        else:
+            rows = [(head.cls_out, 0)] + ([] if head.ins_same_logits else [(head.ins_out, C)])
+            towers = [('cls', s['feat'], s['tape'], list(head.cls_fcs), rows, acts['map'], acts['bag'])]
+        dfeats = []
+        for name, feat, tape, fcs, rows, a_map, a_bag in towers:
+            if a_map is not None:
+                dfeat = self._fc_chain_backward(dmap, a_map, fcs, rows, touched)
+            else:
+                dfeat = torch.zeros(tuple(feat.shape), device=dmap.device, dtype=torch.float32)
+            ds = self._fc_chain_backward(dl_bag, a_bag, fcs, rows, touched)              # (1, G*K, 1, Cf)
+            ops.bag_gather_bwd(ds.view(G, K, -1), s['centers'], s['gt_img'], s['offsets'], dfeat, s['stride'], s['radius_cells'])
+            dfeats.append((dfeat, tape))
+        self._done((head.ins_fcs[0] if two else head.cls_fcs[0]).bias)       # classifiers and FC layers: complete (flat order)
+        dz = None
+        for dfeat, tape in dfeats:
+            d = dfeat
+            for rec in reversed(tape):
+                d = self._gn_conv_backward(rec, d, relu=True, need_dx=True)
+                self._done(rec['module'].conv.weight)
+            dz = d if dz is None else ops.axpby(dz, d, 1.0, 1.0)
         return dz
 
     def _out_conv_backward(self, rec, dout_pad, n_out):
@@ -666,7 +776,11 @@ class CprTrainer(BackwardEngine):
     @staticmethod
     def _head_param_order(head, add):
         add(head.cls_out.weight, head.cls_out.bias, head.ins_out.weight, head.ins_out.bias)
+        for fc in list(reversed(list(getattr(head, 'cls_fcs', [])))) + list(reversed(list(getattr(head, 'ins_fcs', [])))):
+            add(fc.weight, fc.bias)                                    # num_cls_fcs > 0: weight before bias, ins_fcs[0] last
         for cm in reversed(list(head.cls_convs)):
+            add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
+        for cm in reversed(list(getattr(head, 'ins_convs', []))):      # ins_share_head_feat=False: the second tower, last
             add(cm.gn.weight, cm.gn.bias, cm.conv.weight)
 
     def _done(self, p):

@@ -232,6 +232,58 @@ def test_cpr_options_vs_reference(golden_dir, name, record_property):
     record_property('near_threshold_entries', nnear)
 
 
+OPTION_GRAD_CASES = ('r2_independent', 'ins_tower', 'ins_tower_fc')      # oracle.gen_golden_r5.OPTION_GRAD_CASES
+
+
+@pytest.mark.parametrize('name', OPTION_GRAD_CASES)
+def test_option_backward_vs_reference_autograd(golden_dir, name):
+    """The CPRHead options that gained a hand-written backward in round 5 -- num_refine = 2 inputs under the default bag policy
+    (cpr_head.py:1159-1211), a separate instance tower (ins_share_head_feat=False, :992-1008,1037-1040,1061-1070) and the same
+    with FC layers between the sampled features and the classifiers (num_cls_fcs > 0, :999-1005,1055-1059) -- against
+    loss.backward() through the REFERENCE's own modules (tests/golden/cpr_option_grads.npz, oracle/gen_golden_r5.py): total
+    loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the tensor's max.  Then loss.backward() through the autograd bridge
+    on a fresh model must equal the native trainer BIT for bit, as for the shipped options."""
+    from oracle.gen_golden import grad_sample_index
+    from pointtinybenchmark_amd import autograd_bridge
+    from pointtinybenchmark_amd.training import CprTrainer
+    cfg = option_cfg(name)
+    g = np.load(os.path.join(golden_dir, 'cpr_option_grads.npz'))
+    p = name + ':'
+    m, batch = build_hip(cfg)
+    cb = cuda_batch(batch)
+    data = dict(img=cb['img'], img_metas=cb['img_metas'], gt_bboxes=cb['gt_bboxes'], gt_labels=cb['gt_labels'])
+    assert autograd_bridge.unsupported_reason(m, cb['gt_bboxes'], cb['gt_labels']) is None
+    tr = CprTrainer(m)
+    losses = tr.forward_backward(**data)
+    torch.cuda.synchronize()
+    total = float(sum(v for k, v in losses.items() if 'loss' in k))
+    ref_total = float(g[p + 'total_loss'])
+    assert abs(total - ref_total) <= 1e-4 * max(1.0, abs(ref_total)), (total, ref_total)
+    params = dict(m.named_parameters())
+    keys = [k[len(p + 'norm:'):] for k in g.files if k.startswith(p + 'norm:')]
+    assert sorted(keys) == sorted(k for k, q in params.items() if q.requires_grad), \
+        set(keys) ^ set(k for k, q in params.items() if q.requires_grad)
+    gmax = max(float(g[p + 'norm:' + k]) for k in keys)
+    want = {}
+    for k in keys:
+        gr = params[k].grad.detach().double().flatten().cpu()
+        want[k] = params[k].grad.detach().clone()
+        ref_n = float(g[p + 'norm:' + k])
+        assert abs(float(gr.norm()) - ref_n) <= 2e-3 * ref_n + 1e-6 * gmax, (k, float(gr.norm()), ref_n)
+        smp = gr[torch.from_numpy(grad_sample_index(gr.numel()))].numpy()
+        ref = g[p + 'sample:' + k].astype(np.float64)
+        assert np.abs(smp - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-5 * gmax), k
+    del tr, m
+    m2, _ = build_hip(cfg)
+    out = m2.train_step(dict(data), optimizer=None)
+    assert out['loss'].grad_fn is not None
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    for k, q in m2.named_parameters():
+        if q.requires_grad:
+            assert q.grad is not None and torch.equal(q.grad, want[k]), k
+
+
 def test_grid_ellipse_generator_raises_like_the_reference(golden_dir):
     """GridEllipsePtFeatGenerator cannot run in the reference (fixture records its RuntimeError); ours refuses at build."""
     from pointtinybenchmark_amd.registry import build_head

@@ -224,6 +224,41 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
     np.testing.assert_allclose(torch.cat([r['scores'] for r in ref]).numpy(), g[p + 'scores'], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('name', ['r2_independent', 'ins_tower', 'ins_tower_fc'])
+def test_option_oracle_autograd_matches_reference_autograd(golden_dir, name):
+    """Pins the options oracle's BACKWARD (torch autograd over oracle/cpr_options_oracle.py) to loss.backward() through the
+    reference's own modules for the options that gained a hand-written backward in round 5 (tests/golden/cpr_option_grads.npz,
+    oracle/gen_golden_r5.py): per-tensor norm and strided samples, 1e-3."""
+    from oracle import cpr_options_oracle as OO
+    from oracle.gen_golden import grad_sample_index
+    from oracle.gen_golden_r2 import case_inputs, option_cfg
+    cfg = option_cfg(name)
+    g = _load(golden_dir, 'cpr_option_grads')
+    p = name + ':'
+    sd, batch = case_inputs(cfg)
+    keys = [k[len(p + 'norm:'):] for k in g.files if k.startswith(p + 'norm:')]
+    assert len(keys) == int(g[p + 'num_tensors'])
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sd[k].requires_grad_(True)
+    torch.set_num_threads(8)
+    feats = O.fpn_forward(sd, O.resnet_forward(sd, batch['img'], cfg['depth']), cfg['start_level'], 1)
+    cls_feat, _ = O.cpr_head_forward(sd, feats)
+    ins_feat = OO.ins_tower_forward(sd, feats)[0] if cfg.get('ins_tower') else None
+    losses, _ = OO.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg, ins_feat=ins_feat)
+    total = sum(v for k, v in losses.items() if 'loss' in k)
+    assert abs(float(total.detach()) - float(g[p + 'total_loss'])) <= 1e-4 * max(1.0, abs(float(g[p + 'total_loss'])))
+    total.backward()
+    gmax = max(float(g[p + 'norm:' + k]) for k in keys)
+    for k in keys:
+        gr = sd[k].grad.detach().double().flatten()
+        ref_n = float(g[p + 'norm:' + k])
+        assert abs(float(gr.norm()) - ref_n) <= 1e-3 * ref_n + 1e-7 * gmax, (k, float(gr.norm()), ref_n)
+        smp = gr[torch.from_numpy(grad_sample_index(gr.numel()))].numpy()
+        ref = g[p + 'sample:' + k].astype(np.float64)
+        assert np.abs(smp - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6 * gmax), k
+
+
 @pytest.mark.parametrize('ci', [0, 1])
 def test_oracle_p2p_loss_matches_reference_fixture(golden_dir, ci):
     """oracle.cpr_oracle.p2p_loss (round 4: the restatement bench.py times and gates the P2PNet line with) on the reference's OWN
