@@ -35,7 +35,7 @@ def needs_build():
 
 
 BENCH_LIB = os.path.join(CSRC, 'libcprhip_bench.so')
-HOOK_SOURCES = {'conv_mfma.hip', 'conv_wgrad.hip', 'conv_wino.hip', 'conv_mfma_bf16.hip', 'assign.hip', 'conv_wino32.hip'}     # the files that carry #ifdef CPR_BENCH_HOOKS code
+HOOK_SOURCES = {'conv_mfma.hip', 'conv_wgrad.hip', 'conv_wino.hip', 'conv_mfma_bf16.hip', 'conv_bf16_dma.hip', 'assign.hip', 'conv_wino32.hip'}     # the files that carry #ifdef CPR_BENCH_HOOKS code
 
 
 def build(force=False, verbose=True, bench_hooks=False):

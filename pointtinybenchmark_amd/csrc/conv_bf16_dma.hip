@@ -42,7 +42,7 @@ struct ConvDmaParams {
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, out_fp32;
     int tilesM, tilesN;
     int ablate;     // measurement builds only (results are then WRONG): 1 no wait for the DMA, 2 no barrier, 4 no DMA requests, 8 no fragment reads,
-                    // 16 / 32 / 64 epilogue forms, 128 no weight-fragment loads (BD instance)
+                    // 16 / 32 / 64 epilogue forms, 128 no weight-fragment loads (BD instance), 256 request slots staggered by wave (BD)
     // NT-GEMM mode (the bf16 weight gradient, csrc/conv_wgrad_bf16.hip): out[split][tap][m][n] = sum over the split's K range of
     // in[m][k] * wgt_tap[n][k], both operands rows of Kpad (= Cin) elements.  Tiles = splits x taps x tilesM x tilesN.
     int nt_taps;        // 0 = convolution mode
@@ -377,9 +377,10 @@ __device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 
 // drain them with every wait): four k-steps of B fragments live in a ring of 32 registers, slot kk is re-requested for the NEXT
 // chunk one k-step after the MFMAs of k-step kk have been issued, and the loop's two waits (the barrier's vmcnt(0), one counted
 // wait in front of k-step 2) cover them.
-template <int MI, int NJ, int WN, bool BD = false>
+template <int MI, int NJ, int WN, bool BD = false, bool STAG = false>
 __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_kernel   // (threads, waves per SIMD)
 (ConvDmaParams p) {
+    static_assert(!STAG || BD, "staggered request slots exist for the weights-direct instance");
     static_assert(!BD || (MI == 4 && NJ == 2 && WN == 4), "weights direct to registers: the 256 x 256 eight-wave instance");
     using T = DmaTile<MI, NJ, WN, BD>;
     constexpr int DBM = T::BM, DBN = T::BN, DSTAGE = T::STAGE, NM = T::NM, NF = T::NF, NP = T::NP, NPA = T::NPA, NPW = T::NPW;
@@ -568,26 +569,49 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
         //   before k-step 1: B1 landed = vmcnt(7) (B2 B2 P0 P1 B3 B3 P2 younger); before k-step 2: B2 landed = vmcnt(8);
         //   barrier: P3 and everything older (B3, B0') landed = vmcnt(2) (B1' B1' younger).  A request has three k-steps to land.
         static_assert(NPA == 4 && C3 == 2 && C0 == 1 && C1 == 1, "the counted waits below are written for four activation pieces");
+        // an activation piece = one LDS-DMA request; the tap / channel state moves on ONCE per chunk (after its fourth piece), at
+        // a fixed point of the schedule -- the conditional request slots below then hold nothing but the request itself
+        auto piece = [&](int buf, int z) {
+            if (p.ablate & 4) return;
+            dma(rs_in, voffA[z], c0 * 2, lds0 + buf * DSTAGE + wave * 1024 + z * PIECE);
+        };
+        auto next_chunk_rows = [&]() {
+            if (++kw == p.KW) {
+                kw = 0;
+                if (++kh == p.KH) { kh = 0; c0 += DBK; }
+            }
+            if (p.KH * p.KW > 1) refresh_rows();
+        };
 #pragma unroll
-        for (int z = 0; z < NP; ++z) stage_piece(0, 0, z);
+        for (int z = 0; z < NP; ++z) piece(0, z);
+        next_chunk_rows();
         BLOAD_AT(0, 0); BLOAD_AT(1, 0); BLOAD_AT(2, 0);
         int bks_cur = bks;
         b_advance();
-#pragma unroll
-        for (int z = 0; z < C3; ++z) stage_piece(1, 1, z);
+        piece(1, 0);
+        piece(1, 1);
         asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(fbr[0][0]), "+v"(fbr[0][1]), "+v"(fbr[1][0]), "+v"(fbr[1][1]), "+v"(fbr[2][0]),
                      "+v"(fbr[2][1]) : [n] "n"(C3) : "memory");
         __syncthreads();
 #pragma unroll
         for (int z = 0; z < NF; ++z) DFRAG(fa0, fb0, 0, 0, z);
+        // Request slots.  All eight waves leave the chunk's barrier together and walk the same schedule: with every wave's
+        // requests in the same MFMA slot the texture path sees bursts of 16 requests and every wave queues behind them.
+        // STAG (measurement build) spreads them: wave w asks for its weight fragments in slot bsl = 6 w / 8 (k-step 2, which
+        // carries no activation piece: slot w) and for its activation pieces two slots later -- the ORDER of a wave's requests,
+        // and with it every counted wait, is unchanged.
+        const int bsl0 = STAG ? (wave * 6) >> 3 : 0, bsl20 = STAG ? wave : 0, psl0 = STAG ? bsl0 + 2 : NM - 1;
         for (int kt = 0; kt < KT; ++kt) {
             const int buf = kt & 1;
+            int bsl = bsl0, bsl2 = bsl20, psl = psl0;
+            // (STAG: opaque copies -- otherwise the 40 loop-invariant slot comparisons are hoisted as 40 live SGPR pairs and spill)
+            if constexpr (STAG) asm volatile("" : "+s"(bsl), "+s"(bsl2), "+s"(psl));
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 DMFMA(fa0, fbr[0], q);
                 DFRAGS(fa1, fb1, buf, 1, q);
-                if (q == 0) BLOAD_AT(3, bks_cur);
-                if (q >= NM - C0) stage_piece(kt + 1, buf ^ 1, C3 + q - (NM - C0));
+                if (q == bsl) BLOAD_AT(3, bks_cur);
+                if (q == psl) piece(buf ^ 1, 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(7)" : "+v"(fbr[1][0]), "+v"(fbr[1][1]) :: "memory");
@@ -596,17 +620,18 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
             for (int q = 0; q < NM; ++q) {
                 DMFMA(fa1, fbr[1], q);
                 DFRAGS(fa0, fb0, buf, 2, q);
-                if (q == 0) BLOAD_AT(0, bks);
-                if (q >= NM - C1) stage_piece(kt + 1, buf ^ 1, C3 + C0 + q - (NM - C1));
+                if (q == bsl) BLOAD_AT(0, bks);
+                if (q == psl) piece(buf ^ 1, 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            next_chunk_rows();                 // chunk kt + 1 is requested completely: the rows of chunk kt + 2
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(fbr[2][0]), "+v"(fbr[2][1]) :: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 DMFMA(fa0, fbr[2], q);
                 DFRAGS(fa1, fb1, buf, 3, q);
-                if (q == 0) BLOAD_AT(1, bks);
+                if (q == bsl2) BLOAD_AT(1, bks);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(2)" : "+v"(fbr[3][0]), "+v"(fbr[3][1]), "+v"(fbr[0][0]), "+v"(fbr[0][1]) :: "memory");
@@ -618,8 +643,9 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
             for (int q = 0; q < NM; ++q) {
                 DMFMA(fa1, fbr[3], q);
                 DFRAGS(fa0, fb0, buf ^ 1, 0, q);
-                if (q == 0) BLOAD_AT(2, bks);
-                if (q >= NM - C3) stage_piece(kt + 2, buf, q - (NM - C3));
+                if (q == bsl) BLOAD_AT(2, bks);
+                if (q == psl - 1) piece(buf, 0);
+                if (q == psl) piece(buf, 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             bks_cur = bks;
@@ -757,6 +783,9 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
     else if (shape == 4) hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 4, 2>), dim3(grid), dim3(256), 0, stream, p);
 #else
     else if (shape == 4) return CPR_ERR_UNSUPPORTED;
+#endif
+#ifdef CPR_BENCH_HOOKS
+    else if (bd && (ablate & 256)) hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4, true, true>), dim3(grid), dim3(512), 0, stream, p);
 #endif
     else if (bd) hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4, true>), dim3(grid), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4>), dim3(grid), dim3(512), 0, stream, p);
