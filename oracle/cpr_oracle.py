@@ -323,7 +323,7 @@ def point_assign(points, gt_bboxes, gt_labels=None, scale=4, pos_num=3):
 
 def _log_cr(x):
     """Correctly rounded fp32 log.  torch's CPU ``log`` goes through MKL VML, whose last bit depends on the HOST (Xeon /
-    AVX-512 kernel: 0.007 % of values 1 ulp off this; EPYC kernel: 1.7 %, measured with tools/log_probe.py,
+    AVX-512 kernel: 0.007 % of values 1 ulp off this; EPYC kernel: 1.7 %, measured with tools/diag/log_probe.py,
     profiles/round2_log_probe.txt), so the reference's cost bits are not machine independent.  This is the
     host-independent limit both approximate and what the HIP cost kernel computes ((float)log((double)x), checked against
     glibc on 2^22 inputs: tools/diag/logcr.hip).  Evaluated in x87 extended precision (glibc logl, 64-bit mantissa) and

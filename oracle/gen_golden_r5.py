@@ -24,11 +24,25 @@ from oracle import ref_loader  # noqa: E402
 from oracle.gen_golden import GOLDEN, grad_sample_index  # noqa: E402
 from oracle.gen_golden_r2 import build_reference, option_cfg  # noqa: E402
 
-OPTION_GRAD_CASES = ('r2_independent', 'ins_tower', 'ins_tower_fc')
+# name -> (oracle.gen_golden_r2 option case, overrides).  The FC cases use their own seeds: with the seed of the round-3 forward
+# fixture (55) an activation of the instance tower sits on a ReLU boundary -- a 1e-6 relative perturbation of the input image moves
+# the REFERENCE's own gradient of ins_convs.0 / .1 by 5e-3 (a flip, the same at 1e-5), so that fixture cannot pin a backward to
+# 2e-3; with seed 155 the response is 3e-5, with 161 (shared features, two FC layers) 8e-6.
+OPTION_GRAD_CASES = {
+    'r2_independent': ('r2_independent', {}),
+    'ins_tower': ('ins_tower', {}),
+    'ins_tower_fc': ('ins_tower_fc', dict(seed=155)),
+    'fc2_shared': ('ins_tower_fc', dict(ins_tower=False, num_cls_fcs=2, fc_out_channels=64, seed=161)),
+}
+
+
+def grad_option_cfg(name):
+    base, over = OPTION_GRAD_CASES[name]
+    return dict(option_cfg(base), **over)
 
 
 def run_reference_option_grads(R, name):
-    cfg = option_cfg(name)
+    cfg = grad_option_cfg(name)
     torch.manual_seed(0)
     backbone, neck, head, batch = build_reference(R, cfg)
     cls_feat, ins_feat = head(neck(backbone(batch['img'])))

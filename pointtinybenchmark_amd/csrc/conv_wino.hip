@@ -33,7 +33,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Packed fp32 vector ops (two floats per lane per instruction): the input transform and the fused affine work on register pairs,
 // half the instructions in the K loop.  Next to v_mfma_f32_32x32x2_f32 a packed add costs about two scalar ones
-// (tools/diag/mfma_shadow), so the gain is the issue slots only: 0.4-0.7 % (tools/wino_packed_ab.py).  a - b is a + (-b)
+// (tools/diag/mfma_shadow), so the gain is the issue slots only: 0.4-0.7 % (round-2 A/B, git history: tools/wino_packed_ab.py).  a - b is a + (-b)
 // exactly, so the results are the scalar code's bit for bit.
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
     f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;

@@ -232,21 +232,22 @@ def test_cpr_options_vs_reference(golden_dir, name, record_property):
     record_property('near_threshold_entries', nnear)
 
 
-OPTION_GRAD_CASES = ('r2_independent', 'ins_tower', 'ins_tower_fc')      # oracle.gen_golden_r5.OPTION_GRAD_CASES
+from oracle.gen_golden_r5 import OPTION_GRAD_CASES, grad_option_cfg      # name -> (option case, overrides)
 
 
-@pytest.mark.parametrize('name', OPTION_GRAD_CASES)
+@pytest.mark.parametrize('name', list(OPTION_GRAD_CASES))
 def test_option_backward_vs_reference_autograd(golden_dir, name):
     """The CPRHead options that gained a hand-written backward in round 5 -- num_refine = 2 inputs under the default bag policy
-    (cpr_head.py:1159-1211), a separate instance tower (ins_share_head_feat=False, :992-1008,1037-1040,1061-1070) and the same
-    with FC layers between the sampled features and the classifiers (num_cls_fcs > 0, :999-1005,1055-1059) -- against
+    (cpr_head.py:1159-1211), a separate instance tower (ins_share_head_feat=False, :992-1008,1037-1040,1061-1070), the same with an
+    FC layer between the sampled features and the classifiers, and two FC layers on shared features (num_cls_fcs > 0,
+    :999-1005,1055-1059) -- against
     loss.backward() through the REFERENCE's own modules (tests/golden/cpr_option_grads.npz, oracle/gen_golden_r5.py): total
     loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the tensor's max.  Then loss.backward() through the autograd bridge
     on a fresh model must equal the native trainer BIT for bit, as for the shipped options."""
     from oracle.gen_golden import grad_sample_index
     from pointtinybenchmark_amd import autograd_bridge
     from pointtinybenchmark_amd.training import CprTrainer
-    cfg = option_cfg(name)
+    cfg = grad_option_cfg(name)
     g = np.load(os.path.join(golden_dir, 'cpr_option_grads.npz'))
     p = name + ':'
     m, batch = build_hip(cfg)

@@ -83,7 +83,7 @@ def test_train_steps_match_torch_sgd():
     # lr: the first two gradients of this random-init case have norms 547 and ~9000 (clipped to 35); at lr = 0.05 the third
     # step's gradient norm moves 2e-4 under a 1e-6 relative perturbation of the input and 7e-3 under a change of the fp32
     # summation order of the 3x3 convs (direct vs Winograd), i.e. that trajectory amplifies rounding ~1e4 x and cannot be
-    # held to 2e-3 by any fp32 implementation; at 0.01 the same changes move it by 4e-5 and 8e-5 (tools/dbg_train.py)
+    # held to 2e-3 by any fp32 implementation; at 0.01 the same changes move it by 4e-5 and 8e-5 (measured in round 2 with a throw-away script, git history: tools/dbg_train.py)
     lr = 0.01
     tr = CprTrainer(m, lr=lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
     sd = {k: v.clone() for k, v in sd0.items()}

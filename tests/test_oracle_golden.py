@@ -224,15 +224,16 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
     np.testing.assert_allclose(torch.cat([r['scores'] for r in ref]).numpy(), g[p + 'scores'], rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize('name', ['r2_independent', 'ins_tower', 'ins_tower_fc'])
+@pytest.mark.parametrize('name', ['r2_independent', 'ins_tower', 'ins_tower_fc', 'fc2_shared'])
 def test_option_oracle_autograd_matches_reference_autograd(golden_dir, name):
     """Pins the options oracle's BACKWARD (torch autograd over oracle/cpr_options_oracle.py) to loss.backward() through the
     reference's own modules for the options that gained a hand-written backward in round 5 (tests/golden/cpr_option_grads.npz,
     oracle/gen_golden_r5.py): per-tensor norm and strided samples, 1e-3."""
     from oracle import cpr_options_oracle as OO
     from oracle.gen_golden import grad_sample_index
-    from oracle.gen_golden_r2 import case_inputs, option_cfg
-    cfg = option_cfg(name)
+    from oracle.gen_golden_r2 import case_inputs
+    from oracle.gen_golden_r5 import grad_option_cfg
+    cfg = grad_option_cfg(name)
     g = _load(golden_dir, 'cpr_option_grads')
     p = name + ':'
     sd, batch = case_inputs(cfg)

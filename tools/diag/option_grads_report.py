@@ -7,7 +7,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import cpr_oracle as O, cpr_options_oracle as OO  # noqa: E402
-from oracle.gen_golden_r2 import case_inputs, option_cfg  # noqa: E402
+from oracle.gen_golden_r2 import case_inputs  # noqa: E402
+from oracle.gen_golden_r5 import grad_option_cfg as option_cfg  # noqa: E402
 from tests.test_gpu_options import build_hip, cuda_batch  # noqa: E402
 from pointtinybenchmark_amd.training import CprTrainer  # noqa: E402
 
