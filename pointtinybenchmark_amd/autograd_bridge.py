@@ -222,8 +222,12 @@ class _HeadLossFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ entry point
 def forward_train(model, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
-    """BasicLocator.forward_train with a graph: the same dict of losses (bit-identical values: the recorded forward is the
-    forward-only arithmetic), differentiable wrt every trainable parameter."""
+    """BasicLocator.forward_train with a graph: the same dict of losses, differentiable wrt every trainable parameter.  The
+    CPR losses are the forward-only values up to fp32 summation order (<= 2e-6 relative, asserted by tests/test_gpu_train_step.py:
+    the recorded forward fuses the producer GroupNorm into the 3x3 consumers' loads where the forward-only path materialises it
+    and runs Winograd); P2PNet's differ in the last bits for one more reason -- the recorded path keeps the 3x3 output convs on
+    the conv kernel (its backward walks them) where the forward-only path uses the tap projection.  The recorded maps live until
+    ``loss.backward()`` has run or the returned losses die: evaluate losses you do not differentiate under ``torch.no_grad()``."""
     bridge = get_bridge(model)
     eng = bridge.engine
     eng.begin_step()

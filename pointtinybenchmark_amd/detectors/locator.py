@@ -140,7 +140,10 @@ class BasicLocator(nn.Module):
             raw, ab, lmap = self._graphed_logit_map(img)
             return self.bbox_head.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas,
                                        gt_bboxes_ignore=gt_bboxes_ignore, gt_true_bboxes=gt_true_bboxes, lmap=lmap)
-        if torch.is_grad_enabled() and img.is_cuda and any(p.requires_grad for p in self.parameters()):
+        # (train mode only: a model in eval() -- validation losses computed without torch.no_grad() -- keeps the forward-only path
+        # and holds no tapes; CPR_AUTOGRAD=0 switches the bridge off altogether)
+        if torch.is_grad_enabled() and self.training and img.is_cuda and os.environ.get('CPR_AUTOGRAD', '1') != '0' and \
+                any(p.requires_grad for p in self.parameters()):
             # autograd is on: the losses must carry a graph, as the reference's do (its driver calls loss.backward():
             # T/mmdet/models/detectors/base.py:214-247 + mmcv OptimizerHook).  The recorded forward / HIP backward pair sits
             # behind torch.autograd.Functions (autograd_bridge.py); same loss values as the forward-only path below
