@@ -173,7 +173,11 @@ __device__ __forceinline__ void dma_epilogue(const ConvDmaParams& p, f32x16 (&ac
 // WITHOUT a lane exchange, all 64 lanes storing, and a wave instruction writes two whole 128-byte lines (rows m, m + 4) where the
 // shared epilogue above writes four 64-byte halves with half its lanes idle -- PMC had 96 MB written per 67 MB map on the head
 // layer (profiles/round4_pmc_bf16_big_tile.json).  Residual: one 4-byte load per row instead of two 2-byte ones; fp32 output: 8 bytes.
-template <int MI>
+// PRE (round 5, the weights-direct instance: its 219 registers leave room for a second set of 16): the residual of pixel block
+// i + 1 is requested BEFORE block i is scaled and stored -- un-prefetched, every block's 16 loads are issued and awaited in
+// turn, and on the short-K bottleneck layers (1x1 256 -> 1024 + residual on 8 x 128^2: four K chunks) the epilogue is 60 % of the
+// launch (0.196 ms with, 0.076 ms without it; 0.168 with the stores dropped: profiles/round5_bf16_epilogue_ablation.txt).
+template <int MI, bool PRE = false>
 __device__ __forceinline__ void dma_epilogue_pairs(const ConvDmaParams& p, f32x16 (&acc)[MI][2], int tm, int m0, int n0, int wm,
                                                    int wn, int lane) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -190,20 +194,27 @@ __device__ __forceinline__ void dma_epilogue_pairs(const ConvDmaParams& p, f32x1
     const float sc0 = p.scale ? p.scale[cc] : 1.f, sc1 = p.scale ? p.scale[cc + 1] : 1.f;
     const float bi0 = p.bias ? p.bias[cc] : 0.f, bi1 = p.bias ? p.bias[cc + 1] : 0.f;
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    unsigned resbuf[PRE ? 2 : 1][16];
+    auto load_res = [&](int i, unsigned (&dst)[16]) {
+        const unsigned e0 = (unsigned)((m0 + wm * (MI * 32) + i * 32 + 4 * half) * p.Cout + c0);
+        if (p.residual) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dst[r] = __builtin_amdgcn_raw_buffer_load_b32(
+                    rs_res, (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r] = 0u;
+        }
+    };
+    if (PRE) load_res(0, resbuf[0]);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int rbase = m0 + wm * (MI * 32) + i * 32 + 4 * half;
         const unsigned e0 = (unsigned)(rbase * p.Cout + c0);
-        unsigned res[16];
-        if (p.residual) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                res[r] = __builtin_amdgcn_raw_buffer_load_b32(
-                    rs_res, (int)(cok ? (e0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout) * 2u : 0x80000000u), 0, 0);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) res[r] = 0u;
-        }
+        if (PRE) { if (i + 1 < MI) load_res(i + 1, resbuf[PRE ? (i + 1) & 1 : 0]); }
+        else load_res(i, resbuf[0]);
+        unsigned (&res)[16] = resbuf[PRE ? i & 1 : 0];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2);
@@ -521,11 +532,13 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
         }
         bks = (((bkh * p.KW + bkw) * p.Cin + bc0) >> 4) * 2048;
     };
-#define BLOAD_AT(kk, off)                                                                                             \
+    // ok = false: a request of the fixed schedule that lies past the last chunk -- issued all the same (the counted waits need
+    // it), but with a vector offset beyond the buffer range (the range check looks at the vector offset): zeros, no memory traffic
+#define BLOAD_AT(kk, off, ok)                                                                                         \
     do {                                                                                                              \
         if (p.ablate & 128) break;                                                                                    \
         asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:0\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024" \
-                     : "=&v"(fbr[kk][0]), "=&v"(fbr[kk][1]) : "v"(wf_lane), "s"(rs_wf), "s"(wf_group + (off) + (kk) * 2048) : "memory"); \
+                     : "=&v"(fbr[kk][0]), "=&v"(fbr[kk][1]) : "v"((ok) ? wf_lane : (int)0x80000000), "s"(rs_wf), "s"(wf_group + (off) + (kk) * 2048) : "memory"); \
     } while (0)
 
     f32x16 acc[MI][NJ];
@@ -561,9 +574,9 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
 
     constexpr int C3 = T::C3, C0 = T::C0, C1 = T::C1;
     if constexpr (BD) {
-        // Weights direct to registers.  EVERY request of the schedule is issued in every chunk -- past the last chunk the
-        // offsets run into the next cout group / out of the buffer range (zeros) and land in a stage / a ring slot nobody reads
-        // again -- so the number of requests between any two points of the loop is a constant and the waits can be counted:
+        // Weights direct to registers.  EVERY request of the schedule is issued in every chunk -- past the last chunk with a
+        // vector offset beyond the buffer range (zeros, no memory traffic), landing in a stage / a ring slot nobody reads again --
+        // so the number of requests between any two points of the loop is a constant and the waits can be counted:
         //   per chunk   k-step 0: B3 (this chunk, 2 loads) .. P2 | k-step 1: B0' (next chunk) .. P3 | k-step 2: B1' |
         //               wait + barrier | k-step 3: B2' .. P0'', P1'' (the chunk after next -> the stage just freed)
         //   before k-step 1: B1 landed = vmcnt(7) (B2 B2 P0 P1 B3 B3 P2 younger); before k-step 2: B2 landed = vmcnt(8);
@@ -571,9 +584,9 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
         static_assert(NPA == 4 && C3 == 2 && C0 == 1 && C1 == 1, "the counted waits below are written for four activation pieces");
         // an activation piece = one LDS-DMA request; the tap / channel state moves on ONCE per chunk (after its fourth piece), at
         // a fixed point of the schedule -- the conditional request slots below then hold nothing but the request itself
-        auto piece = [&](int buf, int z) {
+        auto piece = [&](int buf, int z, bool ok) {       // ok = false: past the last chunk (see BLOAD_AT)
             if (p.ablate & 4) return;
-            dma(rs_in, voffA[z], c0 * 2, lds0 + buf * DSTAGE + wave * 1024 + z * PIECE);
+            dma(rs_in, ok ? voffA[z] : (int)0x80000000, c0 * 2, lds0 + buf * DSTAGE + wave * 1024 + z * PIECE);
         };
         auto next_chunk_rows = [&]() {
             if (++kw == p.KW) {
@@ -583,13 +596,13 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
             if (p.KH * p.KW > 1) refresh_rows();
         };
 #pragma unroll
-        for (int z = 0; z < NP; ++z) piece(0, z);
+        for (int z = 0; z < NP; ++z) piece(0, z, true);
         next_chunk_rows();
-        BLOAD_AT(0, 0); BLOAD_AT(1, 0); BLOAD_AT(2, 0);
+        BLOAD_AT(0, 0, true); BLOAD_AT(1, 0, true); BLOAD_AT(2, 0, true);
         int bks_cur = bks;
         b_advance();
-        piece(1, 0);
-        piece(1, 1);
+        piece(1, 0, KT > 1);
+        piece(1, 1, KT > 1);
         asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(fbr[0][0]), "+v"(fbr[0][1]), "+v"(fbr[1][0]), "+v"(fbr[1][1]), "+v"(fbr[2][0]),
                      "+v"(fbr[2][1]) : [n] "n"(C3) : "memory");
         __syncthreads();
@@ -603,6 +616,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
         const int bsl0 = STAG ? (wave * 6) >> 3 : 0, bsl20 = STAG ? wave : 0, psl0 = STAG ? bsl0 + 2 : NM - 1;
         for (int kt = 0; kt < KT; ++kt) {
             const int buf = kt & 1;
+            const bool more = kt + 1 < KT, more2 = kt + 2 < KT;        // wave-uniform: do chunks kt + 1 / kt + 2 exist?
             int bsl = bsl0, bsl2 = bsl20, psl = psl0;
             // (STAG: opaque copies -- otherwise the 40 loop-invariant slot comparisons are hoisted as 40 live SGPR pairs and spill)
             if constexpr (STAG) asm volatile("" : "+s"(bsl), "+s"(bsl2), "+s"(psl));
@@ -610,8 +624,8 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
             for (int q = 0; q < NM; ++q) {
                 DMFMA(fa0, fbr[0], q);
                 DFRAGS(fa1, fb1, buf, 1, q);
-                if (q == bsl) BLOAD_AT(3, bks_cur);
-                if (q == psl) piece(buf ^ 1, 2);
+                if (q == bsl) BLOAD_AT(3, bks_cur, true);
+                if (q == psl) piece(buf ^ 1, 2, more);
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(7)" : "+v"(fbr[1][0]), "+v"(fbr[1][1]) :: "memory");
@@ -620,8 +634,8 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
             for (int q = 0; q < NM; ++q) {
                 DMFMA(fa1, fbr[1], q);
                 DFRAGS(fa0, fb0, buf, 2, q);
-                if (q == bsl) BLOAD_AT(0, bks);
-                if (q == psl) piece(buf ^ 1, 3);
+                if (q == bsl) BLOAD_AT(0, bks, more);
+                if (q == psl) piece(buf ^ 1, 3, more);
                 __builtin_amdgcn_sched_barrier(0);
             }
             next_chunk_rows();                 // chunk kt + 1 is requested completely: the rows of chunk kt + 2
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
             for (int q = 0; q < NM; ++q) {
                 DMFMA(fa0, fbr[2], q);
                 DFRAGS(fa1, fb1, buf, 3, q);
-                if (q == bsl2) BLOAD_AT(1, bks);
+                if (q == bsl2) BLOAD_AT(1, bks, more);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(2)" : "+v"(fbr[3][0]), "+v"(fbr[3][1]), "+v"(fbr[0][0]), "+v"(fbr[0][1]) :: "memory");
@@ -643,16 +657,16 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
             for (int q = 0; q < NM; ++q) {
                 DMFMA(fa1, fbr[3], q);
                 DFRAGS(fa0, fb0, buf ^ 1, 0, q);
-                if (q == bsl) BLOAD_AT(2, bks);
-                if (q == psl - 1) piece(buf, 0);
-                if (q == psl) piece(buf, 1);
+                if (q == bsl) BLOAD_AT(2, bks, more);
+                if (q == psl - 1) piece(buf, 0, more2);
+                if (q == psl) piece(buf, 1, more2);
                 __builtin_amdgcn_sched_barrier(0);
             }
             bks_cur = bks;
             b_advance();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the requests past the last chunk must land before the LDS is released
-        dma_epilogue_pairs<MI>(p, acc, tm, m0, n0, wm, wn, lane);
+        dma_epilogue_pairs<MI, true>(p, acc, tm, m0, n0, wm, wn, lane);
         return;
     }
     // prologue: chunk 0 -> stage 0 completely, the first C3 pieces of chunk 1 -> stage 1
