@@ -24,16 +24,26 @@ from oracle import ref_loader  # noqa: E402
 from oracle.gen_golden import GOLDEN, grad_sample_index  # noqa: E402
 from oracle.gen_golden_r2 import build_reference, option_cfg  # noqa: E402
 
-# name -> (oracle.gen_golden_r2 option case, overrides).  The FC cases use their own seeds: with the seed of the round-3 forward
-# fixture (55) an activation of the instance tower sits on a ReLU boundary -- a 1e-6 relative perturbation of the input image moves
-# the REFERENCE's own gradient of ins_convs.0 / .1 by 5e-3 (a flip, the same at 1e-5), so that fixture cannot pin a backward to
-# 2e-3; with seed 155 the response is 3e-5, with 161 (shared features, two FC layers) 8e-6.
+# name -> (oracle.gen_golden_r2 option case, overrides).
+# Seeds of the FC cases.  The instance tower only receives the bag term: a sparse, small gradient of which the few activations
+# that sit within ~1e-5 of a ReLU boundary carry a visible share.  Measured on the oracle (torch autograd, relu(x) -> relu(x + d) - d
+# in the instance tower): d = +-1e-6 moves nothing (4e-6 relative), d = +-1e-5 moves that tower's gradients by 3e-3 .. 7e-3 -- and
+# 1e-5 is what an fp32 Winograd convolution and torch's differ by on O(1) activations.  Where such an element exists the two
+# arithmetics take different branches and the deviation shows exactly as a flipped mask does when GroupNorm's beta is 0: from
+# one layer downwards the GN-bias and conv-weight gradients jump, the GN-weight gradient of that layer does not (xhat = 0 at
+# the boundary).  Device vs oracle on the instance tower, per seed (tools/diag/option_grads_report.py, round 5): 55 -> 5e-3 from
+# layer 1 down, 155 -> 3.6e-3 from layer 1 down, 156 -> 3e-4 from layer 3 down, 158 -> 1.4e-4 at layer 0, 160 -> 3.7e-5 at
+# layer 0; everything above the event agrees to 2e-6 .. 7e-6 in every case, the class tower to 1e-5.  The 2e-3 fixture uses a
+# sample without a visible event (160); 'ins_tower_fc_boundary' keeps one WITH an event (155) under a 1e-2 bar, so the bounded
+# size of the effect stays under test as well.  fc2_shared (shared features, two FC layers): seed 161.
 OPTION_GRAD_CASES = {
     'r2_independent': ('r2_independent', {}),
     'ins_tower': ('ins_tower', {}),
-    'ins_tower_fc': ('ins_tower_fc', dict(seed=155)),
+    'ins_tower_fc': ('ins_tower_fc', dict(seed=160)),
+    'ins_tower_fc_boundary': ('ins_tower_fc', dict(seed=155)),
     'fc2_shared': ('ins_tower_fc', dict(ins_tower=False, num_cls_fcs=2, fc_out_channels=64, seed=161)),
 }
+OPTION_GRAD_BARS = {'ins_tower_fc_boundary': 1e-2}       # per-tensor norm / strided-sample bar; default 2e-3
 
 
 def grad_option_cfg(name):

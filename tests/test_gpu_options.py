@@ -232,7 +232,7 @@ def test_cpr_options_vs_reference(golden_dir, name, record_property):
     record_property('near_threshold_entries', nnear)
 
 
-from oracle.gen_golden_r5 import OPTION_GRAD_CASES, grad_option_cfg      # name -> (option case, overrides)
+from oracle.gen_golden_r5 import OPTION_GRAD_BARS, OPTION_GRAD_CASES, grad_option_cfg      # name -> (option case, overrides)
 
 
 @pytest.mark.parametrize('name', list(OPTION_GRAD_CASES))
@@ -240,14 +240,17 @@ def test_option_backward_vs_reference_autograd(golden_dir, name):
     """The CPRHead options that gained a hand-written backward in round 5 -- num_refine = 2 inputs under the default bag policy
     (cpr_head.py:1159-1211), a separate instance tower (ins_share_head_feat=False, :992-1008,1037-1040,1061-1070), the same with an
     FC layer between the sampled features and the classifiers, and two FC layers on shared features (num_cls_fcs > 0,
-    :999-1005,1055-1059) -- against
-    loss.backward() through the REFERENCE's own modules (tests/golden/cpr_option_grads.npz, oracle/gen_golden_r5.py): total
-    loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the tensor's max.  Then loss.backward() through the autograd bridge
-    on a fresh model must equal the native trainer BIT for bit, as for the shipped options."""
+    :999-1005,1055-1059) -- against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_option_grads.npz,
+    oracle/gen_golden_r5.py): total loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the tensor's max.
+    'ins_tower_fc_boundary' is a sample on which an activation of the sparse-gradient instance tower sits within fp32 conv
+    rounding of a ReLU boundary (the reference's own gradient moves 3e-3 .. 7e-3 when that boundary is shifted by 1e-5:
+    oracle/gen_golden_r5.py) -- same comparison under a 1e-2 bar.  Then loss.backward() through the autograd bridge on a fresh
+    model must equal the native trainer BIT for bit, as for the shipped options."""
     from oracle.gen_golden import grad_sample_index
     from pointtinybenchmark_amd import autograd_bridge
     from pointtinybenchmark_amd.training import CprTrainer
     cfg = grad_option_cfg(name)
+    bar = OPTION_GRAD_BARS.get(name, 2e-3)
     g = np.load(os.path.join(golden_dir, 'cpr_option_grads.npz'))
     p = name + ':'
     m, batch = build_hip(cfg)
@@ -270,10 +273,10 @@ def test_option_backward_vs_reference_autograd(golden_dir, name):
         gr = params[k].grad.detach().double().flatten().cpu()
         want[k] = params[k].grad.detach().clone()
         ref_n = float(g[p + 'norm:' + k])
-        assert abs(float(gr.norm()) - ref_n) <= 2e-3 * ref_n + 1e-6 * gmax, (k, float(gr.norm()), ref_n)
+        assert abs(float(gr.norm()) - ref_n) <= bar * ref_n + 1e-6 * gmax, (k, float(gr.norm()), ref_n)
         smp = gr[torch.from_numpy(grad_sample_index(gr.numel()))].numpy()
         ref = g[p + 'sample:' + k].astype(np.float64)
-        assert np.abs(smp - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-5 * gmax), k
+        assert np.abs(smp - ref).max() <= bar * max(np.abs(ref).max(), 1e-5 * gmax), k
     del tr, m
     m2, _ = build_hip(cfg)
     out = m2.train_step(dict(data), optimizer=None)

@@ -224,7 +224,7 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
     np.testing.assert_allclose(torch.cat([r['scores'] for r in ref]).numpy(), g[p + 'scores'], rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize('name', ['r2_independent', 'ins_tower', 'ins_tower_fc', 'fc2_shared'])
+@pytest.mark.parametrize('name', ['r2_independent', 'ins_tower', 'ins_tower_fc', 'ins_tower_fc_boundary', 'fc2_shared'])
 def test_option_oracle_autograd_matches_reference_autograd(golden_dir, name):
     """Pins the options oracle's BACKWARD (torch autograd over oracle/cpr_options_oracle.py) to loss.backward() through the
     reference's own modules for the options that gained a hand-written backward in round 5 (tests/golden/cpr_option_grads.npz,
