@@ -181,17 +181,18 @@ class ConvProbe:
             OH, OW = pc.out_hw(H, W)
             kind, v = ops.TRACE_CONV_VARIANT[1]          # what the launcher returned through its out-parameter
             if kind == 'wino32':     # csrc/conv_wino32.hip (two workgroups per CU): <XF>
-                variant = 'conv_wino32_kernel<%s>' % ('true' if v & 4 else 'false')
+                variant = 'conv_wino32_kernel<%s, 0>' % ('true' if v & 4 else 'false')        # <XF, ABL = 0>, as rocprof prints it
             elif kind == 'wino':     # template instance of csrc/conv_wino.hip: <ABL = 0, INB8, XF>
                 # <ABL = 0, INB8, XF, TSPREAD, VAR>; the launcher picks TSPREAD = 0 for the fused-affine instances, 1 for the plain
                 # ones; VAR = 4: weights staged by LDS-DMA (WINO_VAR_DEFAULT in conv_wino.hip)
                 variant = 'conv_wino_kernel<0, %s, %s, %d, 4>' % ('true' if v & 1 else 'false', 'true' if v & 4 else 'false',
                                                                   0 if v & 4 else 1)
             elif kind == 'bf16':
-                # conv_bf16_dma.hip reports 256256 (the <MI 4, NJ 2, WN 4, BD false> instance, as rocprof prints it), 3256256 (the same tile
-                # with the weights direct to registers, BD true) and 1128128 (<2, 1, 4, false>: 128 x 128 tiles, two workgroups per CU)
-                variant = ('conv_bf16_dma_kernel<4, 2, 4, false>' if v == 256256 else 'conv_bf16_dma_kernel<4, 2, 4, true>' if v == 3256256 else
-                           'conv_bf16_dma_kernel<2, 1, 4, false>' if v == 1128128 else
+                # conv_bf16_dma.hip reports 256256 (the <MI 4, NJ 2, WN 4, BD false, STAG false> instance, as rocprof prints it), 3256256 (the
+                # same tile with the weights direct to registers, BD true) and 1128128 (<2, 1, 4, false, false>: 128 x 128 tiles, two
+                # workgroups per CU)
+                variant = ('conv_bf16_dma_kernel<4, 2, 4, false, false>' if v == 256256 else 'conv_bf16_dma_kernel<4, 2, 4, true, false>' if v == 3256256 else
+                           'conv_bf16_dma_kernel<2, 1, 4, false, false>' if v == 1128128 else
                            'conv_mfma_bf16_kernel<%d, %d>' % (v // 1000, v % 1000))
             elif v % 10 == 2:    # dual-source launch (conv3 + projection shortcut): <BM, BN, MODE 0, XF false, PIPE 1, ABL 0, DUAL>
                 variant = 'conv_mfma_kernel<%d, %d, 0, false, 1, 0, true>' % (v // 1000000, v // 1000 % 1000)
