@@ -15,7 +15,10 @@ Options beyond the shipped configs, all on the same kernel
 ``ins_share_head_feat=False`` (a second tower ``ins_convs`` / ``ins_fcs`` for the instance classifier, cpr_head.py:992-1008,
 1037,1068), ``out_bg_cls=True`` for one class (:953), ``PointRefiner(return_score_type='max')`` (:840-842).
 generator ``align_corners=True`` (:73-93,126).
-``AnchorPtFeatGenerator(scale_factor != 1)`` and ``GridEllipsePtFeatGenerator`` raise in the reference itself and are refused."""
+``AnchorPtFeatGenerator(scale_factor != 1)`` and ``GridEllipsePtFeatGenerator`` raise in the reference itself and are refused.
+Training (``training.BackwardEngine`` / ``autograd_bridge``): the shipped configs' options and, since round 5, num_refine > 1 under
+the default bag policy, the separate instance tower and ``num_cls_fcs > 0`` have a hand-written backward
+(``train_step_supported``); the other options are forward only."""
 import math
 
 import numpy as np
