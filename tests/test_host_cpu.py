@@ -524,3 +524,23 @@ def test_bench_config_presets_name_the_baseline_shapes():
     cfgm = bench.model_cfg(50, 80, 1, 8, 8)
     assert cfgm['neck']['start_level'] == 1 and cfgm['bbox_head']['strides'] == [8] and cfgm['bbox_head']['num_classes'] == 80
     assert cfgm['bbox_head']['train_pts_extractor']['pos_generator']['radius'] == 8
+
+
+def test_grad_report_of_the_bench_gates():
+    """bench.grad_report (the numbers behind train_step.parity_gate and tests/test_gpu_fullsize_grads.py): per-tensor relative L2
+    worst first, global-norm error, cosine, strided-sample error, and the nil flag for tensors whose true gradient is numerically 0."""
+    from bench import grad_report
+    g = torch.Generator().manual_seed(0)
+    ref = {'a': torch.randn(1000, generator=g), 'b': torch.randn(64, 3, generator=g) * 10, 'nil': torch.zeros(17)}
+    got = {k: v.clone() for k, v in ref.items()}
+    got['a'] = got['a'] * (1 + 1e-3)
+    got['b'][5, 1] += 0.5
+    rep = grad_report(got, ref)
+    rows = {d['key']: d for d in rep['rows']}
+    assert abs(rows['a']['rel_l2'] - 1e-3) < 1e-6 and rows['nil']['nil'] and not rows['a']['nil']
+    assert abs(rows['b']['rel_l2'] - 0.5 / float(ref['b'].double().norm())) < 1e-9
+    assert rep['rows'][0]['key'] == 'b' or rep['rows'][0]['rel_l2'] >= rep['rows'][1]['rel_l2']
+    n_ref = (float(ref['a'].double().norm()) ** 2 + float(ref['b'].double().norm()) ** 2) ** 0.5
+    assert abs(rep['ref_norm'] - n_ref) < 1e-9 and 0 < rep['norm_rel'] < 1e-3 and 0.9999 < rep['cosine'] <= 1.0
+    same = grad_report(ref, ref)
+    assert same['norm_rel'] == 0 and abs(same['cosine'] - 1) < 1e-12 and all(d['rel_l2'] == 0 for d in same['rows'])
