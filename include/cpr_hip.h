@@ -383,6 +383,18 @@ int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* 
 int cpr_bag_gather_bwd(const float* dsample, int J, const float* centers, const int* gt_img, const float* offsets,
                        float* win_ws, int* win_org, int win, float* dmap, int N, int H, int W, int Jd, int G, int K,
                        float stride, void* stream);
+/* The same loss gradients for every CPRHead loss option the forward kernels take (round 5): prob_type 0 sigmoid / 1 softmax /
+ * 2 normed_sigmoid(norm_p) class probabilities (cpr_head.py:1080-1099), MILLoss(binary_ins) / AllPosLoss
+ * (multi_instance_learning_loss.py:153-243), the bag / annotated-point geometry of cpr_mil_loss (refine_bag_policy, gt_loss_type:
+ * cpr_head.py:1159-1211), C = classifier outputs (num_classes + 1 with out_bg_cls), neg_from_gt (with_mil_loss=False: the negative
+ * term is averaged over the annotated-point positives).  dmap (N,H,W,Jd) <- the negative-grid term alone; dbag
+ * (num_bags * bag_stride, J) <- the gradient wrt every bag entry's logits, NOT gathered (cpr_bag_gather_bwd adds it onto dmap). */
+int cpr_loss_bwd_general(const float* lmap, const unsigned char* neg_mask, const float* out5, const float* bag_logits,
+                         const unsigned char* valid, const int* labels, const float* gt_weight, const float* bag_ws, float* dbag,
+                         float* dmap, int N, int H, int W, int J, int Jd, int ins_off, int num_bags, int bag_stride, int bag_off,
+                         int bag_len, int ctr_off, int ctr_stride, int ctr_count, int ctr_mod, int C, float eps, int prob_type,
+                         float norm_p, int binary_ins, int allpos, float w_mil, float w_gt, float w_neg, int neg_from_gt,
+                         const float* upstream, void* stream);
 /* OIHW fp32 master weights -> the conv kernels' layout [rows][KH][KW][cols'] (row stride Kpad, zero padded).
  * transpose 0: forward pack (rows = O).  transpose 1: data-gradient pack (rows = I, taps flipped, optional per-O scale =
  * the folded BatchNorm scale of the forward conv).  colsp = padded column count (4 for <= 4 channels). */

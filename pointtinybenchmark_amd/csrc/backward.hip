@@ -679,6 +679,246 @@ extern "C" int cpr_bag_gather_bwd(const float* dsample, int J, const float* cent
     CPR_LAUNCH_STATUS();
 }
 
+// ------------------------------------------------------------------------------------------------ CPR loss backward, general form
+// (round 5) The same gradients for the CPRHead options the kernels above do not cover -- softmax / normed_sigmoid class
+// probabilities (cpr_head.py:1080-1099), MILLoss(binary_ins=True) and AllPosLoss (multi_instance_learning_loss.py:153-243), the
+// merge_to_gt_bag / only_refine_bag policies and gt_loss_type='gt' (cpr_head.py:1159-1211: the bag / annotated-point geometry of
+// mil_bag_kernel, csrc/cpr_points.hip), out_bg_cls (one more classifier output that is never a label), with_mil_loss=False.
+// The forward kernels already take all of them; these mirror them term by term.  Probabilities p(l) of one point and the
+// product of an upstream vector g = dL/dp with their Jacobian:
+//   sigmoid           p_c = s(l_c)                       dL/dl_c = g_c p_c (1 - p_c)
+//   softmax           p = softmax(l)                     dL/dl_c = p_c (g_c - sum_j g_j p_j)
+//   normed_sigmoid    p_c = s_c / n, n = ||s||_P         dL/dl_c = (g_c / n - (sum_j g_j s_j) s_c^(P-1) n^(-1-P)) s_c (1 - s_c)
+// (n >= 1e-12 always: a sum of sigmoids.)  The shipped configs keep the specialised kernels above: bit-for-bit unchanged.
+#define CPRB_SIGMOID 0
+#define CPRB_SOFTMAX 1
+#define CPRB_NORMED 2
+struct ProbNorm { float m, se, n; };     // softmax: max and sum of exp; normed_sigmoid: the norm
+__device__ __forceinline__ ProbNorm prob_norm(const float* __restrict__ l, int C, int ptype, float P) {
+    ProbNorm r{0.f, 1.f, 1.f};
+    if (ptype == CPRB_SOFTMAX) {
+        r.m = -INFINITY;
+        for (int j = 0; j < C; ++j) r.m = fmaxf(r.m, l[j]);
+        r.se = 0.f;
+        for (int j = 0; j < C; ++j) r.se += expf(l[j] - r.m);
+    } else if (ptype == CPRB_NORMED) {
+        float a = 0.f;
+        for (int j = 0; j < C; ++j) {
+            const float sj = sigm(l[j]);
+            a += (P == 1.f) ? sj : (P == 2.f ? sj * sj : powf(sj, P));
+        }
+        r.n = fmaxf((P == 1.f) ? a : (P == 2.f ? sqrtf(a) : powf(a, 1.f / P)), 1e-12f);
+    }
+    return r;
+}
+__device__ __forceinline__ float prob_of(const float* __restrict__ l, int c, int ptype, const ProbNorm& r) {
+    if (ptype == CPRB_SOFTMAX) return expf(l[c] - r.m) / r.se;
+    const float sc = sigm(l[c]);
+    return ptype == CPRB_NORMED ? sc / r.n : sc;
+}
+// dL/dl_c from g_c = dL/dp_c and the cross term X (softmax: sum_j g_j p_j; normed_sigmoid: sum_j g_j s_j; sigmoid: unused)
+__device__ __forceinline__ float prob_back(const float* __restrict__ l, int c, float gc, float X, int ptype, float P, const ProbNorm& r) {
+    if (ptype == CPRB_SOFTMAX) return expf(l[c] - r.m) / r.se * (gc - X);
+    const float sc = sigm(l[c]);
+    if (ptype == CPRB_SIGMOID) return gc * sc * (1.f - sc);
+    const float spm1 = (P == 1.f) ? 1.f : (P == 2.f ? sc : powf(sc, P - 1.f));
+    return (gc / r.n - X * spm1 * powf(r.n, -1.f - P)) * sc * (1.f - sc);
+}
+__device__ __forceinline__ float prob_cross(int ptype, float gc, float pc, float sc) {   // one term of X
+    return ptype == CPRB_SOFTMAX ? gc * pc : (ptype == CPRB_NORMED ? gc * sc : 0.f);
+}
+
+// negative-grid term, any probability type: dmap (NP, Jd) fully written (zeros beyond the class channels)
+__global__ void neg_loss_bwd_general_kernel(const float* __restrict__ logit, const unsigned char* __restrict__ mask,
+                                            const float* __restrict__ out5, const float* __restrict__ bag, int G,
+                                            float* __restrict__ dmap, long long NP, int J, int Jd, int C, float eps, float w_neg,
+                                            int neg_from_gt, int ptype, float P, const float* __restrict__ up) {
+    __shared__ double red[4];
+    if (up) w_neg *= up[3];
+    double den = (double)out5[4];
+    if (neg_from_gt) {      // with_mil_loss=False: averaged over the annotated-point positives (cpr_head.py:1180,1227)
+        double ng = 0;
+        for (int g = threadIdx.x; g < G; g += blockDim.x) ng += (double)bag[(size_t)g * 5 + 3];
+        ng = wave_sum_d(ng);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ng;
+        __syncthreads();
+        den = fmax(red[0] + red[1] + red[2] + red[3], 1.0);
+    }
+    const float scale = (float)((double)w_neg / den);
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < NP; p += (long long)gridDim.x * blockDim.x) {
+        const float* l = logit + p * J;
+        float* d = dmap + p * Jd;
+        const ProbNorm r = prob_norm(l, C, ptype, P);
+        float X = 0.f;
+        for (int c = 0; c < C; ++c) {
+            if (!mask[p * C + c]) continue;
+            const float pc = prob_of(l, c, ptype, r);
+            X += prob_cross(ptype, gfocal_dp(pc, 0.f, eps) * scale, pc, sigm(l[c]));
+        }
+        for (int c = 0; c < C; ++c) {
+            const float gc = mask[p * C + c] ? gfocal_dp(prob_of(l, c, ptype, r), 0.f, eps) * scale : 0.f;
+            d[c] = (ptype == CPRB_SIGMOID && gc == 0.f) ? 0.f : prob_back(l, c, gc, X, ptype, P, r);
+        }
+        for (int j = C; j < Jd; ++j) d[j] = 0.f;
+    }
+}
+
+// one wave per bag (the geometry of mil_bag_kernel): dbag rows [b * bag_stride, (b + 1) * bag_stride) x J fully written
+#define CPRB_MAXT 256        // class x branch terms whose statistics fit the wave's LDS slice
+__global__ void bag_loss_bwd_general_kernel(const float* __restrict__ logits, int J, int ins_off,
+                                            const unsigned char* __restrict__ valid, const int* __restrict__ labels,
+                                            const float* __restrict__ gt_weight, const float* __restrict__ bag,
+                                            float* __restrict__ dbag, int G, int bag_stride, int bag_off, int K, int ctr_off,
+                                            int ctr_stride, int ctr_count, int ctr_mod, int C, float eps, int ptype, float P,
+                                            int binary_ins, int allpos, float w_mil, float w_gt, const float* __restrict__ up) {
+    __shared__ double red[2][4];
+    __shared__ float st[4][CPRB_MAXT][5];        // per wave, per (class, branch): softmax max, sum, normaliser, P, dL/dP
+    if (up) { w_gt *= up[0]; w_mil *= up[1]; }
+    double ns = 0, ng = 0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        ns += (double)bag[(size_t)g * 5 + 2];
+        ng += (double)bag[(size_t)g * 5 + 3];
+    }
+    ns = wave_sum_d(ns);
+    ng = wave_sum_d(ng);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = ns;
+        red[1][threadIdx.x >> 6] = ng;
+    }
+    __syncthreads();
+    const double num_sample = fmax(red[0][0] + red[0][1] + red[0][2] + red[0][3], 1.0);
+    const double num_pos_gt = fmax(red[1][0] + red[1][1] + red[1][2] + red[1][3], 1.0);
+    const float k_mil = (float)((double)w_mil / num_sample), k_gt = (float)((double)w_gt / num_pos_gt);
+
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (g >= G) return;
+    const size_t full = (size_t)g * bag_stride;
+    const float* L = logits + (full + bag_off) * J;
+    const unsigned char* V = valid + full + bag_off;
+    const int label = labels[g];
+    const float wg = gt_weight ? gt_weight[g] : 1.f;
+    const int nj = binary_ins ? 2 : 1;
+    float (*S)[5] = st[wv];
+    if (!allpos) {
+        float nvalid = 0.f;
+        for (int k = lane; k < K; k += 64) nvalid += V[k] ? 1.f : 0.f;
+        nvalid = wave_sum(nvalid);
+        const float lw = (nvalid * wg > 0.f) ? 1.f : 0.f;
+        for (int c = 0; c < C; ++c) {
+            for (int j = 0; j < nj; ++j) {
+                const int ic = ins_off + c * nj + j;
+                float m = -INFINITY;
+                for (int k = lane; k < K; k += 64) m = fmaxf(m, L[(size_t)k * J + ic]);
+                m = wave_max(m);
+                float se = 0.f;
+                for (int k = lane; k < K; k += 64) se += expf(L[(size_t)k * J + ic] - m);
+                se = wave_sum(se);
+                float sv = 0.f, sp = 0.f;
+                for (int k = lane; k < K; k += 64) {
+                    const float* lk = L + (size_t)k * J;
+                    const float pi = expf(lk[ic] - m) / se * (V[k] ? wg : 0.f);
+                    sv += pi;
+                    sp += prob_of(lk, c, ptype, prob_norm(lk, C, ptype, P)) * pi;
+                }
+                sv = wave_sum(sv);
+                sp = wave_sum(sp);
+                const float den = fmaxf(sv, 1e-12f);
+                const float Pb = sp / den;
+                const float q = (j == 0 && c == label) ? 1.f : 0.f;
+                if (lane == 0) {
+                    float* o = S[c * nj + j];
+                    o[0] = m; o[1] = se; o[2] = sv; o[3] = sp; o[4] = gfocal_dp(Pb, q, eps) * lw * k_mil;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const bool ctr_bag = ctr_count > 0 && (g % ctr_mod) == 0;
+    for (int k = lane; k < bag_stride; k += 64) {
+        const size_t e = full + k;
+        const float* lk = logits + e * J;
+        float* D = dbag + e * J;
+        for (int j = 0; j < J; ++j) D[j] = 0.f;
+        const int kb = k - bag_off;
+        const bool in_bag = kb >= 0 && kb < K;
+        bool is_ctr = false;
+        if (ctr_bag) {
+            const int t = k - ctr_off;
+            is_ctr = t >= 0 && t % ctr_stride == 0 && t / ctr_stride < ctr_count;
+        }
+        if (!in_bag && !is_ctr) continue;
+        const float vk = (in_bag && V[kb]) ? wg : 0.f;               // the bag's validity weight of this entry
+        const float gtv = (is_ctr && valid[e]) ? wg : 0.f;           // the annotated-point term's weight
+        const ProbNorm r = prob_norm(lk, C, ptype, P);
+        // dL/dp_c of this entry: bag term(s) + annotated-point term
+        auto up_c = [&](int c, float pc) {
+            float gc = 0.f;
+            const float q = (c == label) ? 1.f : 0.f;
+            if (in_bag) {
+                if (allpos) gc += gfocal_dp(pc, q, eps) * vk * k_mil;
+                else
+                    for (int j = 0; j < nj; ++j) {
+                        const float* o = S[c * nj + j];
+                        const float pi = expf(lk[ins_off + c * nj + j] - o[0]) / o[1] * vk;
+                        gc += o[4] * pi / fmaxf(o[2], 1e-12f);
+                    }
+            }
+            if (is_ctr) gc += gfocal_dp(pc, q, eps) * gtv * k_gt;
+            return gc;
+        };
+        float X = 0.f;
+        if (ptype != CPRB_SIGMOID)
+            for (int c = 0; c < C; ++c) {
+                const float pc = prob_of(lk, c, ptype, r);
+                X += prob_cross(ptype, up_c(c, pc), pc, sigm(lk[c]));
+            }
+        for (int c = 0; c < C; ++c) {
+            const float pc = prob_of(lk, c, ptype, r);
+            float dcls = prob_back(lk, c, up_c(c, pc), X, ptype, P, r);
+            if (in_bag && !allpos) {
+                for (int j = 0; j < nj; ++j) {      // d/d(instance logit): norm live: w (p - P); clamped: (pi p - sig sp) / den
+                    const float* o = S[c * nj + j];
+                    const int ic = ins_off + c * nj + j;
+                    const float sig = expf(lk[ic] - o[0]) / o[1];
+                    const float pi = sig * vk;
+                    const float den = fmaxf(o[2], 1e-12f);
+                    const float dins = (o[2] > 1e-12f) ? o[4] * (pi / den) * (pc - o[3] / den) : o[4] * (pi * pc - sig * o[3]) / den;
+                    if (ins_off == 0) dcls += dins;          // ins_share_head_classifier on shared features: one logit, both roles
+                    else D[ic] = dins;
+                }
+            }
+            D[c] = dcls;
+        }
+    }
+}
+
+// Launcher of the general form: dmap (N,H,W,Jd) = the negative-grid term alone, dbag (num_bags * bag_stride, J) = the gradient wrt
+// every bag entry's logits (NOT gathered: cpr_bag_gather_bwd adds it onto dmap when the entries were sampled from the map).
+extern "C" int cpr_loss_bwd_general(const float* lmap, const unsigned char* neg_mask, const float* out5, const float* bag_logits,
+                                    const unsigned char* valid, const int* labels, const float* gt_weight, const float* bag_ws,
+                                    float* dbag, float* dmap, int N, int H, int W, int J, int Jd, int ins_off, int num_bags,
+                                    int bag_stride, int bag_off, int bag_len, int ctr_off, int ctr_stride, int ctr_count,
+                                    int ctr_mod, int C, float eps, int prob_type, float norm_p, int binary_ins, int allpos,
+                                    float w_mil, float w_gt, float w_neg, int neg_from_gt, const float* upstream,
+                                    hipStream_t stream) {
+    CPR_CHECK_ARG(lmap && neg_mask && out5 && bag_logits && valid && labels && bag_ws && dbag && dmap);
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && num_bags > 0 && bag_len > 0 && C > 0 && Jd >= J && bag_off >= 0 &&
+                  bag_stride >= bag_off + bag_len && ctr_count >= 0 && ctr_mod >= 1 && ctr_stride >= 1);
+    CPR_CHECK_ARG(J >= ins_off + C * (binary_ins ? 2 : 1) && prob_type >= 0 && prob_type <= 2 && norm_p > 0.f);
+    CPR_CHECK_ARG(C * (binary_ins ? 2 : 1) <= CPRB_MAXT && !(allpos && binary_ins) && !(binary_ins && ins_off == 0));
+    CPR_CHECK_ARG(ctr_count == 0 || (ctr_off >= 0 && ctr_off + (ctr_count - 1) * ctr_stride < bag_stride));
+    const long long NP = (long long)N * H * W;
+    const int grid = (int)(cdivll(NP, 256) < 32768 ? cdivll(NP, 256) : 32768);
+    hipLaunchKernelGGL(neg_loss_bwd_general_kernel, dim3(grid), dim3(256), 0, stream, lmap, neg_mask, out5, bag_ws, num_bags, dmap,
+                       NP, J, Jd, C, eps, w_neg, neg_from_gt, prob_type, norm_p, upstream);
+    hipLaunchKernelGGL(bag_loss_bwd_general_kernel, dim3(cdiv(num_bags, 4)), dim3(256), 0, stream, bag_logits, J, ins_off, valid,
+                       labels, gt_weight, bag_ws, dbag, num_bags, bag_stride, bag_off, bag_len, ctr_off, ctr_stride, ctr_count,
+                       ctr_mod, C, eps, prob_type, norm_p, binary_ins, allpos, w_mil, w_gt, upstream);
+    CPR_LAUNCH_STATUS();
+}
+
 // ------------------------------------------------------------------------------------------------ optimizer
 // global gradient norm (mmcv Fp32/OptimizerHook grad_clip -> torch clip_grad_norm_): sum of squares in double, per-buffer
 // partials reduced by a second launch into norm2[0]; deterministic.

@@ -223,17 +223,22 @@ class CPRHead(nn.Module):
         self.init_weights()
 
     def train_step_supported(self, num_refine=1):
-        """The hand-written backward (training.BackwardEngine) covers the shipped configs' options and, since round 5, a separate
-        instance tower (``ins_share_head_feat=False``, cpr_head.py:992-1008,1037), FC layers between the sampled features and the
-        classifiers (``num_cls_fcs > 0``, cpr_head.py:999-1005,1055-1059) and num_refine > 1 inputs under the default
-        ``refine_bag_policy='independent_with_gt_bag'`` / ``gt_loss_type='gt_refine'`` (cpr_head.py:1159-1211: every refine point
-        is a bag of its own with its own annotated-point term -- the R = 1 loss over G * R bags)."""
-        if num_refine > 1 and (self.loss_cfg.get('refine_bag_policy', 'independent_with_gt_bag') != 'independent_with_gt_bag' or
-                               self.loss_cfg.get('gt_loss_type', 'gt_refine') != 'gt_refine'):
-            return False
-        return (self.prob_type == 'sigmoid' and not self.binary_ins and not self.loss_mil.allpos and
-                not self.train_pts_extractor.pos_is_grid and not self.out_bg_cls and
-                not self.train_pts_extractor.align_corners)
+        """Which option sets have a hand-written backward (training.BackwardEngine).  The shipped configs' (sigmoid, MILLoss,
+        circle bags: the specialised kernels); since round 5 also a separate instance tower (``ins_share_head_feat=False``,
+        cpr_head.py:992-1008,1037), FC layers between the sampled features and the classifiers (``num_cls_fcs > 0``,
+        :999-1005,1055-1059), num_refine > 1 inputs with every ``refine_bag_policy`` / ``gt_loss_type`` (:1159-1211), softmax /
+        normed_sigmoid probabilities (:1080-1099), ``binary_ins``, ``AllPosLoss``, ``out_bg_cls`` and ``with_mil_loss=False`` (the
+        general loss-backward kernels, csrc/backward.hip).  Still forward only: the grid generators (bags of grid cells) and
+        ``align_corners=True`` sampling."""
+        return not self.train_pts_extractor.pos_is_grid and not self.train_pts_extractor.align_corners
+
+    def _loss_backward_general(self, num_refine, bags, centres):
+        """True when the loss gradient needs the general kernels (anything the specialised sigmoid / MIL / one-bag-per-row /
+        centre-is-the-last-entry kernels do not cover)."""
+        cfg = self.loss_cfg
+        default_geometry = bags[1] == bags[3] and bags[2] == 0 and (centres[2] == 0 or centres == (bags[3] - 1, bags[3], 1, 1))
+        return (self.prob_type != 'sigmoid' or self.binary_ins or self.loss_mil.allpos or self.out_bg_cls or
+                not default_geometry or not cfg.get('with_mil_loss', True))
 
     # ------------------------------------------------------------------ init (cpr_head.py:939-948)
     def init_weights(self):
@@ -513,16 +518,19 @@ class CPRHead(nn.Module):
                                            prob_type=self.prob_type, norm_p=self.norm_p, neg_from_gt=not with_mil)
         if save is not None:
             assert self.train_step_supported(gts.R), \
-                'the hand-written backward covers sigmoid / MILLoss / circle bags (CPRHead.train_step_supported)'
+                'no hand-written backward for grid generators / align_corners (CPRHead.train_step_supported)'
             out, bag_ws = out
             # one row per BAG: with num_refine = R > 1 (independent bags) the (G, R * Kv) layout is (G * R, Kv) in memory, every
             # refine point a bag around its own centre (gts.points is gt-major, pt_img ascends)
-            nb, Kv = bags[0], view[1]
+            # rows = sampled points (gt-major, one per annotated / refine point), Kv entries each; with the independent policy a
+            # row is a bag, the merged policies span several rows per bag (geometry in ``bags`` / ``centres``)
+            rows, Kv = gts.G * view[0], view[1]
             save.update(feat=feat, ab=ab, ifeat=ifeat, iab=iab, lmap=lmap, neg_mask=neg_mask, out5=out,
-                        bag_logits=bag_logits.view(nb, Kv, -1), valid=valid.view(nb, Kv),
+                        bag_logits=bag_logits.view(rows, Kv, -1), valid=valid.view(rows, Kv),
                         labels=labels, gt_weight=w, bag_ws=bag_ws, centers=gts.points, gt_img=gts.pt_img,
                         offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride,
-                        radius_cells=ex.window_radius_cells(stride, dev), fc=fc_acts)
+                        radius_cells=ex.window_radius_cells(stride, dev), fc=fc_acts, bags=bags, centres=centres,
+                        general=self._loss_backward_general(gts.R, bags, centres), neg_from_gt=not with_mil)
         return self._loss_dict(out)
 
     def _loss_dict(self, out):

@@ -1099,6 +1099,27 @@ def cpr_loss_bwd(lmap, neg_mask, out5, bag_logits, valid, labels, bag_ws, center
     return dmap, dbag
 
 
+def cpr_loss_bwd_general(lmap, neg_mask, out5, bag_logits, valid, labels, bag_ws, bags, centres, ins_off, num_cls_out, Jd,
+                         w_mil, w_gt, w_neg, gt_weight=None, eps=1e-6, upstream=None, prob_type='sigmoid', norm_p=1.0,
+                         binary_ins=False, allpos=False, neg_from_gt=False):
+    """The loss gradients for any CPRHead loss option (csrc/backward.hip, general form): bags / centres are ops.mil_loss's
+    geometry tuples.  -> (dmap (N,H,W,Jd): the negative-grid term alone, dbag: the gradient wrt every bag entry's logits in the
+    layout of ``bag_logits`` -- not gathered onto the map)."""
+    assert upstream is None or (upstream.numel() == 5 and upstream.dtype == torch.float32 and upstream.is_contiguous())
+    N, H, W, J = _check(lmap).shape
+    E = bag_logits.numel() // J
+    nb, bstride, boff, blen = bags
+    coff, cstride, ccount, cmod = centres
+    assert nb * bstride == E and labels.numel() == nb, (nb, bstride, E)
+    dmap = torch.empty((N, H, W, Jd), device=lmap.device, dtype=torch.float32)
+    dbag = torch.empty(tuple(bag_logits.shape), device=lmap.device, dtype=torch.float32)
+    _lib.call('cpr_loss_bwd_general', _ptr(lmap), _ptr(neg_mask), _ptr(out5), _ptr(_check(bag_logits)), _ptr(valid), _ptr(labels),
+              _ptr(gt_weight), _ptr(bag_ws), _ptr(dbag), _ptr(dmap), N, H, W, J, Jd, int(ins_off), nb, bstride, boff, blen, coff,
+              max(int(cstride), 1), ccount, cmod, int(num_cls_out), float(eps), PROB_TYPES[prob_type], float(norm_p), int(binary_ins),
+              int(allpos), float(w_mil), float(w_gt), float(w_neg), int(neg_from_gt), _ptr(upstream), _stream())
+    return dmap, dbag
+
+
 def bag_gather_bwd(dsample, centers, gt_img, offsets, dmap, stride, radius_cells):
     """dsample (G,K,J): gradient wrt the bilinear samples ``bag_sample`` took from a (N,H,W,J') map, J <= J'; ADDED onto dmap
     (N,H,W,J') through the same taps (deterministic: per-bag windows, per-image gt order).  gt_img must ascend."""

@@ -385,7 +385,7 @@ class BackwardEngine:
     def _backward_head(self, head, s, upstream=None):
         """upstream (5,): gradient of the caller's total wrt the forward's loss vector (autograd bridge); None = unit weights."""
         head_tape = s['tape']
-        C = head.num_classes
+        C = head.num_cls_out                # classifier outputs (num_classes, + 1 with out_bg_cls)
         cfg = head.loss_cfg
         J = s['lmap'].shape[-1]
         Jd = 4 if J <= 4 else (J + 31) // 32 * 32
@@ -394,10 +394,21 @@ class BackwardEngine:
         w_neg = cfg.get('neg_loss_weight', 1.0) if cfg.get('with_neg', True) else 0.0
         assert s['neg_mask'] is not None, 'with_neg=False is not on the training path'
         fc = head.num_cls_fcs > 0
-        dmap, dbag = ops.cpr_loss_bwd(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
-                                      s['bag_ws'], s['centers'], s['gt_img'], s['offsets'], s['ins_off'], C, s['stride'],
-                                      w_mil, w_gt, w_neg, Jd, gt_weight=s['gt_weight'], eps=head.loss_mil.eps,
-                                      upstream=upstream, radius_cells=s['radius_cells'], gather=not fc)
+        if s.get('general'):
+            # any other loss option (probability type, binary_ins, AllPosLoss, bag policy, gt_loss_type, out_bg_cls, no MIL term):
+            # the general kernels leave the bag-entry gradients un-gathered; the gather onto the logit map is a second call
+            dmap, dbag = ops.cpr_loss_bwd_general(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
+                                                  s['bag_ws'], s['bags'], s['centres'], s['ins_off'], C, Jd, w_mil, w_gt, w_neg,
+                                                  gt_weight=s['gt_weight'], eps=head.loss_mil.eps, upstream=upstream,
+                                                  prob_type=head.prob_type, norm_p=head.norm_p, binary_ins=head.binary_ins,
+                                                  allpos=head.loss_mil.allpos, neg_from_gt=s['neg_from_gt'])
+            if not fc:
+                ops.bag_gather_bwd(dbag, s['centers'], s['gt_img'], s['offsets'], dmap, s['stride'], s['radius_cells'])
+        else:
+            dmap, dbag = ops.cpr_loss_bwd(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
+                                          s['bag_ws'], s['centers'], s['gt_img'], s['offsets'], s['ins_off'], C, s['stride'],
+                                          w_mil, w_gt, w_neg, Jd, gt_weight=s['gt_weight'], eps=head.loss_mil.eps,
+                                          upstream=upstream, radius_cells=s['radius_cells'], gather=not fc)
         if fc:
             return self._backward_head_fc(head, s, dmap, dbag, J, Jd)
         if not head.ins_share_head_feat:
@@ -411,9 +422,9 @@ class BackwardEngine:
         _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
         self._g(head.cls_out.weight).copy_(gw[:C, :, 0, 0])
         self._g(head.cls_out.bias).copy_(gb[:C])
-        if not shared:
-            self._g(head.ins_out.weight).copy_(gw[C:2 * C, :, 0, 0])
-            self._g(head.ins_out.bias).copy_(gb[C:2 * C])
+        if not shared:                      # (binary_ins: the instance classifier has 2 C rows)
+            self._g(head.ins_out.weight).copy_(gw[C:J, :, 0, 0])
+            self._g(head.ins_out.bias).copy_(gb[C:J])
         self._done(head.ins_out.bias if not shared else head.cls_out.bias)
         dz = ops.conv2d_dgrad(dmap, ops.dgrad_pack(wpad, 1, 0), (dmap.shape[1], dmap.shape[2]))
         # ---- tower, last layer first; layer 0 consumes the (un-activated) FPN output
@@ -428,21 +439,22 @@ class BackwardEngine:
         tower's.  Each projection is a 1x1 conv whose padded weight holds its classifier's rows and zeros elsewhere, so the shared
         gradient map feeds both weight / data gradients unchanged; the towers' gradients meet at the FPN output."""
         C = head.num_cls_out
-        assert J == 2 * C, 'two towers: [cls ++ ins] logits'
+        assert J == C + head.ins_out.weight.shape[0], 'two towers: [cls ++ ins] logits'
         _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
         same = head.ins_out is head.cls_out                      # ins_share_head_classifier on two towers: one Linear, two inputs
         dz, first = None, True
         for name, lo, mod, feat, ab, tape in (('cls', 0, head.cls_out, s['feat'], s['ab'], s['tape']),
                                               ('ins', C, head.ins_out, s['ifeat'], s['iab'], s['ins_tape'])):
+            n = mod.weight.shape[0]
             wpad = torch.zeros((Jd, mod.weight.shape[1], 1, 1), device=dmap.device, dtype=torch.float32)
-            wpad[lo:lo + C, :, 0, 0] = mod.weight.detach()
+            wpad[lo:lo + n, :, 0, 0] = mod.weight.detach()
             gw = ops.conv2d_wgrad(dmap, self._f32(feat), wpad.shape, 1, 0, in_ab=ab, in_relu=True)
             if same and not first:
-                self._g(mod.weight).add_(gw[lo:lo + C, :, 0, 0])
-                self._g(mod.bias).add_(gb[lo:lo + C])
+                self._g(mod.weight).add_(gw[lo:lo + n, :, 0, 0])
+                self._g(mod.bias).add_(gb[lo:lo + n])
             else:
-                self._g(mod.weight).copy_(gw[lo:lo + C, :, 0, 0])
-                self._g(mod.bias).copy_(gb[lo:lo + C])
+                self._g(mod.weight).copy_(gw[lo:lo + n, :, 0, 0])
+                self._g(mod.bias).copy_(gb[lo:lo + n])
             first = False
             if name == 'ins':
                 self._done(head.ins_out.bias)

@@ -345,14 +345,14 @@ def test_p2p_loss_backward_is_bit_equal_to_the_trainer():
 
 
 def test_unsupported_options_keep_the_forward_only_path_and_say_so():
-    """A head option without a hand-written backward (softmax class probabilities): with autograd on, forward_train still
+    """A head option without a hand-written backward (align_corners=True sampling): with autograd on, forward_train still
     returns the losses, without a graph, and warns once; under no_grad nothing warns.  (The bf16 compute mode, which this
-    test used until round 4, now trains through the bridge: test_mixed_precision_loss_backward_is_bit_equal_to_the_trainer.)"""
+    test used until round 4, and the loss options now train through the bridge.)"""
     from pointtinybenchmark_amd import autograd_bridge
     cfg = CPR_CASES['cpr_r18_c3_128']
     data = _data(cfg)
     m, _ = build_hip_locator(cfg)
-    m.bbox_head.prob_type = 'softmax'
+    m.bbox_head.train_pts_extractor.align_corners = True
     assert not m.bbox_head.train_step_supported()
     autograd_bridge._WARNED.clear()
     with warnings.catch_warnings(record=True) as w:

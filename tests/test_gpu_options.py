@@ -240,11 +240,14 @@ def test_option_backward_vs_reference_autograd(golden_dir, name):
     """The CPRHead options that gained a hand-written backward in round 5 -- num_refine = 2 inputs under the default bag policy
     (cpr_head.py:1159-1211), a separate instance tower (ins_share_head_feat=False, :992-1008,1037-1040,1061-1070), the same with an
     FC layer between the sampled features and the classifiers, and two FC layers on shared features (num_cls_fcs > 0,
-    :999-1005,1055-1059) -- against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_option_grads.npz,
+    :999-1005,1055-1059), and the loss options behind the general loss-backward kernels (softmax / normed_sigmoid class
+    probabilities, binary_ins, AllPosLoss, merge_to_gt_bag / only_refine_bag with gt_loss_type='gt', out_bg_cls,
+    with_mil_loss=False) -- against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_option_grads.npz,
     oracle/gen_golden_r5.py): total loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the tensor's max.
     'ins_tower_fc_boundary' is a sample on which an activation of the sparse-gradient instance tower sits within fp32 conv
     rounding of a ReLU boundary (the reference's own gradient moves 3e-3 .. 7e-3 when that boundary is shifted by 1e-5:
-    oracle/gen_golden_r5.py) -- same comparison under a 2e-2 bar.  Then loss.backward() through the autograd bridge on a fresh
+    oracle/gen_golden_r5.py) -- same comparison under a 2e-2 bar; 'r3_only_refine' and 'bg_cls' are samples WITHOUT such an
+    event, held to 2e-4 on every tensor (measured 5e-6), and the classifier tensors next to the loss to 1e-4 in every case.  Then loss.backward() through the autograd bridge on a fresh
     model must equal the native trainer BIT for bit, as for the shipped options."""
     from oracle.gen_golden import grad_sample_index
     from pointtinybenchmark_amd import autograd_bridge
@@ -265,18 +268,23 @@ def test_option_backward_vs_reference_autograd(golden_dir, name):
     assert abs(total - ref_total) <= 1e-4 * max(1.0, abs(ref_total)), (total, ref_total)
     params = dict(m.named_parameters())
     keys = [k[len(p + 'norm:'):] for k in g.files if k.startswith(p + 'norm:')]
-    assert sorted(keys) == sorted(k for k, q in params.items() if q.requires_grad), \
-        set(keys) ^ set(k for k, q in params.items() if q.requires_grad)
+    trainable = [k for k, q in params.items() if q.requires_grad]
+    unused = sorted(set(trainable) - set(keys))              # parameters the reference's graph never reaches (grad None there)
+    assert not set(keys) - set(trainable) and unused == sorted(k[len(p + 'unused:'):] for k in g.files if k.startswith(p + 'unused:')), (unused, set(keys) ^ set(trainable))
+    for k in unused:                                         # with_mil_loss=False: ins_out -- ours leaves an exactly zero gradient
+        assert params[k].grad is None or not bool(params[k].grad.any()), k
     gmax = max(float(g[p + 'norm:' + k]) for k in keys)
     want = {}
     for k in keys:
         gr = params[k].grad.detach().double().flatten().cpu()
         want[k] = params[k].grad.detach().clone()
         ref_n = float(g[p + 'norm:' + k])
-        assert abs(float(gr.norm()) - ref_n) <= bar * ref_n + 1e-6 * gmax, (k, float(gr.norm()), ref_n)
+        # the classifier tensors sit next to the loss (no ReLU between them and the loss-backward kernels): 1e-4 in every case
+        kbar = min(bar, 1e-4) if k.startswith(('bbox_head.cls_out.', 'bbox_head.ins_out.')) else bar
+        assert abs(float(gr.norm()) - ref_n) <= kbar * ref_n + 1e-6 * gmax, (k, float(gr.norm()), ref_n)
         smp = gr[torch.from_numpy(grad_sample_index(gr.numel()))].numpy()
         ref = g[p + 'sample:' + k].astype(np.float64)
-        assert np.abs(smp - ref).max() <= bar * max(np.abs(ref).max(), 1e-5 * gmax), k
+        assert np.abs(smp - ref).max() <= kbar * max(np.abs(ref).max(), 1e-5 * gmax), k
     del tr, m
     m2, _ = build_hip(cfg)
     out = m2.train_step(dict(data), optimizer=None)
@@ -284,8 +292,10 @@ def test_option_backward_vs_reference_autograd(golden_dir, name):
     out['loss'].backward()
     torch.cuda.synchronize()
     for k, q in m2.named_parameters():
-        if q.requires_grad:
+        if q.requires_grad and k in want:
             assert q.grad is not None and torch.equal(q.grad, want[k]), k
+        elif q.requires_grad:
+            assert q.grad is None or not bool(q.grad.any()), k
 
 
 def test_grid_ellipse_generator_raises_like_the_reference(golden_dir):

@@ -224,7 +224,9 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
     np.testing.assert_allclose(torch.cat([r['scores'] for r in ref]).numpy(), g[p + 'scores'], rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize('name', ['r2_independent', 'ins_tower', 'ins_tower_fc', 'ins_tower_fc_boundary', 'fc2_shared'])
+@pytest.mark.parametrize('name', ['r2_independent', 'ins_tower', 'ins_tower_fc', 'ins_tower_fc_boundary', 'fc2_shared', 'softmax',
+                                  'normed_sigmoid_p1', 'normed_sigmoid_p2', 'binary_ins', 'allpos', 'r2_merge_gt', 'r3_only_refine', 'bg_cls',
+                                  'no_mil_loss'])
 def test_option_oracle_autograd_matches_reference_autograd(golden_dir, name):
     """Pins the options oracle's BACKWARD (torch autograd over oracle/cpr_options_oracle.py) to loss.backward() through the
     reference's own modules for the options that gained a hand-written backward in round 5 (tests/golden/cpr_option_grads.npz,
@@ -252,8 +254,13 @@ def test_option_oracle_autograd_matches_reference_autograd(golden_dir, name):
     total.backward()
     gmax = max(float(g[p + 'norm:' + k]) for k in keys)
     for k in keys:
-        gr = sd[k].grad.detach().double().flatten()
         ref_n = float(g[p + 'norm:' + k])
+        if sd[k].grad is None:
+            # AllPosLoss: the reference computes the instance logits and weights them out, so autograd hands ins_out an exactly
+            # zero gradient; the restatement never touches ins_out there
+            assert ref_n == 0.0, k
+            continue
+        gr = sd[k].grad.detach().double().flatten()
         assert abs(float(gr.norm()) - ref_n) <= 1e-3 * ref_n + 1e-7 * gmax, (k, float(gr.norm()), ref_n)
         smp = gr[torch.from_numpy(grad_sample_index(gr.numel()))].numpy()
         ref = g[p + 'sample:' + k].astype(np.float64)

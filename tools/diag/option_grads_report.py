@@ -40,6 +40,12 @@ for k, g in got.items():
     rows.append((float((g - r).norm() / max(float(r.norm()), 1e-30)), float((g - r).abs().max() / max(float(r.abs().max()), 1e-30)),
                  float(r.norm()), k))
 rows.sort(reverse=True)
+if os.environ.get('SUMMARY'):       # one line per (case, seed): is the fixture smooth (no ReLU-boundary flip between the CPU and GPU forwards)?
+    gm = max(r[2] for r in rows)
+    live = [r for r in rows if r[2] > 1e-5 * gm]
+    print('%s seed %s: worst rel_l2 %.2e (%s)  worst max_abs/max %.2e (%s)' % (
+        name, cfg['seed'], live[0][0], live[0][3], max(r[1] for r in live), max(live, key=lambda r: r[1])[3]))
+    sys.exit(0)
 show = rows if os.environ.get('REPORT_ALL') else rows[:16]
 if os.environ.get('REPORT_ALL'):
     show = sorted([r for r in rows if r[3].startswith('bbox_head') or r[3].startswith('neck')], key=lambda r: r[3])
