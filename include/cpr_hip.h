@@ -383,12 +383,22 @@ int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* 
 int cpr_bag_gather_bwd(const float* dsample, int J, const float* centers, const int* gt_img, const float* offsets,
                        float* win_ws, int* win_org, int win, float* dmap, int N, int H, int W, int Jd, int G, int K,
                        float stride, void* stream);
+/* The gather stage for bags whose taps are not ring offsets around a centre (round 5): GridCirclesPtFeatGenerator bags
+ * (cpr_head.py:296-352,405-438) and align_corners=True sampling (:73-93,126).  Entries are the forward's own outputs: pts (G,Kt,2)
+ * and code (G,Kt) -- cpr_grid_bag's ws_cell: cell index y*W+x | -1 padding slot | <= -2 bilinear sample at pts; NULL = every entry
+ * is a bilinear sample (cpr_bag_sample).  dsample (G,Kt,J) is ADDED onto dmap (N,H,W,Jd) per image in gt order (gt_img ascends),
+ * deterministically.  wout_ws (G*Kt) and dbias (J): both or neither; dbias <- sum over entries of (weight of the entry's dropped
+ * taps) * dsample, the share of the projection's bias when the sampled map held logits (pad_value of cpr_bag_sample / cpr_grid_bag). */
+int cpr_bag_points_gather_bwd(const float* dsample, int J, const float* pts, const int* code, const int* gt_img, float* dmap,
+                              float* wout_ws, float* dbias, int N, int H, int W, int Jd, int G, int Kt, float stride,
+                              int align_corners, void* stream);
 /* The same loss gradients for every CPRHead loss option the forward kernels take (round 5): prob_type 0 sigmoid / 1 softmax /
  * 2 normed_sigmoid(norm_p) class probabilities (cpr_head.py:1080-1099), MILLoss(binary_ins) / AllPosLoss
  * (multi_instance_learning_loss.py:153-243), the bag / annotated-point geometry of cpr_mil_loss (refine_bag_policy, gt_loss_type:
  * cpr_head.py:1159-1211), C = classifier outputs (num_classes + 1 with out_bg_cls), neg_from_gt (with_mil_loss=False: the negative
  * term is averaged over the annotated-point positives).  dmap (N,H,W,Jd) <- the negative-grid term alone; dbag
- * (num_bags * bag_stride, J) <- the gradient wrt every bag entry's logits, NOT gathered (cpr_bag_gather_bwd adds it onto dmap). */
+ * (num_bags * bag_stride, J) <- the gradient wrt every bag entry's logits, NOT gathered (cpr_bag_gather_bwd /
+ * cpr_bag_points_gather_bwd add it onto dmap).  neg_mask NULL: no negative-grid term (loss_cfg with_neg=False), dmap <- zeros. */
 int cpr_loss_bwd_general(const float* lmap, const unsigned char* neg_mask, const float* out5, const float* bag_logits,
                          const unsigned char* valid, const int* labels, const float* gt_weight, const float* bag_ws, float* dbag,
                          float* dmap, int N, int H, int W, int J, int Jd, int ins_off, int num_bags, int bag_stride, int bag_off,

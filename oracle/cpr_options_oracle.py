@@ -174,10 +174,11 @@ def cpr_loss(sd, cls_feat, gt_bboxes, gt_labels, img_metas, cfg, mil_weight=0.25
                 loss = loss + O.gfocal(pb[..., 1], torch.zeros_like(onehot), lw).sum()
             losses['pos_loss'] = loss / num_pos * mil_weight
             losses['bag_acc'] = (pb[..., 0].argmax(-1) == bl).float().mean() * 100
-    # negative loss (:1219-1228): averaged over the LAST num_pos computed above
-    neg_prob = cls_prob(torch.cat([p['neg_logit'] for p in per]), cfg)
-    neg_valid = torch.cat([p['neg_valid'] for p in per]).float()
-    losses['neg_loss'] = neg_weight * (O.gfocal(neg_prob, torch.zeros_like(neg_prob), neg_valid).sum() / num_pos)
+    # negative loss (:1219-1228): averaged over the LAST num_pos computed above; loss_cfg with_neg=False drops the term (:1219)
+    if cfg.get('with_neg', True):
+        neg_prob = cls_prob(torch.cat([p['neg_logit'] for p in per]), cfg)
+        neg_valid = torch.cat([p['neg_valid'] for p in per]).float()
+        losses['neg_loss'] = neg_weight * (O.gfocal(neg_prob, torch.zeros_like(neg_prob), neg_valid).sum() / num_pos)
     return losses, per
 
 

@@ -90,7 +90,7 @@ def cpr_head_kwargs(cfg):
     normal = dict(prob_cls_type=cfg.get('prob', 'sigmoid'), out_bg_cls=cfg.get('out_bg_cls', False))
     if 'norm_p' in cfg:
         normal['normed_sigmoid_p'] = cfg['norm_p']
-    loss_cfg = dict(with_neg=True, neg_loss_weight=1 - alpha, refine_bag_policy=cfg.get('policy', 'independent_with_gt_bag'),
+    loss_cfg = dict(with_neg=cfg.get('with_neg', True), neg_loss_weight=1 - alpha, refine_bag_policy=cfg.get('policy', 'independent_with_gt_bag'),
                     random_remove_rate=0.4, with_gt_loss=True, gt_loss_weight=alpha,
                     with_mil_loss=cfg.get('with_mil_loss', True))
     if 'gt_loss_type' in cfg:

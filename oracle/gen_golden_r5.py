@@ -61,6 +61,14 @@ OPTION_GRAD_CASES = {
     'r3_only_refine': ('r3_only_refine', dict(seed=171)),
     'bg_cls': ('bg_cls', dict(seed=171)),
     'no_mil_loss': ('no_mil_loss', {}),
+    # the gather from the forward's point list (cpr_bag_points_gather_bwd): grid bags, align_corners=True sampling -- on the logit
+    # map (padding slots / dropped taps feed the classifier biases) and, with an FC layer, on the sampled features
+    'grid_circles': ('grid_circles', {}),
+    'grid_circles_r2': ('grid_circles_r2', {}),
+    'align_corners': ('align_corners', {}),
+    'align_corners_grid': ('align_corners_grid', {}),
+    'grid_circles_fc': ('grid_circles', dict(num_cls_fcs=1, fc_out_channels=64, seed=173)),
+    'no_neg': ('softmax', dict(with_neg=False, seed=174)),                  # loss_cfg with_neg=False (cpr_head.py:1219)
 }
 OPTION_GRAD_BARS = {'ins_tower_fc_boundary': 2e-2, 'r3_only_refine': 2e-4, 'bg_cls': 2e-4}       # per-tensor norm / strided-sample bar (measured: 4.5e-3 relative L2 on the worst tensor, 1.7e-2 of its max on the worst entry); default 2e-3; the event-free fixtures 2e-4 (measured 5e-6)
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     'cpr_zero_insert': [_p, _p] + [_i] * 7 + [_p],
     'cpr_loss_bwd': [_p] * 15 + [_i] * 10 + [_f] * 5 + [_p, _p],
     'cpr_bag_gather_bwd': [_p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _p],
+    'cpr_bag_points_gather_bwd': [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     'cpr_loss_bwd_general': [_p] * 10 + [_i] * 15 + [_f, _i, _f, _i, _i, _f, _f, _f, _i, _p, _p],
     # data side
     'cpr_preprocess_u8': [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],

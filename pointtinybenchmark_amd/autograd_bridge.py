@@ -20,8 +20,7 @@ pinned to ``loss.backward()`` through the reference's own modules by tests/golde
 
 Both compute modes (round 5: the bf16 mode = mixed precision, the reference analogue being mmcv's ``Fp16OptimizerHook`` around an
 unmodified ``loss.backward()``, T/mmdet/apis/train.py:116-119 -- see ``Bridge.carrier`` for how bf16 maps cross the Function
-boundaries), every CPRHead option except the grid generators and align_corners=True sampling (``CPRHead.train_step_supported``),
-one FPN output level, a frozen stem.  Anything else keeps the forward-only path and warns once."""
+boundaries), every CPRHead option set that runs forward (``CPRHead.train_step_supported``), one FPN output level, a frozen stem.  Anything else keeps the forward-only path and warns once."""
 import os
 import warnings
 
@@ -104,9 +103,7 @@ def unsupported_reason(model, gt_bboxes=None, gt_labels=None):
         if gt_bboxes is not None and gt_labels is not None and len(gt_labels) and len(gt_labels[0]):
             R = max(1, int(gt_bboxes[0].shape[0]) // int(len(gt_labels[0])))     # (every image brings num_gts * R boxes: the head asserts)
         if not head.train_step_supported(R):
-            return 'this CPRHead option set (grid generator / align_corners) has no hand-written backward (CPRHead.train_step_supported)'
-        if not head.loss_cfg.get('with_neg', True):
-            return 'with_neg=False is not on the training path'
+            return 'this CPRHead option set has no hand-written backward (CPRHead.train_step_supported)'
         if head.num_cls_fcs > 0 and bb.compute_dtype != torch.float32:
             return 'num_cls_fcs > 0 trains in the fp32 compute mode (the FC backward reads fp32 activations)'
     elif kind == 'P2PHead':

@@ -648,7 +648,7 @@ extern "C" int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, co
                             float w_mil, float w_gt, float w_neg, const float* upstream, hipStream_t stream) {
     CPR_CHECK_ARG(lmap && neg_mask && out5 && bag_logits && valid && labels && bag_ws && centers && gt_img && dbag_ws && dmap);
     CPR_CHECK_ARG(win == 0 || (win_ws && win_org && win >= 3 && (size_t)K * 16 <= 60000));
-    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && G > 0 && K > 0 && C > 0 && J >= ins_off + C && Jd >= J && (K == 1 || offsets));
+    CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && G > 0 && K > 0 && C > 0 && J >= ins_off + C && Jd >= J && (win == 0 || K == 1 || offsets));
     const long long NP = (long long)N * H * W;
     const int grid = (int)(cdivll(NP * Jd, 256) < 32768 ? cdivll(NP * Jd, 256) : 32768);
     hipLaunchKernelGGL(neg_loss_bwd_kernel, dim3(grid), dim3(256), 0, stream, lmap, neg_mask, out5, dmap, NP, J, Jd, C,
@@ -676,6 +676,147 @@ extern "C" int cpr_bag_gather_bwd(const float* dsample, int J, const float* cent
                        win_org, win, K, H, W, stride);
     hipLaunchKernelGGL(bag_window_add_kernel, dim3(N), dim3(win * win * J >= 4096 ? 1024 : 256), 0, stream, win_ws, win_org,
                        win, J, gt_img, dmap, Jd, G, H, W);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------ gather from a point list
+// (round 5) The gather stage for the generators whose taps the window kernels above do not describe: GridCirclesPtFeatGenerator
+// (cpr_head.py:296-352,405-438: a bag is the grid cells inside the circles of the gt's refine points -- exact cell values, zero
+// padded -- followed by the refine points themselves) and align_corners=True sampling (:73-93,126: grid 2x/(w-1)-1, zeros
+// padding, no clip).  Entries are described by the forward's own outputs: pts (E,2) and, for grid bags, code (E) = cell index
+// y*W+x (exact cell value, weight 1) | -1 padding slot | <= -2 a bilinear sample at pts (NULL: every entry is a bilinear sample).
+// One workgroup per (image, 32-channel slice) walks the image's gts in order; per gt the taps of its Kt entries go to LDS, the
+// bounding box of the live taps is the gather window, thread (cell, j) sums the taps landing on its cell in entry order and adds
+// onto dmap: one owner per output, fixed order -- deterministic like the window kernels.  wout (E), optional: the weight of each
+// entry's DROPPED taps (padding slot: 1; bilinear tap outside the map under align_corners: its weight) -- what the projection's
+// bias receives when the sampled map holds logits (sample_point4, csrc/cpr_points.hip: pad[c] * wout).
+#define CPRG_SLICE 32
+__global__ void bag_points_gather_kernel(const float* __restrict__ dsample, int J, const float* __restrict__ pts,
+                                         const int* __restrict__ code, const int* __restrict__ gt_img, int Kt,
+                                         float* __restrict__ dmap, int Jd, float* __restrict__ wout, int G, int H, int W,
+                                         float stride, int align) {
+    extern __shared__ unsigned char smem_raw[];
+    int* tx0 = reinterpret_cast<int*>(smem_raw);                 // [Kt] tap cell x0
+    int* ty0 = tx0 + Kt;                                          // [Kt] tap cell y0
+    float* tww = reinterpret_cast<float*>(ty0 + Kt);              // [Kt] weight of x0 + 1
+    float* twn = tww + Kt;                                        // [Kt] weight of y0 + 1
+    int* tin = reinterpret_cast<int*>(twn + Kt);                  // [Kt] live taps: bit 0 nw, 1 ne, 2 sw, 3 se
+    __shared__ int box[4], range[2];
+    const int n = blockIdx.x;
+    const int j0 = blockIdx.y * CPRG_SLICE, jn = min(CPRG_SLICE, J - j0);
+    if (threadIdx.x == 0) {        // the gts of image n (gt_img ascends: CSR order)
+        int lo = 0;
+        while (lo < G && gt_img[lo] < n) ++lo;
+        int hi = lo;
+        while (hi < G && gt_img[hi] == n) ++hi;
+        range[0] = lo;
+        range[1] = hi;
+    }
+    __syncthreads();
+    const int lo = range[0], hi = range[1];
+    const float fw = (float)W, fh = (float)H;
+    float* base = dmap + (size_t)n * H * W * Jd;
+    for (int g = lo; g < hi; ++g) {
+        if (threadIdx.x == 0) { box[0] = 0x7fffffff; box[1] = 0x7fffffff; box[2] = -1; box[3] = -1; }
+        __syncthreads();
+        for (int k = threadIdx.x; k < Kt; k += blockDim.x) {
+            const size_t e = (size_t)g * Kt + k;
+            const int c = code ? code[e] : -2;
+            int x0 = 0, y0 = 0, in = 0;
+            float ww = 0.f, wn_ = 0.f, dropped = 0.f;
+            if (c >= 0) {                                   // a grid cell: its value, weight 1
+                x0 = c % W; y0 = c / W; in = 1;
+            } else if (c == -1) {                           // padding slot
+                dropped = 1.f;
+            } else {
+                const float px = pts[e * 2], py = pts[e * 2 + 1];
+                if (align) {                                // sample_point4, align != 0
+                    const float gx = __fsub_rn(__fdiv_rn(2.f * __fdiv_rn(px, stride), fw - 1.f), 1.f);
+                    const float gy = __fsub_rn(__fdiv_rn(2.f * __fdiv_rn(py, stride), fh - 1.f), 1.f);
+                    const float ix = __fmul_rn(__fadd_rn(gx, 1.f), (fw - 1.f) * 0.5f), iy = __fmul_rn(__fadd_rn(gy, 1.f), (fh - 1.f) * 0.5f);
+                    const float x0f = floorf(ix), y0f = floorf(iy);
+                    ww = __fsub_rn(ix, x0f); wn_ = __fsub_rn(iy, y0f);
+                    const bool xin0 = (x0f >= 0.f) && (x0f <= fw - 1.f), xin1 = (x0f + 1.f >= 0.f) && (x0f + 1.f <= fw - 1.f);
+                    const bool yin0 = (y0f >= 0.f) && (y0f <= fh - 1.f), yin1 = (y0f + 1.f >= 0.f) && (y0f + 1.f <= fh - 1.f);
+                    in = (xin0 && yin0 ? 1 : 0) | (xin1 && yin0 ? 2 : 0) | (xin0 && yin1 ? 4 : 0) | (xin1 && yin1 ? 8 : 0);
+                    // the cell of the nw tap, also when only its neighbours are inside (x0 = -1 is a legal origin)
+                    x0 = (x0f >= -1.f && x0f <= fw) ? (int)x0f : -4;
+                    y0 = (y0f >= -1.f && y0f <= fh) ? (int)y0f : -4;
+                    if (x0 == -4 || y0 == -4) in = 0;
+                    const float we = __fsub_rn(1.f, ww), ws = __fsub_rn(1.f, wn_);
+                    const float wt[4] = {__fmul_rn(ws, we), __fmul_rn(ws, ww), __fmul_rn(wn_, we), __fmul_rn(wn_, ww)};
+                    for (int t = 0; t < 4; ++t) dropped += ((in >> t) & 1) ? 0.f : wt[t];
+                } else {                                    // sample_point4, border clip
+                    float gx = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(px, stride), 1.f), fw), 1.f);
+                    float gy = __fsub_rn(__fdiv_rn(__fadd_rn(2.f * __fdiv_rn(py, stride), 1.f), fh), 1.f);
+                    float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), fw), 1.f) * 0.5f;
+                    float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), fh), 1.f) * 0.5f;
+                    ix = fminf(fw - 1.f, fmaxf(ix, 0.f));
+                    iy = fminf(fh - 1.f, fmaxf(iy, 0.f));
+                    const float x0f = floorf(ix), y0f = floorf(iy);
+                    x0 = (int)x0f; y0 = (int)y0f;
+                    ww = ix - x0f; wn_ = iy - y0f;
+                    const bool x1ok = x0 + 1 < W, y1ok = y0 + 1 < H;
+                    in = 1 | (x1ok ? 2 : 0) | (y1ok ? 4 : 0) | (x1ok && y1ok ? 8 : 0);   // (a clipped tap carries weight 0)
+                }
+            }
+            tx0[k] = x0; ty0[k] = y0; tww[k] = ww; twn[k] = wn_; tin[k] = in;
+            if (wout && blockIdx.y == 0) wout[e] = dropped;
+            if (in) {
+                const int xa = (in & 5) ? x0 : x0 + 1, xb = (in & 10) ? x0 + 1 : x0;
+                const int ya = (in & 3) ? y0 : y0 + 1, yb = (in & 12) ? y0 + 1 : y0;
+                atomicMin(&box[0], xa); atomicMin(&box[1], ya); atomicMax(&box[2], xb); atomicMax(&box[3], yb);
+            }
+        }
+        __syncthreads();
+        const int ox = box[0], oy = box[1], bw = box[2] - box[0] + 1, bh = box[3] - box[1] + 1;
+        if (box[2] >= 0) {
+            const float* D = dsample + (size_t)g * Kt * J;
+            const int total = bw * bh * jn;
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const int j = j0 + i % jn, cell = i / jn;
+                const int x = ox + cell % bw, y = oy + cell / bw;
+                float acc = 0.f;
+                for (int k = 0; k < Kt; ++k) {
+                    const unsigned dx = (unsigned)(x - tx0[k]), dy = (unsigned)(y - ty0[k]);
+                    if (dx > 1u || dy > 1u || !((tin[k] >> (dy * 2 + dx)) & 1)) continue;
+                    const float d = D[(size_t)k * J + j];
+                    if (d == 0.f) continue;
+                    const float ww = tww[k], wn_ = twn[k];
+                    acc += d * (dy ? wn_ : 1.f - wn_) * (dx ? ww : 1.f - ww);
+                }
+                if (acc != 0.f) base[((size_t)y * W + x) * Jd + j] += acc;
+            }
+        }
+        __syncthreads();           // the next gt reuses the LDS taps and may touch the same cells
+    }
+}
+// dbias[j] = sum_e wout[e] * dsample[e][j]: one workgroup per channel, fixed partition + fixed-order reduce (deterministic)
+__global__ void pad_bias_grad_kernel(const float* __restrict__ dsample, int J, const float* __restrict__ wout, long long E,
+                                     float* __restrict__ dbias) {
+    __shared__ double red[4];
+    const int j = blockIdx.x;
+    double a = 0;
+    for (long long e = threadIdx.x; e < E; e += blockDim.x) {
+        const float w = wout[e];
+        if (w != 0.f) a += (double)w * (double)dsample[e * J + j];
+    }
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) dbias[j] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+// dsample (G, Kt, J) ADDED onto dmap (N,H,W,Jd) through the taps of the entries (pts, code); wout_ws (G*Kt) + dbias (J): both or
+// neither -- dbias <- what the projection's bias receives from the dropped taps / padding slots.
+extern "C" int cpr_bag_points_gather_bwd(const float* dsample, int J, const float* pts, const int* code, const int* gt_img,
+                                         float* dmap, float* wout_ws, float* dbias, int N, int H, int W, int Jd, int G, int Kt,
+                                         float stride, int align_corners, hipStream_t stream) {
+    CPR_CHECK_ARG(dsample && pts && gt_img && dmap && N > 0 && H > 0 && W > 0 && G > 0 && Kt > 0 && J > 0 && Jd >= J && stride > 0);
+    CPR_CHECK_ARG((!wout_ws) == (!dbias) && (size_t)Kt * 20 <= 60000 && (!align_corners || (H > 1 && W > 1)));
+    hipLaunchKernelGGL(bag_points_gather_kernel, dim3(N, cdiv(J, CPRG_SLICE)), dim3(256), (size_t)Kt * 20, stream, dsample, J, pts,
+                       code, gt_img, Kt, dmap, Jd, wout_ws, G, H, W, stride, align_corners);
+    if (dbias)
+        hipLaunchKernelGGL(pad_bias_grad_kernel, dim3(J), dim3(256), 0, stream, dsample, J, wout_ws, (long long)G * Kt, dbias);
     CPR_LAUNCH_STATUS();
 }
 
@@ -728,7 +869,8 @@ __device__ __forceinline__ float prob_cross(int ptype, float gc, float pc, float
     return ptype == CPRB_SOFTMAX ? gc * pc : (ptype == CPRB_NORMED ? gc * sc : 0.f);
 }
 
-// negative-grid term, any probability type: dmap (NP, Jd) fully written (zeros beyond the class channels)
+// negative-grid term, any probability type: dmap (NP, Jd) fully written (zeros beyond the class channels; all zeros when
+// mask is NULL: loss_cfg with_neg=False, cpr_head.py:1219)
 __global__ void neg_loss_bwd_general_kernel(const float* __restrict__ logit, const unsigned char* __restrict__ mask,
                                             const float* __restrict__ out5, const float* __restrict__ bag, int G,
                                             float* __restrict__ dmap, long long NP, int J, int Jd, int C, float eps, float w_neg,
@@ -751,12 +893,12 @@ __global__ void neg_loss_bwd_general_kernel(const float* __restrict__ logit, con
         const ProbNorm r = prob_norm(l, C, ptype, P);
         float X = 0.f;
         for (int c = 0; c < C; ++c) {
-            if (!mask[p * C + c]) continue;
+            if (!mask || !mask[p * C + c]) continue;
             const float pc = prob_of(l, c, ptype, r);
             X += prob_cross(ptype, gfocal_dp(pc, 0.f, eps) * scale, pc, sigm(l[c]));
         }
         for (int c = 0; c < C; ++c) {
-            const float gc = mask[p * C + c] ? gfocal_dp(prob_of(l, c, ptype, r), 0.f, eps) * scale : 0.f;
+            const float gc = (mask && mask[p * C + c]) ? gfocal_dp(prob_of(l, c, ptype, r), 0.f, eps) * scale : 0.f;
             d[c] = (ptype == CPRB_SIGMOID && gc == 0.f) ? 0.f : prob_back(l, c, gc, X, ptype, P, r);
         }
         for (int j = C; j < Jd; ++j) d[j] = 0.f;
@@ -903,7 +1045,7 @@ extern "C" int cpr_loss_bwd_general(const float* lmap, const unsigned char* neg_
                                     int ctr_mod, int C, float eps, int prob_type, float norm_p, int binary_ins, int allpos,
                                     float w_mil, float w_gt, float w_neg, int neg_from_gt, const float* upstream,
                                     hipStream_t stream) {
-    CPR_CHECK_ARG(lmap && neg_mask && out5 && bag_logits && valid && labels && bag_ws && dbag && dmap);
+    CPR_CHECK_ARG(lmap && out5 && bag_logits && valid && labels && bag_ws && dbag && dmap);     // neg_mask NULL: with_neg=False
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && num_bags > 0 && bag_len > 0 && C > 0 && Jd >= J && bag_off >= 0 &&
                   bag_stride >= bag_off + bag_len && ctr_count >= 0 && ctr_mod >= 1 && ctr_stride >= 1);
     CPR_CHECK_ARG(J >= ins_off + C * (binary_ins ? 2 : 1) && prob_type >= 0 && prob_type <= 2 && norm_p > 0.f);

@@ -16,9 +16,9 @@ Options beyond the shipped configs, all on the same kernel
 1037,1068), ``out_bg_cls=True`` for one class (:953), ``PointRefiner(return_score_type='max')`` (:840-842).
 generator ``align_corners=True`` (:73-93,126).
 ``AnchorPtFeatGenerator(scale_factor != 1)`` and ``GridEllipsePtFeatGenerator`` raise in the reference itself and are refused.
-Training (``training.BackwardEngine`` / ``autograd_bridge``): the shipped configs' options and, since round 5, num_refine > 1 under
-the default bag policy, the separate instance tower and ``num_cls_fcs > 0`` have a hand-written backward
-(``train_step_supported``); the other options are forward only."""
+Training (``training.BackwardEngine`` / ``autograd_bridge``): every option set listed above has a hand-written backward since round 5
+(``train_step_supported``): the shipped configs' on the specialised loss-backward kernels, the other loss options on the general
+ones, grid bags / align_corners through the point-list gather (csrc/backward.hip)."""
 import math
 
 import numpy as np
@@ -228,9 +228,9 @@ class CPRHead(nn.Module):
         cpr_head.py:992-1008,1037), FC layers between the sampled features and the classifiers (``num_cls_fcs > 0``,
         :999-1005,1055-1059), num_refine > 1 inputs with every ``refine_bag_policy`` / ``gt_loss_type`` (:1159-1211), softmax /
         normed_sigmoid probabilities (:1080-1099), ``binary_ins``, ``AllPosLoss``, ``out_bg_cls`` and ``with_mil_loss=False`` (the
-        general loss-backward kernels, csrc/backward.hip).  Still forward only: the grid generators (bags of grid cells) and
-        ``align_corners=True`` sampling."""
-        return not self.train_pts_extractor.pos_is_grid and not self.train_pts_extractor.align_corners
+        general loss-backward kernels, csrc/backward.hip), the grid generator and ``align_corners=True`` sampling (the point-list
+        gather, ``cpr_bag_points_gather_bwd``) and ``with_neg=False``: every option set the head can run forward."""
+        return True
 
     def _loss_backward_general(self, num_refine, bags, centres):
         """True when the loss gradient needs the general kernels (anything the specialised sigmoid / MIL / one-bag-per-row /
@@ -238,7 +238,7 @@ class CPRHead(nn.Module):
         cfg = self.loss_cfg
         default_geometry = bags[1] == bags[3] and bags[2] == 0 and (centres[2] == 0 or centres == (bags[3] - 1, bags[3], 1, 1))
         return (self.prob_type != 'sigmoid' or self.binary_ins or self.loss_mil.allpos or self.out_bg_cls or
-                not default_geometry or not cfg.get('with_mil_loss', True))
+                not default_geometry or not cfg.get('with_mil_loss', True) or not cfg.get('with_neg', True))
 
     # ------------------------------------------------------------------ init (cpr_head.py:939-948)
     def init_weights(self):
@@ -370,14 +370,17 @@ class CPRHead(nn.Module):
             return self._logit_map(feat, ab, acts=rec)
         return torch.cat([self._logit_map(feat, ab, 'cls', acts=rec), self._logit_map(ifeat, iab, 'ins')], dim=-1).contiguous()
 
-    def _sample(self, ex, src, gts, stride, pad):
+    def _sample(self, ex, src, gts, stride, pad, rec=None):
         """The positive generator on one map: bag points, validity, samples and the bag view.  pad: what a slot / tap without
-        a feature contributes (the projection's bias on a logit map, nothing on a feature map)."""
+        a feature contributes (the projection's bias on a logit map, nothing on a feature map).  rec (dict, training): receives
+        the grid generator's entry codes (what the point-list gather of the backward walks)."""
         if ex.pos_is_grid:
             # the reference pads to max_pos_num + num_refine grid slots and THEN appends the num_refine points (cpr_head.py:325-349)
             kmax = ex.max_pos_num + gts.R
-            pts, valid, out, count = ops.grid_bag(src, gts.points, gts.gt_img, gts.R, kmax, ex.pos_radius * stride, stride,
-                                                  pad_value=pad, align_corners=ex.align_corners)
+            pts, valid, out, count, cell = ops.grid_bag(src, gts.points, gts.gt_img, gts.R, kmax, ex.pos_radius * stride, stride,
+                                                        pad_value=pad, align_corners=ex.align_corners, want_cell=True)
+            if rec is not None:
+                rec['code'] = cell
             # the reference fails inside generate() when a bag overflows (cpr_head.py:331-333: shape mismatch on assignment)
             worst = int(count.max().item()) if count.numel() else 0
             if worst > kmax:
@@ -388,7 +391,7 @@ class CPRHead(nn.Module):
                                          align_corners=ex.align_corners, pad_value=pad if ex.align_corners else None)
         return pts, valid, out, (gts.R, pts.shape[1])
 
-    def _bags(self, ex, feat, lmap, gts, stride, ifeat=None, part=None, acts=None):
+    def _bags(self, ex, feat, lmap, gts, stride, ifeat=None, part=None, acts=None, rec=None):
         """Bag points (E,2), validity (E) and bag logits (E,J) of the positive generator, E = G * entries-per-gt, plus
         the bag view (sub_bags per gt, entries per sub-bag).  num_cls_fcs == 0: Linear commutes with bilinear sampling, so
         the logits are sampled from the projected map ``lmap``.  Otherwise the 256-channel features are sampled and run
@@ -400,11 +403,13 @@ class CPRHead(nn.Module):
             if ex.pos_is_grid or ex.align_corners:
                 pad = self._proj(lmap.dtype, part)[1] if (self.ins_share_head_feat or part is not None) else \
                     torch.cat([self._proj(lmap.dtype, 'cls')[1], self._proj(lmap.dtype, 'ins')[1]])
-            pts, valid, out, view = self._sample(ex, lmap, gts, stride, pad)
+            pts, valid, out, view = self._sample(ex, lmap, gts, stride, pad, rec)
+            if rec is not None:
+                rec['pad'] = pad is not None
         else:
             # acts (dict, training): the sampled features and the FC activations of each path ('bag': shared features;
             # 'bag_cls' / 'bag_ins': the two towers)
-            pts, valid, out, view = self._sample(ex, feat, gts, stride, None)
+            pts, valid, out, view = self._sample(ex, feat, gts, stride, None, rec)
             E, K, Cf = out.shape
             if self.ins_share_head_feat:
                 out = self._logit_map(out.view(1, E * K, 1, Cf), part=part,
@@ -418,6 +423,8 @@ class CPRHead(nn.Module):
                                                  acts=None if acts is None else acts.setdefault('bag_ins', [])).view(E, K, -1))
                 out = torch.cat(parts, dim=-1).contiguous()
         G = gts.G
+        if rec is not None:
+            rec['pts'] = pts
         return pts.view(G, -1, 2), valid.view(G, -1), out.view(G, -1, out.shape[-1]), view
 
     def _gt_tensors(self, gt_bboxes, gt_labels, img_metas, device, shape_key='pad_shape'):
@@ -498,7 +505,9 @@ class CPRHead(nn.Module):
         if lmap is None:                            # (a caller that replays a hipGraph hands the projected map over)
             lmap = self._lmap_all(feat, ab, ifeat, iab, acts=fc_acts)
         gts = self._gt_tensors(gt_bboxes, gt_labels, img_metas, dev)
-        _, valid, bag_logits, view = self._bags(ex, feat, lmap, gts, stride, ifeat=ifeat, acts=fc_acts)
+        # grid generators / align_corners=True sampling: the backward gathers through the forward's own point list
+        plist = {} if (save is not None and (ex.pos_is_grid or ex.align_corners)) else None
+        _, valid, bag_logits, view = self._bags(ex, feat, lmap, gts, stride, ifeat=ifeat, acts=fc_acts, rec=plist)
         cfg = self.loss_cfg
         with_mil, with_gt, with_neg = cfg.get('with_mil_loss', True), cfg.get('with_gt_loss', False), cfg.get('with_neg', True)
         assert with_mil or with_gt, 'loss0 needs num_pos from the MIL or the gt loss (cpr_head.py:1180,1213,1227)'
@@ -517,8 +526,6 @@ class CPRHead(nn.Module):
                                            want_bag_ws=save is not None, bags=bags, centres=centres,
                                            prob_type=self.prob_type, norm_p=self.norm_p, neg_from_gt=not with_mil)
         if save is not None:
-            assert self.train_step_supported(gts.R), \
-                'no hand-written backward for grid generators / align_corners (CPRHead.train_step_supported)'
             out, bag_ws = out
             # one row per BAG: with num_refine = R > 1 (independent bags) the (G, R * Kv) layout is (G * R, Kv) in memory, every
             # refine point a bag around its own centre (gts.points is gt-major, pt_img ascends)
@@ -527,10 +534,15 @@ class CPRHead(nn.Module):
             rows, Kv = gts.G * view[0], view[1]
             save.update(feat=feat, ab=ab, ifeat=ifeat, iab=iab, lmap=lmap, neg_mask=neg_mask, out5=out,
                         bag_logits=bag_logits.view(rows, Kv, -1), valid=valid.view(rows, Kv),
-                        labels=labels, gt_weight=w, bag_ws=bag_ws, centers=gts.points, gt_img=gts.pt_img,
-                        offsets=ex.offsets(stride, dev), ins_off=ins_off, stride=stride,
-                        radius_cells=ex.window_radius_cells(stride, dev), fc=fc_acts, bags=bags, centres=centres,
-                        general=self._loss_backward_general(gts.R, bags, centres), neg_from_gt=not with_mil)
+                        labels=labels, gt_weight=w, bag_ws=bag_ws, centers=gts.points, ins_off=ins_off, stride=stride,
+                        fc=fc_acts, bags=bags, centres=centres, general=self._loss_backward_general(gts.R, bags, centres),
+                        neg_from_gt=not with_mil, plist=plist)
+            if plist is None:      # ring offsets around every (gt, refine) point: the window gather
+                save.update(gt_img=gts.pt_img, offsets=ex.offsets(stride, dev), radius_cells=ex.window_radius_cells(stride, dev))
+            else:                  # one row per gt (grid) or per point (circle + align_corners); codes only for grid bags
+                plist.setdefault('code', None)
+                plist.update(pts=plist['pts'].reshape(rows, Kv, 2), align=ex.align_corners)
+                save.update(gt_img=gts.gt_img if ex.pos_is_grid else gts.pt_img, offsets=None, radius_cells=0)
         return self._loss_dict(out)
 
     def _loss_dict(self, out):

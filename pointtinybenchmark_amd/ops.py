@@ -583,10 +583,12 @@ def bag_sample(fmap, centers, gt_img, pad_hw, offsets, stride, align_corners=Fal
     return pts, valid, out
 
 
-def grid_bag(fmap, points, gt_img, num_refine, max_pos_num, radius_px, stride, pad_value=None, align_corners=False):
+def grid_bag(fmap, points, gt_img, num_refine, max_pos_num, radius_px, stride, pad_value=None, align_corners=False,
+             want_cell=False):
     """GridCirclesPtFeatGenerator bags: fmap (N,H,W,J), points (G*R,2), gt_img (G) -> pts (G,Kmax+R,2),
     valid (G,Kmax+R) uint8, sampled (G,Kmax+R,J), count (G) int32 (grid points found per gt).  pad_value (J,): what the
-    padding slots hold (default zeros)."""
+    padding slots hold (default zeros).  want_cell: also the entry codes (G,Kmax+R) int32 -- cell index | -1 padding slot |
+    <= -2 refine point (bilinear sample) -- which ``bag_points_gather_bwd`` walks."""
     N, H, W, J = _check(fmap).shape
     R = int(num_refine)
     G = points.shape[0] // R
@@ -601,7 +603,7 @@ def grid_bag(fmap, points, gt_img, num_refine, max_pos_num, radius_px, stride, p
     _lib.call('cpr_grid_bag', _ptr(fmap), J, _ptr(_check(points)), _ptr(gt_img), R, int(max_pos_num), float(radius_px),
               _ptr(pad_value), _ptr(pts), _ptr(valid), _ptr(cell), _ptr(count), _ptr(out), G, H, W, float(stride),
               int(align_corners), _stream())
-    return pts, valid, out, count
+    return (pts, valid, out, count, cell) if want_cell else (pts, valid, out, count)
 
 
 def mil_loss(logits, ins_off, valid, labels, num_classes, neg_partial, w_mil, w_gt, w_neg, gt_weight=None, eps=1e-6,
@@ -1131,6 +1133,20 @@ def bag_gather_bwd(dsample, centers, gt_img, offsets, dmap, stride, radius_cells
     _lib.call('cpr_bag_gather_bwd', _ptr(dsample), J, _ptr(centers), _ptr(gt_img), _ptr(offsets), _ptr(win_ws), _ptr(win_org), win,
               _ptr(dmap), N, H, W, Jd, G, K, float(stride), _stream())
     return dmap
+
+
+def bag_points_gather_bwd(dsample, pts, code, gt_img, dmap, stride, align_corners=False, want_bias=False):
+    """The gather stage from the forward's point list (grid generators, align_corners=True): dsample (G,Kt,J) ADDED onto dmap
+    (N,H,W,J'), J <= J'; pts (G,Kt,2); code (G,Kt) int32 from ``grid_bag(want_cell=True)`` or None (every entry a bilinear sample).
+    want_bias: also return (J,) = what the projection's bias receives through padding slots / dropped taps."""
+    G, Kt, J = _check(dsample).shape
+    N, H, W, Jd = _check(dmap).shape
+    assert pts.numel() == G * Kt * 2 and (code is None or (code.numel() == G * Kt and code.dtype == torch.int32))
+    wout = torch.empty((G * Kt,), device=dmap.device, dtype=torch.float32) if want_bias else None
+    dbias = torch.empty((J,), device=dmap.device, dtype=torch.float32) if want_bias else None
+    _lib.call('cpr_bag_points_gather_bwd', _ptr(dsample), J, _ptr(_check(pts)), _ptr(code), _ptr(gt_img), _ptr(dmap), _ptr(wout),
+              _ptr(dbias), N, H, W, Jd, G, Kt, float(stride), int(align_corners), _stream())
+    return dbias
 
 
 def p2p_loss_bwd(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, beta, pos_w, neg_w, reg_norm, w_cls,

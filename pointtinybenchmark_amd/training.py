@@ -392,8 +392,8 @@ class BackwardEngine:
         w_mil = head.loss_mil.loss_weight if cfg.get('with_mil_loss', True) else 0.0
         w_gt = cfg.get('gt_loss_weight', 1.0) if cfg.get('with_gt_loss', False) else 0.0
         w_neg = cfg.get('neg_loss_weight', 1.0) if cfg.get('with_neg', True) else 0.0
-        assert s['neg_mask'] is not None, 'with_neg=False is not on the training path'
         fc = head.num_cls_fcs > 0
+        plist = s.get('plist')              # grid generator / align_corners=True: the gather walks the forward's point list
         if s.get('general'):
             # any other loss option (probability type, binary_ins, AllPosLoss, bag policy, gt_loss_type, out_bg_cls, no MIL term):
             # the general kernels leave the bag-entry gradients un-gathered; the gather onto the logit map is a second call
@@ -402,17 +402,23 @@ class BackwardEngine:
                                                   gt_weight=s['gt_weight'], eps=head.loss_mil.eps, upstream=upstream,
                                                   prob_type=head.prob_type, norm_p=head.norm_p, binary_ins=head.binary_ins,
                                                   allpos=head.loss_mil.allpos, neg_from_gt=s['neg_from_gt'])
-            if not fc:
+            if not fc and plist is None:
                 ops.bag_gather_bwd(dbag, s['centers'], s['gt_img'], s['offsets'], dmap, s['stride'], s['radius_cells'])
         else:
             dmap, dbag = ops.cpr_loss_bwd(s['lmap'], s['neg_mask'], s['out5'], s['bag_logits'], s['valid'], s['labels'],
                                           s['bag_ws'], s['centers'], s['gt_img'], s['offsets'], s['ins_off'], C, s['stride'],
                                           w_mil, w_gt, w_neg, Jd, gt_weight=s['gt_weight'], eps=head.loss_mil.eps,
-                                          upstream=upstream, radius_cells=s['radius_cells'], gather=not fc)
+                                          upstream=upstream, radius_cells=s['radius_cells'], gather=not fc and plist is None)
         if fc:
             return self._backward_head_fc(head, s, dmap, dbag, J, Jd)
+        dbias = None
+        if plist is not None:
+            # padding slots / dropped taps sampled the projection's BIAS (zero features through the Linear, cpr_head.py:323-324):
+            # their share of the bag gradient goes to the classifier biases, not onto the map
+            dbias = ops.bag_points_gather_bwd(dbag, plist['pts'], plist['code'], s['gt_img'], dmap, s['stride'], plist['align'],
+                                              want_bias=plist.get('pad', False))
         if not head.ins_share_head_feat:
-            return self._backward_head_two_towers(head, s, dmap, J, Jd)
+            return self._backward_head_two_towers(head, s, dmap, J, Jd, dbias)
         # ---- logit projection (cls_out ++ ins_out as one 1x1 conv over the un-normalised last tower layer)
         shared = head.ins_share_head_classifier
         wcat = head.cls_out.weight if shared else torch.cat([head.cls_out.weight, head.ins_out.weight], 0)
@@ -420,6 +426,8 @@ class BackwardEngine:
         wpad[:J, :, 0, 0] = wcat.detach()
         gw = ops.conv2d_wgrad(dmap, self._f32(s['feat']), wpad.shape, 1, 0, in_ab=s['ab'], in_relu=True)
         _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
+        if dbias is not None:
+            gb[:J] += dbias
         self._g(head.cls_out.weight).copy_(gw[:C, :, 0, 0])
         self._g(head.cls_out.bias).copy_(gb[:C])
         if not shared:                      # (binary_ins: the instance classifier has 2 C rows)
@@ -433,7 +441,7 @@ class BackwardEngine:
             self._done(rec['module'].conv.weight)
         return dz
 
-    def _backward_head_two_towers(self, head, s, dmap, J, Jd):
+    def _backward_head_two_towers(self, head, s, dmap, J, Jd, dbias=None):
         """ins_share_head_feat=False (cpr_head.py:992-1008,1037-1040,1061-1070): the class logits (channels [0, C) of the map the
         loss reads) are cls_out over the class tower's last layer, the instance logits (channels [C, 2C)) ins_out over the instance
         tower's.  Each projection is a 1x1 conv whose padded weight holds its classifier's rows and zeros elsewhere, so the shared
@@ -441,6 +449,8 @@ class BackwardEngine:
         C = head.num_cls_out
         assert J == C + head.ins_out.weight.shape[0], 'two towers: [cls ++ ins] logits'
         _, gb = ops.relu_bwd_colsum(dmap, None, want_g=False)
+        if dbias is not None:
+            gb[:J] += dbias
         same = head.ins_out is head.cls_out                      # ins_share_head_classifier on two towers: one Linear, two inputs
         dz, first = None, True
         for name, lo, mod, feat, ab, tape in (('cls', 0, head.cls_out, s['feat'], s['ab'], s['tape']),
@@ -527,7 +537,11 @@ class BackwardEngine:
             else:
                 dfeat = torch.zeros(tuple(feat.shape), device=dmap.device, dtype=torch.float32)
             ds = self._fc_chain_backward(dl_bag, a_bag, fcs, rows, touched)              # (1, G*K, 1, Cf)
-            ops.bag_gather_bwd(ds.view(G, K, -1), s['centers'], s['gt_img'], s['offsets'], dfeat, s['stride'], s['radius_cells'])
+            if s.get('plist') is not None:       # (features were sampled: padding slots / dropped taps hold zeros, no bias share)
+                pl = s['plist']
+                ops.bag_points_gather_bwd(ds.view(G, K, -1), pl['pts'], pl['code'], s['gt_img'], dfeat, s['stride'], pl['align'])
+            else:
+                ops.bag_gather_bwd(ds.view(G, K, -1), s['centers'], s['gt_img'], s['offsets'], dfeat, s['stride'], s['radius_cells'])
             dfeats.append((dfeat, tape))
         self._done((head.ins_fcs[0] if two else head.cls_fcs[0]).bias)       # classifiers and FC layers: complete (flat order)
         dz = None

@@ -345,15 +345,16 @@ def test_p2p_loss_backward_is_bit_equal_to_the_trainer():
 
 
 def test_unsupported_options_keep_the_forward_only_path_and_say_so():
-    """A head option without a hand-written backward (align_corners=True sampling): with autograd on, forward_train still
-    returns the losses, without a graph, and warns once; under no_grad nothing warns.  (The bf16 compute mode, which this
-    test used until round 4, and the loss options now train through the bridge.)"""
+    """A model the bridge has no rule for (a stage with only some of its blocks frozen): with autograd on, forward_train still
+    returns the losses, without a graph, and warns once; under no_grad nothing warns.  (The bf16 compute mode and the head
+    options this test used until round 5 now all train through the bridge.)"""
     from pointtinybenchmark_amd import autograd_bridge
     cfg = CPR_CASES['cpr_r18_c3_128']
     data = _data(cfg)
     m, _ = build_hip_locator(cfg)
-    m.bbox_head.train_pts_extractor.align_corners = True
-    assert not m.bbox_head.train_step_supported()
+    for p in m.backbone.layer3[0].parameters():
+        p.requires_grad_(False)
+    assert 'partly frozen' in autograd_bridge.unsupported_reason(m)
     autograd_bridge._WARNED.clear()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
@@ -363,7 +364,7 @@ def test_unsupported_options_keep_the_forward_only_path_and_say_so():
             m.forward_train(**data)
     assert not any(v.requires_grad for v in losses.values())
     msgs = [str(x.message) for x in w if 'WITHOUT a graph' in str(x.message)]
-    assert len(msgs) == 1 and 'option set' in msgs[0], msgs
+    assert len(msgs) == 1 and 'partly frozen' in msgs[0], msgs
 
 
 def test_backward_releases_the_recorded_maps():

@@ -242,7 +242,8 @@ def test_option_backward_vs_reference_autograd(golden_dir, name):
     FC layer between the sampled features and the classifiers, and two FC layers on shared features (num_cls_fcs > 0,
     :999-1005,1055-1059), and the loss options behind the general loss-backward kernels (softmax / normed_sigmoid class
     probabilities, binary_ins, AllPosLoss, merge_to_gt_bag / only_refine_bag with gt_loss_type='gt', out_bg_cls,
-    with_mil_loss=False) -- against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_option_grads.npz,
+    with_mil_loss=False, with_neg=False) and the point-list gather (grid bags, align_corners=True; on the logit map and, with an FC
+    layer, on the sampled features) -- against loss.backward() through the REFERENCE's own modules (tests/golden/cpr_option_grads.npz,
     oracle/gen_golden_r5.py): total loss 1e-4, per-tensor norm 2e-3, strided samples 2e-3 of the tensor's max.
     'ins_tower_fc_boundary' is a sample on which an activation of the sparse-gradient instance tower sits within fp32 conv
     rounding of a ReLU boundary (the reference's own gradient moves 3e-3 .. 7e-3 when that boundary is shifted by 1e-5:

@@ -26,6 +26,8 @@ def main():
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
     ap.add_argument('--bf16-dma', type=int, default=1, help='bf16 mode: 0 = every layer on the register-staged kernels (A/B)')
     ap.add_argument('--stream', type=int, default=1, help='0 = the streamed 1x1 kernel is never chosen (A/B of conv1x1_stream.hip)')
+    ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--size', type=int, default=640, help='square image side (configs[4]: --depth 101 --size 1024 --dtype bf16 --batch 8)')
     args = ap.parse_args()
     from pointtinybenchmark_amd import _lib
     _lib.call('cpr_bf16_set_dma', args.bf16_dma)
@@ -33,10 +35,10 @@ def main():
     _lib.call('cpr_conv_set_pipeline', args.pipeline)
     _lib.call('cpr_conv_force_tile', *[int(v) for v in args.tile.split(',')])
     _lib.call('cpr_conv_set_extra_lds', args.extra_lds)
-    model = P.build_detector(bench.model_cfg()).cuda()
-    model.load_state_dict(synthetic.locator_state_dict(50, 1, 0, 'cpr', 0), strict=True)
+    model = P.build_detector(bench.model_cfg(depth=args.depth)).cuda()
+    model.load_state_dict(synthetic.locator_state_dict(args.depth, 1, 0, 'cpr', 0), strict=True)
     model.set_compute_dtype(args.dtype)
-    batch = synthetic.synthetic_batch(args.batch, 640, 640, 32, 1, 0)
+    batch = synthetic.synthetic_batch(args.batch, args.size, args.size, 32, 1, 0)
     img = batch['img'].cuda()
     gtb = [b.cuda() for b in batch['gt_bboxes']]
     gtl = [l.cuda() for l in batch['gt_labels']]
@@ -78,6 +80,10 @@ def main():
         byts = 4.0 * (N * H * W * Cin + N * OH * OW * Cout * (2 if res else 1) + Cout * KH * KH * Cin)
         for _ in range(3):
             orig(x, pc, *a, **k)
+        ops.TRACE_CONV_VARIANT[0] = True
+        orig(x, pc, *a, **k)
+        variant = ops.TRACE_CONV_VARIANT[1]
+        ops.TRACE_CONV_VARIANT[0] = False
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(args.iters):
@@ -89,7 +95,7 @@ def main():
             byts *= 0.5
         roof = max(flops / (2500e12 if (args.dtype == 'bf16' and Cin != 4) else 157.3e12), byts / 6.3e12)
         rows.append(dict(key=str(key), count=cnt, ms=t * 1e3, tflops=flops / t / 1e12, gbs=byts / t / 1e9,
-                         roof_frac=roof / t, gflop=flops / 1e9, mb=byts / 1e6))
+                         roof_frac=roof / t, gflop=flops / 1e9, mb=byts / 1e6, variant=str(variant)))
         tot_t += cnt * t
         tot_f += cnt * flops
     for x, pc, x2, pc2, a, k in duals:      # conv3 + projection shortcut in one launch (ops.conv2d_dual)
@@ -114,8 +120,8 @@ def main():
     rows.sort(key=lambda r: -r['ms'] * r['count'])
     print('%-62s %3s %8s %8s %8s %6s %7s' % ('N,H,W,Cin,Cout,K,s,res,xf,gn', 'cnt', 'ms', 'TF/s', 'GB/s', 'roof', 'tot ms'))
     for r in rows:
-        print('%-62s %3d %8.3f %8.1f %8.0f %6.2f %7.2f' % (r['key'], r['count'], r['ms'], r['tflops'], r['gbs'],
-                                                          r['roof_frac'], r['ms'] * r['count']))
+        print('%-62s %3d %8.3f %8.1f %8.0f %6.2f %7.2f  %s' % (r['key'], r['count'], r['ms'], r['tflops'], r['gbs'],
+                                                              r['roof_frac'], r['ms'] * r['count'], r.get('variant', '')))
     print('conv total per step: %.2f ms, %.1f TF/s aggregate (B=%d)' % (tot_t * 1e3, tot_f / tot_t / 1e12, args.batch))
     if args.out:
         json.dump(rows, open(args.out, 'w'), indent=1)
