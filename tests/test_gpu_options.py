@@ -299,6 +299,52 @@ def test_option_backward_vs_reference_autograd(golden_dir, name):
             assert q.grad is None or not bool(q.grad.any()), k
 
 
+@pytest.mark.parametrize('name', ['r2_merge_gt', 'softmax', 'ins_tower', 'grid_circles', 'align_corners'])
+def test_option_backward_in_the_mixed_precision_mode(name):
+    """The option backward rules in the bf16 compute mode (mixed precision: bf16 recorded maps, fp32 logit map / loss backward /
+    gradients): the trainer's gradient against torch autograd over the fp32 options oracle at the mixed-precision bar of
+    tests/test_gpu_train_step.py (global cosine >= 0.99, total loss 3e-2 -- the mode's arithmetic is not the reference's), and
+    loss.backward() through the bridge BIT-equal to the mixed-precision trainer (bf16 maps behind the fp32 carriers)."""
+    from oracle import cpr_oracle as O, cpr_options_oracle as OO
+    from pointtinybenchmark_amd.training import CprTrainer
+    cfg = grad_option_cfg(name)
+    m, batch = build_hip(cfg)
+    m.set_compute_dtype('bf16')
+    cb = cuda_batch(batch)
+    data = dict(img=cb['img'], img_metas=cb['img_metas'], gt_bboxes=cb['gt_bboxes'], gt_labels=cb['gt_labels'])
+    tr = CprTrainer(m)
+    losses = tr.forward_backward(**data)
+    torch.cuda.synchronize()
+    got = {k: q.grad.detach().clone() for k, q in m.named_parameters() if q.requires_grad}
+    total = float(sum(v for k, v in losses.items() if 'loss' in k))
+    sd, _ = case_inputs(cfg)
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in got:
+        sd[k].requires_grad_(True)
+    feats = O.fpn_forward(sd, O.resnet_forward(sd, batch['img'], cfg['depth']), cfg['start_level'], 1)
+    cf, _ = O.cpr_head_forward(sd, feats)
+    inf = OO.ins_tower_forward(sd, feats)[0] if cfg.get('ins_tower') else None
+    lo, _ = OO.cpr_loss(sd, cf[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg, ins_feat=inf)
+    ref_total = sum(v for k, v in lo.items() if 'loss' in k)
+    ref_total.backward()
+    ref_val = float(ref_total.detach())
+    assert abs(total - ref_val) <= 3e-2 * max(1.0, abs(ref_val)), (total, ref_val)
+    a = torch.cat([got[k].double().flatten().cpu() for k in got])
+    b = torch.cat([(sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])).double().flatten() for k in got])
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos >= 0.99, 'mixed-precision gradient cosine %.5f' % cos
+    del tr, m
+    m2, _ = build_hip(cfg)
+    m2.set_compute_dtype('bf16')
+    out = m2.train_step(dict(data), optimizer=None)
+    assert out['loss'].grad_fn is not None
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    for k, q in m2.named_parameters():
+        if q.requires_grad:
+            assert q.grad is not None and torch.equal(q.grad, got[k]), k
+
+
 def test_grid_ellipse_generator_raises_like_the_reference(golden_dir):
     """GridEllipsePtFeatGenerator cannot run in the reference (fixture records its RuntimeError); ours refuses at build."""
     from pointtinybenchmark_amd.registry import build_head
