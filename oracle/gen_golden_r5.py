@@ -69,6 +69,9 @@ OPTION_GRAD_CASES = {
     'align_corners_grid': ('align_corners_grid', {}),
     'grid_circles_fc': ('grid_circles', dict(num_cls_fcs=1, fc_out_channels=64, seed=173)),
     'no_neg': ('softmax', dict(with_neg=False, seed=174)),                  # loss_cfg with_neg=False (cpr_head.py:1219)
+    # combinations: general loss kernels + FC stack + merged bags; two towers with a 2C-row instance classifier
+    'combo_fc_softmax_merge': ('r2_merge_gt', dict(prob='softmax', num_cls_fcs=1, fc_out_channels=64, seed=175)),
+    'combo_tower_binary_normed': ('ins_tower', dict(binary_ins=True, prob='normed_sigmoid', norm_p=2, seed=178)),     # (per-seed device-vs-oracle worst tensor: 176 1.6e-3, 177 8e-4, 178 2.3e-4, 179 1.4e-3, 181 2.3e-3, 182 3.6e-3)
 }
 OPTION_GRAD_BARS = {'ins_tower_fc_boundary': 2e-2, 'r3_only_refine': 2e-4, 'bg_cls': 2e-4}       # per-tensor norm / strided-sample bar (measured: 4.5e-3 relative L2 on the worst tensor, 1.7e-2 of its max on the worst entry); default 2e-3; the event-free fixtures 2e-4 (measured 5e-6)
 

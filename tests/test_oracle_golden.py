@@ -227,7 +227,7 @@ def test_option_oracle_matches_reference_fixture(golden_dir, name):
 @pytest.mark.parametrize('name', ['r2_independent', 'ins_tower', 'ins_tower_fc', 'ins_tower_fc_boundary', 'fc2_shared', 'softmax',
                                   'normed_sigmoid_p1', 'normed_sigmoid_p2', 'binary_ins', 'allpos', 'r2_merge_gt', 'r3_only_refine', 'bg_cls',
                                   'no_mil_loss', 'grid_circles', 'grid_circles_r2', 'align_corners', 'align_corners_grid',
-                                  'grid_circles_fc', 'no_neg'])
+                                  'grid_circles_fc', 'no_neg', 'combo_fc_softmax_merge', 'combo_tower_binary_normed'])
 def test_option_oracle_autograd_matches_reference_autograd(golden_dir, name):
     """Pins the options oracle's BACKWARD (torch autograd over oracle/cpr_options_oracle.py) to loss.backward() through the
     reference's own modules for the options that gained a hand-written backward in round 5 (tests/golden/cpr_option_grads.npz,
