@@ -544,3 +544,35 @@ def test_grad_report_of_the_bench_gates():
     assert abs(rep['ref_norm'] - n_ref) < 1e-9 and 0 < rep['norm_rel'] < 1e-3 and 0.9999 < rep['cosine'] <= 1.0
     same = grad_report(ref, ref)
     assert same['norm_rel'] == 0 and abs(same['cosine'] - 1) < 1e-12 and all(d['rel_l2'] == 0 for d in same['rows'])
+
+
+def test_loss_backward_dispatch_per_option_set():
+    """Host logic of the training path (no GPU): which loss-backward kernels a CPRHead option set takes.  The shipped option set
+    and the options that only change the towers / bag count (num_refine > 1 with independent bags, instance tower, FC layers, grid
+    bags, align_corners) keep the SPECIALISED kernels -- their outputs are the bit-for-bit record of rounds 1-4; everything that
+    changes the loss formula or the bag / annotated-point geometry goes to the general kernels.  Every option set trains."""
+    from types import SimpleNamespace
+    from oracle.gen_golden_r2 import cpr_head_kwargs
+    from oracle.gen_golden_r5 import OPTION_GRAD_CASES, grad_option_cfg
+    from pointtinybenchmark_amd.registry import build_head
+    general = {'r2_independent': False, 'ins_tower': False, 'ins_tower_fc': False, 'ins_tower_fc_boundary': False,
+               'fc2_shared': False, 'grid_circles': False, 'grid_circles_r2': False, 'align_corners': False,
+               'align_corners_grid': False, 'grid_circles_fc': False,
+               'softmax': True, 'normed_sigmoid_p1': True, 'normed_sigmoid_p2': True, 'binary_ins': True, 'allpos': True,
+               'r2_merge_gt': True, 'r3_only_refine': True, 'bg_cls': True, 'no_mil_loss': True, 'no_neg': True,
+               'combo_fc_softmax_merge': True, 'combo_tower_binary_normed': True}
+    assert set(general) == set(OPTION_GRAD_CASES)
+    for name, want in general.items():
+        cfg = grad_option_cfg(name)
+        head = build_head(dict(type='CPRHead', **cpr_head_kwargs(cfg)))
+        assert head.train_step_supported(cfg.get('num_refine', 1)), name
+        ex, R, G = head.train_pts_extractor, cfg.get('num_refine', 1), 7
+        if ex.pos_is_grid:
+            view = (1, ex.max_pos_num + 2 * R)
+        else:
+            from pointtinybenchmark_amd.dense_heads.cpr_head import circle_offsets
+            view = (R, int(circle_offsets(ex.pos_radius, cfg['stride'], **ex.pos_kw).shape[0]) + 1)
+        gts = SimpleNamespace(G=G, R=R, labels=torch.zeros(G, dtype=torch.int32), pt_labels=torch.zeros(G * R, dtype=torch.int32))
+        bags, centres, labels, _ = head._loss_geometry(gts, view, None, torch.device('cpu'))
+        assert labels.numel() == bags[0] and bags[0] * bags[1] == G * view[0] * view[1], (name, bags, view)
+        assert head._loss_backward_general(R, bags, centres) == want, (name, bags, centres)
