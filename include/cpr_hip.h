@@ -338,6 +338,12 @@ int cpr_conv3x3_wino_wgrad(const float* dy, const float* x, const float* in_a, c
 int cpr_gn_bwd(const float* x, const float* dz, const float* a, const float* b, const float* mean, const float* rstd,
                const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws_part, float* ws_k, int N, int HW,
                int C, int G, int P, int relu, int accumulate, void* stream);
+/* The same backward reading the bf16 map the mixed-precision forward recorded (widened in registers: the values are those of
+ * cpr_gn_bwd on the widened map) and writing dx (fp32) and / or dx_bf16 (its round-to-nearest-even narrowing, what the bf16 weight /
+ * data gradient kernels read) -- at least one of the two. */
+int cpr_gn_bwd_bf16(const void* x_bf16, const float* dz, const float* a, const float* b, const float* mean, const float* rstd,
+                    const float* gamma, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* ws_part, float* ws_k, int N,
+                    int HW, int C, int G, int P, int relu, int accumulate, void* stream);
 /* FPN top-down path backward (fpn.py:176-185): dcoarse (N,UH,UW,C) (+)= sum over the nearest-upsample children of dfine */
 int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W, int UH, int UW, int C, int accumulate,
                          void* stream);

@@ -14,7 +14,22 @@ __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); 
 //   dx = dy*a + x*k2[n,g] + k3[n,g],  k2 = -rstd^2 * m2, k3 = -rstd*m1 + mean*rstd^2*m2,
 //        m1 = mean_g(dy*gamma), m2 = mean_g(dy*gamma*xhat)
 // pass 1: per (image, slot, channel) partial (sum dy, sum dy*xhat)   -- same [N][P][C][2] layout as the forward stats
-__global__ void gn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+// (round 5) XB: x is the bf16 map the mixed-precision forward recorded, widened in registers (exact) -- the fp32 copy the step
+// used to make first (and the bf16 copy of dx it made afterwards: OUT of the apply pass) cost 9 GB of traffic per head layer.
+typedef __attribute__((ext_vector_type(2))) __bf16 gnb_bf16x2_t;
+template <bool XB> __device__ __forceinline__ f32x4 gnb_load4(const void* __restrict__ x, size_t o) {
+    if constexpr (XB) {
+        const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(x) + o);
+        f32x4 v;
+        v.x = __uint_as_float(u.x << 16); v.y = __uint_as_float(u.x & 0xffff0000u);
+        v.z = __uint_as_float(u.y << 16); v.w = __uint_as_float(u.y & 0xffff0000u);
+        return v;
+    } else {
+        return *reinterpret_cast<const f32x4*>(static_cast<const float*>(x) + o);
+    }
+}
+template <bool XB>
+__global__ void gn_bwd_stats_kernel(const void* __restrict__ x, const float* __restrict__ dz,
                                     const float* __restrict__ a, const float* __restrict__ b,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     float* __restrict__ part, int HW, int C, int G, int P, int relu) {
@@ -37,7 +52,7 @@ __global__ void gn_bwd_stats_kernel(const float* __restrict__ x, const float* __
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     for (int p = p0 + pl; p < p1; p += PP) {
         const size_t o = ((size_t)n * HW + p) * C + q * 4;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+        const f32x4 xv = gnb_load4<XB>(x, o);
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dz + o);
         const f32x4 y = xv * av + bv;
 #pragma unroll
@@ -115,18 +130,19 @@ __global__ void gn_bwd_params_kernel(const float* __restrict__ dgb_part, float* 
     dgamma[c] = accumulate ? dgamma[c] + (float)sg : (float)sg;
 }
 
-// pass 2: dx = dy*a + x*k2 + k3
-__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+// pass 2: dx = dy*a + x*k2 + k3   (dx and / or its bf16 rounding dx16: whichever pointer is given)
+template <bool XB>
+__global__ void gn_bwd_apply_kernel(const void* __restrict__ x, const float* __restrict__ dz,
                                     const float* __restrict__ a, const float* __restrict__ b,
                                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
-                                    int N, int HW, int C4, int G, int relu) {
+                                    unsigned short* __restrict__ dx16, int N, int HW, int C4, int G, int relu) {
     const long long total = (long long)N * HW * C4;
     const int cpg4 = (C4 * 4) / G;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         const int n = (int)(i / ((long long)HW * C4));
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 xv = gnb_load4<XB>(x, (size_t)i * 4);
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dz + i * 4);
         const f32x4 av = *reinterpret_cast<const f32x4*>(a + ((size_t)n * C4 + c) * 4);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(b + ((size_t)n * C4 + c) * 4);
@@ -138,21 +154,29 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
             const float dy = (relu && !(y[k] > 0.f)) ? 0.f : dv[k];
             o[k] = dy * av[k] + xv[k] * k2[n * G + g] + k3[n * G + g];
         }
-        *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+        if (dx) *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+        if (dx16) {
+            const gnb_bf16x2_t lo = {(__bf16)o.x, (__bf16)o.y}, hi = {(__bf16)o.z, (__bf16)o.w};   // round to nearest even, as torch's .to(bfloat16)
+            uint2 u;
+            u.x = __builtin_bit_cast(unsigned, lo);
+            u.y = __builtin_bit_cast(unsigned, hi);
+            *reinterpret_cast<uint2*>(dx16 + i * 4) = u;
+        }
     }
 }
 
-extern "C" int cpr_gn_bwd(const float* x, const float* dz, const float* a, const float* b, const float* mean,
-                          const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws_part,
-                          float* ws_k, int N, int HW, int C, int G, int P, int relu, int accumulate, hipStream_t stream) {
+template <bool XB>
+static int gn_bwd_launch(const void* x, const float* dz, const float* a, const float* b, const float* mean, const float* rstd,
+                         const float* gamma, float* dx, unsigned short* dx16, float* dgamma, float* dbeta, float* ws_part,
+                         float* ws_k, int N, int HW, int C, int G, int P, int relu, int accumulate, hipStream_t stream) {
     // ws_part: N*P*C*2 floats; ws_k: 2*N*G + 2*N*C floats (k2 | k3 | per-image dgamma/dbeta contributions)
-    CPR_CHECK_ARG(x && dz && a && b && mean && rstd && gamma && dx && dgamma && dbeta && ws_part && ws_k);
+    CPR_CHECK_ARG(x && dz && a && b && mean && rstd && gamma && (dx || dx16) && dgamma && dbeta && ws_part && ws_k);
     CPR_CHECK_ARG(N > 0 && HW > 0 && G > 0 && P > 0 && C % G == 0 && (C / G) % 4 == 0 || (C / G) >= 1);
     CPR_CHECK_ARG(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0);
     float* k2 = ws_k;
     float* k3 = ws_k + (size_t)N * G;
     float* dgb = ws_k + (size_t)2 * N * G;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(P, N), dim3(256), 0, stream, x, dz, a, b, mean, rstd, ws_part, HW, C, G,
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<XB>, dim3(P, N), dim3(256), 0, stream, x, dz, a, b, mean, rstd, ws_part, HW, C, G,
                        P, relu);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), (size_t)2 * C * sizeof(double), stream, ws_part, gamma,
                        mean, rstd, k2, k3, dgb, P, C, G, (double)HW * (C / G));
@@ -160,9 +184,25 @@ extern "C" int cpr_gn_bwd(const float* x, const float* dz, const float* a, const
                        accumulate);
     const long long total = (long long)N * HW * (C / 4);
     const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, x, dz, a, b, k2, k3, dx, N, HW, C / 4, G,
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<XB>, dim3(grid), dim3(256), 0, stream, x, dz, a, b, k2, k3, dx, dx16, N, HW, C / 4, G,
                        relu);
     CPR_LAUNCH_STATUS();
+}
+extern "C" int cpr_gn_bwd(const float* x, const float* dz, const float* a, const float* b, const float* mean,
+                          const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws_part,
+                          float* ws_k, int N, int HW, int C, int G, int P, int relu, int accumulate, hipStream_t stream) {
+    CPR_CHECK_ARG(dx);
+    return gn_bwd_launch<false>(x, dz, a, b, mean, rstd, gamma, dx, nullptr, dgamma, dbeta, ws_part, ws_k, N, HW, C, G, P, relu,
+                                accumulate, stream);
+}
+// The mixed-precision step's form: x is the bf16 recorded map; dx (fp32) and / or dx16 (its bf16 rounding) are written -- the same
+// values cpr_gn_bwd gives on the widened map, followed by a round-to-nearest-even narrowing.
+extern "C" int cpr_gn_bwd_bf16(const void* x_bf16, const float* dz, const float* a, const float* b, const float* mean,
+                               const float* rstd, const float* gamma, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
+                               float* ws_part, float* ws_k, int N, int HW, int C, int G, int P, int relu, int accumulate,
+                               hipStream_t stream) {
+    return gn_bwd_launch<true>(x_bf16, dz, a, b, mean, rstd, gamma, dx, (unsigned short*)dx_bf16, dgamma, dbeta, ws_part, ws_k, N,
+                               HW, C, G, P, relu, accumulate, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ FPN top-down add

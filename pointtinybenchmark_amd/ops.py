@@ -1011,10 +1011,12 @@ def conv2d_wgrad(dy, x, weight_shape, stride, padding, in_ab=None, in_relu=False
     return grad
 
 
-def gn_bwd(x, dz, a, b, mean, rstd, gamma, relu, dgamma=None, dbeta=None, slots=None, out_dgamma=None, out_dbeta=None):
+def gn_bwd(x, dz, a, b, mean, rstd, gamma, relu, dgamma=None, dbeta=None, slots=None, out_dgamma=None, out_dbeta=None,
+           want16=False, want32=True):
     """GroupNorm(+ReLU) backward -> (dx, dgamma, dbeta); accumulates into dgamma/dbeta when given, writes into
-    out_dgamma/out_dbeta when given."""
-    N, H, W, C = _check(x).shape
+    out_dgamma/out_dbeta when given.  x bf16 (the map the mixed-precision forward recorded): read as it is, and with want16 the
+    bf16 rounding of dx is written by the same pass -> (dx | None, dgamma, dbeta, dx16)."""
+    N, H, W, C = _check(x, ACT).shape
     HW, G = H * W, mean.shape[1]
     if slots is None:
         slots = max(1, min(256, HW // 256))
@@ -1022,9 +1024,18 @@ def gn_bwd(x, dz, a, b, mean, rstd, gamma, relu, dgamma=None, dbeta=None, slots=
     if not acc:
         dgamma = out_dgamma if out_dgamma is not None else torch.empty((C,), device=x.device, dtype=torch.float32)
         dbeta = out_dbeta if out_dbeta is not None else torch.empty((C,), device=x.device, dtype=torch.float32)
-    dx = torch.empty_like(x)
     ws_part = torch.empty((N * slots * C * 2,), device=x.device, dtype=torch.float32)
     ws_k = torch.empty((2 * N * G + 2 * N * C,), device=x.device, dtype=torch.float32)
+    if x.dtype == torch.bfloat16:
+        assert want16 or want32
+        dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32) if want32 else None
+        dx16 = torch.empty_like(x) if want16 else None
+        _lib.call('cpr_gn_bwd_bf16', _ptr(x), _ptr(_check(dz)), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(_check(gamma)),
+                  _ptr(dx), _ptr(dx16), _ptr(dgamma), _ptr(dbeta), _ptr(ws_part), _ptr(ws_k), N, HW, C, G, slots, int(relu),
+                  int(acc), _stream())
+        return dx, dgamma, dbeta, dx16
+    assert want32 and not want16
+    dx = torch.empty_like(x)
     _lib.call('cpr_gn_bwd', _ptr(x), _ptr(_check(dz)), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(_check(gamma)),
               _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws_part), _ptr(ws_k), N, HW, C, G, slots, int(relu), int(acc),
               _stream())

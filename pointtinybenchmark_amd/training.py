@@ -215,6 +215,10 @@ class StepLrSchedule:
         return reg * (1 - (1 - it / self.warmup_iters) * (1 - self.warmup_ratio))
 
 
+# mixed precision: dtype hand-offs fused into the producing kernels (CPR_MIXED_FUSED_CAST=0: the separate torch passes of rounds 3-4, A/B)
+FUSED_CAST = os.environ.get('CPR_MIXED_FUSED_CAST', '1') != '0'
+
+
 class BackwardEngine:
     """The backward rules of the recorded forward -- shared by ``CprTrainer`` (gradients written straight into the views of
     its flat buffer, bucketed reducer, native optimizer) and by the autograd bridge (``autograd_bridge.py``: the same rules
@@ -341,14 +345,23 @@ class BackwardEngine:
         cm = rec['module']
         w, gn = cm.conv.weight, cm.gn
         assert cm.conv.bias is None
-        draw, _, _ = ops.gn_bwd(self._f32(rec['raw']), dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
-                                out_dgamma=self._g(gn.weight), out_dbeta=self._g(gn.bias))
-        d16 = None             # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight and data gradients
+        # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight and data gradients
         dgrad16 = need_dx and rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and w.shape[0] % 64 == 0
-        if rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
-                rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0]):
+        wgrad16 = rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
+            rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0])
+        if rec['raw'].dtype == torch.bfloat16 and FUSED_CAST:
+            # the GroupNorm backward reads the bf16 recorded map as it is and writes the bf16 rounding of its result itself (and the
+            # fp32 map only when a fp32 kernel still reads it): no widening / narrowing passes around it
+            need32 = (not wgrad16) or (need_dx and not dgrad16)
+            draw, _, _, d16 = ops.gn_bwd(rec['raw'], dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
+                                         out_dgamma=self._g(gn.weight), out_dbeta=self._g(gn.bias),
+                                         want16=wgrad16 or dgrad16, want32=need32)
+        else:
+            draw, _, _ = ops.gn_bwd(self._f32(rec['raw']), dz, rec['a'], rec['b'], rec['mean'], rec['rstd'], gn.weight, relu,
+                                    out_dgamma=self._g(gn.weight), out_dbeta=self._g(gn.bias))
+            d16 = draw.to(torch.bfloat16) if wgrad16 else None
+        if wgrad16:
             x = rec['x']       # the weight gradient on the bf16 matrix pipe, straight from the recorded map
-            d16 = draw.to(torch.bfloat16)
             gw = self._g(w)
             self._param_side(lambda: ops.conv_wgrad_bf16(d16, x, w.shape, out=gw), d16, x)
         else:

@@ -156,6 +156,58 @@ def test_mixed_precision_step_tracks_the_fp32_step(name):
         assert p_.dtype == torch.float32 and torch.isfinite(p_).all(), k
 
 
+def test_gn_backward_reads_the_bf16_map_and_writes_its_own_bf16_rounding():
+    """cpr_gn_bwd_bf16 (round 5: the mixed-precision step's dtype hand-offs fused into the producing kernel): on a bf16 recorded
+    map it gives BIT for bit what cpr_gn_bwd gives on the widened map, and its bf16 output is torch's round-to-nearest-even
+    narrowing of that result -- with the fp32 output on or off."""
+    from pointtinybenchmark_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C, G = 3, 24, 40, 256, 32
+    x16 = (torch.randn((N, H, W, C), generator=g) * 2).bfloat16().cuda()
+    dz = torch.randn((N, H, W, C), generator=g).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = torch.randn(C, generator=g).cuda()
+    # the forward's statistics and affine straight from their definition (any consistent values serve this test)
+    xf = x16.float().view(N, H * W, G, C // G)
+    mean = xf.mean(dim=(1, 3)).contiguous()
+    rstd = (xf.var(dim=(1, 3), unbiased=False) + 1e-5).rsqrt().contiguous()
+    a = (rstd.repeat_interleave(C // G, dim=1) * gamma).contiguous()
+    b = (beta - mean.repeat_interleave(C // G, dim=1) * a).contiguous()
+    for relu in (False, True):
+        ref, dg_ref, db_ref = ops.gn_bwd(x16.float(), dz, a, b, mean, rstd, gamma, relu)
+        dx, dg, db, dx16 = ops.gn_bwd(x16, dz, a, b, mean, rstd, gamma, relu, want16=True, want32=True)
+        assert torch.equal(dx, ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+        assert dx16.dtype == torch.bfloat16 and torch.equal(dx16, ref.to(torch.bfloat16))
+        none32, _, _, only16 = ops.gn_bwd(x16, dz, a, b, mean, rstd, gamma, relu, want16=True, want32=False)
+        assert none32 is None and torch.equal(only16, dx16)
+
+
+@pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
+def test_mixed_precision_fused_casts_change_no_bit(name):
+    """The mixed-precision step with the dtype hand-offs fused into the GroupNorm backward (default) against the separate torch
+    passes of rounds 3-4 (training.FUSED_CAST = False): widening is exact and the narrowing is the same rounding, so losses and
+    every gradient must be BIT-equal."""
+    from pointtinybenchmark_amd import training
+    cfg = CPR_CASES[name]
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'],
+                                      cfg['seed'], cfg.get('ragged', False))
+    cb = to_cuda(batch)
+    runs = []
+    try:
+        for fused in (True, False):
+            training.FUSED_CAST = fused
+            m, _ = build_hip_locator(cfg)
+            m.set_compute_dtype('bf16')
+            tr = training.CprTrainer(m)
+            losses = tr.forward_backward(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+            torch.cuda.synchronize()
+            runs.append(({k: float(v) for k, v in losses.items()}, tr.flat_g.clone()))
+    finally:
+        training.FUSED_CAST = True
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]), 'fused casts changed %d gradient entries' % int((runs[0][1] != runs[1][1]).sum())
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 def test_two_stream_step_is_bit_repeatable_under_allocator_pressure(mode):
     """The parameter-gradient work runs on a side stream and reads maps the main stream frees right afterwards -- in the
