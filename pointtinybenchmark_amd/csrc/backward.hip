@@ -502,14 +502,20 @@ __device__ __forceinline__ float gfocal_dp(float p, float q, float eps) {
     return -(2.f * (p - q) * l2 + (p - q) * (p - q) * (q / (p + eps) - (1.f - q) / (1.f - p + eps)));
 }
 
-// one wave per bag: gradient of (pos_loss + gt_loss) wrt the sampled bag logits dbag (G,K,J)
+// gradient of (pos_loss + gt_loss) wrt the sampled bag logits dbag (G,K,J)
 //   P = sum_k s_k w_k, w_k = softmax_k(ins)*valid / sum;  dP/dcls_k = w_k s_k (1-s_k);  dP/dins_k = w_k (s_k - P)
+// CLS == false: one wave per bag, the classes one after the other.  CLS == true (round 5; C >= 8, e.g. the 80 classes of
+// BASELINE.json configs[2]: 0.92 ms per step on 48 workgroups there): one 8-wave workgroup per bag, wave w takes classes w, w + 8, ...
+// -- every class's lanes-over-the-bag passes and wave reductions are the same code, and a class owns its own columns of dbag:
+// BIT-identical outputs (the forward's mil_bag_cls_kernel makes the same split).
+template <bool CLS>
 __global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int ins_off,
                                     const unsigned char* __restrict__ valid, const int* __restrict__ labels,
                                     const float* __restrict__ gt_weight, const float* __restrict__ bag,
                                     float* __restrict__ dbag, int G, int K, int C, float eps, float w_mil, float w_gt,
                                     const float* __restrict__ up) {
-    __shared__ double red[2][4];
+    constexpr int NWV = CLS ? 8 : 4;
+    __shared__ double red[2][NWV];
     if (up) { w_gt *= up[0]; w_mil *= up[1]; }     // upstream gradients of gt_loss / pos_loss
     // num_sample / num_pos_gt: deterministic block-local recount of the forward's per-bag flags
     double ns = 0, ng = 0;
@@ -524,11 +530,16 @@ __global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int
         red[1][threadIdx.x >> 6] = ng;
     }
     __syncthreads();
-    const double num_sample = fmax(red[0][0] + red[0][1] + red[0][2] + red[0][3], 1.0);
-    const double num_pos_gt = fmax(red[1][0] + red[1][1] + red[1][2] + red[1][3], 1.0);
+    // (counts of bags held in double: exact however the partial sums are grouped, so the 4- and the 8-wave form agree)
+    double ns_t = 0, ng_t = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) { ns_t += red[0][w]; ng_t += red[1][w]; }
+    const double num_sample = fmax(ns_t, 1.0);
+    const double num_pos_gt = fmax(ng_t, 1.0);
     const float k_mil = (float)((double)w_mil / num_sample), k_gt = (float)((double)w_gt / num_pos_gt);
 
-    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const int g = CLS ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
     const int lane = threadIdx.x & 63;
     if (g >= G) return;
     const float* L = logits + (size_t)g * K * J;
@@ -536,7 +547,12 @@ __global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int
     const unsigned char* V = valid + (size_t)g * K;
     const int label = labels[g];
     const float wg = gt_weight ? gt_weight[g] : 1.f;
-    for (int i = lane; i < K * J; i += 64) D[i] = 0.f;
+    if (CLS) {
+        for (int i = threadIdx.x; i < K * J; i += 64 * NWV) D[i] = 0.f;
+        __syncthreads();             // (workgroup-scope release / acquire: the zero fill is ordered before the other waves' stores)
+    } else {
+        for (int i = lane; i < K * J; i += 64) D[i] = 0.f;
+    }
     float nvalid = 0.f;
     for (int k = lane; k < K; k += 64) nvalid += V[k] ? 1.f : 0.f;
     nvalid = wave_sum(nvalid);
@@ -544,7 +560,7 @@ __global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int
     const float gtv = V[K - 1] ? wg : 0.f;
     __builtin_amdgcn_s_waitcnt(0);   // the zero fill above is ordered before the accumulating stores (same lanes/addresses differ)
     __builtin_amdgcn_wave_barrier();
-    for (int c = 0; c < C; ++c) {
+    for (int c = CLS ? wave : 0; c < C; c += CLS ? NWV : 1) {
         float m = -INFINITY;
         for (int k = lane; k < K; k += 64) m = fmaxf(m, L[(size_t)k * J + ins_off + c]);
         m = wave_max(m);
@@ -596,14 +612,20 @@ __global__ void bag_loss_bwd_kernel(const float* __restrict__ logits, int J, int
 //   bag_window_add_kernel  one workgroup per image: adds the windows of the image's bags onto dmap bag after bag (barrier in
 //                          between: overlapping bags are summed in gt order).
 // The tap arithmetic is bag_sample's (grid_sample coordinate round trip, border clamp, align_corners = False).
+// (round 5) cap > 0: before the gather every window cell collects, once, the list of points whose 2 x 2 taps cover it (ascending k,
+// at most `cap`; a longer list falls back to the full walk) -- the (cell, channel) threads then walk ~5 points instead of all K.
+// With 80 classes (J = 160, K = 289 at radius 8: BASELINE.json configs[2]) the full walk was 16.7 M tap tests per bag, 4.3 ms per
+// step; same points in the same order, same arithmetic: bit-identical windows.
 __global__ void bag_window_kernel(const float* __restrict__ dbag, int J, const float* __restrict__ ctr,
                                   const float* __restrict__ offs, float* __restrict__ win, int* __restrict__ win_org, int WIN,
-                                  int K, int H, int W, float stride) {
+                                  int K, int H, int W, float stride, int cap) {
     extern __shared__ unsigned char smem_raw[];
     int* tx0 = reinterpret_cast<int*>(smem_raw);                 // [K] tap cell x0
     int* ty0 = tx0 + K;                                           // [K] tap cell y0
     float* tww = reinterpret_cast<float*>(ty0 + K);               // [K] weight of x0 + 1
     float* twn = tww + K;                                         // [K] weight of y0 + 1
+    int* hcnt = reinterpret_cast<int*>(twn + K);                  // [WIN * WIN] points covering the cell (cap > 0)
+    unsigned short* hits = reinterpret_cast<unsigned short*>(hcnt + WIN * WIN);   // [WIN * WIN][cap]
     __shared__ int org[2];
     const int g = blockIdx.x;
     if (threadIdx.x == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
@@ -630,6 +652,20 @@ __global__ void bag_window_kernel(const float* __restrict__ dbag, int J, const f
     __syncthreads();
     const int ox = org[0], oy = org[1];
     if (threadIdx.x == 0) { win_org[g * 2] = ox; win_org[g * 2 + 1] = oy; }
+    if (cap > 0) {
+        for (int cell = threadIdx.x; cell < WIN * WIN; cell += blockDim.x) {
+            const int x = ox + cell % WIN, y = oy + cell / WIN;
+            int n = 0;
+            for (int k = 0; k < K; ++k) {
+                const unsigned dx = (unsigned)(x - tx0[k]), dy = (unsigned)(y - ty0[k]);
+                if (dx > 1u || dy > 1u) continue;
+                if (n < cap) hits[cell * cap + n] = (unsigned short)k;
+                ++n;
+            }
+            hcnt[cell] = n;
+        }
+        __syncthreads();
+    }
     const float* D = dbag + (size_t)g * K * J;
     float* Wg = win + (size_t)g * WIN * WIN * J;
     const int total = WIN * WIN * J;
@@ -638,7 +674,10 @@ __global__ void bag_window_kernel(const float* __restrict__ dbag, int J, const f
         const int x = ox + cell % WIN, y = oy + cell / WIN;
         float acc = 0.f;
         if (x < W && y < H) {
-            for (int k = 0; k < K; ++k) {
+            const int n = cap > 0 ? hcnt[cell] : K;
+            const bool listed = cap > 0 && n <= cap;
+            for (int t = 0; t < (listed ? n : K); ++t) {
+                const int k = listed ? (int)hits[cell * cap + t] : t;
                 const unsigned dx = (unsigned)(x - tx0[k]), dy = (unsigned)(y - ty0[k]);
                 if (dx > 1u || dy > 1u) continue;
                 const float d = D[(size_t)k * J + j];
@@ -651,10 +690,14 @@ __global__ void bag_window_kernel(const float* __restrict__ dbag, int J, const f
         Wg[i] = acc;
     }
 }
+// (round 5: blockIdx.y takes a slice of BWA_SLICE channels -- with 160 logit channels five times the workgroups per image; an
+// output element still meets its bags in gt order)
+#define BWA_SLICE 32
 __global__ void __launch_bounds__(1024) bag_window_add_kernel(const float* __restrict__ win, const int* __restrict__ win_org, int WIN, int J,
                                       const int* __restrict__ gt_img, float* __restrict__ dmap, int Jd, int G, int H, int W) {
     __shared__ int range[2];
     const int n = blockIdx.x;
+    const int j0 = blockIdx.y * BWA_SLICE, jn = min(BWA_SLICE, J - j0);
     if (threadIdx.x == 0) {        // the bags of image n (gt_img ascends: CSR order)
         int lo = 0;
         while (lo < G && gt_img[lo] < n) ++lo;
@@ -666,18 +709,32 @@ __global__ void __launch_bounds__(1024) bag_window_add_kernel(const float* __res
     __syncthreads();
     const int lo = range[0], hi = range[1];
     float* base = dmap + (size_t)n * H * W * Jd;
-    const int total = WIN * WIN * J;
+    const int total = WIN * WIN * jn;
     for (int g = lo; g < hi; ++g) {
         const int ox = win_org[g * 2], oy = win_org[g * 2 + 1];
-        const float* Wg = win + (size_t)g * total;
+        const float* Wg = win + (size_t)g * WIN * WIN * J;
         for (int i = threadIdx.x; i < total; i += blockDim.x) {
-            const int j = i % J, cell = i / J;
+            const int j = j0 + i % jn, cell = i / jn;
             const int x = ox + cell % WIN, y = oy + cell / WIN;
-            const float v = Wg[i];
+            const float v = Wg[(size_t)cell * J + j];
             if (v != 0.f && x < W && y < H) base[((size_t)y * W + x) * Jd + j] += v;
         }
         __syncthreads();           // the next bag may touch the same cells (workgroup-scope fence + barrier)
     }
+}
+
+// the two launches of the window gather.  Hit lists (16 per cell) when they fit beside the taps in 60 KB of LDS and the bag is long
+// enough to pay for building them; the add kernel over 32-channel slices.
+static void bag_gather_launch(const float* dsample, int J, const float* centers, const int* gt_img, const float* offsets,
+                              float* win_ws, int* win_org, int win, float* dmap, int N, int H, int W, int Jd, int G, int K,
+                              float stride, hipStream_t stream) {
+    const size_t taps = (size_t)K * 16, lists = (size_t)win * win * (4 + 16 * 2);
+    const int cap = (K >= 32 && K <= 65535 && taps + lists <= 60000) ? 16 : 0;
+    hipLaunchKernelGGL(bag_window_kernel, dim3(G), dim3(256), taps + (cap ? lists : 0), stream, dsample, J, centers, offsets, win_ws,
+                       win_org, win, K, H, W, stride, cap);
+    const int slice = J < BWA_SLICE ? J : BWA_SLICE;
+    hipLaunchKernelGGL(bag_window_add_kernel, dim3(N, cdiv(J, BWA_SLICE)), dim3(win * win * slice >= 4096 ? 1024 : 256), 0, stream,
+                       win_ws, win_org, win, J, gt_img, dmap, Jd, G, H, W);
 }
 
 extern "C" int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, const float* out5, const float* bag_logits,
@@ -693,13 +750,14 @@ extern "C" int cpr_loss_bwd(const float* lmap, const unsigned char* neg_mask, co
     const int grid = (int)(cdivll(NP * Jd, 256) < 32768 ? cdivll(NP * Jd, 256) : 32768);
     hipLaunchKernelGGL(neg_loss_bwd_kernel, dim3(grid), dim3(256), 0, stream, lmap, neg_mask, out5, dmap, NP, J, Jd, C,
                        eps, w_neg, upstream);
-    hipLaunchKernelGGL(bag_loss_bwd_kernel, dim3(cdiv(G, 4)), dim3(256), 0, stream, bag_logits, J, ins_off, valid, labels,
-                       gt_weight, bag_ws, dbag_ws, G, K, C, eps, w_mil, w_gt, upstream);
+    if (C >= 8)       // many classes: one workgroup per bag, the classes over its eight waves (bit-identical)
+        hipLaunchKernelGGL(bag_loss_bwd_kernel<true>, dim3(G), dim3(512), 0, stream, bag_logits, J, ins_off, valid, labels,
+                           gt_weight, bag_ws, dbag_ws, G, K, C, eps, w_mil, w_gt, upstream);
+    else
+        hipLaunchKernelGGL(bag_loss_bwd_kernel<false>, dim3(cdiv(G, 4)), dim3(256), 0, stream, bag_logits, J, ins_off, valid, labels,
+                           gt_weight, bag_ws, dbag_ws, G, K, C, eps, w_mil, w_gt, upstream);
     if (win == 0) { CPR_LAUNCH_STATUS(); }     // the bag logits were not sampled from the map (num_cls_fcs > 0): dbag_ws is the result
-    hipLaunchKernelGGL(bag_window_kernel, dim3(G), dim3(256), (size_t)K * 16, stream, dbag_ws, J, centers, offsets, win_ws,
-                       win_org, win, K, H, W, stride);
-    hipLaunchKernelGGL(bag_window_add_kernel, dim3(N), dim3(win * win * J >= 4096 ? 1024 : 256), 0, stream, win_ws, win_org,
-                       win, J, gt_img, dmap, Jd, G, H, W);
+    bag_gather_launch(dbag_ws, J, centers, gt_img, offsets, win_ws, win_org, win, dmap, N, H, W, Jd, G, K, stride, stream);
     CPR_LAUNCH_STATUS();
 }
 
@@ -712,10 +770,7 @@ extern "C" int cpr_bag_gather_bwd(const float* dsample, int J, const float* cent
                                   float stride, hipStream_t stream) {
     CPR_CHECK_ARG(dsample && centers && gt_img && win_ws && win_org && dmap && win >= 3 && (size_t)K * 16 <= 60000);
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && G > 0 && K > 0 && J > 0 && Jd >= J && (K == 1 || offsets));
-    hipLaunchKernelGGL(bag_window_kernel, dim3(G), dim3(256), (size_t)K * 16, stream, dsample, J, centers, offsets, win_ws,
-                       win_org, win, K, H, W, stride);
-    hipLaunchKernelGGL(bag_window_add_kernel, dim3(N), dim3(win * win * J >= 4096 ? 1024 : 256), 0, stream, win_ws, win_org,
-                       win, J, gt_img, dmap, Jd, G, H, W);
+    bag_gather_launch(dsample, J, centers, gt_img, offsets, win_ws, win_org, win, dmap, N, H, W, Jd, G, K, stride, stream);
     CPR_LAUNCH_STATUS();
 }
 
