@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before the HIP runtime initialises: see pointtinybenchmark_amd/__init__.py
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -233,6 +233,7 @@ class BackwardEngine:
         self._sink = None                       # None: p.grad (CprTrainer); dict: id(p) -> fresh tensor (autograd bridge)
         # weight gradients run on a second stream: they are off the critical path (nothing downstream of the backward
         # chain reads them) and the deep layers' launches are too small to fill 256 CUs on their own
+        # (the two streams only overlap when they sit on different HARDWARE queues: see GPU_MAX_HW_QUEUES in __init__.py)
         self.side = torch.cuda.Stream(device=dev) if two_streams and dev.type == 'cuda' else None
 
     def _g(self, p):
@@ -741,6 +742,7 @@ class CprTrainer(BackwardEngine):
         self.flat_p = torch.empty((n,), device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros((n,), device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros((n,), device=dev, dtype=torch.float32)
+        self._launch = None      # stream the gradient collectives are issued from (two-stream backward on a device)
         self.offset, off = {}, 0
         for p in order:
             k = p.numel()
@@ -826,7 +828,17 @@ class CprTrainer(BackwardEngine):
         """The gradient of ``p`` (and of everything before it in the flat order) has been enqueued."""
         end = self.offset[id(p)][1]
         if self.side is not None and self.buckets.would_launch(end):
-            torch.cuda.current_stream().wait_stream(self.side)      # the collective must see the side stream's grads
+            # The collective must see the gradients both streams wrote.  The process group orders its own stream behind the
+            # stream that is current when the collective is issued: issue it from a third stream that waits for the two, so
+            # NEITHER compute stream stalls (until round 5 the main stream waited for the side stream here, 20-37 times per
+            # backward, i.e. the data-gradient chain could idle behind the weight gradients at every bucket boundary).
+            if self._launch is None:
+                self._launch = torch.cuda.Stream(device=self.flat_g.device)
+            self._launch.wait_stream(torch.cuda.current_stream())
+            self._launch.wait_stream(self.side)
+            with torch.cuda.stream(self._launch):
+                self.buckets.ready(end)
+            return
         self.buckets.ready(end)
 
     # ------------------------------------------------------------------ forward (recorded) + backward

@@ -576,3 +576,17 @@ def test_loss_backward_dispatch_per_option_set():
         bags, centres, labels, _ = head._loss_geometry(gts, view, None, torch.device('cpu'))
         assert labels.numel() == bags[0] and bags[0] * bags[1] == G * view[0] * view[1], (name, bags, view)
         assert head._loss_backward_general(R, bags, centres) == want, (name, bags, centres)
+
+
+def test_package_asks_for_enough_hardware_queues():
+    """RCCL's queues exhaust the HIP runtime's default of 4 hardware queues and the two-stream backward then serialises on one
+    (pointtinybenchmark_amd/__init__.py: measured 119 vs 138 img/s on the configs[4] training line under torchrun): importing
+    the package -- and bench.py, before it imports torch -- must leave GPU_MAX_HW_QUEUES set, without overriding a caller's choice."""
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import pointtinybenchmark_amd; "
+            "print(os.environ['GPU_MAX_HW_QUEUES']); os.environ['GPU_MAX_HW_QUEUES'] = '12'; import importlib; "
+            "importlib.reload(pointtinybenchmark_amd); print(os.environ['GPU_MAX_HW_QUEUES'])" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.split() == ['8', '12'], out.stdout
+    head = open(os.path.join(ROOT, 'bench.py')).read().split('import torch')[0]
+    assert "setdefault('GPU_MAX_HW_QUEUES'" in head
