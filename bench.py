@@ -943,6 +943,7 @@ def main():
                         opt.step()
                         return o
                     autograd_step()
+                    autograd_step()       # two untimed steps (allocator growth of torch's own optimizer state and clip buffers)
                     barrier()
                     t1 = time.perf_counter()
                     for _ in range(args.train_steps):
