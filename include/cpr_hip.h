@@ -416,6 +416,11 @@ int cpr_loss_bwd_general(const float* lmap, const unsigned char* neg_mask, const
  * the folded BatchNorm scale of the forward conv).  colsp = padded column count (4 for <= 4 channels). */
 int cpr_pack_weights(const float* w, const float* scale, float* out, int O, int I, int KH, int KW, int colsp, int Kpad,
                      int transpose, void* stream);
+/* The same packs for the bf16 conv kernels: out [rows][KH][KW][cols] bf16 (cols even, no padding), each element the
+ * round-to-nearest-even of the fp32 value cpr_pack_weights would write; frag (NULL or rows % 64 == 0, KH*KW*cols % 16 == 0): the
+ * same values in the fragment order cpr_conv2d_fwd_bf16's wgt_frag documents.  One launch per layer. */
+int cpr_pack_weights_bf16(const float* w, const float* scale, void* out, void* frag, int O, int I, int KH, int KW, int transpose,
+                          void* stream);
 /* eval-mode BatchNorm (resnet.py norm_eval) -> conv-epilogue affine: scale = gamma/sqrt(var+eps), shift = beta - mean*scale,
  * inv_sigma (optional) = 1/sqrt(var+eps) */
 int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,

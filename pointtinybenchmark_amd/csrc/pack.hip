@@ -38,6 +38,53 @@ extern "C" int cpr_pack_weights(const float* w, const float* scale, float* out, 
     CPR_LAUNCH_STATUS();
 }
 
+// The same two packs for the bf16 kernels (round 5): out[rows][KH][KW][cols] bf16 (no padding: cols % 64 == 0), rounded to nearest
+// even from the fp32 value (scale multiplied in fp32 first) -- bit for bit what `w.permute(..).reshape(..).to(torch.bfloat16)`
+// gave in three torch launches per layer -- and, when frag != NULL (rows % 64 == 0, K % 16 == 0), the fragment-order image of
+// conv_bf16_dma_kernel<4, 2, 4, true> by the same thread: frag[rows / 64][K / 16][j][h][l][8] = out[64 g + 2 l + j][16 ks + 8 h ..].
+// The mixed-precision step re-packs every bf16 layer after each optimizer update: ~330 tiny launches per configs[4] step before.
+typedef __attribute__((ext_vector_type(2))) __bf16 pk_bf16x2_t;
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                         unsigned short* __restrict__ out, unsigned short* __restrict__ frag, int O, int I, int KH,
+                                         int KW, int transpose) {
+    const int rows = transpose ? I : O, cols = transpose ? O : I;
+    const int K = KH * KW * cols, KS = K >> 4;
+    const long long total = (long long)rows * (K >> 1);          // two consecutive k per thread (cols is even)
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / (K >> 1));
+        const int k = (int)(idx - (long long)r * (K >> 1)) * 2;
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = (k + u) % cols;
+            const int t = (k + u) / cols;
+            const int kw = t % KW, kh = t / KW;
+            v[u] = transpose ? w[(((size_t)c * I + r) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)] * (scale ? scale[c] : 1.f)
+                             : w[(((size_t)r * I + c) * KH + kh) * KW + kw];
+        }
+        const pk_bf16x2_t p = {(__bf16)v[0], (__bf16)v[1]};
+        const unsigned bits = __builtin_bit_cast(unsigned, p);
+        *reinterpret_cast<unsigned*>(out + (size_t)r * K + k) = bits;
+        if (frag) {
+            const int g = r >> 6, l = (r & 63) >> 1, j = r & 1;
+            const int ks = k >> 4, h = (k >> 3) & 1, e = k & 7;
+            *reinterpret_cast<unsigned*>(frag + ((((((size_t)g * KS + ks) * 2 + j) * 2 + h) * 32 + l) << 3) + e) = bits;
+        }
+    }
+}
+extern "C" int cpr_pack_weights_bf16(const float* w, const float* scale, void* out, void* frag, int O, int I, int KH, int KW,
+                                     int transpose, hipStream_t stream) {
+    CPR_CHECK_ARG(w && out && O > 0 && I > 0 && KH > 0 && KW > 0);
+    const int rows = transpose ? I : O, cols = transpose ? O : I;
+    CPR_CHECK_ARG(cols % 2 == 0 && (!frag || (rows % 64 == 0 && (KH * KW * cols) % 16 == 0)));
+    const long long total = (long long)rows * (KH * KW * cols / 2);
+    const int grid = (int)(cdivll(total, 256) < 4096 ? cdivll(total, 256) : 4096);
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(grid), dim3(256), 0, stream, w, scale, (unsigned short*)out,
+                       (unsigned short*)frag, O, I, KH, KW, transpose);
+    CPR_LAUNCH_STATUS();
+}
+
 // eval-mode BatchNorm folded for the conv epilogue: inv_sigma = 1/sqrt(var+eps), scale = gamma*inv_sigma,
 // shift = beta - mean*scale (same operation order as the torch expression it replaces: layers.folded_bn)
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,

@@ -86,9 +86,12 @@ class PackedConv:
         if dtype == torch.bfloat16:
             # bf16 kernel: K chunks of 64 elements, no stem mode (the 3-channel stem stays on the fp32 kernel)
             assert Cin % 64 == 0, 'bf16 conv needs Cin % 64 == 0'
-            self.w = w.reshape(Cout, KH * KW * Cin).to(torch.bfloat16).contiguous()
             self.Cout, self.Cin, self.KH, self.KW, self.Kpad = Cout, Cin, KH, KW, KH * KW * Cin
             self.stride, self.padding = stride, padding
+            if weight.is_cuda and PACK_BF16_KERNEL[0]:
+                self._pack_bf16(weight, None, 0)      # one launch: the [Cout][K] image and, where it is used, the fragment image
+                return
+            self.w = w.reshape(Cout, KH * KW * Cin).to(torch.bfloat16).contiguous()
             return
         if Cin <= 4:
             cin_p = 4
@@ -112,6 +115,36 @@ class PackedConv:
         packed = torch.zeros((Cout, Kpad), device=weight.device, dtype=torch.float32)
         packed[:, :K] = wp.reshape(Cout, K)
         self.w = packed.contiguous()
+
+    def _pack_bf16(self, weight, scale, transpose):
+        """csrc/pack.hip, cpr_pack_weights_bf16: OIHW fp32 master -> self.w (bf16 [rows][K]) and, for rows % 256 == 0, self.wfrag.
+        transpose: the data-gradient pack (rows = input channels, taps flipped, ``scale`` of the forward conv folded in)."""
+        src = weight.detach()
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        O, I, KH, KW = src.shape
+        rows = self.Cout
+        self.w = torch.empty((rows, self.Kpad), device=src.device, dtype=torch.bfloat16)
+        want_frag = rows % 256 == 0 and self.Kpad % 64 == 0 and WFRAG[0]
+        if want_frag:
+            self.wfrag = torch.empty((rows // 64, self.Kpad // 16, 2, 2, 32, 8), device=src.device, dtype=torch.bfloat16)
+        _lib.call('cpr_pack_weights_bf16', _ptr(src), _ptr(scale), _ptr(self.w), _ptr(self.wfrag if want_frag else None), O, I, KH, KW,
+                  int(transpose), _stream())
+        self._packed()
+
+    @classmethod
+    def for_dgrad_bf16(cls, weight, padding, scale=None):
+        """The bf16 pack of the stride-1 conv over dy that yields the data gradient of a stride-1 conv (mixed-precision step): in / out
+        channels swapped, taps flipped, the forward conv's folded-BN ``scale`` multiplied in (fp32) before the rounding, padding
+        K-1-p.  The same bits as PackedConv((w * scale).flip(2, 3).permute(1, 0, 2, 3), 1, K-1-p, bf16), one launch."""
+        Cout, Cin, KH, KW = weight.shape
+        assert KH == KW and weight.is_cuda and Cout % 64 == 0
+        self = cls.__new__(cls)
+        self.dtype = torch.bfloat16
+        self.Cout, self.Cin, self.KH, self.KW, self.Kpad = Cin, Cout, KH, KW, KH * KW * Cout
+        self.stride, self.padding = 1, KH - 1 - padding
+        self._pack_bf16(weight, scale, 1)
+        return self
 
     def frag_image(self):
         """bf16 weights in the fragment order of conv_bf16_dma_kernel<4, 2, 4, true> (include/cpr_hip.h, cpr_conv2d_fwd_bf16):
@@ -157,6 +190,8 @@ CONV_RELU, CONV_OUT_BF16, CONV_RES_MASK, CONV_COLSUM = 1, 2, 4, 8      # include
 # bf16 mode: hand the fragment-order weight image to the conv launcher (the 256 x 256 tile then loads its weight operand
 # straight into registers, csrc/conv_bf16_dma.hip BD instance).  CPR_BF16_WFRAG=0 keeps both operands on the LDS-DMA path (A/B).
 WFRAG = [os.environ.get('CPR_BF16_WFRAG', '1') != '0']
+# bf16 weight packs by one HIP launch per layer (csrc/pack.hip); CPR_PACK_BF16_KERNEL=0: the torch expression of rounds 3-4 (A/B, tests)
+PACK_BF16_KERNEL = [os.environ.get('CPR_PACK_BF16_KERNEL', '1') != '0']
 # profilers (bench.py) set [0] = True; the template instance of the last conv launch is then left in [1] as
 # (kind, code).  Host-side, single-threaded bookkeeping of a value the C ABI returns through an out-parameter.
 TRACE_CONV_VARIANT = [False, None]

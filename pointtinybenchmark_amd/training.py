@@ -382,9 +382,12 @@ class BackwardEngine:
         """Mixed precision: the data gradient of a stride-1 conv on the bf16 matrix pipe -- a forward conv of the bf16-rounded
         gradient map with the rotated weights (channels swapped, taps flipped, padding K-1-p), fp32 out.  The weight gradient
         next to it keeps reading the fp32 map."""
-        k = w.shape[2]
-        wt = w.detach().flip(2, 3).permute(1, 0, 2, 3)
-        pc = ops.PackedConv(wt, 1, k - 1 - padding, torch.bfloat16)
+        if ops.PACK_BF16_KERNEL[0]:
+            pc = ops.PackedConv.for_dgrad_bf16(w, padding)
+        else:
+            k = w.shape[2]
+            wt = w.detach().flip(2, 3).permute(1, 0, 2, 3)
+            pc = ops.PackedConv(wt, 1, k - 1 - padding, torch.bfloat16)
         return ops.conv2d(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), pc, out_dtype=torch.float32)
 
     # ------------------------------------------------------------------ CPR head
@@ -672,6 +675,8 @@ class BackwardEngine:
             # mixed precision: the 3x3 data gradient on the bf16 matrix pipe (its fp32 form cannot be a Winograd launch: the mask /
             # column-sum epilogue), the ReLU mask and the column sums as one streaming pass over the (small) result
             def pack16():
+                if ops.PACK_BF16_KERNEL[0]:
+                    return ops.PackedConv.for_dgrad_bf16(w, conv.padding[0], scale=scale)
                 wt = (w.detach() * scale[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3)
                 return ops.PackedConv(wt, 1, 2 - conv.padding[0], torch.bfloat16)
             pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16)

@@ -310,3 +310,39 @@ def test_conv_wgrad_bf16_head_layer_shape_vs_fp32_kernel():
     torch.cuda.synchronize()
     rel = float((got - ref).norm() / ref.norm())
     assert rel <= 1e-2, rel
+
+
+@pytest.mark.parametrize('shape', [(256, 256, 3), (512, 128, 1), (64, 64, 3), (1024, 256, 1)])
+def test_bf16_weight_pack_kernel_equals_the_torch_expression(shape):
+    """csrc/pack.hip cpr_pack_weights_bf16 (round 5: one launch per layer instead of three torch launches; the mixed-precision step
+    re-packs every bf16 layer after each optimizer update): the [Cout][K] image, the fragment-order image and the data-gradient
+    pack (channels swapped, taps flipped, folded-BN scale multiplied in fp32 before the rounding) must be the torch expressions'
+    bits."""
+    from pointtinybenchmark_amd import ops
+    Cout, Cin, k = shape
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn((Cout, Cin, k, k), generator=g) * 0.05).cuda()
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    assert ops.PACK_BF16_KERNEL[0]
+    pc = ops.PackedConv(w, 1, k // 2, torch.bfloat16)
+    ref = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).to(torch.bfloat16).contiguous()
+    assert pc.w.dtype == torch.bfloat16 and torch.equal(pc.w, ref)
+    if Cout % 256 == 0:
+        G, KS = Cout // 64, k * k * Cin // 16
+        assert pc.wfrag is not None and torch.equal(pc.frag_image().reshape(-1),
+                                                    ref.view(G, 32, 2, KS, 2, 8).permute(0, 3, 2, 4, 1, 5).reshape(-1))
+    else:
+        assert pc.frag_image() is None
+    for sc in (None, scale):
+        pd = ops.PackedConv.for_dgrad_bf16(w, k // 2, scale=sc)
+        ws = w if sc is None else w * sc[:, None, None, None]
+        wt = ws.flip(2, 3).permute(1, 0, 2, 3)
+        ops.PACK_BF16_KERNEL[0] = False
+        try:
+            old = ops.PackedConv(wt, 1, k - 1 - k // 2, torch.bfloat16)
+        finally:
+            ops.PACK_BF16_KERNEL[0] = True
+        assert (pd.Cout, pd.Cin, pd.KH, pd.Kpad, pd.padding) == (old.Cout, old.Cin, old.KH, old.Kpad, old.padding)
+        assert torch.equal(pd.w, old.w)
+        fo = old.frag_image()
+        assert (fo is None) == (pd.frag_image() is None) and (fo is None or torch.equal(pd.frag_image().reshape(-1), fo.reshape(-1)))
