@@ -421,6 +421,9 @@ int cpr_pack_weights(const float* w, const float* scale, float* out, int O, int 
  * same values in the fragment order cpr_conv2d_fwd_bf16's wgt_frag documents.  One launch per layer. */
 int cpr_pack_weights_bf16(const float* w, const float* scale, void* out, void* frag, int O, int I, int KH, int KW, int transpose,
                           void* stream);
+/* One idle wave for `ticks` of the 100 MHz wall clock (<= 1 s) on `stream`: a probe for whether two streams share a hardware queue
+ * (the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES queues; two of these launches on one queue run back to back). */
+int cpr_spin(long long ticks, void* stream);
 /* eval-mode BatchNorm (resnet.py norm_eval) -> conv-epilogue affine: scale = gamma/sqrt(var+eps), shift = beta - mean*scale,
  * inv_sigma (optional) = 1/sqrt(var+eps) */
 int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,

@@ -85,6 +85,7 @@ SIGNATURES = {
     'cpr_clip_flip_boxes': [_p, _p, _p, _p, _i, _i, _p],
     'cpr_pack_weights': [_p, _p, _p] + [_i] * 7 + [_p],
     'cpr_pack_weights_bf16': [_p, _p, _p, _p] + [_i] * 5 + [_p],
+    'cpr_spin': [ctypes.c_longlong, _p],
     'cpr_bn_fold': [_p, _p, _p, _p, _f, _p, _p, _p, _i, _p],
     'cpr_p2p_loss_bwd': [_p] * 9 + [_i] * 5 + [_f] * 9 + [_p, _p],
     'cpr_grad_sumsq': [_p, _l, _p, _p, _i, _p],

@@ -85,6 +85,18 @@ extern "C" int cpr_pack_weights_bf16(const float* w, const float* scale, void* o
     CPR_LAUNCH_STATUS();
 }
 
+// One wave that does nothing for `ticks` of the 100 MHz wall clock: the probe training.BackwardEngine uses to find a second stream
+// that sits on a different HARDWARE queue than the caller's (two of these on one queue take twice as long as on two).
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int cpr_spin(long long ticks, hipStream_t stream) {
+    CPR_CHECK_ARG(ticks > 0 && ticks <= 100000000ll);        // at most a second
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
+    CPR_LAUNCH_STATUS();
+}
+
 // eval-mode BatchNorm folded for the conv epilogue: inv_sigma = 1/sqrt(var+eps), scale = gamma*inv_sigma,
 // shift = beta - mean*scale (same operation order as the torch expression it replaces: layers.folded_bn)
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,

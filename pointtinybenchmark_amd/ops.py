@@ -1115,6 +1115,35 @@ def bn_fold_bwd(Gw, weight, scale, mean, inv_sigma, colsum_g, want_affine=True, 
     return dg, db
 
 
+def concurrent_stream(device, tries=8, spin_us=150.0):
+    """A new torch stream that runs CONCURRENTLY with the current one, i.e. sits on another hardware queue.  The HIP runtime
+    multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, so a fresh stream shares the current stream's queue
+    with probability 1 / queues (and always, once RCCL has taken the queues: pointtinybenchmark_amd/__init__.py) -- work on it
+    then simply runs after the current stream's.  Probe: one idle wave of ``spin_us`` on each of the two streams (csrc/pack.hip,
+    cpr_spin); together they take ~spin_us on two queues and ~2 spin_us on one.  -> (stream, concurrent: bool); after ``tries``
+    shared candidates the last one is returned with concurrent = False."""
+    cur = torch.cuda.current_stream(device)
+    ticks = int(spin_us * 100)                                    # 100 MHz wall clock
+    s, ok = None, False
+    for _ in range(tries):
+        s = torch.cuda.Stream(device=device)
+        _lib.call('cpr_spin', 1, s.cuda_stream)                    # first use of a stream creates its queue: keep that out of the timing
+        _lib.call('cpr_spin', 1, cur.cuda_stream)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        s.wait_stream(cur)                                         # both spins start after e0
+        _lib.call('cpr_spin', ticks, cur.cuda_stream)
+        _lib.call('cpr_spin', ticks, s.cuda_stream)
+        cur.wait_stream(s)
+        e1.record(cur)
+        e1.synchronize()
+        if e0.elapsed_time(e1) * 1e3 < 1.6 * spin_us:
+            ok = True
+            break
+    return s, ok
+
+
 def axpby(y, x, alpha=1.0, beta=1.0):
     assert y.numel() == x.numel()
     _lib.call('cpr_axpby', _ptr(_check(y)), _ptr(_check(x)), float(alpha), float(beta), y.numel(), _stream())

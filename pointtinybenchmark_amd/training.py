@@ -12,6 +12,7 @@ flat buffers of the same layout.  Buckets are contiguous ranges of the gradient 
 soon as its last gradient has been enqueued, overlapping with the rest of the backward; the optimizer is one kernel over
 the flat buffers (the clip coefficient is read from the device, no host sync)."""
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -233,8 +234,14 @@ class BackwardEngine:
         self._sink = None                       # None: p.grad (CprTrainer); dict: id(p) -> fresh tensor (autograd bridge)
         # weight gradients run on a second stream: they are off the critical path (nothing downstream of the backward
         # chain reads them) and the deep layers' launches are too small to fill 256 CUs on their own
-        # (the two streams only overlap when they sit on different HARDWARE queues: see GPU_MAX_HW_QUEUES in __init__.py)
-        self.side = torch.cuda.Stream(device=dev) if two_streams and dev.type == 'cuda' else None
+        # The two streams only overlap when they sit on different HARDWARE queues (__init__.py: GPU_MAX_HW_QUEUES): the side stream
+        # is chosen by a probe (ops.concurrent_stream), not by luck of the stream pool -- a shared queue costs 2 .. 15 % of a step.
+        self.side = None
+        if two_streams and dev.type == 'cuda':
+            self.side, concurrent = ops.concurrent_stream(dev)
+            if not concurrent:
+                warnings.warn('no hardware queue left for the weight-gradient stream: the backward runs on one queue '
+                              '(export GPU_MAX_HW_QUEUES=8 before the process touches the device; RCCL takes several queues)')
 
     def _g(self, p):
         """Where the gradient of ``p`` is written."""

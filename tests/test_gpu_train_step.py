@@ -436,3 +436,28 @@ def test_two_ranks_on_the_gpu_equal_the_averaged_single_process_step(tmp_path, r
     for a, b in zip(res[0]['losses'], mean_losses):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (res[0]['losses'], mean_losses)
 
+
+
+def test_side_stream_is_chosen_on_its_own_hardware_queue():
+    """ops.concurrent_stream (round 5): the backward's second stream must sit on another hardware queue than the caller's -- the
+    probe's own criterion re-measured here: an idle wave on each of the two streams finishes in about the time of one."""
+    from pointtinybenchmark_amd import _lib, ops
+    dev = torch.device('cuda', torch.cuda.current_device())
+    s, ok = ops.concurrent_stream(dev)
+    assert ok, 'no concurrent stream found (GPU_MAX_HW_QUEUES=%s)' % os.environ.get('GPU_MAX_HW_QUEUES')
+    cur = torch.cuda.current_stream()
+    times = []
+    for both in (False, True):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        s.wait_stream(cur)
+        _lib.call('cpr_spin', 30000, cur.cuda_stream)              # 300 us
+        if both:
+            _lib.call('cpr_spin', 30000, s.cuda_stream)
+        cur.wait_stream(s)
+        e1.record(cur)
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1))
+    assert 0.25 <= times[0] <= 0.6, times                          # the spin is what it says (ms)
+    assert times[1] <= 1.5 * times[0], 'the two streams ran back to back: %s' % times
