@@ -9,8 +9,9 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcprhip.so')
-SOURCES = ['conv_mfma.hip', 'conv1x1_stream.hip', 'conv_mfma_bf16.hip', 'conv_bf16_dma.hip', 'stem_bf16.hip', 'stem_f32.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad.hip', 'norm_pool.hip', 'cpr_points.hip', 'assign.hip',
+SOURCES = ['conv_mfma.hip', 'conv1x1_stream.hip', 'conv_mfma_bf16.hip', 'conv_bf16_dma.hip', 'conv_bf16_pp.hip', 'stem_bf16.hip', 'stem_f32.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad.hip', 'norm_pool.hip', 'cpr_points.hip', 'assign.hip',
            'postproc.hip', 'backward.hip', 'preprocess.hip', 'pack.hip', 'project.hip', 'conv_wino.hip', 'conv_wino32.hip', 'conv_wino_wgrad.hip']
+HEADERS = ['common.h', 'conv_bf16_dma.h']
 # Kernels whose integer / mask / index outputs are held bit-exact against the reference's CPU arithmetic restate it
 # operation by operation.  hipcc's default -ffp-contract=fast fuses a*b+c into one fma EVEN ACROSS the __fmul_rn/__fadd_rn
 # intrinsics (plain operators in the HIP headers), which changes the last bit (round 1 shipped a Hungarian cost whose
@@ -30,12 +31,12 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.h')]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
 BENCH_LIB = os.path.join(CSRC, 'libcprhip_bench.so')
-HOOK_SOURCES = {'conv_mfma.hip', 'conv_wgrad.hip', 'conv_wino.hip', 'conv_mfma_bf16.hip', 'conv_bf16_dma.hip', 'assign.hip', 'conv_wino32.hip'}     # the files that carry #ifdef CPR_BENCH_HOOKS code
+HOOK_SOURCES = {'conv_mfma.hip', 'conv_wgrad.hip', 'conv_wino.hip', 'conv_mfma_bf16.hip', 'conv_bf16_dma.hip', 'conv_bf16_pp.hip', 'assign.hip', 'conv_wino32.hip'}     # the files that carry #ifdef CPR_BENCH_HOOKS code
 
 
 def build(force=False, verbose=True, bench_hooks=False):
@@ -44,7 +45,7 @@ def build(force=False, verbose=True, bench_hooks=False):
     lib = BENCH_LIB if bench_hooks else LIB
     if not force and not (needs_build() if not bench_hooks else (
             not os.path.exists(lib) or any(os.path.getmtime(os.path.join(CSRC, s)) > os.path.getmtime(lib)
-                                           for s in SOURCES + ['common.h']))):
+                                           for s in SOURCES + HEADERS))):
         return lib
     objs = []
     for s in SOURCES:
@@ -54,7 +55,7 @@ def build(force=False, verbose=True, bench_hooks=False):
         hooked = bench_hooks and s in HOOK_SOURCES
         obj = os.path.join(CSRC, s.replace('.hip', '.bench.o' if hooked else '.o'))
         if bench_hooks and not hooked and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src) \
-                and os.path.getmtime(obj) >= os.path.getmtime(os.path.join(CSRC, 'common.h')):
+                and all(os.path.getmtime(obj) >= os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS):
             objs.append(obj)          # identical object as in the product build
             continue
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + \

@@ -326,7 +326,7 @@ extern "C" int cpr_bf16_set_wfrag(int on) {  // measurement build: 0 = ignore th
     return CPR_OK;
 }
 extern "C" int cpr_bf16_set_dma(int on) {   // measurement build: 0 = keep every layer on the register-staged kernels (A/B);
-    CPR_CHECK_ARG(on >= 0 && on < 8192);     // bits 1..4 = loop ablations of the DMA kernel (results are then WRONG); bit 11 = no weight-fragment loads (BD), bit 12 = request slots staggered by wave (BD: results stay right);
+    CPR_CHECK_ARG(on >= 0 && on < 262144);  // ping-pong instance: bit 13 = fragment reads before the requests, 14 = phase clocks instead of results, 15 = K-split clusters, 16 = schedule 2 (requests inside the clusters), 17 = schedule 3 (no vector ALU work in the memory parts)     // bits 1..4 = loop ablations of the DMA kernel (results are then WRONG); bit 11 = no weight-fragment loads (BD), bit 12 = request slots staggered by wave (BD: results stay right);
     bf16_dma_on = on & 1;                    // bits 5..7: 0 = the dispatch rule, 1 + shape = that DMA tile shape wherever it fits,
     bf16_dma_ablate = ((on >> 1) & 15) | ((on >> 8) << 4);   //    6 = only the 256 x 256 rule of round 3
     bf16_dma_force = (on >> 5) & 7;          // bits 8..10: epilogue (16 = stores dropped by the range check, 32 = none, 64 = the direct round-3 form)
@@ -344,6 +344,7 @@ constexpr int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0, bf16_wfr
 static int bf16_dma_shape(long long M, int Cin, int Cout, int kchunks, bool gn) {
     if (Cin % 64 != 0 || kchunks < 1) return -1;
     if (bf16_dma_force >= 1 && bf16_dma_force <= 5) return bf16_dma_force - 1;
+    if (bf16_dma_force == 7) return 5;          // the ping-pong instance (conv_bf16_pp.hip) wherever it fits
     const long long t256 = Cout % 256 == 0 ? ((M + 255) / 256) * (Cout / 256) : 0;
     if (bf16_dma_force == 6) return t256 >= 384 && kchunks >= 2 ? 0 : -1;       // the round-3 rule
     if (t256 >= 384) return 0;

@@ -218,6 +218,10 @@ class StepLrSchedule:
 
 # mixed precision: dtype hand-offs fused into the producing kernels (CPR_MIXED_FUSED_CAST=0: the separate torch passes of rounds 3-4, A/B)
 FUSED_CAST = os.environ.get('CPR_MIXED_FUSED_CAST', '1') != '0'
+# measurement switches (tests/report_mixed_precision_grads.py: where the mixed-precision gradient error comes from): the weight /
+# data gradients of the mixed-precision step on the fp32 kernels; force = bf16 backward rules behind an fp32 recorded forward
+MIXED_BF16 = dict(wgrad=os.environ.get('CPR_MIXED_WGRAD', 'bf16') != 'fp32', dgrad=os.environ.get('CPR_MIXED_DGRAD', 'bf16') != 'fp32',
+                  force=False)
 
 
 class BackwardEngine:
@@ -267,7 +271,7 @@ class BackwardEngine:
         return tuple(out)
 
     def begin_step(self):
-        self._mixed = self.model.backbone.compute_dtype == torch.bfloat16
+        self._mixed = self.model.backbone.compute_dtype == torch.bfloat16 or MIXED_BF16['force']
         self._wide = {}
 
     def _done(self, p):
@@ -354,8 +358,9 @@ class BackwardEngine:
         w, gn = cm.conv.weight, cm.gn
         assert cm.conv.bias is None
         # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight and data gradients
-        dgrad16 = need_dx and rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and w.shape[0] % 64 == 0
-        wgrad16 = rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
+        dgrad16 = need_dx and MIXED_BF16['dgrad'] and rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and \
+            w.shape[0] % 64 == 0
+        wgrad16 = MIXED_BF16['wgrad'] and rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
             rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0])
         if rec['raw'].dtype == torch.bfloat16 and FUSED_CAST:
             # the GroupNorm backward reads the bf16 recorded map as it is and writes the bf16 rounding of its result itself (and the
@@ -659,8 +664,10 @@ class BackwardEngine:
                               lambda: ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, True)[2])
         w = conv.weight
         # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight gradient and the bf16 3x3 data gradient
-        w16 = w.requires_grad and self._mixed and ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0])
-        d16 = need_dx and self._mixed and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and add is None
+        w16 = w.requires_grad and self._mixed and MIXED_BF16['wgrad'] and \
+            ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0])
+        d16 = need_dx and self._mixed and MIXED_BF16['dgrad'] and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and \
+            w.shape[0] % 64 == 0 and add is None
         g16 = g.to(torch.bfloat16) if (w16 or d16) else None
         if w.requires_grad:
             aff = bn.weight.requires_grad
