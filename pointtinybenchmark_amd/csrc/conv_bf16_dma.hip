@@ -406,11 +406,11 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
 // barrier, the partner one barrier behind -- i.e. a different kernel, not a re-timing of this one.  Removed; see git history and
 // profiles/round3_bf16_dma_kernel_development.txt.)
 
-void conv_bf16_pp_launch(const ConvDmaParams& p, unsigned grid, int variant, hipStream_t stream);     // conv_bf16_pp.hip
+void conv_bf16_pp_launch(const ConvDmaParams& p, unsigned grid, hipStream_t stream);     // conv_bf16_pp.hip
 
 // The launcher of conv_mfma_bf16.hip calls this for the layers that fit the tile; returns CPR_ERR_UNSUPPORTED otherwise.
 // shape: 0 = 256 x 256, 1 = 128 (pixels) x 256 (couts), 2 = 256 x 128, 3 = 128 x 128 (64 KB of LDS: two workgroups per CU),
-// 4 = 256 x 256 on four waves (wave = 128 x 128), 5 = 256 x 256 in two-group ping-pong (conv_bf16_pp.hip).
+// 4 = 256 x 256 on four waves (wave = 128 x 128), 5 = 256 x 256 in two-group ping-pong (conv_bf16_pp.hip; shape 0 takes it by itself for >= 4 K chunks).
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                          const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
@@ -436,12 +436,15 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
     if (gn_part && bm != 256) return CPR_ERR_UNSUPPORTED;         // a wave of the 128-pixel tile owns half a statistics slot
     p.tilesM = (int)((M + bm - 1) / bm);
     p.tilesN = Cout / bn;
+    // the 256 x 256 tile has three instances: both operands through LDS in lock step (no fragment image given: the reference the
+    // other two are bit-equal to), two-group ping-pong (conv_bf16_pp.hip: >= 4 K chunks), weights direct to registers (short K)
+    if (shape == 0 && wfrag != nullptr && Kpad / DBK >= 4 && !(ablate & 512)) shape = 5;      // (ablate bit 9, measurement build: keep shape 0 off the ping-pong instance)
     const bool bd = shape == 0 && wfrag != nullptr;      // the 256 x 256 instance with the weights direct to registers
     if (variant_out) *variant_out = bm * 1000 + bn + (shape == 3 ? 1000000 : shape == 4 ? 2000000 : shape == 5 ? 5000000 : bd ? 3000000 : 0);       // 128128 alone is the register-staged <128, 128>
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
     if (shape == 1 || shape == 2) return CPR_ERR_UNSUPPORTED;      // <2, 2> and <4, 1> were measured and dropped
-    if (shape == 5) conv_bf16_pp_launch(p, (unsigned)grid, ((ablate >> 9) & 1) | (((ablate >> 11) & 7) << 1), stream);   // ablate bit 9: reads first (schedule 2: no s_setprio), 10: phase clocks, 11: K-split clusters, 12: schedule 2, 13: schedule 3
+    if (shape == 5) conv_bf16_pp_launch(p, (unsigned)grid, stream);
     else if (shape == 3) hipLaunchKernelGGL((conv_bf16_dma_kernel<2, 1, 4>), dim3(grid), dim3(512), 0, stream, p);
 #ifdef CPR_BENCH_HOOKS   // measured 10-12 % slower than the eight-wave instance (profiles/round4_bf16_four_wave_tile.txt): measurement build only
     else if (shape == 4) hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 4, 2>), dim3(grid), dim3(256), 0, stream, p);

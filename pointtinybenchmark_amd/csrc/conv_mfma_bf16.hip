@@ -326,7 +326,7 @@ extern "C" int cpr_bf16_set_wfrag(int on) {  // measurement build: 0 = ignore th
     return CPR_OK;
 }
 extern "C" int cpr_bf16_set_dma(int on) {   // measurement build: 0 = keep every layer on the register-staged kernels (A/B);
-    CPR_CHECK_ARG(on >= 0 && on < 262144);  // ping-pong instance: bit 13 = fragment reads before the requests, 14 = phase clocks instead of results, 15 = K-split clusters, 16 = schedule 2 (requests inside the clusters), 17 = schedule 3 (no vector ALU work in the memory parts)     // bits 1..4 = loop ablations of the DMA kernel (results are then WRONG); bit 11 = no weight-fragment loads (BD), bit 12 = request slots staggered by wave (BD: results stay right);
+    CPR_CHECK_ARG(on >= 0 && on < 32768);    // bits 1..4 = loop ablations of the DMA kernels (results are then WRONG); bits 8..10 epilogue forms; bit 11 = no weight-fragment loads (BD) / no row arithmetic (ping-pong), bit 12 = request slots staggered by wave (BD) / requests before reads (ping-pong); bit 14 = phase clocks (ping-pong)
     bf16_dma_on = on & 1;                    // bits 5..7: 0 = the dispatch rule, 1 + shape = that DMA tile shape wherever it fits,
     bf16_dma_ablate = ((on >> 1) & 15) | ((on >> 8) << 4);   //    6 = only the 256 x 256 rule of round 3
     bf16_dma_force = (on >> 5) & 7;          // bits 8..10: epilogue (16 = stores dropped by the range check, 32 = none, 64 = the direct round-3 form)

@@ -68,19 +68,24 @@ def test_conv2d_bf16_vs_torch(case):
 # shapes that reach the LDS-DMA staged kernels (csrc/conv_bf16_dma.hip; dispatch rule: bf16_dma_shape in conv_mfma_bf16.hip).
 # 256 x 256 tiles (interleaved cout layout, whole-line pair stores): every layer with >= 384 such tiles; 128 x 128 tiles, two
 # workgroups per CU, output through LDS (round 4): the rest with Cout % 128 == 0 and >= 256 tiles
-# the variant words conv_bf16_dma_launch reports.  BIG = the 256 x 256 tile with the weights loaded straight into registers from the
-# fragment-order image (round 5, conv_bf16_dma_kernel<4, 2, 4, true>); BIG_LDS = the same tile with both operands through LDS-DMA
-# (ops.WFRAG[0] = False) -- identical MFMA sequence on identical operands, so the two must agree BIT for bit
+# the variant words conv_bf16_dma_launch reports.  The 256 x 256 tile has three instances: PP = two wave groups in ping-pong (round 6,
+# csrc/conv_bf16_pp.hip: every layer with >= 4 K chunks), BIG = the weights loaded straight into registers from the fragment-order
+# image (round 5, conv_bf16_dma_kernel<4, 2, 4, true>: the short-K layers), BIG_LDS = both operands through LDS-DMA in lock step
+# (ops.WFRAG[0] = False) -- identical MFMA sequence per accumulator on identical operands, so all three must agree BIT for bit
 BIG, BIG_LDS, SMALL = 3000000 + 256 * 1000 + 256, 256 * 1000 + 256, 1000000 + 128 * 1000 + 128
+PP = 5000000 + 256 * 1000 + 256
 DMA_CASES = [
-    (8, 64, 128, 128, 256, 3, 1, 1, 'gn', BIG),                  # 3x3, borders on every side, GroupNorm statistics (two slots per tile)
-    (8, 128, 128, 128, 256, 3, 1, 1, 'bn res relu', BIG),        # K = 1152 + residual (4-byte pair loads)
-    (10, 128, 121, 119, 256, 3, 1, 1, 'bias relu', BIG),         # ragged M: the last tile is partial
-    (6, 128, 256, 192, 512, 3, 2, 1, 'bn', BIG),                 # stride 2, two cout tiles
-    (8, 1024, 128, 128, 256, 1, 1, 0, 'bias f32out', BIG),       # plain GEMM path, fp32 output (8-byte pair stores)
+    (8, 64, 128, 128, 256, 3, 1, 1, 'gn', PP),                  # 3x3, borders on every side, GroupNorm statistics (two slots per tile)
+    (8, 128, 128, 128, 256, 3, 1, 1, 'bn res relu', PP),        # K = 1152 + residual (4-byte pair loads)
+    (10, 128, 121, 119, 256, 3, 1, 1, 'bias relu', PP),         # ragged M: the last tile is partial
+    (6, 128, 256, 192, 512, 3, 2, 1, 'bn', PP),                 # stride 2, two cout tiles
+    (8, 1024, 128, 128, 256, 1, 1, 0, 'bias f32out', PP),       # plain GEMM path, fp32 output (8-byte pair stores)
     (8, 128, 128, 128, 256, 1, 1, 0, 'bn res relu', BIG),        # bottleneck conv3 form, two K chunks
     (8, 64, 128, 128, 256, 1, 1, 0, 'bn res relu', BIG),         # a single K chunk (layer1 conv3: 64 -> 256)
-    (8, 64, 96, 128, 512, 3, 1, 1, 'bias relu gn', BIG),         # statistics behind bias + ReLU, two cout tiles
+    (8, 64, 96, 128, 512, 3, 1, 1, 'bias relu gn', PP),
+    (13, 256, 80, 96, 256, 3, 1, 1, 'gn', PP),                    # K = 2304: 36 chunks (the head layer's K), 390 tiles
+    (8, 256, 128, 128, 512, 1, 1, 0, 'bn res relu', PP),          # exactly 4 chunks: the shortest K the ping-pong instance takes
+    (8, 320, 128, 128, 256, 1, 1, 0, 'bn relu', PP),              # 5 chunks: an odd count through the 3-stage / 2-stage rings         # statistics behind bias + ReLU, two cout tiles
     (8, 256, 64, 64, 256, 3, 1, 1, 'bn relu', SMALL),            # R101 layer3 conv2 at 1024^2 B = 8: 128 big tiles would idle half the CUs
     (8, 1024, 64, 64, 256, 1, 1, 0, 'bn res relu', SMALL),       # layer3 conv1 form, K = 1024
     (3, 64, 121, 119, 256, 3, 1, 1, 'bias res relu', SMALL),     # ragged M + residual: rows past M neither read nor written
@@ -129,7 +134,7 @@ def test_conv2d_bf16_dma_kernel_vs_torch(case):
     finally:
         ops.TRACE_CONV_VARIANT[0] = False
     assert variant == ('bf16', want), 'this shape must run the LDS-DMA staged instance %d, got %r' % (want, variant)
-    if want == BIG:         # the same launch with both operands staged through LDS: bit-equal outputs and statistics
+    if want in (BIG, PP):   # the same launch with both operands staged through LDS in lock step: bit-equal outputs and statistics
         ops.WFRAG[0], ops.TRACE_CONV_VARIANT[0] = False, True
         try:
             out2 = ops.conv2d(xin, pc, scale=None if scale is None else scale.cuda(), bias=None if bias is None else bias.cuda(),
@@ -140,7 +145,7 @@ def test_conv2d_bf16_dma_kernel_vs_torch(case):
             ops.WFRAG[0], ops.TRACE_CONV_VARIANT[0] = True, False
         assert variant2 == ('bf16', BIG_LDS), variant2
         for u, v in zip(out if isinstance(out, tuple) else (out,), out2 if isinstance(out2, tuple) else (out2,)):
-            assert torch.equal(u, v), 'weights-direct-to-registers instance differs from the LDS-staged one: max abs %.3e' % float(
+            assert torch.equal(u, v), 'instance %d differs from the lock-step LDS-staged one: max abs %%.3e' % want % float(
                 (u.float() - v.float()).abs().max())
     part = None
     if 'gn' in flags:

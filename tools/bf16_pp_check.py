@@ -1,7 +1,7 @@
 """Measurement build: the two-group ping-pong 256 x 256 bf16 instance (csrc/conv_bf16_pp.hip, hook word 1 + 32 * 7 = 225) against the
-lock-step LDS-staged instance (word 1, fragment image off) -- bit-equality on the shapes of tests/test_gpu_bf16.py DMA_CASES that take
-the big tile (several launches each: a staging race shows as a difference that comes and goes), then timings of both and of the
-weights-direct instance on the layer shapes that matter.  `--words` adds ablation words for the timing table."""
+lock-step LDS-staged instance (word 1, fragment image off) -- bit-equality on big-tile shapes (several launches each: a staging race
+shows as a difference that comes and goes), then timings of the three instances and of the ping-pong instance's compile-time
+ablations on the layer shapes that matter, then its phase clocks.  `--words` adds hook words to the timing table."""
 import os
 os.environ.setdefault('CPR_BENCH_HOOKS', '1')
 import argparse
@@ -17,10 +17,9 @@ ap.add_argument('--words', default='', help='comma-separated extra cpr_bf16_set_
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--skip-check', action='store_true')
 args = ap.parse_args()
-PP, PP_R, PP_K, PP_KR = 225, 225 + 8192, 225 + 32768, 225 + 32768 + 8192
+PP = 225                  # hook word: the ping-pong instance wherever the 256 x 256 tile fits (1 + 32 * 7)
+KEEP0 = 8192              # ablate bit 9: shape 0 stays on its own instances (weights-direct with the fragment image, lock-step without)
 STAMPS = 16384
-PP3, PP3_P = 225 + 131072 + 8192, 225 + 131072       # schedule 3 (no vector ALU work in the memory parts), with s_setprio
-PP2, PP2_NP = 225 + 65536, 225 + 65536 + 8192      # schedule 2 (requests inside the clusters), without s_setprio
 
 CHECK = [   # N, Cin, H, W, Cout, k, stride, pad, flags
     (8, 64, 128, 128, 256, 3, 1, 1, 'gn'), (8, 128, 128, 128, 256, 3, 1, 1, 'bn res relu'), (10, 128, 121, 119, 256, 3, 1, 1, 'bias relu'),
@@ -65,7 +64,7 @@ if not args.skip_check:
     for ci, case in enumerate(CHECK):
         x, pc, kw = make(case, ci)
         ref, v0 = run(1, 0, x, pc, kw)
-        for word in (PP3, PP3_P):
+        for word in (PP,):
             for rep in range(6):
                 got, v1 = run(word, 0, x, pc, kw)
                 torch.cuda.synchronize()
@@ -86,11 +85,11 @@ TIMING_ALL = [  # label, N, Cin, HW, Cout, k, flags
     ('1x1 512->256 B=8 256^2', 8, 512, 256, 256, 1, 'bn res relu'),
     ('1x1 1024->256 B=64 40^2', 64, 1024, 40, 256, 1, 'bn relu'),
 ]
-words = [(1, 1, 'weights-direct'), (1, 0, 'lock-step LDS'), (PP2, 0, 'schedule 2'), (PP3, 0, 'schedule 3'), (PP3_P, 0, 'schedule 3 + setprio'),
-         (PP3 + 8, 0, 'schedule 3 no requests'), (PP3 + 16, 0, 'schedule 3 no reads'), (PP3 + 24, 0, 'schedule 3 neither'),
-         (PP3_P + 2, 0, 'schedule 3 no vmcnt wait'), (PP3_P + 4, 0, 'schedule 3 same-address requests'), (PP3_P + 2048, 0, 'schedule 3 no row arithmetic')] + \
+words = [(1 + KEEP0, 1, 'weights-direct'), (1, 0, 'lock-step LDS'), (PP, 0, 'ping-pong'), (1, 1, 'dispatch rule'),
+         (PP + 8, 0, 'pp no requests'), (PP + 16, 0, 'pp no reads'), (PP + 24, 0, 'pp neither'), (PP + 2, 0, 'pp no counted wait'),
+         (PP + 4, 0, 'pp same-KB requests'), (PP + 2048, 0, 'pp no row arithmetic'), (PP + 4096, 0, 'pp requests first')] + \
     [(int(w), 0, 'word %s' % w) for w in args.words.split(',') if w]
-TIMING = TIMING_ALL[:2]
+TIMING = TIMING_ALL
 for label, N, Cin, HW, Cout, k, flags in TIMING:
     x, pc, kw = make((N, Cin, HW, HW, Cout, k, 1, k // 2, flags), 7)
     fl = 2.0 * N * HW * HW * Cout * Cin * k * k
@@ -111,7 +110,7 @@ for label, N, Cin, HW, Cout, k, flags in TIMING:
 
 # phase clocks (s_memtime) of chunk 8 of workgroup 16 (tile 2: its own output rows carry the stamps), wave 0 of each group: PP_STAMP in csrc/conv_bf16_pp.hip
 x, pc, kw = make((8, 256, 256, 256, 256, 3, 1, 1, 'gn'), 7)
-for word, name in ((PP3_P, 'schedule 3'), (PP3_P + 8, 'schedule 3 no requests'), (PP3_P + 16, 'schedule 3 no reads'), (PP3_P + 24, 'schedule 3 neither')):
+for word, name in ((PP, 'ping-pong'), (PP + 8, 'pp no requests'), (PP + 16, 'pp no reads'), (PP + 24, 'pp neither')):
     for rep in range(2):
         _lib.call('cpr_bf16_set_dma', word + STAMPS)
         _lib.call('cpr_bf16_set_wfrag', 0)
