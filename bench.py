@@ -591,35 +591,30 @@ def train_parity_gate(trainer, model, args, batch, ref=None):
                 oracle_seconds=round(t_oracle, 2)), ref
 
 
-def measure_small_batch(model, b, size, num_gts, steps=30, graph_too=True, width=None, num_classes=1):
+def measure_small_batch(model, b, size, num_gts, steps=30, width=None, num_classes=1):
     """The reference's own per-GPU batch (samples_per_gpu = 2, T/configs2/TinyPersonV2/coarsepointv2/
-    coarse_point_refine_base_TinyPersonV2_640.py:50).  ~150 launches of a few microseconds: launch-bound when issued one by
-    one, so the step is also timed as ONE hipGraph replay (backbone .. logit projection) + the eager 5-launch loss tail."""
+    coarse_point_refine_base_TinyPersonV2_640.py:50), eager launches.  (A hipGraph replay of the step was timed beside it until round 5
+    and lost in both modes -- 514 vs 558 img/s fp32, 526 vs 608 at configs[4]; removed in round 6.)"""
     from pointtinybenchmark_amd import synthetic
     batch = synthetic.synthetic_batch(b, size, size if width is None else width, num_gts, num_classes, seed=123)
     img, metas = batch['img'].cuda(), batch['img_metas']
     gtb, gtl = [x.cuda() for x in batch['gt_bboxes']], [x.cuda() for x in batch['gt_labels']]
     res = {'B': b}
-    keep = model.use_graph
     try:
-        for graph in ((False, True) if graph_too else (False,)):
-            model.use_graph = graph
-            with torch.no_grad():
-                for _ in range(5):
-                    losses = model.forward_train(img, metas, gtb, gtl)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    losses = model.forward_train(img, metas, gtb, gtl)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / steps
-            key = 'hipgraph' if graph else 'eager'
-            res[key] = {'img_per_s': b / dt, 'ms_per_step': dt * 1e3, 'losses': {k: float(v) for k, v in losses.items()}}
-        res['img_per_s'] = max(v['img_per_s'] for k, v in res.items() if isinstance(v, dict))
-        res['what'] = 'forward + loss at the reference batch size; hipgraph = one graph replay (backbone .. projection) + eager loss tail'
+        with torch.no_grad():
+            for _ in range(5):
+                losses = model.forward_train(img, metas, gtb, gtl)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                losses = model.forward_train(img, metas, gtb, gtl)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        res['eager'] = {'img_per_s': b / dt, 'ms_per_step': dt * 1e3, 'losses': {k: float(v) for k, v in losses.items()}}
+        res['img_per_s'] = b / dt
+        res['what'] = 'forward + loss at the reference batch size (eager launches)'
     except Exception as e:   # noqa: BLE001
         res['error'] = repr(e)[:300]
-    model.use_graph = keep
     return res
 
 
@@ -734,7 +729,6 @@ def main():
                          "gradient all-reduce, clip + SGD) as the timed step")
     ap.add_argument('--dry', action='store_true',
                     help='plumbing check without a GPU: ranks rendezvous over gloo, barrier, max-over-ranks, one JSON line (tests)')
-    ap.add_argument('--graph', action='store_true', help='replay backbone..projection as one hipGraph (forward + loss only)')
     ap.add_argument('--small-batch', type=int, default=2,
                     help="also report this per-GPU batch (the reference's samples_per_gpu) as 'small_batch' (0 = skip)")
     ap.add_argument('--train-timeout', type=int, default=300, help='watchdog for the train_step extra (seconds)')
@@ -804,7 +798,6 @@ def main():
         model.load_state_dict(synthetic.locator_state_dict(args.depth, args.classes, args.start_level, 'cpr', 0), strict=True)
     model.train()
     model.set_compute_dtype(args.dtype)
-    model.use_graph = bool(args.graph)
     batch = synthetic.synthetic_batch(args.batch, args.height, args.width, args.num_gts, args.classes, seed=rank)   # per-rank shard
     img = batch['img'].cuda()
     # per-image gt lists as the device pipeline hands them over (datasets.GpuImagePipeline: ONE device tensor, torch.split
@@ -1095,13 +1088,12 @@ def main():
         if world == 1 and args.batch_sweep and (args.model, args.mode) == ('cpr', 'fwd_loss'):
             out['batch_sweep'] = {}
             for bs in [int(v) for v in args.batch_sweep.split(',') if v and int(v) != args.batch]:
-                r = measure_small_batch(model, bs, args.height, args.num_gts, steps=8, graph_too=False, width=args.width,
+                r = measure_small_batch(model, bs, args.height, args.num_gts, steps=8, width=args.width,
                                         num_classes=args.classes)
                 out['batch_sweep'][str(bs)] = r.get('eager', r)
         if world == 1 and not args.no_cpu_baseline:
             def hip_losses(b):
                 with torch.no_grad():
-                    model.use_graph = False
                     r = model.forward_train(b['img'].cuda(), b['img_metas'], [x.cuda() for x in b['gt_bboxes']],
                                             [x.cuda() for x in b['gt_labels']])
                     return {k: float(sum(v)) if isinstance(v, (list, tuple)) else float(v) for k, v in r.items()}

@@ -11,7 +11,22 @@ import os as _os
 # under a 1-rank torchrun (rocprofv3 kernel trace: every kernel of the step on a single queue): configs[4] training 119 img/s
 # against 141 without a process group; with 8 hardware queues 138.  The variable is read when the HIP runtime initialises (first
 # device call), so it is set here -- before this package touches the device -- unless the caller has chosen a value.
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# It is a process-wide setting, so it is applied only when the caller has not chosen one AND HIP is not initialised yet (afterwards it
+# would be read by nobody: training.BackwardEngine then warns, naming the import order); CPR_SET_HW_QUEUES=0 leaves the environment alone.
+HW_QUEUES_SET_BY_PACKAGE = False
+
+
+def _hip_initialised():
+    try:
+        import torch as _torch
+        return bool(_torch.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+if 'GPU_MAX_HW_QUEUES' not in _os.environ and _os.environ.get('CPR_SET_HW_QUEUES', '1') != '0' and not _hip_initialised():
+    _os.environ['GPU_MAX_HW_QUEUES'] = '8'
+    HW_QUEUES_SET_BY_PACKAGE = True
 
 from . import registry  # noqa: F401,E402
 from .backbones import ResNet  # noqa: F401,E402

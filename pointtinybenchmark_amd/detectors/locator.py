@@ -79,70 +79,19 @@ class BasicLocator(nn.Module):
             out.append(t.permute(0, 3, 1, 2))
         return out, out
 
-    # Small per-GPU batches (the reference trains with samples_per_gpu = 2) are launch-bound: ~150 kernel launches of a few
-    # microseconds each.  ``model.use_graph = True`` (or CPR_GRAPH=1) captures backbone -> neck -> head towers -> logit
-    # projection into ONE hipGraph per input shape and replays it; only the ragged, gt-dependent tail (bag sampling, masks,
-    # losses: 5 launches) stays eager.  Forward + loss only.  A captured graph bakes in the device pointers of the packed
-    # weights / folded norms of the moment of capture: the entry carries the signature of every parameter and buffer (storage
-    # pointer, version counter, the native optimizer's weight epoch) and is re-captured when it no longer matches (optimizer
-    # step, load_state_dict, .to()); it also holds the pack caches' tensors so they cannot be freed while the graph lives.
-    use_graph = False
-
-    def _weights_signature(self):
-        from ..layers import _WEIGHT_EPOCH
-        sig = [_WEIGHT_EPOCH[0]]
-        for t in self.parameters():
-            sig.append((t.data_ptr(), t._version))
-        for t in self.buffers():
-            sig.append((t.data_ptr(), t._version))
-        return tuple(sig)
-
-    def _graphed_logit_map(self, img):
-        head = self.bbox_head
-        key = (tuple(img.shape), img.dtype, self.backbone.compute_dtype)
-        if not hasattr(self, '_graphs'):
-            self._graphs = {}
-        entry = self._graphs.get(key)
-        sig = self._weights_signature()
-        if entry is not None and entry[3] != sig:      # weights changed since the capture: the graph reads stale packs
-            del self._graphs[key]
-            entry = None
-        if entry is None:
-            def run(x):
-                raw, ab = head._tower(*self.neck.forward_lazy(self.backbone(x), out_b8=getattr(head, 'accepts_b8', False))[0],
-                                      in_relu=False, own_input=True)
-                return raw, ab, head._logit_map(raw, ab)
-            static_img = img.clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):       # warm-up off the capture: packs weights, fills the allocator
-                for _ in range(2):
-                    run(static_img)
-            torch.cuda.current_stream().wait_stream(side)
-            side.synchronize()                  # every weight pack of the warm-up is complete before the capture starts
-            graph = torch.cuda.CUDAGraph()      # a hipGraph on ROCm
-            with torch.cuda.graph(graph):
-                outs = run(static_img)
-            packs = [dict(m._cache._d) for m in self.modules() if hasattr(m, '_cache') and hasattr(m._cache, '_d')]
-            entry = self._graphs[key] = (graph, static_img, outs, sig, packs)
-        graph, static_img, outs = entry[:3]
-        static_img.copy_(img)
-        graph.replay()
-        return outs
+    # (Rounds 2-5 carried a hipGraph replay of backbone .. logit projection for the reference's samples_per_gpu = 2.  Measured in round 5 it
+    # LOST to eager launches in both modes -- fp32 514 vs 558 img/s, configs[4] 526 vs 608: the capture needs whole-tensor statistics
+    # buffers that the eager path fuses away, and at B = 2 the step is bound by tile quantisation over 256 CUs, not by launch
+    # gaps -- so it was removed in round 6 together with its weight-signature tracking; git history has it.)
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_true_bboxes=None):
         batch_input_shape = tuple(img[0].size()[-2:])
         for m in img_metas:
             m['batch_input_shape'] = batch_input_shape
-        if (self.use_graph or os.environ.get('CPR_GRAPH', '0') == '1') and img.is_cuda and not torch.is_grad_enabled() \
-                and hasattr(self.bbox_head, 'forward_train_lazy') and getattr(self.bbox_head, 'num_cls_fcs', 1) == 0 \
-                and getattr(self.bbox_head, 'ins_share_head_feat', True):
-            raw, ab, lmap = self._graphed_logit_map(img)
-            return self.bbox_head.loss([(raw, ab)], None, gt_bboxes, gt_labels, img_metas,
-                                       gt_bboxes_ignore=gt_bboxes_ignore, gt_true_bboxes=gt_true_bboxes, lmap=lmap)
-        # (train mode only: a model in eval() -- validation losses computed without torch.no_grad() -- keeps the forward-only path
-        # and holds no tapes; CPR_AUTOGRAD=0 switches the bridge off altogether)
-        if torch.is_grad_enabled() and self.training and img.is_cuda and os.environ.get('CPR_AUTOGRAD', '1') != '0' and \
+        # (whenever autograd is on, in train() AND eval() mode -- the reference's forward_train is differentiable in either, e.g.
+        # fine-tuning with the whole model in eval() for its frozen norm layers; validation losses belong under torch.no_grad(), which
+        # keeps the forward-only path and holds no tapes.  CPR_AUTOGRAD=0 switches the bridge off altogether)
+        if torch.is_grad_enabled() and img.is_cuda and os.environ.get('CPR_AUTOGRAD', '1') != '0' and \
                 any(p.requires_grad for p in self.parameters()):
             # autograd is on: the losses must carry a graph, as the reference's do (its driver calls loss.backward():
             # T/mmdet/models/detectors/base.py:214-247 + mmcv OptimizerHook).  The recorded forward / HIP backward pair sits

@@ -245,7 +245,9 @@ class BackwardEngine:
             self.side, concurrent = ops.concurrent_stream(dev)
             if not concurrent:
                 warnings.warn('no hardware queue left for the weight-gradient stream: the backward runs on one queue '
-                              '(export GPU_MAX_HW_QUEUES=8 before the process touches the device; RCCL takes several queues)')
+                              '(GPU_MAX_HW_QUEUES=%s; export GPU_MAX_HW_QUEUES=8 -- or import pointtinybenchmark_amd -- BEFORE the process '
+                              'touches the device: the HIP runtime reads it once, and RCCL takes several queues)'
+                              % os.environ.get('GPU_MAX_HW_QUEUES', 'unset'))
 
     def _g(self, p):
         """Where the gradient of ``p`` is written."""
