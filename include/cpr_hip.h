@@ -272,8 +272,11 @@ int cpr_nms_candidates(const float* boxes, int box_stride, const float* scores, 
                        int* count, void* stream);
 /* mmcv.ops.nms.batched_nms as called by multiclass_nms (T/mmdet/core/post_processing/bbox_nms.py:85; mmcv-full
  * 1.3.x, third-party): class-offset trick, sort by score (descending, ties by index), greedy IoU > thr suppression.
- * boxes (n,4), scores (n), labels (n) int32, n <= 16384.  keep_idx (n) int64: indices of kept boxes in descending
- * score order; num_keep (1) int32.  ws_order (n) int32, ws_boxes (n,4) float, ws_mask (n*ceil(n/64)) uint64. */
+ * boxes (n,4), scores (n), labels (n) int32.  keep_idx (n) int64: indices of kept boxes in descending score order; num_keep (1)
+ * int32.  ws_order (n) int32, ws_boxes (n,4) float, ws_mask cpr_nms_workspace(n) uint64 words.  No candidate ceiling below
+ * 262 144 (round 6; the reference has none: bbox_nms.py:7-94): above 8192 candidates the pair mask is computed and scanned a
+ * band of 8192 rows at a time, the removed bits and the keep count carried from band to band. */
+int cpr_nms_workspace(int n);
 int cpr_nms(const float* boxes, const float* scores, const int* labels, int n, float iou_thr, long long* keep_idx,
             int* num_keep, int* ws_order, float* ws_boxes, unsigned long long* ws_mask, void* stream);
 /* The same three stages for ALL images of a batch with no host round trip in between (P2PHead.get_bboxes loops

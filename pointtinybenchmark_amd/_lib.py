@@ -55,6 +55,7 @@ SIGNATURES = {
     'cpr_lsa_topk': [_p, _p, _p, _p, _p, _p, _i, _i] + [_p] * 14 + [_i, _i, _p],
     'cpr_topk_desc': [_p, _i, _i, _p, _p, _p],
     'cpr_nms_candidates': [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p],
+    'cpr_nms_workspace': [_i],
     'cpr_nms': [_p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
     'cpr_topk_desc_batched': [_p, _i, _i, _i, _p, _p, _p],
     'cpr_nms_candidates_batched': [_p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p],

@@ -254,8 +254,10 @@ __global__ void nms_prepare_kernel(const float* __restrict__ boxes, const float*
     }
 }
 
-__global__ void nms_mask_kernel(const float* __restrict__ b, NmsBatch nb, float thr, unsigned long long* __restrict__ mask) {
-    const int rb = blockIdx.y, cb = blockIdx.x;
+// rb0: first 64-row block of this launch (the streamed form of cpr_nms computes the mask a band of rows at a time; the mask rows
+// are stored band-relative).  0 for the whole-matrix launches.
+__global__ void nms_mask_kernel(const float* __restrict__ b, NmsBatch nb, float thr, unsigned long long* __restrict__ mask, int rb0) {
+    const int rb = rb0 + blockIdx.y, cb = blockIdx.x;
     const int n = nms_n(nb, blockIdx.z);
     const int nblk = (n + 63) / 64;       // mask row stride of THIS image (the scan kernel derives the same value)
     if (cb < rb || cb >= nblk) return;    // only j > i matters; tiles past this image's candidates do not exist
@@ -286,38 +288,66 @@ __global__ void nms_mask_kernel(const float* __restrict__ b, NmsBatch nb, float 
         const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, aj), inter));
         if (ovr > thr) bits |= 1ull << t;
     }
-    mask[(size_t)i * nblk + cb] = bits;
+    mask[(size_t)(i - rb0 * 64) * nblk + cb] = bits;
 }
 
+// NMS_SCAN_WORDS 64-bit words of "removed" bits live in LDS: 4096 words = 262 144 candidates per problem.
+constexpr int NMS_SCAN_WORDS = 4096;
+// Rows [i0, i1) of the greedy scan; the mask rows are band-relative (row i of the band at (i - i0) * nblk).  The whole-matrix
+// launches pass (0, n, nullptr); the streamed form carries the removed bits and the keep count from band to band in `carry`
+// (nblk words + 1 word for the count).
 __global__ void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order, NmsBatch nb,
-                                long long* __restrict__ keep_idx, int* __restrict__ num_keep) {
-    __shared__ unsigned long long removed[256];
+                                long long* __restrict__ keep_idx, int* __restrict__ num_keep, int i0, int i1,
+                                unsigned long long* __restrict__ carry) {
+    __shared__ unsigned long long removed[NMS_SCAN_WORDS];
     const int lane = threadIdx.x;
     const int n = nms_n(nb, blockIdx.x), nblk = (n + 63) / 64;
     {
         const size_t b = blockIdx.x;
         mask += b * nb.ws_stride; order += b * nb.cap; keep_idx += b * nb.cap; num_keep += b;
     }
-    for (int c = lane; c < nblk; c += 64) removed[c] = 0ull;
+    if (i1 > n) i1 = n;
+    const bool first = carry == nullptr || i0 == 0;
+    for (int c = lane; c < nblk; c += 64) removed[c] = first ? 0ull : carry[c];
     __syncthreads();
-    int cnt = 0;
-    for (int i = 0; i < n; ++i) {
+    int cnt = first ? 0 : (int)carry[nblk];
+    for (int i = i0; i < i1; ++i) {
         const unsigned long long w = removed[i >> 6];
         if (!((w >> (i & 63)) & 1ull)) {
             if (lane == 0) keep_idx[cnt] = order[i];
             ++cnt;
             const int c0 = i >> 6;  // columns before c0 hold only j <= i: nothing left to suppress there
-            for (int c = c0 + lane; c < nblk; c += 64) removed[c] |= mask[(size_t)i * nblk + c];
+            for (int c = c0 + lane; c < nblk; c += 64) removed[c] |= mask[(size_t)(i - i0) * nblk + c];
         }
         __syncthreads();
+    }
+    if (carry) {
+        for (int c = lane; c < nblk; c += 64) carry[c] = removed[c];
+        if (lane == 0) carry[nblk] = (unsigned long long)cnt;
     }
     if (lane == 0) *num_keep = cnt;
 }
 
+// rows of the pair mask one band of the streamed form holds (64-bit words: band * ceil(n / 64))
+constexpr int NMS_BAND_ROWS = 8192;
+extern "C" int cpr_nms_workspace(int n) {      // 64-bit words of ws_mask cpr_nms needs for n candidates (-> include/cpr_hip.h)
+    if (n <= 0) return 1;
+    if (n > 64 * NMS_SCAN_WORDS) return CPR_ERR_ARG;
+    const long long nblk = (n + 63) / 64;
+    long long P = 1;
+    while (P < n) P <<= 1;
+    const long long band = n < NMS_BAND_ROWS ? n : NMS_BAND_ROWS;
+    const long long m = band * nblk + nblk + 1;
+    return (int)(m > P ? m : P);
+}
+
+// n is unlimited up to 64 * NMS_SCAN_WORDS: the pair mask is computed and scanned a band of NMS_BAND_ROWS rows at a time (the
+// reference has no ceiling either: T/mmdet/core/post_processing/bbox_nms.py:7-94; round 5 refused more than 16 384 candidates).
+// ws_mask: cpr_nms_workspace(n) words.
 extern "C" int cpr_nms(const float* boxes, const float* scores, const int* labels, int n, float iou_thr,
                        long long* keep_idx, int* num_keep, int* ws_order, float* ws_boxes,
                        unsigned long long* ws_mask, hipStream_t stream) {
-    CPR_CHECK_ARG(n >= 0 && n <= 16384 && num_keep);
+    CPR_CHECK_ARG(n >= 0 && n <= 64 * NMS_SCAN_WORDS && num_keep);
     if (n == 0) {
         hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int), stream);
         return e == hipSuccess ? CPR_OK : -(int)e;
@@ -328,8 +358,17 @@ extern "C" int cpr_nms(const float* boxes, const float* scores, const int* label
     nb.n_dev = nullptr; nb.n = n; nb.cap = n; nb.nblk_cap = nblk; nb.ws_stride = 0;
     hipLaunchKernelGGL(nms_prepare_kernel, dim3(1), dim3(1024), 0, stream, boxes, scores, labels, nb, ws_order, ws_boxes,
                        ws_mask);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, 1), dim3(64), 0, stream, ws_boxes, nb, iou_thr, ws_mask);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, ws_mask, ws_order, nb, keep_idx, num_keep);
+    if (n <= NMS_BAND_ROWS) {
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, 1), dim3(64), 0, stream, ws_boxes, nb, iou_thr, ws_mask, 0);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, ws_mask, ws_order, nb, keep_idx, num_keep, 0, n, nullptr);
+        CPR_LAUNCH_STATUS();
+    }
+    unsigned long long* carry = ws_mask + (size_t)NMS_BAND_ROWS * nblk;
+    for (int i0 = 0; i0 < n; i0 += NMS_BAND_ROWS) {
+        const int i1 = i0 + NMS_BAND_ROWS < n ? i0 + NMS_BAND_ROWS : n;
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, cdiv(i1 - i0, 64), 1), dim3(64), 0, stream, ws_boxes, nb, iou_thr, ws_mask, i0 / 64);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, ws_mask, ws_order, nb, keep_idx, num_keep, i0, i1, carry);
+    }
     CPR_LAUNCH_STATUS();
 }
 
@@ -356,8 +395,8 @@ extern "C" int cpr_nms_batched(const float* boxes, const float* scores, const in
     nb.n_dev = n_dev; nb.n = 0; nb.cap = cap; nb.nblk_cap = nblk; nb.ws_stride = (size_t)ws_stride;
     hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(1024), 0, stream, boxes, scores, labels, nb, ws_order, ws_boxes,
                        ws_mask);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, B), dim3(64), 0, stream, ws_boxes, nb, iou_thr, ws_mask);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, stream, ws_mask, ws_order, nb, keep_idx, num_keep);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, B), dim3(64), 0, stream, ws_boxes, nb, iou_thr, ws_mask, 0);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, stream, ws_mask, ws_order, nb, keep_idx, num_keep, 0, cap, nullptr);
     CPR_LAUNCH_STATUS();
 }
 

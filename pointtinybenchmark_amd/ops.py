@@ -787,15 +787,12 @@ def nms(boxes, scores, labels, iou_thr):
     dev = boxes.device
     if n == 0:
         return torch.zeros((0,), device=dev, dtype=torch.int64)
-    nblk = (n + 63) // 64
-    P = 1
-    while P < n:
-        P <<= 1
     keep = torch.empty((n,), device=dev, dtype=torch.int64)
     num = torch.zeros((1,), device=dev, dtype=torch.int32)
     order = torch.empty((n,), device=dev, dtype=torch.int32)
     sboxes = torch.empty((n, 4), device=dev, dtype=torch.float32)
-    mask = torch.empty((max(n * nblk, P),), device=dev, dtype=torch.int64)
+    # (sort workspace, then the pair mask -- whole for n <= 8192, else one band of 8192 rows + the carried removed bits)
+    mask = torch.empty((_lib.call('cpr_nms_workspace', n, positive=True),), device=dev, dtype=torch.int64)
     _lib.call('cpr_nms', _ptr(_check(boxes)), _ptr(_check(scores)), _ptr(_check(labels, torch.int32)), n,
               float(iou_thr), _ptr(keep), _ptr(num), _ptr(order), _ptr(sboxes), _ptr(mask), _stream())
     return keep[:int(num.item())]
