@@ -243,6 +243,13 @@ int cpr_point_assign(const float* points, const float* gt_bboxes, int n, int k, 
 int cpr_hungarian_cost(const float* pred, int pred_stride, const float* logits, int C, const float* gt,
                        const int* labels, float* costT, int M, int G, float w_cls, float alpha, float gamma,
                        float eps, float w_dis, float fx, float fy, int p_norm, void* stream);
+/* The general cost matrix of HungarianAssignerV2 / HungarianAssigner (hungarian_assigner.py:15-145,166-229): any list of the costs of
+ * T/mmdet/core/bbox/match_costs/match_cost.py, summed as ``sum(cls_costs) + sum(reg_costs)`` sums them.  terms [host]: 6 floats per
+ * term (type, weight, a, b, c, d), the ncls classification terms first -- cls 0 FocalLossCost (alpha, gamma, eps), 1 ClassificationCost
+ * (-softmax[label]), 2 ClassificationCostV2(use_sigmoid) (-sigmoid[label]), 3 ZeroCost; reg 0 DisCostV2 (p, fx, fy) on points (pdim 2),
+ * 1 BBoxL1Cost, 2 IoUCost 'iou', 3 IoUCost 'giou' on xyxy boxes (pdim 4).  costT (G, M) as cpr_hungarian_cost. */
+int cpr_match_cost(const float* pred, int pdim, const float* logits, int C, const float* gt, const int* labels, float* costT,
+                   int M, int G, const float* terms, int ncls, int nreg, void* stream);
 
 /* The linear_sum_assignment loop of HungarianAssignerV2.assign (hungarian_assigner.py:229-268; replaces scipy and
  * the device->host->device round trip), including scipy's tie-breaking order.  A batch of problems, one workgroup
@@ -308,13 +315,16 @@ int cpr_tap_sum3x3(const float* R, const float* bias, float* out, int N, int H, 
 int cpr_rowmax_sigmoid(const float* logits, float* out, long long M, int C, void* stream);
 /* elementwise sigmoid with the bits of torch's CPU kernel (p2p_head.py:362: the scores that order top-k and NMS) */
 int cpr_sigmoid(const float* x, float* y, long long n, void* stream);
-/* P2PHead.loss_single + sample_result_to_target (p2p_head.py:220-248,308-328): sigmoid focal loss
- * (T/mmdet/models/losses/focal_loss.py:11-56) + SmoothL1 (smooth_l1_loss.py:11-28) straight from gt_inds (B,M) int64.
- * ws_partial (B*ceil(M/256)*3) double; out (B,2) = per image {loss_cls, loss_pts}, averaged by the batch's positives. */
+/* P2PHead.loss_single + sample_result_to_target (p2p_head.py:220-248,308-328) straight from gt_inds (B,M) int64.
+ * cls_mode 0: sigmoid focal loss (T/mmdet/models/losses/focal_loss.py:11-56), averaged by the batch's positives; 1: CrossEntropyLoss
+ * (use_sigmoid=True) = BCE with logits on the one-hot labels (cross_entropy_loss.py:58-99), averaged by ALL proposals of the batch
+ * (p2p_head.py:222-224); 2: softmax cross entropy over C = num_classes + 1 logits, background last.  reg_mode 0: SmoothL1(beta)
+ * (smooth_l1_loss.py:11-28), 1: MSE (mse_loss.py), 2: L1; averaged by the positives.  (1, 1) are the reference head's own defaults
+ * (p2p_head.py:38-46), (0, 0) the shipped config.  ws_partial (B*ceil(M/256)*3) double; out (B,2) = per image {loss_cls, loss_pts}. */
 int cpr_p2p_loss(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
                  const int* gt_labels, const int* gt_start, double* ws_partial, float* out, int B, int M, int C,
                  float alpha, float gamma, float beta, float pos_w, float neg_w, float reg_norm, float w_cls,
-                 float w_reg, void* stream);
+                 float w_reg, int cls_mode, int reg_mode, void* stream);
 
 /* ---- training step: backward + optimizer ------------------------------------------------
  * The reference gets these from torch autograd over mmcv ConvModule / nn.GroupNorm / F.grid_sample and
@@ -354,8 +364,9 @@ int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W
  * (resnet.py Bottleneck.forward): g = dy*(y>0) (y NULL: g = dy) is the shortcut gradient and the un-scaled conv-output
  * gradient; colsum (C) (+)= per-channel sums of g (= dshift; also the Linear/conv bias gradient).  (M,C) row-major,
  * C%4==0.  g_out may be NULL (sums only).  ws_part (ceil(M/128)+64)*C floats. */
-int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out, float* colsum, float* ws_part, long long M, int C,
-                        int accumulate, void* stream);
+int cpr_relu_bwd_colsum(const float* dy, const void* y, int y_bf16, float* g_out, void* g16_out, float* colsum, float* ws_part,
+                        long long M, int C, int accumulate, void* stream);   /* y_bf16: y is the bf16 map the mixed-precision forward recorded;
+                        g16_out (optional): the bf16 rounding of g, written by the same pass (round 6) */
 /* column sums (C) of a conv output from the epilogue partials cpr_conv2d_fwd wrote into gn_part [tiles][C][2];
  * ws: 64*C floats */
 int cpr_part_colsum(const float* part, float* out, float* ws, int tiles, int C, void* stream);
@@ -440,7 +451,7 @@ int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const 
 int cpr_p2p_loss_bwd(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
                      const int* gt_labels, const int* gt_start, const float* npos, float* dcls, float* dreg, int B, int M,
                      int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w, float neg_w, float reg_norm,
-                     float w_cls, float w_reg, float gamma_p, const float* upstream, void* stream);
+                     float w_cls, float w_reg, float gamma_p, const float* upstream, int cls_mode, int reg_mode, void* stream);
 /* sum of squares of a flat gradient buffer into out[0] (double; accumulate across buffers); ws_partial 1024 doubles */
 int cpr_grad_sumsq(const float* g, long long n, double* ws_partial, double* out, int accumulate, void* stream);
 /* torch.optim.SGD step (momentum, weight decay) with clip_grad_norm_'s coefficient taken from norm2 on the device:

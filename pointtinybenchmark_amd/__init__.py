@@ -30,8 +30,8 @@ if 'GPU_MAX_HW_QUEUES' not in _os.environ and _os.environ.get('CPR_SET_HW_QUEUES
 
 from . import registry  # noqa: F401,E402
 from .backbones import ResNet  # noqa: F401,E402
-from .core import (AssignResult, DisCostV2, FocalLossCost, HungarianAssignerV2, PointAssigner,  # noqa: F401,E402
-                   PointGenerator, PseudoSampler)
+from .core import (AssignResult, BBoxL1Cost, ClassificationCost, ClassificationCostV2, DisCostV2, FocalLossCost,  # noqa: F401,E402
+                   HungarianAssigner, HungarianAssignerV2, IoUCost, IoUCostV2, PointAssigner, PointGenerator, PseudoSampler, ZeroCost)
 from .dense_heads import CPRHead, P2PHead  # noqa: F401,E402
 from .detectors import BasicLocator  # noqa: F401,E402
 from .losses import MILLoss  # noqa: F401,E402

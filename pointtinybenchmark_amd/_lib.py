@@ -64,14 +64,15 @@ SIGNATURES = {
     'cpr_p2p_decode': [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     'cpr_rowmax_sigmoid': [_p, _p, ctypes.c_longlong, _i, _p],
     'cpr_sigmoid': [_p, _p, ctypes.c_longlong, _p],
-    'cpr_p2p_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p],
+    'cpr_p2p_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _p],
+    'cpr_match_cost': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _i, _i, _p],
     # training step: backward + optimizer
     'cpr_conv2d_wgrad_workspace': [_i] * 7,
     'cpr_conv2d_wgrad': [_p] * 6 + [_i] * 11 + [_p],
     'cpr_gn_bwd': [_p] * 12 + [_i] * 7 + [_p],
     'cpr_gn_bwd_bf16': [_p] * 13 + [_i] * 7 + [_p],
     'cpr_upsample_add_bwd': [_p, _p] + [_i] * 7 + [_p],
-    'cpr_relu_bwd_colsum': [_p] * 5 + [_l, _i, _i, _p],
+    'cpr_relu_bwd_colsum': [_p, _p, _i, _p, _p, _p, _p, _l, _i, _i, _p],
     'cpr_bn_fold_bwd': [_p] * 8 + [_i, _i, _p],
     'cpr_part_colsum': [_p, _p, _p, _i, _i, _p],
     'cpr_axpby': [_p, _p, _f, _f, _l, _p],
@@ -88,7 +89,7 @@ SIGNATURES = {
     'cpr_pack_weights_bf16': [_p, _p, _p, _p] + [_i] * 5 + [_p],
     'cpr_spin': [ctypes.c_longlong, _p],
     'cpr_bn_fold': [_p, _p, _p, _p, _f, _p, _p, _p, _i, _p],
-    'cpr_p2p_loss_bwd': [_p] * 9 + [_i] * 5 + [_f] * 9 + [_p, _p],
+    'cpr_p2p_loss_bwd': [_p] * 9 + [_i] * 5 + [_f] * 9 + [_p, _i, _i, _p],
     'cpr_grad_sumsq': [_p, _l, _p, _p, _i, _p],
     'cpr_sgd_step': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p],
 }

@@ -159,6 +159,113 @@ extern "C" int cpr_hungarian_cost(const float* pred, int pred_stride, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// The general cost matrix of HungarianAssignerV2 / HungarianAssigner (round 6): any LIST of the reference's classification and
+// regression costs (T/mmdet/core/bbox/match_costs/match_cost.py), summed the way ``sum(cls_costs) + sum(reg_costs)`` sums them
+// (hungarian_assigner.py:225-229: left to right from 0).  The shipped P2P pair keeps the fused kernel above.  Terms:
+//   cls  0 FocalLossCost (weight, alpha, gamma, eps)   1 ClassificationCost / ClassificationCostV2(use_sigmoid=False): -softmax[label]
+//        2 ClassificationCostV2(use_sigmoid=True): -sigmoid[label]   3 ZeroCost
+//   reg  0 DisCostV2 (weight, p, fx, fy) on (x, y) points   1 BBoxL1Cost on xyxy boxes (L1 over the four coordinates)
+//        2 IoUCost 'iou' / 3 IoUCost 'giou' on xyxy boxes (bbox_overlaps, eps 1e-6)
+// sigmoid, the focal logs and both distances carry the CPU bits as in the fused kernel; the softmax is max-subtracted with the
+// Sleef exp and a left-to-right sum (ATen's vectorised row reduction adds in lane order: the last bit can differ -- the indices
+// are pinned on reference fixtures, the cost to 2 ulp).
+struct CostTerm { int type; float w, a, b, c, d; };
+struct CostTerms { int ncls, nreg; CostTerm cls[4], reg[4]; };
+__global__ void match_cost_kernel(const float* __restrict__ pred, int pdim, const float* __restrict__ logits, int C,
+                                  const float* __restrict__ gt, const int* __restrict__ labels, float* __restrict__ costT,
+                                  int M, int G, CostTerms t) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (m >= M) return;
+    const int l = labels[g];
+    float cls = 0.f;
+    for (int k = 0; k < t.ncls; ++k) {
+        const CostTerm& ct = t.cls[k];
+        float v = 0.f;
+        const float x = logits[(size_t)m * C + l];
+        if (ct.type == 0) {
+            const float alpha = ct.a, gamma = ct.b, eps = ct.c;
+            const float p = sigmoid_torch_cpu(x);
+            const float pg = (gamma == 2.f) ? __fmul_rn(p, p) : powf(p, gamma);
+            const float q1 = __fsub_rn(1.f, p);
+            const float qg = (gamma == 2.f) ? __fmul_rn(q1, q1) : powf(q1, gamma);
+            const float neg = __fmul_rn(__fmul_rn(-log_cr(__fadd_rn(q1, eps)), 1.f - alpha), pg);
+            const float pos = __fmul_rn(__fmul_rn(-log_cr(__fadd_rn(p, eps)), alpha), qg);
+            v = __fmul_rn(__fsub_rn(pos, neg), ct.w);
+        } else if (ct.type == 1) {
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[(size_t)m * C + c]);
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se = __fadd_rn(se, sleef_expf_u10(__fsub_rn(logits[(size_t)m * C + c], mx)));
+            v = __fmul_rn(-__fdiv_rn(sleef_expf_u10(__fsub_rn(x, mx)), se), ct.w);
+        } else if (ct.type == 2) {
+            v = __fmul_rn(-sigmoid_torch_cpu(x), ct.w);
+        }
+        cls = __fadd_rn(cls, v);
+    }
+    float reg = 0.f;
+    for (int k = 0; k < t.nreg; ++k) {
+        const CostTerm& rt = t.reg[k];
+        float v = 0.f;
+        const float* pb = pred + (size_t)m * pdim;
+        const float* gb = gt + (size_t)g * pdim;
+        if (rt.type == 0) {
+            const float fx = rt.b, fy = rt.c;
+            const float px = __fdiv_rn(pb[0], fx), py = __fdiv_rn(pb[1], fy), gx = __fdiv_rn(gb[0], fx), gy = __fdiv_rn(gb[1], fy);
+            float dist;
+            if (rt.a == 1.f) dist = __fadd_rn(fabsf(__fsub_rn(px, gx)), fabsf(__fsub_rn(py, gy)));
+            else if (M > 25 || G > 25) dist = __fsqrt_rn(fmaxf(d2_chain(px, py, sq_norm(px, py), gx, gy, sq_norm(gx, gy)), 0.f));
+            else {
+                const float dx = __fsub_rn(px, gx), dy = __fsub_rn(py, gy);
+                dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            }
+            v = __fmul_rn(dist, rt.w);
+        } else if (rt.type == 1) {
+            float d = 0.f;
+            for (int c = 0; c < 4; ++c) d = __fadd_rn(d, fabsf(__fsub_rn(pb[c], gb[c])));
+            v = __fmul_rn(d, rt.w);
+        } else {
+            // bbox_overlaps(mode, is_aligned=False, eps=1e-6): T/mmdet/core/bbox/iou_calculators/iou2d_calculator.py
+            const float a1 = __fmul_rn(__fsub_rn(pb[2], pb[0]), __fsub_rn(pb[3], pb[1]));
+            const float a2 = __fmul_rn(__fsub_rn(gb[2], gb[0]), __fsub_rn(gb[3], gb[1]));
+            const float w = fmaxf(__fsub_rn(fminf(pb[2], gb[2]), fmaxf(pb[0], gb[0])), 0.f);
+            const float h = fmaxf(__fsub_rn(fminf(pb[3], gb[3]), fmaxf(pb[1], gb[1])), 0.f);
+            const float ov = __fmul_rn(w, h);
+            const float uni = fmaxf(__fsub_rn(__fadd_rn(a1, a2), ov), 1e-6f);
+            float iou = __fdiv_rn(ov, uni);
+            if (rt.type == 3) {
+                const float ew = fmaxf(__fsub_rn(fmaxf(pb[2], gb[2]), fminf(pb[0], gb[0])), 0.f);
+                const float eh = fmaxf(__fsub_rn(fmaxf(pb[3], gb[3]), fminf(pb[1], gb[1])), 0.f);
+                const float ea = fmaxf(__fmul_rn(ew, eh), 1e-6f);
+                iou = __fsub_rn(iou, __fdiv_rn(__fsub_rn(ea, uni), ea));
+            }
+            v = __fmul_rn(-iou, rt.w);
+        }
+        reg = __fadd_rn(reg, v);
+    }
+    costT[(size_t)g * M + m] = __fadd_rn(cls, reg);
+}
+
+// terms: 6 floats per term (type, weight, a, b, c, d), the ncls classification terms first (host memory)
+extern "C" int cpr_match_cost(const float* pred, int pdim, const float* logits, int C, const float* gt, const int* labels,
+                              float* costT, int M, int G, const float* terms, int ncls, int nreg, hipStream_t stream) {
+    CPR_CHECK_ARG(M >= 0 && G >= 0 && C > 0 && (pdim == 2 || pdim == 4) && ncls >= 0 && ncls <= 4 && nreg >= 0 && nreg <= 4 && terms);
+    if (M == 0 || G == 0) return CPR_OK;
+    CPR_CHECK_ARG(pred && logits && gt && labels && costT);
+    CostTerms t;
+    t.ncls = ncls; t.nreg = nreg;
+    for (int k = 0; k < ncls + nreg; ++k) {
+        CostTerm& x = k < ncls ? t.cls[k] : t.reg[k - ncls];
+        const float* f = terms + 6 * k;
+        x.type = (int)f[0]; x.w = f[1]; x.a = f[2]; x.b = f[3]; x.c = f[4]; x.d = f[5];
+        CPR_CHECK_ARG(x.type >= 0 && x.type <= 3);
+        if (k >= ncls) CPR_CHECK_ARG(x.type == 0 ? pdim == 2 : pdim == 4);
+    }
+    hipLaunchKernelGGL(match_cost_kernel, dim3(cdiv(M, 256), G), dim3(256), 0, stream, pred, pdim, logits, C, gt, labels, costT, M, G, t);
+    CPR_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Rectangular linear sum assignment, shortest augmenting path with float64 duals: an operation-for-operation
 // parallelisation of scipy's linear_sum_assignment (rectangular_lsap.cpp, Crouse 2016), INCLUDING its tie-breaking.
 // The L1 distance term makes exactly tied optima common (swapping two matches often leaves the total unchanged), so

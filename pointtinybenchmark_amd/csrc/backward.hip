@@ -296,9 +296,16 @@ static void launch_colsum(const float* src, float* out, float* tmp, int rows, in
 // gradient of the shortcut and (times s, folded into the data-gradient weights / applied to the weight gradient by
 // bn_fold_bwd) of the conv output.  This kernel writes g and the per-channel column sums of g (= dshift).
 // (M, C) row-major, C % 4 == 0.  y == nullptr: no mask (g = dy; g_out may be null -> column sums only).
-__global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ g_out,
-                                       float* __restrict__ part, long long M, int C, int rows_per_block) {
+// Round 6 (mixed precision): YB = the mask source y is the bf16 map the forward recorded (read as it is: no widened copy), g16_out
+// (optional) = the bf16 rounding of g, written by the same pass (the bf16 weight / data gradients read it: no torch narrowing pass).
+template <bool YB>
+__global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const void* __restrict__ yv_, float* __restrict__ g_out,
+                                       unsigned short* __restrict__ g16_out, float* __restrict__ part, long long M, int C,
+                                       int rows_per_block) {
     __shared__ float red[256 * 4];
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    const float* y = reinterpret_cast<const float*>(yv_);
+    const unsigned short* y16 = reinterpret_cast<const unsigned short*>(yv_);
     const int c0 = blockIdx.y * 1024;               // blockIdx.y: 1024-channel column group
     const int Q = min(1024, C - c0) >> 2;
     const int PP = 256 / Q;                         // rows handled per pass; threads >= PP*Q idle
@@ -316,20 +323,30 @@ __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float
                 ok[u] = ru < r1;
                 const size_t o = (size_t)(ok[u] ? ru : r) * C + c0 + q * 4;
                 g[u] = *reinterpret_cast<const f32x4*>(dy + o);
-                if (y) yv[u] = *reinterpret_cast<const f32x4*>(y + o);
+                if (yv_) {
+                    if (YB) {
+                        const u16x4 h = *reinterpret_cast<const u16x4*>(y16 + o);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) yv[u][k] = __uint_as_float(((unsigned)h[k]) << 16);
+                    } else yv[u] = *reinterpret_cast<const f32x4*>(y + o);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (!ok[u]) continue;
-                if (y) {
+                if (yv_) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g[u][k] = (yv[u][k] > 0.f) ? g[u][k] : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s1[k] += g[u][k];
-                if (g_out) {
-                    const size_t o = (size_t)(r + (long long)u * PP) * C + c0 + q * 4;
-                    *reinterpret_cast<f32x4*>(g_out + o) = g[u];
+                const size_t o = (size_t)(r + (long long)u * PP) * C + c0 + q * 4;
+                if (g_out) *reinterpret_cast<f32x4*>(g_out + o) = g[u];
+                if (g16_out) {
+                    u16x4 h;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) h[k] = __builtin_bit_cast(unsigned short, (__bf16)g[u][k]);      // round to nearest even, as torch's .to(bfloat16)
+                    *reinterpret_cast<u16x4*>(g16_out + o) = h;
                 }
             }
         }
@@ -347,14 +364,17 @@ __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float
         for (int k = 0; k < 4; ++k) dst[k] = acc[k];
     }
 }
-extern "C" int cpr_relu_bwd_colsum(const float* dy, const float* y, float* g_out, float* colsum, float* ws_part,
-                                   long long M, int C, int accumulate, hipStream_t stream) {
+
+extern "C" int cpr_relu_bwd_colsum(const float* dy, const void* y, int y_bf16, float* g_out, unsigned short* g16_out, float* colsum,
+                                   float* ws_part, long long M, int C, int accumulate, hipStream_t stream) {
     // ws_part: (ceil(M/128) + 64)*C floats
     CPR_CHECK_ARG(dy && colsum && ws_part && M > 0 && C > 0 && C % 4 == 0);
     const int rows_per_block = 128;
     const int blocks = (int)cdivll(M, rows_per_block);
-    hipLaunchKernelGGL(relu_bwd_colsum_kernel, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, y, g_out, ws_part,
-                       M, C, rows_per_block);
+    if (y_bf16) hipLaunchKernelGGL(relu_bwd_colsum_kernel<true>, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, y, g_out, g16_out,
+                                   ws_part, M, C, rows_per_block);
+    else hipLaunchKernelGGL(relu_bwd_colsum_kernel<false>, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, y, g_out, g16_out, ws_part,
+                            M, C, rows_per_block);
     launch_colsum(ws_part, colsum, ws_part + (size_t)blocks * C, blocks, C, (long long)C, 1, accumulate, stream);
     CPR_LAUNCH_STATUS();
 }
@@ -1234,30 +1254,46 @@ __global__ void p2p_loss_bwd_kernel(const float* __restrict__ logits, const floa
                                     const float* __restrict__ npos, float* __restrict__ dcls, float* __restrict__ dreg,
                                     int M, int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w,
                                     float neg_w, float reg_norm, float w_cls, float w_reg, float gamma_p,
-                                    const float* __restrict__ up) {
+                                    const float* __restrict__ up, int cls_mode, int reg_mode, float cls_total) {
     const int b = blockIdx.y;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     if (up) { w_cls *= up[b * 2]; w_reg *= up[b * 2 + 1]; }     // upstream gradients of this image's (loss_cls, loss_pts)
     const size_t r = (size_t)b * M + m;
     const float inv_n = 1.f / fmaxf(npos[0], 1.f);
+    const float inv_c = cls_mode == 0 ? inv_n : 1.f / cls_total;          // CrossEntropyLoss modes: averaged over all proposals
     const long long gi = gt_inds[r];
     const bool pos = gi > 0;
     const int g = pos ? gt_start[b] + (int)gi - 1 : 0;
-    const int label = pos ? gt_labels[g] : C;
+    const int nfg = cls_mode == 2 ? C - 1 : C;
+    const int label = pos ? gt_labels[g] : nfg;
     const float w = (gi < 0) ? 0.f : pos ? pos_w : (neg_w <= 0.f ? 1.f : neg_w);   // gi < 0: invalid cell, label weight 0
+    float mx = -INFINITY, se = 0.f;
+    if (cls_mode == 2) {
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[r * C + c]);
+        for (int c = 0; c < C; ++c) se += expf(logits[r * C + c] - mx);
+    }
     for (int c = 0; c < Cp; ++c) {
         float d = 0.f;
         if (c < C) {
             const float x = logits[r * C + c];
-            const float p = 1.f / (1.f + expf(-x));
-            const float t = (c == label) ? 1.f : 0.f;
-            const float pt = (1.f - p) * t + p * (1.f - t);
-            const float at = alpha * t + (1.f - alpha) * (1.f - t);
-            const float ptg = (gamma == 2.f) ? pt * pt : powf(pt, gamma);
-            const float ptg1 = (gamma == 2.f) ? pt : powf(pt, gamma - 1.f);
-            const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-            d = at * (ptg * (p - t) + bce * gamma * ptg1 * (1.f - 2.f * t) * p * (1.f - p)) * w * w_cls * inv_n;
+            if (cls_mode == 2) {
+                const int lab = gi < 0 ? 0 : label;
+                d = (expf(x - mx) / se - (c == lab ? 1.f : 0.f)) * w * w_cls * inv_c;
+            } else {
+                const float p = 1.f / (1.f + expf(-x));
+                const float t = (c == label) ? 1.f : 0.f;
+                if (cls_mode == 1) {
+                    d = (p - t) * w * w_cls * inv_c;
+                } else {
+                    const float pt = (1.f - p) * t + p * (1.f - t);
+                    const float at = alpha * t + (1.f - alpha) * (1.f - t);
+                    const float ptg = (gamma == 2.f) ? pt * pt : powf(pt, gamma);
+                    const float ptg1 = (gamma == 2.f) ? pt : powf(pt, gamma - 1.f);
+                    const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+                    d = at * (ptg * (p - t) + bce * gamma * ptg1 * (1.f - 2.f * t) * p * (1.f - p)) * w * w_cls * inv_c;
+                }
+            }
         }
         dcls[r * Cp + c] = d;
     }
@@ -1266,7 +1302,8 @@ __global__ void p2p_loss_bwd_kernel(const float* __restrict__ logits, const floa
         float d = 0.f;
         if (pos && k < 2) {
             const float e = pred[r * 3 + k] / s / reg_norm - gt_pts[g * 2 + k] / s / reg_norm;
-            const float de = (fabsf(e) < beta) ? e / beta : (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+            const float sg = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+            const float de = reg_mode == 1 ? 2.f * e : reg_mode == 2 ? sg : (fabsf(e) < beta) ? e / beta : sg;
             d = de * gamma_p / reg_norm * w_reg * inv_n;
         }
         dreg[r * Rp + k] = d;
@@ -1276,11 +1313,12 @@ extern "C" int cpr_p2p_loss_bwd(const float* logits, const float* pred, const lo
                                 const int* gt_labels, const int* gt_start, const float* npos, float* dcls, float* dreg,
                                 int B, int M, int C, int Cp, int Rp, float alpha, float gamma, float beta, float pos_w,
                                 float neg_w, float reg_norm, float w_cls, float w_reg, float gamma_p, const float* upstream,
-                                hipStream_t stream) {
-    CPR_CHECK_ARG(B > 0 && M > 0 && C > 0 && Cp >= C && Rp >= 2 && beta > 0);
+                                int cls_mode, int reg_mode, hipStream_t stream) {
+    CPR_CHECK_ARG(B > 0 && M > 0 && C > 0 && Cp >= C && Rp >= 2 && (beta > 0 || reg_mode != 0));
+    CPR_CHECK_ARG(cls_mode >= 0 && cls_mode <= 2 && reg_mode >= 0 && reg_mode <= 2 && (cls_mode != 2 || C >= 2));
     CPR_CHECK_ARG(logits && pred && gt_inds && gt_pts && gt_labels && gt_start && npos && dcls && dreg);
     hipLaunchKernelGGL(p2p_loss_bwd_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, stream, logits, pred, gt_inds, gt_pts,
                        gt_labels, gt_start, npos, dcls, dreg, M, C, Cp, Rp, alpha, gamma, beta, pos_w, neg_w, reg_norm,
-                       w_cls, w_reg, gamma_p, upstream);
+                       w_cls, w_reg, gamma_p, upstream, cls_mode, reg_mode, (float)((double)B * (double)M));
     CPR_LAUNCH_STATUS();
 }

@@ -24,6 +24,7 @@
 // cannot fill the chip with big tiles, and -- in the 256 x 256 instance -- an interleaved cout layout that lets every lane store
 // adjacent couts (dma_epilogue_pairs).  Which layer takes which instance: bf16_dma_shape in conv_mfma_bf16.hip.
 #include "conv_bf16_dma.h"
+#include <cstdlib>
 
 // BD = true (round 5, <4, 2, 4, true> only): the WEIGHT operand goes global -> VGPR directly, only the activations go through LDS.
 // The host hands over a second image of the weights in fragment order -- wfrag[g = cout / 64][ks = k / 16][j][lane][8]: lane
@@ -477,6 +478,11 @@ int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, in
     p.nt_taps = k * k; p.nt_k = k; p.nt_pad = pad; p.nt_Wp = Wp; p.nt_chunks = chunks; p.nt_copy = copy;
     const long long blocks = (long long)splits * p.nt_taps * p.tilesM * p.tilesN;
     if (blocks >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    // the ping-pong instance (conv_bf16_pp.hip) takes this mode too (bit-equal partials) but measured SLOWER here -- configs[4] training
+    // step 55.3 ms with it, 54.3 without (profiles/round6_mixed_train_ab.txt): the splits are short (a few chunks), its prologue is
+    // longer -- so the lock-step instance stays; CPR_BF16_NT_PP=1 switches for A/B
+    static const bool nt_pp = []() { const char* e = getenv("CPR_BF16_NT_PP"); return e && e[0] == '1'; }();
+    if (chunks >= 4 && nt_pp) conv_bf16_pp_launch(p, (unsigned)blocks, stream);
+    else hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }

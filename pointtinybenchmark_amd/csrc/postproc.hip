@@ -503,11 +503,15 @@ extern "C" int cpr_rowmax_sigmoid(const float* logits, float* out, long long M, 
 // P2PHead.loss_single (p2p_head.py:220-248) fused with sample_result_to_target (:308-328): sigmoid focal loss
 // (py_sigmoid_focal_loss, T/mmdet/models/losses/focal_loss.py:11-56) + SmoothL1 (smooth_l1_loss.py:11-28) straight
 // from the assignment.  One image per blockIdx.y; per-block partial sums in double, reduced by p2p_loss_finalize.
+// cls_mode: 0 sigmoid focal (avg factor = positives), 1 CrossEntropyLoss(use_sigmoid=True) = binary_cross_entropy_with_logits on the
+// one-hot labels (cross_entropy_loss.py:58-99; avg factor = ALL proposals of the batch, p2p_head.py:222-224), 2 softmax cross
+// entropy over C = num_classes + 1 logits, background = the last (cross_entropy_loss.py:9-40).  reg_mode: 0 SmoothL1(beta), 1 MSE
+// (mse_loss.py), 2 L1.  The reference's own P2PHead defaults are modes (1, 1) (p2p_head.py:38-46).
 __global__ void p2p_loss_kernel(const float* __restrict__ logits, const float* __restrict__ pred,
                                 const long long* __restrict__ gt_inds, const float* __restrict__ gt_pts,
                                 const int* __restrict__ gt_labels, const int* __restrict__ gt_start,
                                 double* __restrict__ partial, int M, int C, float alpha, float gamma, float beta,
-                                float pos_w, float neg_w, float reg_norm) {
+                                float pos_w, float neg_w, float reg_norm, int cls_mode, int reg_mode) {
     __shared__ double red[3][4];
     const int b = blockIdx.y;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -517,27 +521,38 @@ __global__ void p2p_loss_kernel(const float* __restrict__ logits, const float* _
         const long long gi = gt_inds[r];
         const bool pos = gi > 0;
         const int g = pos ? gt_start[b] + (int)gi - 1 : 0;
-        const int label = pos ? gt_labels[g] : C;
+        const int nfg = cls_mode == 2 ? C - 1 : C;                   // foreground classes; the background label
+        const int label = pos ? gt_labels[g] : nfg;
         // gi < 0: a cell outside the padded image (valid_flags false): the reference un-maps it with label weight 0
-        // (p2p_head.py:300-305, unmap fill 0), i.e. it contributes to neither loss
+        // (p2p_head.py:300-305, unmap fill 0), i.e. it contributes to neither loss -- and with LABEL 0 (softmax mode: class 0)
         const float w = (gi < 0) ? 0.f : pos ? pos_w : (neg_w <= 0.f ? 1.f : neg_w);
-        for (int c = 0; c < C; ++c) {
-            const float x = logits[r * C + c];
-            const float p = 1.f / (1.f + expf(-x));
-            const float t = (c == label) ? 1.f : 0.f;
-            const float pt = (1.f - p) * t + p * (1.f - t);
-            const float fw = (alpha * t + (1.f - alpha) * (1.f - t)) * ((gamma == 2.f) ? pt * pt : powf(pt, gamma));
-            // binary_cross_entropy_with_logits: max(x,0) - x*t + log(1 + exp(-|x|))
-            const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-            lc += (double)(bce * fw * w);
+        if (cls_mode == 2) {
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[r * C + c]);
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += expf(logits[r * C + c] - mx);
+            const int lab = gi < 0 ? 0 : label;
+            lc += (double)((logf(se) + mx - logits[r * C + lab]) * w);
+        } else {
+            for (int c = 0; c < C; ++c) {
+                const float x = logits[r * C + c];
+                const float t = (c == label) ? 1.f : 0.f;
+                // binary_cross_entropy_with_logits: max(x,0) - x*t + log(1 + exp(-|x|))
+                const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+                if (cls_mode == 1) { lc += (double)(bce * w); continue; }
+                const float p = 1.f / (1.f + expf(-x));
+                const float pt = (1.f - p) * t + p * (1.f - t);
+                const float fw = (alpha * t + (1.f - alpha) * (1.f - t)) * ((gamma == 2.f) ? pt * pt : powf(pt, gamma));
+                lc += (double)(bce * fw * w);
+            }
         }
         if (pos) {
             np_ = 1.0;
             const float s = pred[r * 3 + 2];
             for (int d = 0; d < 2; ++d) {
                 const float a = pred[r * 3 + d] / s / reg_norm, t = gt_pts[g * 2 + d] / s / reg_norm;
-                const float diff = fabsf(a - t);
-                lp += (double)((diff < beta) ? 0.5f * diff * diff / beta : diff - 0.5f * beta);
+                const float e = a - t, diff = fabsf(e);
+                lp += (double)(reg_mode == 1 ? e * e : reg_mode == 2 ? diff : (diff < beta) ? 0.5f * diff * diff / beta : diff - 0.5f * beta);
             }
         }
     }
@@ -551,8 +566,9 @@ __global__ void p2p_loss_kernel(const float* __restrict__ logits, const float* _
 }
 
 // out (B,2): per image {loss_cls, loss_pts}; avg factor = total positives over the batch (p2p_head.py:199-200)
+// (cls_total > 0: the classification loss is averaged over ALL proposals of the batch -- the CrossEntropyLoss modes)
 __global__ void p2p_loss_finalize_kernel(const double* __restrict__ partial, int B, int nblk, float w_cls, float w_reg,
-                                         float* __restrict__ out) {
+                                         float* __restrict__ out, double cls_total) {
     // round 4: every sum is a fixed-shape tree (strided per-thread partials -> wave shuffle -> 16 wave totals in order) instead
     // of one thread walking B * nblk doubles (171 us at B = 16); deterministic, double accumulation as before
     __shared__ double red[16];
@@ -578,7 +594,7 @@ __global__ void p2p_loss_finalize_kernel(const double* __restrict__ partial, int
         lc = wave_sum_d(lc);
         lp = wave_sum_d(lp);
         if (lane == 0) {
-            out[b * 2] = (float)(lc / np_ * w_cls);
+            out[b * 2] = (float)(lc / (cls_total > 0 ? cls_total : np_) * w_cls);
             out[b * 2 + 1] = (float)(lp / np_ * w_reg);
         }
     }
@@ -587,13 +603,14 @@ __global__ void p2p_loss_finalize_kernel(const double* __restrict__ partial, int
 extern "C" int cpr_p2p_loss(const float* logits, const float* pred, const long long* gt_inds, const float* gt_pts,
                             const int* gt_labels, const int* gt_start, double* ws_partial, float* out, int B, int M,
                             int C, float alpha, float gamma, float beta, float pos_w, float neg_w, float reg_norm,
-                            float w_cls, float w_reg, hipStream_t stream) {
-    CPR_CHECK_ARG(B > 0 && B <= 1024 && M > 0 && C > 0 && beta > 0);
+                            float w_cls, float w_reg, int cls_mode, int reg_mode, hipStream_t stream) {
+    CPR_CHECK_ARG(B > 0 && B <= 1024 && M > 0 && C > 0 && (beta > 0 || reg_mode != 0));
+    CPR_CHECK_ARG(cls_mode >= 0 && cls_mode <= 2 && reg_mode >= 0 && reg_mode <= 2 && (cls_mode != 2 || C >= 2));
     CPR_CHECK_ARG(logits && pred && gt_inds && gt_pts && gt_labels && gt_start && ws_partial && out);
     const int nblk = cdiv(M, 256);
     hipLaunchKernelGGL(p2p_loss_kernel, dim3(nblk, B), dim3(256), 0, stream, logits, pred, gt_inds, gt_pts, gt_labels,
-                       gt_start, ws_partial, M, C, alpha, gamma, beta, pos_w, neg_w, reg_norm);
+                       gt_start, ws_partial, M, C, alpha, gamma, beta, pos_w, neg_w, reg_norm, cls_mode, reg_mode);
     hipLaunchKernelGGL(p2p_loss_finalize_kernel, dim3(1), dim3(1024), 0, stream, ws_partial, B, nblk, w_cls, w_reg,
-                       out);
+                       out, cls_mode == 0 ? 0.0 : (double)B * (double)M);
     CPR_LAUNCH_STATUS();
 }

@@ -2,8 +2,9 @@
 
   forward        two towers of 4 x [conv3x3 -> GN32 -> ReLU] + 3x3 cls_out / reg_out; GroupNorm statistics ride in the
                  conv epilogues and every GN-apply+ReLU is folded into the consumer conv's load (nothing materialised)
-  loss           decode kernel -> fused FocalLossCost + DisCostV2 cost -> ONE batched device LSA launch for all images
-                 (topk_k rounds) -> fused sigmoid-focal + SmoothL1 loss straight from the assignment
+  loss           decode kernel -> cost kernel (the shipped FocalLossCost + DisCostV2 pair fused; any other list of the registered costs
+                 through the general kernel, round 6) -> ONE batched device LSA launch for all images (topk_k rounds) -> fused
+                 classification (sigmoid focal | BCE | softmax CE) + regression (SmoothL1 | MSE | L1) loss straight from the assignment
   get_bboxes     sigmoid row-max -> radix-select top-k -> 16x16 pseudo boxes -> bitmask NMS
 NHWC makes the reference's permute/reshape of the output maps (p2p_head.py:143-148) a free view."""
 import math
@@ -40,15 +41,20 @@ class P2PHead(nn.Module):
                  feat_channels=256, stacked_convs=4, strides=(4, 8, 16, 32, 64), dcn_on_last_conv=False,
                  conv_bias='auto', loss_bbox=None, conv_cfg=None, norm_cfg=None, train_cfg=None, test_cfg=None):
         super().__init__()
-        assert loss_cls['type'] == 'FocalLoss' and loss_cls.get('use_sigmoid', False) and \
-            loss_reg['type'] == 'SmoothL1Loss', 'the fused loss kernel implements the shipped P2P config ' \
-            '(FocalLoss + SmoothL1Loss, T/configs2/TinyPersonV2/p2p/p2p_r50_fpns4_1x_fl_sl1_TinyPersonV2_640.py:40-47)'
+        # round 6: the head's own defaults (CrossEntropyLoss(use_sigmoid) + MSELoss, p2p_head.py:38-46) and the other registered losses
+        # the fused loss kernels take (ops.P2P_CLS_MODES / P2P_REG_MODES), next to the shipped FocalLoss + SmoothL1Loss
+        assert loss_cls['type'] in ('FocalLoss', 'CrossEntropyLoss') and loss_reg['type'] in ops.P2P_REG_MODES, (loss_cls, loss_reg)
+        assert loss_cls['type'] != 'FocalLoss' or loss_cls.get('use_sigmoid', False), 'FocalLoss: only the sigmoid version exists (focal_loss.py:170)'
         assert norm_cfg is not None and norm_cfg['type'] == 'GN' and not dcn_on_last_conv
-        assert len(strides) == 1, 'single FPN level, as in the shipped config'
         self.point_anchor = torch.FloatTensor(point_anchor)
         self.num_points = len(point_anchor)
-        self.use_sigmoid_cls = True
-        self.num_classes = self.num_cls_out = self.cls_out_channels = num_classes
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)          # p2p_head.py:61-65
+        self.num_classes = num_classes
+        self.num_cls_out = self.cls_out_channels = num_classes if self.use_sigmoid_cls else num_classes + 1
+        self.loss_cls_type = loss_cls['type']
+        self.cls_mode = ops.P2P_CLS_MODES['FocalLoss' if loss_cls['type'] == 'FocalLoss' else
+                                          'CrossEntropyLoss_sigmoid' if self.use_sigmoid_cls else 'CrossEntropyLoss']
+        self.reg_mode = ops.P2P_REG_MODES[loss_reg['type']]
         self.loss_cls_cfg, self.loss_reg_cfg = dict(loss_cls), dict(loss_reg)
         self.in_channels, self.feat_channels, self.stacked_convs = in_channels, feat_channels, stacked_convs
         self.strides, self.conv_bias = list(strides), conv_bias
@@ -124,30 +130,42 @@ class P2PHead(nn.Module):
 
     # ------------------------------------------------------------------ points (p2p_head.py:125-170, 425-465)
     def get_pred_points(self, cls_outs, pts_outs, img_metas):
-        assert len(cls_outs) == 1
-        cls = ops.from_nchw(cls_outs[0])
-        reg = ops.from_nchw(pts_outs[0])
-        B, H, W, _ = cls.shape
-        stride = self.strides[0]
-        pa = self._cache.get('pa', [], lambda: self.point_anchor.to(cls.device).contiguous())
-        pred, anchor = ops.p2p_decode(reg, pa, stride, self.pts_gamma, want_anchor=True)
-        cls = cls.reshape(B, H * W * self.num_points, self.num_cls_out)
-        # valid_flags (p2p_head.py:451-463, PointGenerator.valid_flags): cells beyond ceil(pad_shape / stride) -- an image
-        # padded less than the batch maximum -- are invalid: not assigned, label weight 0
-        valid = None
-        for b, m in enumerate(img_metas):
-            ph, pw = m['pad_shape'][:2]
-            vh, vw = min(int(np.ceil(ph / stride)), H), min(int(np.ceil(pw / stride)), W)
-            if vh != H or vw != W:
-                if valid is None:
-                    valid = torch.ones((B, H, W, self.num_points), dtype=torch.bool)
-                valid[b, vh:] = False
-                valid[b, :, vw:] = False
-        if valid is None:
-            valid = torch.ones((B, H * W * self.num_points), dtype=torch.bool, device=cls.device)
+        """p2p_head.py:125-170: every level decoded by the decode kernel, levels concatenated along the proposal axis in level order
+        (the reference's torch.cat over levels)."""
+        assert len(cls_outs) == len(pts_outs) == len(self.strides)
+        pa = None
+        anchors, preds, valids, clss = [], [], [], []
+        for lvl, stride in enumerate(self.strides):
+            cls = ops.from_nchw(cls_outs[lvl])
+            reg = ops.from_nchw(pts_outs[lvl])
+            B, H, W, _ = cls.shape
+            if pa is None:
+                pa = self._cache.get('pa', [], lambda: self.point_anchor.to(cls.device).contiguous())
+            pred, anchor = ops.p2p_decode(reg, pa, stride, self.pts_gamma, want_anchor=True)
+            clss.append(cls.reshape(B, H * W * self.num_points, self.num_cls_out))
+            anchors.append(anchor), preds.append(pred)
+            # valid_flags (p2p_head.py:451-463, PointGenerator.valid_flags): cells beyond ceil(pad_shape / stride) -- an image
+            # padded less than the batch maximum -- are invalid: not assigned, label weight 0
+            valid = None
+            for b, m in enumerate(img_metas):
+                ph, pw = m['pad_shape'][:2]
+                vh, vw = min(int(np.ceil(ph / stride)), H), min(int(np.ceil(pw / stride)), W)
+                if vh != H or vw != W:
+                    if valid is None:
+                        valid = torch.ones((B, H, W, self.num_points), dtype=torch.bool)
+                    valid[b, vh:] = False
+                    valid[b, :, vw:] = False
+            valids.append(None if valid is None else valid.reshape(B, -1))
+        if len(self.strides) == 1:
+            anchor, pred, cls = anchors[0], preds[0], clss[0]
+        else:
+            anchor, pred, cls = torch.cat(anchors, 1), torch.cat(preds, 1), torch.cat(clss, 1)
+        B = cls.shape[0]
+        if all(v is None for v in valids):
+            valid = torch.ones((B, cls.shape[1]), dtype=torch.bool, device=cls.device)
             valid.all_valid = True
         else:
-            valid = valid.reshape(B, -1).to(cls.device)
+            valid = torch.cat([torch.ones((B, c.shape[1]), dtype=torch.bool) if v is None else v for v, c in zip(valids, clss)], 1).to(cls.device)
             valid.all_valid = False
         return anchor, pred, valid, cls
 
@@ -218,7 +236,7 @@ class P2PHead(nn.Module):
                            torch.cat(gt_labels).to(torch.int32).contiguous(), start, lc.get('alpha', 0.25),
                            lc.get('gamma', 2.0), lr.get('beta', 1.0), _get(self.train_cfg, 'pos_weight', 1.0),
                            _get(self.train_cfg, 'neg_weight', 1.0), self.reg_norm, lc.get('loss_weight', 1.0),
-                           lr.get('loss_weight', 1.0))
+                           lr.get('loss_weight', 1.0), self.cls_mode, self.reg_mode)
         B = out.shape[0]
         if save is not None:      # what the loss backward re-reads (training.P2PTrainer)
             save.update(cls=cls.contiguous(), pred=pred, gt_inds=gt_inds.contiguous(), gt_pts=torch.cat(gt_points).contiguous(),
@@ -252,32 +270,72 @@ class P2PHead(nn.Module):
 
     # ------------------------------------------------------------------ inference (p2p_head.py:330-423)
     def get_bboxes(self, cls_outs, pts_outs, img_metas, cfg=None, rescale=False, with_nms=True):
+        """p2p_head.py:330-343.  ``with_nms`` is accepted and, as in the reference, NOT forwarded: its get_bboxes calls
+        _get_bboxes_single without it (:339-340), so the NMS branch always runs; the no-NMS branch (:405-423) is reachable only by
+        calling _get_bboxes_single directly (softmax heads: see there)."""
         anchor, pred, valid, cls = self.get_pred_points(cls_outs, pts_outs, img_metas)
-        if BATCHED_POSTPROCESS[0]:
-            return self._get_bboxes_batched(pred[..., :2], cls, img_metas, cfg, rescale, with_nms)
+        if BATCHED_POSTPROCESS[0] and self.use_sigmoid_cls and len(self.strides) == 1:
+            return self._get_bboxes_batched(pred[..., :2], cls, img_metas, cfg, rescale, True)
         res = []
         for b in range(len(img_metas)):
             pts_scores, labels = self._get_bboxes_single(pred[b][..., :2], valid[b], cls[b], img_metas[b]['img_shape'],
-                                                         img_metas[b]['scale_factor'], cfg, rescale, with_nms)
+                                                         img_metas[b]['scale_factor'], cfg, rescale)
             res.append((self.center_to_pseudo_bbox([pts_scores])[0], labels))
         return res
+
+    def _scores(self, logits):
+        """cls_score.sigmoid() / .softmax(-1) of p2p_head.py:362 -> (scores (n, C'), the per-proposal maximum over the FOREGROUND classes).
+        sigmoid: torch's CPU bits (the scores order top-k and NMS); softmax (CrossEntropyLoss without use_sigmoid): torch's device softmax."""
+        if self.use_sigmoid_cls:
+            if self.num_cls_out == 1:
+                m = ops.rowmax_sigmoid(logits)
+                return m[:, None], m
+            return ops.sigmoid_exact(logits), ops.rowmax_sigmoid(logits)
+        sc = torch.softmax(logits, dim=-1)
+        return sc, sc[:, :-1].max(dim=1)[0]
 
     def _get_bboxes_single(self, pred_pts, valid_flag, cls_outs, img_shape, scale_factor, cfg, rescale=False,
                            with_nms=True):
         cfg = self.test_cfg if cfg is None else cfg
-        assert with_nms
         nms_pre = _get(cfg, 'nms_pre', -1)
-        logits = cls_outs.contiguous()
-        if 0 < nms_pre < logits.shape[0]:
-            _, topk_inds = ops.topk_desc(ops.rowmax_sigmoid(logits), nms_pre)
-            logits, pred_pts = logits[topk_inds], pred_pts[topk_inds]
-        scores = ops.rowmax_sigmoid(logits)[:, None] if self.num_cls_out == 1 else ops.sigmoid_exact(logits)
-        x = pred_pts[:, 0].clamp(min=0, max=img_shape[1])
-        y = pred_pts[:, 1].clamp(min=0, max=img_shape[0])
-        pts = torch.stack([x, y], dim=-1)
+        # p2p_head.py:357-376: the concatenated proposals are cut into len(strides) EQUAL chunks (a reshape, whatever the levels' true
+        # sizes are) and the top nms_pre of every chunk survive -- restated as it stands
+        L = len(self.strides)
+        assert pred_pts.shape[0] % L == 0, 'the reference reshapes the proposals to (len(strides), -1, 2) (p2p_head.py:357)'
+        pts_l, sc_l = [], []
+        for logits, pp in zip(cls_outs.contiguous().reshape(L, -1, self.num_cls_out), pred_pts.reshape(L, -1, 2)):
+            logits = logits.contiguous()
+            scores, rowmax = self._scores(logits)
+            if 0 < nms_pre < logits.shape[0]:
+                _, topk_inds = ops.topk_desc(rowmax.contiguous(), nms_pre)
+                scores, pp = scores[topk_inds], pp[topk_inds]
+            x = pp[:, 0].clamp(min=0, max=img_shape[1])
+            y = pp[:, 1].clamp(min=0, max=img_shape[0])
+            pts_l.append(torch.stack([x, y], dim=-1)), sc_l.append(scores)
+        pts, scores = (pts_l[0], sc_l[0]) if L == 1 else (torch.cat(pts_l), torch.cat(sc_l))
         if rescale:
             pts = pts / pts.new_tensor(scale_factor[:2])
-        scores = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
+        if self.use_sigmoid_cls:
+            scores = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
+        if not with_nms:
+            # p2p_head.py:405-423: every (point, class) pair -- the background column included, as the reference expands num_cls_out + 1
+            # ... it expands to num_cls_out columns of a (n, num_cls_out [+ 1]) score matrix: restated through its own reshape
+            n, Cs = scores.shape
+            cols = self.num_cls_out
+            mp = pts[:, None].expand(n, cols, 2).reshape(-1, 2)
+            labels = torch.arange(cols, dtype=torch.long, device=pts.device).view(1, -1).expand(n, cols)
+            # mlvl_scores (n, Cs) is flattened whole while points / labels are expanded to num_cls_out columns: equal only when Cs == cols
+            assert Cs == cols, 'with_nms=False indexes (n * %d) points with (n * %d) scores in the reference (p2p_head.py:408-418): ' \
+                'only a softmax head (no padded background column) runs there' % (cols, Cs)
+            ms, labels = scores.reshape(-1), labels.reshape(-1)
+            inds = (ms > _get(cfg, 'score_thr')).nonzero(as_tuple=False).squeeze(1)
+            points, sc, labels = mp[inds], ms[inds], labels[inds]
+            dets = torch.cat([points, sc[:, None]], -1)
+            max_per_img = _get(cfg, 'max_per_img')
+            if 0 < max_per_img < len(sc):
+                _, idx = ops.topk_desc(sc.contiguous(), max_per_img)
+                dets, labels = dets[idx], labels[idx]
+            return dets, labels
         wh = pts.new_tensor(_get(self.test_cfg, 'pseudo_wh', (16, 16)))
         boxes = torch.cat([pts - wh / 2, pts + wh / 2], dim=-1)
         dets, labels = multiclass_nms(boxes, scores, _get(cfg, 'score_thr'), _get(cfg, 'nms'), _get(cfg, 'max_per_img'))

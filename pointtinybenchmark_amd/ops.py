@@ -881,9 +881,14 @@ def rowmax_sigmoid(logits):
     return out
 
 
+P2P_CLS_MODES = {'FocalLoss': 0, 'CrossEntropyLoss_sigmoid': 1, 'CrossEntropyLoss': 2}
+P2P_REG_MODES = {'SmoothL1Loss': 0, 'MSELoss': 1, 'L1Loss': 2}
+
+
 def p2p_loss(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, beta, pos_w, neg_w, reg_norm, w_cls,
-             w_reg):
-    """logits (B,M,C), pred (B,M,3), gt_inds (B,M) int64 -> (B,2) {loss_cls, loss_pts} per image."""
+             w_reg, cls_mode=0, reg_mode=0):
+    """logits (B,M,C), pred (B,M,3), gt_inds (B,M) int64 -> (B,2) {loss_cls, loss_pts} per image.  cls_mode / reg_mode:
+    P2P_CLS_MODES / P2P_REG_MODES (include/cpr_hip.h, cpr_p2p_loss)."""
     B, M, C = _check(logits).shape
     nblk = (M + 255) // 256
     ws = torch.empty((B * nblk * 3,), device=logits.device, dtype=torch.float64)
@@ -891,8 +896,22 @@ def p2p_loss(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, b
     _lib.call('cpr_p2p_loss', _ptr(logits), _ptr(_check(pred)), _ptr(_check(gt_inds, torch.int64)), _ptr(_check(gt_pts)),
               _ptr(_check(gt_labels, torch.int32)), _ptr(_check(gt_start, torch.int32)), _ptr(ws), _ptr(out), B, M, C,
               float(alpha), float(gamma), float(beta), float(pos_w), float(neg_w), float(reg_norm), float(w_cls),
-              float(w_reg), _stream())
+              float(w_reg), int(cls_mode), int(reg_mode), _stream())
     return out
+
+
+def match_cost(pred, logits, gt, labels, cls_terms, reg_terms):
+    """The general cost matrix of the Hungarian assigners (csrc/assign.hip, match_cost_kernel) -> cost^T (G, M).  pred (M, 2) points or
+    (M, 4) xyxy boxes, gt alike; cls_terms / reg_terms: lists of (type, weight, a, b, c, d) (include/cpr_hip.h, cpr_match_cost)."""
+    import ctypes
+    M, G = pred.shape[0], gt.shape[0]
+    assert pred.shape[1] == gt.shape[1] and pred.shape[1] in (2, 4) and len(cls_terms) <= 4 and len(reg_terms) <= 4
+    costT = torch.empty((G, M), device=pred.device, dtype=torch.float32)
+    flat = [float(v) for t in list(cls_terms) + list(reg_terms) for v in (tuple(t) + (0.,) * 6)[:6]]
+    terms = (ctypes.c_float * max(len(flat), 1))(*flat)
+    _lib.call('cpr_match_cost', _ptr(_check(pred)), pred.shape[1], _ptr(_check(logits)), logits.shape[1], _ptr(_check(gt)),
+              _ptr(_check(labels, torch.int32)), _ptr(costT), M, G, terms, len(cls_terms), len(reg_terms), _stream())
+    return costT
 
 
 # ------------------------------------------------------------------------------------------------ backward / optimizer
@@ -1086,18 +1105,22 @@ def upsample_add_bwd(dfine, dcoarse_or_shape, accumulate=True):
     return dc
 
 
-def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None):
-    """g = dy*(y>0) (y None: g = dy) and per-channel column sums of g -> (g|None, colsum (C))."""
+def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None, want16=False):
+    """g = dy*(y>0) (y None: g = dy) and per-channel column sums of g -> (g|None, colsum (C)[, g16]).  y fp32 or the bf16 map the
+    mixed-precision forward recorded (read as it is); want16: also the bf16 rounding of g, written by the same pass."""
     C = dy.shape[-1]
     M = dy.numel() // C
     acc = colsum is not None
     if not acc:
         colsum = torch.empty((C,), device=dy.device, dtype=torch.float32)
     g = torch.empty_like(dy) if want_g else None
+    g16 = torch.empty(tuple(dy.shape), device=dy.device, dtype=torch.bfloat16) if want16 else None
     ws = torch.empty((((M + 127) // 128 + 64) * C,), device=dy.device, dtype=torch.float32)
-    _lib.call('cpr_relu_bwd_colsum', _ptr(_check(dy)), _ptr(y), _ptr(g), _ptr(colsum), _ptr(ws), M, C, int(acc),
-              _stream())
-    return g, colsum
+    if y is not None:
+        assert y.dtype in (torch.float32, torch.bfloat16) and y.is_contiguous() and y.numel() == dy.numel()
+    _lib.call('cpr_relu_bwd_colsum', _ptr(_check(dy)), _ptr(y), int(y is not None and y.dtype == torch.bfloat16), _ptr(g), _ptr(g16),
+              _ptr(colsum), _ptr(ws), M, C, int(acc), _stream())
+    return (g, colsum, g16) if want16 else (g, colsum)
 
 
 def bn_fold_bwd(Gw, weight, scale, mean, inv_sigma, colsum_g, want_affine=True, out_dgamma=None, out_dbeta=None):
@@ -1229,7 +1252,7 @@ def bag_points_gather_bwd(dsample, pts, code, gt_img, dmap, stride, align_corner
 
 
 def p2p_loss_bwd(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamma, beta, pos_w, neg_w, reg_norm, w_cls,
-                 w_reg, gamma_p, Cp, Rp, upstream=None):
+                 w_reg, gamma_p, Cp, Rp, upstream=None, cls_mode=0, reg_mode=0):
     """-> (dcls (B,M,Cp), dreg (B,M,Rp)): gradient of the summed P2P losses wrt class logits / regression output.
     upstream (B,2): gradient of the caller's total wrt each image's (loss_cls, loss_pts); None = unit weights."""
     B, M, C = _check(logits).shape
@@ -1240,7 +1263,7 @@ def p2p_loss_bwd(logits, pred, gt_inds, gt_pts, gt_labels, gt_start, alpha, gamm
     _lib.call('cpr_p2p_loss_bwd', _ptr(logits), _ptr(_check(pred)), _ptr(gt_inds), _ptr(gt_pts), _ptr(gt_labels),
               _ptr(gt_start), _ptr(npos), _ptr(dcls), _ptr(dreg), B, M, C, Cp, Rp, float(alpha), float(gamma), float(beta),
               float(pos_w), float(neg_w), float(reg_norm), float(w_cls), float(w_reg), float(gamma_p), _ptr(upstream),
-              _stream())
+              int(cls_mode), int(reg_mode), _stream())
     return dcls, dreg
 
 

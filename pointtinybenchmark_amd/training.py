@@ -221,7 +221,7 @@ FUSED_CAST = os.environ.get('CPR_MIXED_FUSED_CAST', '1') != '0'
 # measurement switches (tests/report_mixed_precision_grads.py: where the mixed-precision gradient error comes from): the weight /
 # data gradients of the mixed-precision step on the fp32 kernels; force = bf16 backward rules behind an fp32 recorded forward
 MIXED_BF16 = dict(wgrad=os.environ.get('CPR_MIXED_WGRAD', 'bf16') != 'fp32', dgrad=os.environ.get('CPR_MIXED_DGRAD', 'bf16') != 'fp32',
-                  force=False)
+                  dgrad1x1=os.environ.get('CPR_MIXED_DGRAD_1X1', 'bf16') != 'fp32', force=False)
 
 
 class BackwardEngine:
@@ -656,21 +656,27 @@ class BackwardEngine:
             dx = self._block_backward(c, blk, rec, dx, need_dx)
         self._wide = {}      # nothing below the lowest trainable block reads a widened copy
 
-    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx, mask=None, add=None, want_colsum=False):
+    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx, mask=None, add=None, want_colsum=False, g16=None, want16=False):
         """conv -> folded eval-BN given g = d(pre-activation output) (un-scaled) and its column sums.  Parameter
         gradients go to the side stream; returns the data gradient wrt x -- with ``mask`` (x itself, when x is the
         output of a fused ReLU) already taken through that ReLU, with ``add`` summed in, with ``want_colsum`` as
-        (gradient, column sums): all three ride in the conv epilogue."""
+        (gradient, column sums): all three ride in the conv epilogue (fp32 kernels) or in one streaming pass over the result
+        (bf16 data gradients).  ``x`` / ``mask`` are the maps AS RECORDED (bf16 in the mixed-precision step): they are widened only
+        where an fp32 kernel reads them.  g16: the bf16 rounding of g when the producer already wrote it; want16 (with
+        want_colsum): also return the bf16 rounding of the result -> (gradient, column sums, gradient16 | None)."""
         scale, _ = folded_bn(cache, bn)
         inv_sigma = cache.get(('bn_is', id(bn)), [bn.running_var],
                               lambda: ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, True)[2])
         w = conv.weight
-        # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight gradient and the bf16 3x3 data gradient
+        k = conv.kernel_size[0]
+        # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight gradient and the bf16 data gradient (round 6: the
+        # stride-1 1x1 layers too -- their fp32 form was 13 % of the step's kernel time, profiles/round5_train_cfg4_kernel_stats.csv)
         w16 = w.requires_grad and self._mixed and MIXED_BF16['wgrad'] and \
             ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0])
-        d16 = need_dx and self._mixed and MIXED_BF16['dgrad'] and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and \
-            w.shape[0] % 64 == 0 and add is None
-        g16 = g.to(torch.bfloat16) if (w16 or d16) else None
+        d16 = need_dx and self._mixed and MIXED_BF16['dgrad'] and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and \
+            (k == 3 and add is None or k == 1 and MIXED_BF16['dgrad1x1'] and w.shape[1] % 64 == 0)
+        if g16 is None and (w16 or d16):
+            g16 = g.to(torch.bfloat16)
         if w.requires_grad:
             aff = bn.weight.requires_grad
 
@@ -678,65 +684,79 @@ class BackwardEngine:
                 cs = colsum.reduce() if isinstance(colsum, ops.TilePartials) else colsum
                 gw = self._g(w)
                 if w16:
-                    ops.conv_wgrad_bf16(g16, x, w.shape, out=gw)    # (x is the widened recorded map: rounds back exactly)
+                    ops.conv_wgrad_bf16(g16, x, w.shape, out=gw)    # (x: the bf16 recorded map, or a widened copy that rounds back exactly)
                 else:
-                    ops.conv2d_wgrad(g, x, w.shape, conv.stride[0], conv.padding[0], out=gw)
+                    ops.conv2d_wgrad(g, self._f32(x), w.shape, conv.stride[0], conv.padding[0], out=gw)
                 ops.bn_fold_bwd(gw, w, scale, bn.running_mean, inv_sigma, cs,
                                 out_dgamma=self._g(bn.weight) if aff else None, out_dbeta=self._g(bn.bias) if aff else None)
             # x may be a widened fp32 temporary of the mixed-precision step that the main stream frees right after this call
             self._param_side(param_grads, g, colsum, g16, x)
         if not need_dx:
             return None
+
+        def finish(dx):
+            """mask / column sums / bf16 rounding as one streaming pass over the data gradient."""
+            if mask is None and not want_colsum:
+                return dx
+            r = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None, want16=want16)
+            dxm = r[0] if mask is not None else dx
+            if not want_colsum:
+                return dxm
+            if want16:
+                return dxm, r[1], r[2]
+            return dxm, r[1]
         if d16:
-            # mixed precision: the 3x3 data gradient on the bf16 matrix pipe (its fp32 form cannot be a Winograd launch: the mask /
-            # column-sum epilogue), the ReLU mask and the column sums as one streaming pass over the (small) result
+            # mixed precision: the data gradient on the bf16 matrix pipe (a forward conv of the bf16-rounded gradient map with the
+            # rotated, BN-scaled weights, fp32 out), the residual add, the ReLU mask (the bf16 recorded map as it is) and the column
+            # sums as streaming passes over the (small) result
             def pack16():
                 if ops.PACK_BF16_KERNEL[0]:
                     return ops.PackedConv.for_dgrad_bf16(w, conv.padding[0], scale=scale)
                 wt = (w.detach() * scale[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3)
-                return ops.PackedConv(wt, 1, 2 - conv.padding[0], torch.bfloat16)
+                return ops.PackedConv(wt, 1, k - 1 - conv.padding[0], torch.bfloat16)
             pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16)
             dx = ops.conv2d(g16, pc16, out_dtype=torch.float32)
-            if mask is None and not want_colsum:
-                return dx
-            gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
-            dx = gm if mask is not None else dx
-            return (dx, cs) if want_colsum else dx
+            if add is not None:
+                dx = ops.axpby(dx, add, 1.0, 1.0)
+            return finish(dx)
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
                        lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
-        if WINO_DGRAD[0] and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and add is None and \
+        if WINO_DGRAD[0] and k == 3 and conv.stride[0] == 1 and add is None and \
                 (mask is not None or want_colsum) and ops.wino_eligible(pt, x.shape[1], x.shape[2], torch.float32):
             # a 3x3 stride-1 data gradient with a mask / column-sum epilogue would run the direct kernel (2.25x the multiplies of
             # the Winograd launch the plain form gets); the epilogue as one streaming pass over the result is cheaper
-            dx = ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), 1)
-            gm, cs = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None)
-            dx = gm if mask is not None else dx
-            return (dx, cs) if want_colsum else dx
-        return ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=mask, add=add, colsum=want_colsum)
+            return finish(ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), 1))
+        r = ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=self._f32(mask), add=add, colsum=want_colsum)
+        if want_colsum and want16:
+            return r[0], r[1], None
+        return r
 
     def _block_backward(self, cache, blk, rec, dout, need_dx, keep=None):
-        # x = the output of the block below: when that block's backward runs next (keep; default: whenever a gradient flows
-        # down, need_dx) it reads the same recorded tensor -- the widened copy of a bf16 map is then held for it
-        x = self._f32(rec['x'], keep=need_dx if keep is None else keep)
-        g3, cs3 = ops.relu_bwd_colsum(dout, self._f32(rec['out']))            # also the shortcut gradient
-        o1 = self._f32(rec['o1'])
+        # the recorded maps are handed on as recorded (bf16 in the mixed-precision step): the ReLU masks are read as they are, the bf16
+        # gradient kernels read x as it is, and only an fp32 fallback kernel widens what it reads (round 6: rounds 3-5 widened every
+        # recorded map up front -- 5.6 % of the step's kernel time in torch copy kernels)
+        mixed = self._mixed
+        x = rec['x']
+        r3 = ops.relu_bwd_colsum(dout, rec['out'], want16=mixed)              # also the shortcut gradient
+        g3, cs3, g3h = r3 if mixed else (r3[0], r3[1], None)
+        o1 = rec['o1']
         if blk.kind == 'bottleneck':
-            o2 = self._f32(rec['o2'])
-            g2, cs2 = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, o2, True, mask=o2, want_colsum=True)
+            o2 = rec['o2']
+            g2, cs2, g2h = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, o2, True, mask=o2, want_colsum=True, g16=g3h, want16=True)
             del o2
-            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, o1, True, mask=o1, want_colsum=True)
+            g1, cs1, g1h = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, o1, True, mask=o1, want_colsum=True, g16=g2h, want16=True)
             last = blk.bn3
         else:
-            g1, cs1 = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, o1, True, mask=o1, want_colsum=True)
+            g1, cs1, g1h = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, o1, True, mask=o1, want_colsum=True, g16=g3h, want16=True)
             last = blk.bn2
         del o1
         self._done(last.bias if last.bias.requires_grad else blk.conv2.weight)
         if blk.downsample is not None:     # the shortcut conv sees the same g3 (no activation on that branch)
-            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx)
-            dx = self._conv_bn_backward(cache, blk.downsample[0], blk.downsample[1], g3, cs3, x, need_dx, add=dx)
+            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx, g16=g1h)
+            dx = self._conv_bn_backward(cache, blk.downsample[0], blk.downsample[1], g3, cs3, x, need_dx, add=dx, g16=g3h)
             tail = blk.downsample[1].bias if blk.downsample[1].bias.requires_grad else blk.downsample[0].weight
         else:
-            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx, add=g3)
+            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx, add=g3, g16=g1h)
             tail = blk.bn1.bias if blk.bn1.bias.requires_grad else blk.conv1.weight
         self._done(tail)
         return dx
@@ -958,7 +978,7 @@ class P2PHeadRules:
                                       lc.get('alpha', 0.25), lc.get('gamma', 2.0), lr.get('beta', 1.0),
                                       _get(head.train_cfg, 'pos_weight', 1.0), _get(head.train_cfg, 'neg_weight', 1.0),
                                       head.reg_norm, lc.get('loss_weight', 1.0), lr.get('loss_weight', 1.0),
-                                      head.pts_gamma, Cp, 4, upstream=upstream)
+                                      head.pts_gamma, Cp, 4, upstream=upstream, cls_mode=head.cls_mode, reg_mode=head.reg_mode)
         dz = None
         for tape, dout, n_out, last in ((s['reg_tape'], dreg.view(B, H, W, 4), 2, head.reg_convs[0]),
                                         (s['cls_tape'], dcls.view(B, H, W, Cp), C, head.cls_convs[0])):
