@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round-5 evidence visit (everything lands in gpurun_out/; the summaries are copied to profiles/round5_*):
+# Round-6 evidence visit (everything lands in gpurun_out/; the summaries are copied to profiles/round6_*):
 #   full GPU suite + smoke | PMC passes (three separate --pmc runs each, never with tracing) of the dominant fp32 kernel and of the
 #   bf16 256 x 256 instance | the default bench line | rocprofv3 --kernel-trace --stats of the same command (B=64, B=2, configs[2],
-#   P2PNet, configs[4], training step on two streams and on one) | one gated line per BASELINE config and mode: forward+loss, P2PNet
-#   inference, training steps of configs[1..4] under a 1-rank torchrun (reducer timeline + gradient gate) | torchrun-1-rank vs
-#   plain agreement in both modes | bf16 epilogue ablation, LSA phases, B=2 layer table.
+#   P2PNet, configs[4], training step on two streams and on one, the mixed-precision configs[4] step) | one gated line per BASELINE config
+#   and mode: forward+loss, P2PNet inference, training steps of configs[1..4] under a 1-rank torchrun (reducer timeline + gradient gate) |
+#   torchrun-1-rank vs plain agreement in both modes | the bf16 ping-pong instance's check / ablation table, LSA phases, layer tables.
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${1:-r5fin}
+TAG=${1:-r6fin}
 STAGE=${2:-all}        # all | core (suite, smoke, default bench, PMC) | lines (config / training lines, profiles)
 run_bench() { # name, args...
   local n=$1; shift
@@ -34,8 +34,8 @@ python tools/pmc_to_json.py ${TAG} 64 conv_wino_kernel pmc_dominant_kernel.json 
 for g in sq fetch write; do mv gpurun_out/${TAG}_${g}_counters.csv gpurun_out/${TAG}_wino_${g}_counters.csv 2>/dev/null; done
 ( export ALGO_BYTES=$((2*131072*256*2 + 256*2304*2)) SHAPE_DESC="bf16 3x3 256->256 + GroupNorm statistics on (8,128,128,256): head layer at 1024^2, stride 8"
   PMC_SCRIPT=conv_single.py CONV_ARGS="--bf16 --batch 8 --hw 128 --cin 256 --cout 256 --k 3 --iters 3" bash tools/gpu_pmc.sh ${TAG}bf > /dev/null 2>&1
-  python tools/pmc_to_json.py ${TAG}bf 8 "conv_bf16_dma_kernel<4, 2" round5_pmc_bf16_big_tile.json | grep "mfma_busy\|duration_us\|wait_any\|traffic_over" )
-cp profiles/round5_pmc_bf16_big_tile.json gpurun_out/ 2>/dev/null
+  python tools/pmc_to_json.py ${TAG}bf 8 "conv_bf16_pp_kernel" round6_pmc_bf16_big_tile.json | grep "mfma_busy\|duration_us\|wait_any\|traffic_over" )
+cp profiles/round6_pmc_bf16_big_tile.json gpurun_out/ 2>/dev/null
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 echo "bench exit: $?"; cut -c1-300 gpurun_out/${TAG}_bench.json; echo
 fi
@@ -47,6 +47,7 @@ prof p2p --config cfg3 --steps 5 --warmup 2 --no-cpu-baseline --no-probe --train
 prof cfg4 --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline --no-probe --train-steps 0 --small-batch 0 --batch-sweep ''
 prof train_b64 --mode train --steps 3 --warmup 1 --no-cpu-baseline --no-probe
 CPR_TRAIN_STREAMS=1 prof train_b64_one_stream --mode train --steps 3 --warmup 1 --no-cpu-baseline --no-probe
+CPR_TRAIN_STREAMS=1 prof train_cfg4_one_stream --config cfg4 --mode train --steps 3 --warmup 1 --no-cpu-baseline --no-probe
 find /tmp/prof_${TAG} -name "*kernel_stats*" -exec cp {} gpurun_out/ \; 2>/dev/null
 # one line per BASELINE config at its own shape: roofline + cpu_baseline + the mode's parity gate
 run_bench configcfg0 --config cfg0 --steps 10 --warmup 3 --batch-sweep '' --train-steps 0
@@ -78,15 +79,8 @@ for mode in ('fwd', 'train'):
                      reducer=(a.get('train_step') or {}).get('reducer'))
 json.dump(out, open('gpurun_out/${TAG}_torchrun_vs_plain.json', 'w'), indent=1); print({k: (v['ratio'], v['within_2_percent']) for k, v in out.items()})
 P
-{
-echo "conv_bf16_dma_kernel<4, 2, 4, true>: epilogue ablations, head layer (8,128,128,256) and (64,160,160,256), GN statistics (results WRONG by design)"
-for spec in "1:product" "257:stores dropped by the range check" "513:no epilogue"; do
-  w=${spec%%:*}; what=${spec#*:}
-  for shape in "--batch 64 --hw 160" "--batch 8 --hw 128"; do
-    echo -n "word $w ($what) $shape: "; timeout 120 python tools/conv_single.py --bf16 $shape --iters 20 --bf16-dma $w 2>&1 | grep -v amdgpu | tail -1
-  done
-done
-} > gpurun_out/${TAG}_bf16_epilogue_ablation.txt 2>&1; cat gpurun_out/${TAG}_bf16_epilogue_ablation.txt
+timeout 600 python tools/bf16_pp_check.py > gpurun_out/${TAG}_bf16_pp_check.txt 2>&1; grep -i 'equal' gpurun_out/${TAG}_bf16_pp_check.txt
+timeout 300 python tools/conv_bench.py --depth 101 --size 1024 --dtype bf16 --batch 8 > gpurun_out/${TAG}_convbench_cfg4.txt 2>&1; tail -1 gpurun_out/${TAG}_convbench_cfg4.txt
 timeout 120 python tools/lsa_bench.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_lsa_bench.txt; head -3 gpurun_out/${TAG}_lsa_bench.txt
 timeout 300 python tools/conv_bench.py --batch 2 > gpurun_out/${TAG}_convbench_b2.txt 2>&1; tail -1 gpurun_out/${TAG}_convbench_b2.txt
 python - <<P
