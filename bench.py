@@ -509,7 +509,9 @@ def train_parity_gate(trainer, model, args, batch, ref=None):
     layer; the stride-2 phase data gradient alone is 5e-7 off an fp64 transposed conv).  So the gate has two parts:
       backward kernels: the product step against the SAME bf16 forward with fp32 gradients (one more device step), per tensor <= 0.02;
       forward rounding: against the oracle, relative L2 per BLOCK (a block's tensors concatenated) <= 0.04 head, 0.05 neck, 0.5
-      backbone (2x the measured 0.017 / 0.022 / 0.25; the worst block is named in the line), cosine >= 0.9999, loss <= 3e-2.
+      backbone (2x the measured 0.017-0.020 / 0.022 / 0.25; the worst block is named in the line), loss <= 3e-2, and cosine >= 0.9992:
+      the head carries nearly all of the gradient's norm, so the whole gradient's relative error e is the head block's and the cosine
+      is 1 - e^2 / 2 (configs[4]: head 0.0202 -> 0.99980 predicted, 0.99981 measured; R50 640^2: 0.99995); 0.9992 is the head bar.
     P2PNet: 3e-2 per tensor (an fp32 ReLU flip on the few dozen positives moves a whole
     regression-tower tensor: tests/test_gpu_p2p.py), global norm 1e-3.  ``ref``: (total, grads) of a previous call on the same
     weights (re-used for the mixed-precision gate)."""
@@ -568,9 +570,9 @@ def train_parity_gate(trainer, model, args, batch, ref=None):
                 e = float((gA[k].double() - p.grad.double()).norm() / p.grad.double().norm())
                 if e > bk:
                     bk, bk_key = e, k
-        bars = dict(cosine_min=0.9999, per_block_rel_l2=dict(head=0.04, neck=0.05, backbone=0.5), backward_kernels_per_tensor_rel_l2=0.02,
+        bars = dict(cosine_min=0.9992, per_block_rel_l2=dict(head=0.04, neck=0.05, backbone=0.5), backward_kernels_per_tensor_rel_l2=0.02,
                     loss_rel=3e-2)
-        ok = rep['cosine'] >= 0.9999 and all(v <= bar_of(b_) for b_, v in per_block.items()) and bk <= 0.02 and loss_rel <= 3e-2
+        ok = rep['cosine'] >= bars['cosine_min'] and all(v <= bar_of(b_) for b_, v in per_block.items()) and bk <= 0.02 and loss_rel <= 3e-2
 
         def fam(prefix):
             return round(max([v for b_, v in per_block.items() if b_.startswith(prefix)] or [0.0]), 4)

@@ -120,6 +120,14 @@ int cpr_gn_apply_b8(const float* x, const float* a, const float* b, float* y, in
 int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, const void* wgt_frag, void* out, const float* scale, const float* bias,
                         const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                         int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, void* stream);
+/* Mask mode of the call above (relu == 2; the mixed-precision backward, training.py: a data gradient is a forward convolution of the
+ * gradient map with the rotated weights): `residual` is the bf16 map a forward ReLU produced, out = v where that map is positive, 0
+ * elsewhere (nothing is added), and gn_part receives per-channel SUMS of the masked result, [slots][Cout][2] floats with the sum in
+ * element 0 (cpr_part_colsum adds the slots up).  Only the LDS-DMA instances know the mode: cpr_conv2d_bf16_mask_slots returns the
+ * number of slots a launch of this shape writes, or 0 when the shape would not run in mask mode (cpr_conv2d_fwd_bf16 then returns
+ * CPR_ERR_UNSUPPORTED for relu == 2).  Reference: torch autograd's ReLU backward + conv2d input gradient + the bias-gradient row sum,
+ * three kernels behind mmcv's Fp16OptimizerHook (T/mmdet/apis/train.py:116-119). */
+int cpr_conv2d_bf16_mask_slots(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int out_fp32);
 /* bf16 compute mode stem: conv 7x7 / stride 2 / pad 3, 3 -> 64 channels + folded BatchNorm + ReLU (resnet.py:630-636) on the
  * bf16 matrix cores.  in: layout 0 = (N,H,W,4) fp32 (4th channel ignored), layout 1 = (N,3,H,W) fp32 planes (the NCHW network input); wgt (64, 224) bf16 with k = (kh * 8 + kw) * 4 + c (kw = 7 and
  * c = 3 zero), out (N, (H-1)/2+1, (W-1)/2+1, 64) bf16.  CPR_ERR_UNSUPPORTED when the output reaches 2 GiB. */
@@ -364,9 +372,10 @@ int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W
  * (resnet.py Bottleneck.forward): g = dy*(y>0) (y NULL: g = dy) is the shortcut gradient and the un-scaled conv-output
  * gradient; colsum (C) (+)= per-channel sums of g (= dshift; also the Linear/conv bias gradient).  (M,C) row-major,
  * C%4==0.  g_out may be NULL (sums only).  ws_part (ceil(M/128)+64)*C floats. */
-int cpr_relu_bwd_colsum(const float* dy, const void* y, int y_bf16, float* g_out, void* g16_out, float* colsum, float* ws_part,
-                        long long M, int C, int accumulate, void* stream);   /* y_bf16: y is the bf16 map the mixed-precision forward recorded;
-                        g16_out (optional): the bf16 rounding of g, written by the same pass (round 6) */
+int cpr_relu_bwd_colsum(const float* dy, const float* add, const void* y, int y_bf16, float* g_out, void* g16_out, float* colsum,
+                        float* ws_part, long long M, int C, int accumulate, void* stream);   /* y_bf16: y is the bf16 map the mixed-precision
+                        forward recorded; g16_out (optional): the bf16 rounding of g, written by the same pass; add (optional, fp32, same
+                        shape): g = (dy + add) masked -- the shortcut gradient joining a block's data gradient (round 6) */
 /* column sums (C) of a conv output from the epilogue partials cpr_conv2d_fwd wrote into gn_part [tiles][C][2];
  * ws: 64*C floats */
 int cpr_part_colsum(const float* part, float* out, float* ws, int tiles, int C, void* stream);

@@ -31,6 +31,7 @@ SIGNATURES = {
     'cpr_conv3x3_wino_wgrad': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_gn_apply_b8': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'cpr_conv2d_fwd_bf16': [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p, _p],
+    'cpr_conv2d_bf16_mask_slots': [_i] * 10,
     'cpr_stem7x7s2_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'cpr_stem7x7s2_pool_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'cpr_maxpool3x3s2_bf16': [_p, _p, _i, _i, _i, _i, _p],
@@ -72,7 +73,7 @@ SIGNATURES = {
     'cpr_gn_bwd': [_p] * 12 + [_i] * 7 + [_p],
     'cpr_gn_bwd_bf16': [_p] * 13 + [_i] * 7 + [_p],
     'cpr_upsample_add_bwd': [_p, _p] + [_i] * 7 + [_p],
-    'cpr_relu_bwd_colsum': [_p, _p, _i, _p, _p, _p, _p, _l, _i, _i, _p],
+    'cpr_relu_bwd_colsum': [_p, _p, _p, _i, _p, _p, _p, _p, _l, _i, _i, _p],
     'cpr_bn_fold_bwd': [_p] * 8 + [_i, _i, _p],
     'cpr_part_colsum': [_p, _p, _p, _i, _i, _p],
     'cpr_axpby': [_p, _p, _f, _f, _l, _p],

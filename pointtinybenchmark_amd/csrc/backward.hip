@@ -298,10 +298,11 @@ static void launch_colsum(const float* src, float* out, float* tmp, int rows, in
 // (M, C) row-major, C % 4 == 0.  y == nullptr: no mask (g = dy; g_out may be null -> column sums only).
 // Round 6 (mixed precision): YB = the mask source y is the bf16 map the forward recorded (read as it is: no widened copy), g16_out
 // (optional) = the bf16 rounding of g, written by the same pass (the bf16 weight / data gradients read it: no torch narrowing pass).
+// add (optional, fp32): g = (dy + add) masked -- the shortcut gradient joins in the same pass (it was an axpby launch of its own).
 template <bool YB>
-__global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const void* __restrict__ yv_, float* __restrict__ g_out,
-                                       unsigned short* __restrict__ g16_out, float* __restrict__ part, long long M, int C,
-                                       int rows_per_block) {
+__global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ add, const void* __restrict__ yv_,
+                                       float* __restrict__ g_out, unsigned short* __restrict__ g16_out, float* __restrict__ part,
+                                       long long M, int C, int rows_per_block) {
     __shared__ float red[256 * 4];
     typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
     const float* y = reinterpret_cast<const float*>(yv_);
@@ -323,6 +324,7 @@ __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const void*
                 ok[u] = ru < r1;
                 const size_t o = (size_t)(ok[u] ? ru : r) * C + c0 + q * 4;
                 g[u] = *reinterpret_cast<const f32x4*>(dy + o);
+                if (add) g[u] += *reinterpret_cast<const f32x4*>(add + o);
                 if (yv_) {
                     if (YB) {
                         const u16x4 h = *reinterpret_cast<const u16x4*>(y16 + o);
@@ -365,16 +367,16 @@ __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const void*
     }
 }
 
-extern "C" int cpr_relu_bwd_colsum(const float* dy, const void* y, int y_bf16, float* g_out, unsigned short* g16_out, float* colsum,
-                                   float* ws_part, long long M, int C, int accumulate, hipStream_t stream) {
+extern "C" int cpr_relu_bwd_colsum(const float* dy, const float* add, const void* y, int y_bf16, float* g_out, unsigned short* g16_out,
+                                   float* colsum, float* ws_part, long long M, int C, int accumulate, hipStream_t stream) {
     // ws_part: (ceil(M/128) + 64)*C floats
     CPR_CHECK_ARG(dy && colsum && ws_part && M > 0 && C > 0 && C % 4 == 0);
     const int rows_per_block = 128;
     const int blocks = (int)cdivll(M, rows_per_block);
-    if (y_bf16) hipLaunchKernelGGL(relu_bwd_colsum_kernel<true>, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, y, g_out, g16_out,
-                                   ws_part, M, C, rows_per_block);
-    else hipLaunchKernelGGL(relu_bwd_colsum_kernel<false>, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, y, g_out, g16_out, ws_part,
-                            M, C, rows_per_block);
+    if (y_bf16) hipLaunchKernelGGL(relu_bwd_colsum_kernel<true>, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, add, y, g_out,
+                                   g16_out, ws_part, M, C, rows_per_block);
+    else hipLaunchKernelGGL(relu_bwd_colsum_kernel<false>, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, add, y, g_out, g16_out,
+                            ws_part, M, C, rows_per_block);
     launch_colsum(ws_part, colsum, ws_part + (size_t)blocks * C, blocks, C, (long long)C, 1, accumulate, stream);
     CPR_LAUNCH_STATUS();
 }

@@ -18,6 +18,10 @@ struct ConvDmaParams {
     const unsigned short* residual;
     float* gn_part;
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, out_fp32;
+    // relu: 0 none, 1 ReLU behind the residual add, 2 = MASK mode (round 6, the mixed-precision backward): `residual` is the bf16 map a
+    // forward ReLU produced and the result is v where that map is positive, 0 elsewhere (nothing is added); gn_part then carries
+    // per-channel SUMS of the masked result (element 0 of each pair; [slot][Cout][2], slot = 128 pixels), i.e. the column sums the
+    // folded-BN bias gradient needs -- data gradient, ReLU backward, bf16 rounding and column sums in one launch.
     int tilesM, tilesN;
     int ablate;     // measurement builds only (results are then WRONG): 1 no wait for the DMA, 2 no barrier, 4 no DMA requests, 8 no fragment reads,
                     // 16 / 32 / 64 epilogue forms, 128 no weight-fragment loads (BD instance), 256 request slots staggered by wave (BD)
@@ -102,8 +106,12 @@ __device__ __forceinline__ void dma_epilogue(const ConvDmaParams& p, f32x16 (&ac
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = rbase + (r & 3) + 8 * (r >> 2);
-                float x = acc[i][j][r] * sc + bi + res[r];
-                if (p.relu) x = fmaxf(x, 0.f);
+                float x = acc[i][j][r] * sc + bi;
+                if (p.relu == 2) x = res[r] > 0.f ? x : 0.f;
+                else {
+                    x += res[r];
+                    if (p.relu) x = fmaxf(x, 0.f);
+                }
                 v[r] = x;
                 if (p.gn_part) {
                     const float u = (cok && m < p.M) ? x : 0.f;
@@ -196,11 +204,18 @@ __device__ __forceinline__ void dma_epilogue_pairs(const ConvDmaParams& p, f32x1
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2);
-            float x0 = acc[i][0][r] * sc0 + bi0 + __uint_as_float(res[r] << 16);
-            float x1 = acc[i][1][r] * sc1 + bi1 + __uint_as_float(res[r] & 0xffff0000u);
-            if (p.relu) {
-                x0 = fmaxf(x0, 0.f);
-                x1 = fmaxf(x1, 0.f);
+            float x0 = acc[i][0][r] * sc0 + bi0, x1 = acc[i][1][r] * sc1 + bi1;
+            const float r0 = __uint_as_float(res[r] << 16), r1 = __uint_as_float(res[r] & 0xffff0000u);
+            if (p.relu == 2) {
+                x0 = r0 > 0.f ? x0 : 0.f;
+                x1 = r1 > 0.f ? x1 : 0.f;
+            } else {
+                x0 += r0;
+                x1 += r1;
+                if (p.relu) {
+                    x0 = fmaxf(x0, 0.f);
+                    x1 = fmaxf(x1, 0.f);
+                }
             }
             if (p.gn_part) {
                 const bool ok = cok && rbase + rr < p.M;
@@ -265,6 +280,8 @@ __device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 
         gsq[j] = 0.f;
     }
     const bool relu_here = p.relu && !p.residual;              // with a residual the ReLU follows the add, in the read-out
+    const bool mask_mode = p.relu == 2;                        // (the residual is a ReLU mask source; column sums in the read-out)
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int rl = lane / LPR, cl = (lane % LPR) * 4;
     __syncthreads();                                           // every wave's last fragment reads are done: the stages are free
     // (the row arithmetic hangs on an opaque copy of the wave's first row: computed where it is used -- hoisted above the tile's
@@ -307,13 +324,24 @@ __device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 
             const int lr = ps * 8 * RPI + wrow;
             f32x4 v = *reinterpret_cast<const f32x4*>(tile + lr * BN + cl);
             if (p.residual) {
-                v[0] += __uint_as_float(rv[ps][0] << 16);
-                v[1] += __uint_as_float(rv[ps][0] & 0xffff0000u);
-                v[2] += __uint_as_float(rv[ps][1] << 16);
-                v[3] += __uint_as_float(rv[ps][1] & 0xffff0000u);
-                if (p.relu) {
+                const float r0 = __uint_as_float(rv[ps][0] << 16), r1 = __uint_as_float(rv[ps][0] & 0xffff0000u);
+                const float r2 = __uint_as_float(rv[ps][1] << 16), r3 = __uint_as_float(rv[ps][1] & 0xffff0000u);
+                if (mask_mode) {            // rows past M / couts past Cout read a zero mask: they add nothing to the sums
+                    v[0] = r0 > 0.f ? v[0] : 0.f;
+                    v[1] = r1 > 0.f ? v[1] : 0.f;
+                    v[2] = r2 > 0.f ? v[2] : 0.f;
+                    v[3] = r3 > 0.f ? v[3] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) csum[e] += v[e];
+                } else {
+                    v[0] += r0;
+                    v[1] += r1;
+                    v[2] += r2;
+                    v[3] += r3;
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
                 }
             }
             u32x2 pk;
@@ -340,7 +368,25 @@ __device__ __forceinline__ void dma_epilogue_lds(const ConvDmaParams& p, f32x16 
     write_half(std::integral_constant<int, 1>{});
     __syncthreads();
     read_half(1, rv1);
-    if (p.gn_part) {            // (MI == 4 only: the launcher keeps statistics layers off the 128-pixel tile)
+    if (p.gn_part && mask_mode) {
+        // column sums of the masked tile, in a fixed order (the step stays bit-repeatable): lane pairs, then the eight waves through
+        // the LDS behind the half tile, one slot per tile (BM pixels)
+        static_assert(HROWS * BN * 4 + 8 * BN * 4 <= 2 * DmaTile<MI, NJ, 4>::STAGE, "room for the waves' column sums");
+        float* sums = tile + HROWS * BN;
+        if (RPI == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] += __shfl_xor(csum[e], 32, 64);
+        }
+        if (lane < LPR) *reinterpret_cast<f32x4*>(sums + wave * BN + cl) = f32x4{csum[0], csum[1], csum[2], csum[3]};
+        __syncthreads();
+        const int t = wave * 64 + lane;
+        if (t < BN && n0 + t < p.Cout) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += sums[w * BN + t];
+            p.gn_part[((size_t)tm * p.Cout + n0 + t) * 2] = a;
+        }
+    } else if (p.gn_part) {     // (MI == 4 only: the launcher keeps statistics layers off the 128-pixel tile)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             float a = gsum[j], b = gsq[j];

@@ -432,9 +432,11 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
         M * Cout * (out_fp32 ? 4 : 2) >= (1ll << 31))
         return CPR_ERR_UNSUPPORTED;
     p.M = (int)M;
-    if (gn_part && (p.OH * p.OW) % 128 != 0) return CPR_ERR_UNSUPPORTED;
-    if (gn_part && M % 256 != 0) return CPR_ERR_UNSUPPORTED;      // both 128-pixel slots of every tile must exist
-    if (gn_part && bm != 256) return CPR_ERR_UNSUPPORTED;         // a wave of the 128-pixel tile owns half a statistics slot
+    const bool stats = gn_part && relu != 2;                      // GroupNorm statistics (mask mode: plain column sums, any slot shape)
+    if (stats && (p.OH * p.OW) % 128 != 0) return CPR_ERR_UNSUPPORTED;
+    if (stats && M % 256 != 0) return CPR_ERR_UNSUPPORTED;        // both 128-pixel slots of every tile must exist
+    if (stats && bm != 256) return CPR_ERR_UNSUPPORTED;           // a wave of the 128-pixel tile owns half a statistics slot
+    if (relu == 2 && !residual) return CPR_ERR_UNSUPPORTED;
     p.tilesM = (int)((M + bm - 1) / bm);
     p.tilesN = Cout / bn;
     // the 256 x 256 tile has three instances: both operands through LDS in lock step (no fragment image given: the reference the

@@ -372,15 +372,18 @@ static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, const void* w
         M * Cout * (out_fp32 ? 4 : 2) >= (1ll << 31))
         return CPR_ERR_UNSUPPORTED;
     p.M = (int)M;
-    if (gn_part) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
+    const bool mask_mode = relu == 2;       // `residual` is a ReLU mask source, gn_part takes column sums (the LDS-DMA kernels only)
+    if (mask_mode) CPR_CHECK_ARG(residual != nullptr);
+    if (gn_part && !mask_mode) CPR_CHECK_ARG((p.OH * p.OW) % 128 == 0);
     // the wide layers with enough 256 x 256 tiles for two rounds over the CUs: LDS-DMA staged kernel (conv_bf16_dma.hip)
-    const int dshape = bf16_dma_on ? bf16_dma_shape(M, Cin, Cout, Kpad / BKH, gn_part != nullptr) : -1;
+    const int dshape = bf16_dma_on ? bf16_dma_shape(M, Cin, Cout, Kpad / BKH, gn_part != nullptr && !mask_mode) : -1;
     if (dshape >= 0) {
         const int rc = conv_bf16_dma_launch(in, wgt, out, scale, bias, residual, gn_part, N, H, W, Cin, Cout, KH, KW, stride,
                                             pad, Kpad, relu, out_fp32, variant_out, stream, bf16_dma_ablate, dshape,
                                             bf16_wfrag_on ? wfrag : nullptr);
         if (rc != CPR_ERR_UNSUPPORTED) return rc;
     }
+    if (mask_mode) return CPR_ERR_UNSUPPORTED;      // (cpr_conv2d_bf16_mask_slots tells the caller beforehand)
     const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
     const bool big = gn_part || (Kpad / BKH >= 8 && t128 >= 4096 && Cout > 64);
     const int bm = big ? 128 : 64, bn = big ? 128 : 64;
@@ -392,6 +395,23 @@ static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, const void* w
     if (big) hipLaunchKernelGGL((conv_mfma_bf16_kernel<128, 128>), dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_mfma_bf16_kernel<64, 64>), dim3(grid), dim3(256), 0, stream, p);
     CPR_LAUNCH_STATUS();
+}
+
+// Mask mode (relu == 2: data gradient + ReLU backward + column sums in one launch, see ConvDmaParams): the number of column-sum
+// slots ([slots][Cout][2] floats, element 0 = sum) a launch of this shape writes, 0 = this shape does not run in mask mode (the caller
+// keeps the plain launch + streaming pass).  Mirrors the dispatch of conv2d_fwd_bf16_launch / conv_bf16_dma_launch.
+extern "C" int cpr_conv2d_bf16_mask_slots(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int out_fp32) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0 || Cin % BKH != 0 || !bf16_dma_on) return 0;
+    const long long M = (long long)N * OH * OW;
+    const long long oe = out_fp32 ? 4 : 2;
+    if (cpr_images_per_launch(N, cpr_max2((long long)H * W * Cin * 2, (long long)OH * OW * Cout * oe)) != N) return 0;
+    if ((long long)N * H * W * Cin * 2 >= (1ll << 31) || (long long)Cout * KH * KW * Cin * 2 >= (1ll << 31) || M * Cout * oe >= (1ll << 31)) return 0;
+    const int shape = bf16_dma_shape(M, Cin, Cout, KH * KW * Cin / BKH, false);
+    if (shape == 0 || shape == 5) return Cout % 256 == 0 ? (int)((M + 255) / 256) * 2 : 0;       // two wave rows of 128 pixels per tile
+    if (shape == 3) return Cout % 128 == 0 ? (int)((M + 127) / 128) * (out_fp32 ? 2 : 1) : 0;    // direct epilogue: per wave row; through LDS: per tile
+    return 0;
 }
 
 // >= 2 GiB maps: balanced chunks of whole images (see cpr_images_per_launch)

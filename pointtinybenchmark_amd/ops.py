@@ -349,13 +349,24 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     if gn_part:
         assert (OH * OW) % 128 == 0 and not colsum
         part = torch.empty((N * OH * OW // 128, pc.Cout, 2), device=x.device, dtype=torch.float32)
-    if colsum:
+    if colsum and x.dtype != torch.bfloat16:
         part = torch.empty(((N * OH * OW + 63) // 64, pc.Cout, 2), device=x.device, dtype=torch.float32)
     variant = ctypes.c_int(0) if (colsum or TRACE_CONV_VARIANT[0]) else None   # [host] out-parameter of the launcher
     vref = ctypes.byref(variant) if variant is not None else None
     if x.dtype == torch.bfloat16:
-        assert not (res_mask or colsum), 'backward helpers are fp32'
         assert in_ab is None, 'the bf16 kernel does not fuse the producer GroupNorm (materialise with gn_apply)'
+        if res_mask or colsum:
+            # mask mode (round 6): data gradient + ReLU backward + column sums (+ the bf16 rounding: out_dtype) in one launch
+            assert res_mask and colsum and residual is not None and residual.dtype == torch.bfloat16 and not relu and not gn_part
+            slots = conv2d_bf16_mask_slots(x.shape, pc, odt)
+            assert slots > 0, 'this shape has no mask-mode instance (ask conv2d_bf16_mask_slots first)'
+            part = torch.empty((slots, pc.Cout, 2), device=x.device, dtype=torch.float32)
+            _lib.call('cpr_conv2d_fwd_bf16', _ptr(x), _ptr(pc.w), _ptr(pc.frag_image()), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
+                      _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding, pc.Kpad, 2,
+                      int(odt == torch.float32), vref, _stream())
+            if variant is not None:
+                TRACE_CONV_VARIANT[1] = ('bf16', variant.value)
+            return out, TilePartials(part, slots, pc.Cout)
         _lib.call('cpr_conv2d_fwd_bf16', _ptr(x), _ptr(pc.w), _ptr(pc.frag_image()), _ptr(out), _ptr(scale), _ptr(bias), _ptr(residual),
                   _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding, pc.Kpad, int(relu),
                   int(odt == torch.float32), vref, _stream())
@@ -376,6 +387,14 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
         bm = variant.value // 1000000     # tile edge the launcher picked
         return out, TilePartials(part, (N * OH * OW + bm - 1) // bm, pc.Cout)
     return (out, part) if gn_part else out
+
+
+def conv2d_bf16_mask_slots(x_shape, pc, out_dtype=torch.bfloat16):
+    """Column-sum slots a mask-mode launch (``conv2d(bf16 x, pc, residual=mask, res_mask=True, colsum=True)``) of this shape writes;
+    0 = the shape's kernel does not know the mode (include/cpr_hip.h, cpr_conv2d_bf16_mask_slots)."""
+    N, H, W, Cin = x_shape
+    return _lib.call('cpr_conv2d_bf16_mask_slots', N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding,
+                     int(out_dtype == torch.float32), positive=True)
 
 
 def conv1x1_stream(x, pc, scale=None, bias=None, residual=None, relu=False, res_mask=False):
@@ -967,11 +986,15 @@ class PhasedDgrad:
 def conv2d_dgrad(dy, pc_t, in_hw, stride=1, mask=None, add=None, colsum=False):
     """dx (N,H,W,Cin) of a conv whose transposed/flipped weights are ``pc_t`` (dgrad_pack).
     mask: the forward's post-ReLU input -- the result is the gradient BEFORE that ReLU (dx * (mask > 0)), fused into
-    the epilogue; add: another gradient of the same tensor summed in the epilogue; colsum: also return the
+    the epilogue; add: another gradient of the same tensor summed in the epilogue (before the mask when both are given); colsum: also return the
     per-channel sums of the result as TilePartials (-> (dx, partials); ``partials.reduce()`` gives the (C,) vector)."""
-    assert mask is None or add is None
     N, OH, OW, Cout = _check(dy).shape
     H, W = in_hw
+    if mask is not None and add is not None:
+        # the conv epilogue has one extra operand (the sum OR the mask source): the sum rides in the epilogue, mask and column sums
+        # are one streaming pass over the result
+        g, cs = relu_bwd_colsum(conv2d_dgrad(dy, pc_t, in_hw, stride, add=add), mask)
+        return (g, cs) if colsum else g
     if isinstance(pc_t, PhasedDgrad):
         dx = pc_t(dy, in_hw, add=add)
         if mask is not None or colsum:
@@ -1105,9 +1128,10 @@ def upsample_add_bwd(dfine, dcoarse_or_shape, accumulate=True):
     return dc
 
 
-def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None, want16=False):
+def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None, want16=False, add=None):
     """g = dy*(y>0) (y None: g = dy) and per-channel column sums of g -> (g|None, colsum (C)[, g16]).  y fp32 or the bf16 map the
-    mixed-precision forward recorded (read as it is); want16: also the bf16 rounding of g, written by the same pass."""
+    mixed-precision forward recorded (read as it is); want16: also the bf16 rounding of g, written by the same pass; add (fp32, same
+    shape): g = (dy + add)*(y>0) -- a shortcut gradient joining in the same pass."""
     C = dy.shape[-1]
     M = dy.numel() // C
     acc = colsum is not None
@@ -1118,7 +1142,9 @@ def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None, want16=False):
     ws = torch.empty((((M + 127) // 128 + 64) * C,), device=dy.device, dtype=torch.float32)
     if y is not None:
         assert y.dtype in (torch.float32, torch.bfloat16) and y.is_contiguous() and y.numel() == dy.numel()
-    _lib.call('cpr_relu_bwd_colsum', _ptr(_check(dy)), _ptr(y), int(y is not None and y.dtype == torch.bfloat16), _ptr(g), _ptr(g16),
+    if add is not None:
+        assert add.dtype == torch.float32 and add.is_contiguous() and add.numel() == dy.numel() and want_g
+    _lib.call('cpr_relu_bwd_colsum', _ptr(_check(dy)), _ptr(add), _ptr(y), int(y is not None and y.dtype == torch.bfloat16), _ptr(g), _ptr(g16),
               _ptr(colsum), _ptr(ws), M, C, int(acc), _stream())
     return (g, colsum, g16) if want16 else (g, colsum)
 

@@ -221,7 +221,8 @@ FUSED_CAST = os.environ.get('CPR_MIXED_FUSED_CAST', '1') != '0'
 # measurement switches (tests/report_mixed_precision_grads.py: where the mixed-precision gradient error comes from): the weight /
 # data gradients of the mixed-precision step on the fp32 kernels; force = bf16 backward rules behind an fp32 recorded forward
 MIXED_BF16 = dict(wgrad=os.environ.get('CPR_MIXED_WGRAD', 'bf16') != 'fp32', dgrad=os.environ.get('CPR_MIXED_DGRAD', 'bf16') != 'fp32',
-                  dgrad1x1=os.environ.get('CPR_MIXED_DGRAD_1X1', 'bf16') != 'fp32', force=False)
+                  dgrad1x1=os.environ.get('CPR_MIXED_DGRAD_1X1', 'bf16') != 'fp32',
+                  mask_mode=os.environ.get('CPR_MIXED_MASK_MODE', '1') != '0', force=False)
 
 
 class BackwardEngine:
@@ -294,7 +295,8 @@ class BackwardEngine:
         dx = dout
         for idx in range(len(tape) - 1, -1, -1):
             rec = tape[idx]
-            dx = self._block_backward(cache, rec['block'], rec, dx, need_dx=(idx > 0 or need_in), keep=idx > 0)
+            dx = self._block_backward(cache, rec['block'], rec, dx, need_dx=(idx > 0 or need_in), keep=idx > 0,
+                                      mask_in=idx > 0 and rec['block'].downsample is None)
         return dx if need_in else None
 
     def forward_laterals(self, xs):
@@ -653,17 +655,36 @@ class BackwardEngine:
                     dx = lat if dx is None else ops.axpby(dx, lat, 1.0, 1.0)
             assert dx is not None, 'no gradient reaches backbone stage %d' % stage
             need_dx = idx > 0
-            dx = self._block_backward(c, blk, rec, dx, need_dx)
+            # a block without a projection shortcut reads the output of the block below it and nothing else adds to that gradient
+            dx = self._block_backward(c, blk, rec, dx, need_dx,
+                                      mask_in=need_dx and blk.downsample is None and tape[idx - 1]['stage'] == stage)
         self._wide = {}      # nothing below the lowest trainable block reads a widened copy
 
-    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx, mask=None, add=None, want_colsum=False, g16=None, want16=False):
+    def _reads_bf16_only(self, conv, x, has_add, need_dx):
+        """True when the backward rule of ``conv`` (input map x) reads nothing but the bf16 rounding of its output gradient: both of
+        its gradients run on the bf16 matrix pipe (the conditions of _conv_bn_backward), so the producer need not write the fp32 map."""
+        if not self._mixed:
+            return False
+        w = conv.weight
+        k = conv.kernel_size[0]
+        w16 = not w.requires_grad or (MIXED_BF16['wgrad'] and
+                                      ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0]))
+        d16 = not need_dx or (MIXED_BF16['dgrad'] and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and
+                              (k == 3 and not has_add or k == 1 and MIXED_BF16['dgrad1x1'] and w.shape[1] % 64 == 0))
+        return bool(w16 and d16)
+
+    def _conv_bn_backward(self, cache, conv, bn, g, colsum, x, need_dx, mask=None, add=None, want_colsum=False, g16=None, want16=False,
+                          need32=True):
         """conv -> folded eval-BN given g = d(pre-activation output) (un-scaled) and its column sums.  Parameter
         gradients go to the side stream; returns the data gradient wrt x -- with ``mask`` (x itself, when x is the
         output of a fused ReLU) already taken through that ReLU, with ``add`` summed in, with ``want_colsum`` as
         (gradient, column sums): all three ride in the conv epilogue (fp32 kernels) or in one streaming pass over the result
         (bf16 data gradients).  ``x`` / ``mask`` are the maps AS RECORDED (bf16 in the mixed-precision step): they are widened only
         where an fp32 kernel reads them.  g16: the bf16 rounding of g when the producer already wrote it; want16 (with
-        want_colsum): also return the bf16 rounding of the result -> (gradient, column sums, gradient16 | None)."""
+        want_colsum): also return the bf16 rounding of the result -> (gradient, column sums, gradient16 | None).  need32=False (the
+        consumer reads only the bf16 rounding, _reads_bf16_only): a bf16 data gradient with a mask then runs in the kernel's mask mode
+        -- ReLU backward, bf16 rounding and column sums in its epilogue, no fp32 map, no streaming pass -- and returns
+        (None, column-sum partials, gradient16).  g may be None when g16 is given and both gradients of this conv are bf16."""
         scale, _ = folded_bn(cache, bn)
         inv_sigma = cache.get(('bn_is', id(bn)), [bn.running_var],
                               lambda: ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, True)[2])
@@ -694,12 +715,13 @@ class BackwardEngine:
         if not need_dx:
             return None
 
-        def finish(dx):
-            """mask / column sums / bf16 rounding as one streaming pass over the data gradient."""
+        def finish(dx, add=None):
+            """sum / mask / column sums / bf16 rounding as one streaming pass over the data gradient."""
             if mask is None and not want_colsum:
-                return dx
-            r = ops.relu_bwd_colsum(dx, mask, want_g=mask is not None, want16=want16)
-            dxm = r[0] if mask is not None else dx
+                return dx if add is None else ops.axpby(dx, add, 1.0, 1.0)
+            keep = mask is not None or add is not None
+            r = ops.relu_bwd_colsum(dx, mask, want_g=keep, want16=want16, add=add)
+            dxm = r[0] if keep else dx
             if not want_colsum:
                 return dxm
             if want16:
@@ -715,10 +737,11 @@ class BackwardEngine:
                 wt = (w.detach() * scale[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3)
                 return ops.PackedConv(wt, 1, k - 1 - conv.padding[0], torch.bfloat16)
             pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16)
-            dx = ops.conv2d(g16, pc16, out_dtype=torch.float32)
-            if add is not None:
-                dx = ops.axpby(dx, add, 1.0, 1.0)
-            return finish(dx)
+            if MIXED_BF16['mask_mode'] and not need32 and mask is not None and add is None and want_colsum and want16 and \
+                    mask.dtype == torch.bfloat16 and ops.conv2d_bf16_mask_slots(g16.shape, pc16) > 0:
+                dx16, part = ops.conv2d(g16, pc16, residual=mask, res_mask=True, colsum=True)
+                return None, part, dx16
+            return finish(ops.conv2d(g16, pc16, out_dtype=torch.float32), add)
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
                        lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
         if WINO_DGRAD[0] and k == 3 and conv.stride[0] == 1 and add is None and \
@@ -726,28 +749,42 @@ class BackwardEngine:
             # a 3x3 stride-1 data gradient with a mask / column-sum epilogue would run the direct kernel (2.25x the multiplies of
             # the Winograd launch the plain form gets); the epilogue as one streaming pass over the result is cheaper
             return finish(ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), 1))
+        if mask is not None and add is not None:
+            # the fp32 epilogue has one extra operand: the sum rides in it, mask / column sums / bf16 rounding are the streaming pass
+            return finish(ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], add=add))
         r = ops.conv2d_dgrad(g, pt, (x.shape[1], x.shape[2]), conv.stride[0], mask=self._f32(mask), add=add, colsum=want_colsum)
         if want_colsum and want16:
             return r[0], r[1], None
         return r
 
-    def _block_backward(self, cache, blk, rec, dout, need_dx, keep=None):
+    def _block_backward(self, cache, blk, rec, dout, need_dx, keep=None, mask_in=False):
+        """dout: the gradient of the block's output -- or the triple (g, column sums, bf16 g | None) when the block above has already
+        taken it through this block's output ReLU.  mask_in (the caller guarantees that x is the output of the block whose backward
+        comes next and that nothing else adds to its gradient): a block without a projection shortcut returns that triple for the
+        block below -- shortcut sum, ReLU mask, column sums and bf16 rounding leave with the data gradient (round 6: they were an
+        axpby launch here plus a pass of their own at the top of the next call)."""
         # the recorded maps are handed on as recorded (bf16 in the mixed-precision step): the ReLU masks are read as they are, the bf16
         # gradient kernels read x as it is, and only an fp32 fallback kernel widens what it reads (round 6: rounds 3-5 widened every
         # recorded map up front -- 5.6 % of the step's kernel time in torch copy kernels)
         mixed = self._mixed
         x = rec['x']
-        r3 = ops.relu_bwd_colsum(dout, rec['out'], want16=mixed)              # also the shortcut gradient
-        g3, cs3, g3h = r3 if mixed else (r3[0], r3[1], None)
+        if isinstance(dout, tuple):
+            g3, cs3, g3h = dout
+        else:
+            r3 = ops.relu_bwd_colsum(dout, rec['out'], want16=mixed)          # also the shortcut gradient
+            g3, cs3, g3h = r3 if mixed else (r3[0], r3[1], None)
         o1 = rec['o1']
         if blk.kind == 'bottleneck':
             o2 = rec['o2']
-            g2, cs2, g2h = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, o2, True, mask=o2, want_colsum=True, g16=g3h, want16=True)
+            g2, cs2, g2h = self._conv_bn_backward(cache, blk.conv3, blk.bn3, g3, cs3, o2, True, mask=o2, want_colsum=True, g16=g3h, want16=True,
+                                                  need32=not self._reads_bf16_only(blk.conv2, o1, False, True))
             del o2
-            g1, cs1, g1h = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, o1, True, mask=o1, want_colsum=True, g16=g2h, want16=True)
+            g1, cs1, g1h = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g2, cs2, o1, True, mask=o1, want_colsum=True, g16=g2h, want16=True,
+                                                  need32=not self._reads_bf16_only(blk.conv1, x, blk.downsample is None, need_dx))
             last = blk.bn3
         else:
-            g1, cs1, g1h = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, o1, True, mask=o1, want_colsum=True, g16=g3h, want16=True)
+            g1, cs1, g1h = self._conv_bn_backward(cache, blk.conv2, blk.bn2, g3, cs3, o1, True, mask=o1, want_colsum=True, g16=g3h, want16=True,
+                                                  need32=not self._reads_bf16_only(blk.conv1, x, blk.downsample is None, need_dx))
             last = blk.bn2
         del o1
         self._done(last.bias if last.bias.requires_grad else blk.conv2.weight)
@@ -755,6 +792,10 @@ class BackwardEngine:
             dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx, g16=g1h)
             dx = self._conv_bn_backward(cache, blk.downsample[0], blk.downsample[1], g3, cs3, x, need_dx, add=dx, g16=g3h)
             tail = blk.downsample[1].bias if blk.downsample[1].bias.requires_grad else blk.downsample[0].weight
+        elif mask_in and need_dx:
+            dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, True, mask=x, add=g3, want_colsum=True, g16=g1h, want16=mixed)
+            dx = dx if mixed else (dx[0], dx[1], None)
+            tail = blk.bn1.bias if blk.bn1.bias.requires_grad else blk.conv1.weight
         else:
             dx = self._conv_bn_backward(cache, blk.conv1, blk.bn1, g1, cs1, x, need_dx, add=g3, g16=g1h)
             tail = blk.bn1.bias if blk.bn1.bias.requires_grad else blk.conv1.weight

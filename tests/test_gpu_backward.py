@@ -156,6 +156,16 @@ def test_bn_fold_relu_backward():
         _cmp('colsum C=%d' % C, cs, t.sum((0, 1, 2)), atol=1e-4)
         gt, cs = ops.relu_bwd_colsum(t.cuda(), (t * 0 + torch.randn(t.shape, generator=g)).cuda())
         assert float((gt != 0).float().mean()) > 0.3
+        # round 6: a second gradient of the same tensor (the shortcut's) joins before the mask; fp32 or bf16 mask source; the bf16
+        # rounding of the result written by the same pass -- bit-equal to the torch expression
+        a2, y2 = torch.randn(t.shape, generator=g).cuda(), torch.randn(t.shape, generator=g).clamp_min(0)
+        ref = (t.cuda() + a2) * (y2.cuda() > 0)
+        for ymap in (y2.cuda(), y2.bfloat16().cuda()):
+            gt, cs, g16 = ops.relu_bwd_colsum(t.cuda(), ymap, want16=True, add=a2)
+            assert torch.equal(gt, ref) and torch.equal(g16, ref.to(torch.bfloat16))
+            _cmp('colsum with add C=%d' % C, cs, ref.double().sum((0, 1, 2)).float(), atol=1e-4)
+        gt, cs = ops.relu_bwd_colsum(t.cuda(), None, add=a2)
+        assert torch.equal(gt, t.cuda() + a2)
 
 
 def test_sgd_clip_vs_torch():

@@ -351,3 +351,69 @@ def test_bf16_weight_pack_kernel_equals_the_torch_expression(shape):
         assert torch.equal(pd.w, old.w)
         fo = old.frag_image()
         assert (fo is None) == (pd.frag_image() is None) and (fo is None or torch.equal(pd.frag_image().reshape(-1), fo.reshape(-1)))
+
+
+MASK_CASES = [
+    # N, Cin, H, W, Cout, k, out fp32, instance: every epilogue that knows the mode, ragged pixel counts included
+    (8, 128, 64, 64, 128, 3, False, SMALL),       # conv2 of layer2 at 512^2 B=8: 128 x 128 tile, output through LDS, one slot per tile
+    (14, 512, 50, 50, 128, 1, False, SMALL),      # conv3's data gradient (1x1, 4 planes -> planes), M = 35 000: ragged last tile
+    (8, 128, 100, 99, 128, 3, True, SMALL),       # the same tile's direct epilogue (fp32 out): a slot per wave row, ragged
+    (13, 256, 80, 97, 256, 3, False, PP),         # ping-pong instance (>= 4 K chunks), pair epilogue with the mask prefetched, ragged
+    (13, 128, 80, 95, 512, 1, False, BIG),        # weights-direct instance (2 K chunks), M = 98 800: ragged
+]
+
+
+@pytest.mark.parametrize('case', MASK_CASES, ids=lambda c: 'n%d_c%d_%dx%d_o%d_k%d_%s_%d' % (c[:6] + ('f32' if c[6] else 'bf16', c[7])))
+def test_conv2d_bf16_mask_mode_equals_conv_then_streaming_pass(case):
+    """Round 6: the bf16 data gradient with the ReLU backward, the bf16 rounding and the column sums in its epilogue (relu == 2 of
+    cpr_conv2d_fwd_bf16) against the launch + streaming pass it replaces (fp32 result, ops.relu_bwd_colsum with want16): the map must
+    be BIT-equal (same accumulators, same single rounding), the column sums equal up to the order of the fp32 additions."""
+    from pointtinybenchmark_amd import ops
+    N, Cin, H, W, Cout, k, f32out, want = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn((N, H, W, Cin), generator=g).bfloat16().cuda()
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5)
+    mask = torch.randn((N, H, W, Cout), generator=g).clamp_min(0).bfloat16().cuda()          # a ReLU output: half of it zeros
+    pc = ops.PackedConv(w.cuda(), 1, k // 2, torch.bfloat16)
+    odt = torch.float32 if f32out else torch.bfloat16
+    slots = ops.conv2d_bf16_mask_slots(x.shape, pc, odt)
+    assert slots > 0
+    ops.TRACE_CONV_VARIANT[0] = True
+    try:
+        out, part = ops.conv2d(x, pc, residual=mask, res_mask=True, colsum=True, out_dtype=odt)
+        variant = ops.TRACE_CONV_VARIANT[1]
+    finally:
+        ops.TRACE_CONV_VARIANT[0] = False
+    assert variant == ('bf16', want), variant
+    assert part.tiles == slots and out.dtype == odt
+    cs = part.reduce()
+    plain = ops.conv2d(x, pc, out_dtype=torch.float32)
+    g32, cs_ref, g16 = ops.relu_bwd_colsum(plain, mask, want16=True)
+    torch.cuda.synchronize()
+    ref = g32 if f32out else g16
+    assert torch.equal(out, ref), 'mask-mode map differs in %d entries' % int((out != ref).sum())
+    scale = float(g32.abs().sum(dim=(0, 1, 2)).max())
+    assert float((cs - cs_ref).abs().max()) <= 1e-5 * scale, (float((cs - cs_ref).abs().max()), scale)
+    # the column sums against fp64 of the map itself
+    np.testing.assert_allclose(cs.cpu().numpy(), g32.double().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=0, atol=2e-5 * scale)
+
+
+def test_conv2d_bf16_mask_mode_says_which_shapes_it_takes():
+    """Shapes whose kernel is the register-staged one (too few tiles for an LDS-DMA instance) report 0 slots, and asking for the
+    mode anyway is refused by the library (CPR_ERR_UNSUPPORTED), not computed some other way."""
+    from pointtinybenchmark_amd import ops
+    from pointtinybenchmark_amd._lib import CprHipError
+    w = torch.randn((128, 128, 3, 3)).cuda() * 0.03
+    pc = ops.PackedConv(w, 1, 1, torch.bfloat16)
+    assert ops.conv2d_bf16_mask_slots((2, 16, 16, 128), pc) == 0
+    assert ops.conv2d_bf16_mask_slots((8, 64, 64, 128), pc) == 8 * 64 * 64 // 128
+    x = torch.randn((2, 16, 16, 128)).bfloat16().cuda()
+    with pytest.raises(AssertionError):
+        ops.conv2d(x, pc, residual=torch.ones_like(x), res_mask=True, colsum=True)
+    import ctypes
+    from pointtinybenchmark_amd import _lib
+    out = torch.empty_like(x)
+    part = torch.empty((16, 128, 2), device='cuda')
+    with pytest.raises(CprHipError, match='unsupported'):
+        _lib.call('cpr_conv2d_fwd_bf16', x.data_ptr(), pc.w.data_ptr(), None, out.data_ptr(), None, None, x.data_ptr(), part.data_ptr(),
+                  2, 16, 16, 128, 128, 3, 3, 1, 1, pc.Kpad, 2, 0, None, None)

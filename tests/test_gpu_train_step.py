@@ -229,6 +229,40 @@ def test_mixed_precision_fused_casts_change_no_bit(name):
     assert torch.equal(runs[0][1], runs[1][1]), 'fused casts changed %d gradient entries' % int((runs[0][1] != runs[1][1]).sum())
 
 
+def test_mixed_precision_mask_mode_changes_only_the_column_sum_order():
+    """Round 6: where a block's inner data gradients run in the bf16 kernels' mask mode (ReLU backward, bf16 rounding and column sums
+    in the conv epilogue: no fp32 map, no streaming pass) the gradient maps are BIT-equal to the unfused step's, so every conv weight
+    gradient is; the folded-BN gradients read column sums added up in another order (<= 1e-4 of the tensor's scale).  R50 at 512^2
+    B = 8 is the smallest step whose layer2 reaches an LDS-DMA instance; the test asserts that the mode was taken."""
+    from pointtinybenchmark_amd import ops, training
+    cfg = dict(CPR_CASES['cpr_r50_c1_160_spread'], batch=8, height=512, width=512)
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'], cfg['seed'], False)
+    cb = to_cuda(batch)
+    runs, taken = [], []
+    real = ops.conv2d_bf16_mask_slots
+    ops.conv2d_bf16_mask_slots = lambda *a, **k: (taken.append(real(*a, **k)), taken[-1])[1]
+    try:
+        for fused in (True, False):
+            training.MIXED_BF16['mask_mode'] = fused
+            m, _ = build_hip_locator(cfg)
+            m.set_compute_dtype('bf16')
+            tr = training.CprTrainer(m)
+            losses = tr.forward_backward(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+            torch.cuda.synchronize()
+            runs.append(({k: float(v) for k, v in losses.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}))
+    finally:
+        training.MIXED_BF16['mask_mode'] = True
+        ops.conv2d_bf16_mask_slots = real
+    assert sum(1 for t in taken if t > 0) >= 7, 'layer2 (4 blocks x 2 inner data gradients) must have run in mask mode: %r' % taken
+    assert runs[0][0] == runs[1][0]
+    for n, ga in runs[0][1].items():
+        gb = runs[1][1][n]
+        if ga.dim() == 4:
+            assert torch.equal(ga, gb), '%s: %d entries differ' % (n, int((ga != gb).sum()))
+        else:
+            assert float((ga - gb).abs().max()) <= 1e-4 * max(float(gb.abs().max()), 1e-6), (n, float((ga - gb).abs().max()), float(gb.abs().max()))
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 def test_two_stream_step_is_bit_repeatable_under_allocator_pressure(mode):
     """The parameter-gradient work runs on a side stream and reads maps the main stream frees right afterwards -- in the
