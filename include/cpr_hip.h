@@ -371,7 +371,8 @@ int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W
 /* backward of the fused conv epilogue y = relu?(conv*scale + shift (+ identity)) of an eval-mode BatchNorm
  * (resnet.py Bottleneck.forward): g = dy*(y>0) (y NULL: g = dy) is the shortcut gradient and the un-scaled conv-output
  * gradient; colsum (C) (+)= per-channel sums of g (= dshift; also the Linear/conv bias gradient).  (M,C) row-major,
- * C%4==0.  g_out may be NULL (sums only).  ws_part (ceil(M/128)+64)*C floats. */
+ * C%4==0.  g_out may be NULL (sums only).  ws_part: cpr_relu_bwd_colsum_ws(M, C) floats. */
+int cpr_relu_bwd_colsum_ws(long long M, int C);
 int cpr_relu_bwd_colsum(const float* dy, const float* add, const void* y, int y_bf16, float* g_out, void* g16_out, float* colsum,
                         float* ws_part, long long M, int C, int accumulate, void* stream);   /* y_bf16: y is the bf16 map the mixed-precision
                         forward recorded; g16_out (optional): the bf16 rounding of g, written by the same pass; add (optional, fp32, same

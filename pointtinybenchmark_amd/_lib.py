@@ -73,6 +73,7 @@ SIGNATURES = {
     'cpr_gn_bwd': [_p] * 12 + [_i] * 7 + [_p],
     'cpr_gn_bwd_bf16': [_p] * 13 + [_i] * 7 + [_p],
     'cpr_upsample_add_bwd': [_p, _p] + [_i] * 7 + [_p],
+    'cpr_relu_bwd_colsum_ws': [_l, _i],
     'cpr_relu_bwd_colsum': [_p, _p, _p, _i, _p, _p, _p, _p, _l, _i, _i, _p],
     'cpr_bn_fold_bwd': [_p] * 8 + [_i, _i, _p],
     'cpr_part_colsum': [_p, _p, _p, _i, _i, _p],

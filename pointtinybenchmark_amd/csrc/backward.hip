@@ -367,11 +367,25 @@ __global__ void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float
     }
 }
 
+// rows per workgroup: 128, halved until the launch has 2048 workgroups (down to 16).  A workgroup is 4 waves and the pass is pure
+// streaming: layer3 of R101 at 1024^2 B = 8 (32 768 rows x 1024 channels) was 256 workgroups = one per CU = 4 waves per CU and ran at
+// 3.2 TB/s (profiles/round6_train_cfg4_one_stream_after_mask_mode_kernel_stats.csv: 168 us for 537 MB).
+static int relu_bwd_rows_per_block(long long M) {
+    int rows = 128;
+    while (rows > 16 && cdivll(M, rows) < 2048) rows >>= 1;
+    return rows;
+}
+// floats of workspace cpr_relu_bwd_colsum needs for an (M, C) map
+extern "C" int cpr_relu_bwd_colsum_ws(long long M, int C) {
+    if (M <= 0 || C <= 0) return CPR_ERR_ARG;
+    const long long n = (cdivll(M, relu_bwd_rows_per_block(M)) + 64) * C;
+    return n < (1ll << 31) ? (int)n : CPR_ERR_UNSUPPORTED;
+}
 extern "C" int cpr_relu_bwd_colsum(const float* dy, const float* add, const void* y, int y_bf16, float* g_out, unsigned short* g16_out,
                                    float* colsum, float* ws_part, long long M, int C, int accumulate, hipStream_t stream) {
-    // ws_part: (ceil(M/128) + 64)*C floats
+    // ws_part: cpr_relu_bwd_colsum_ws(M, C) floats
     CPR_CHECK_ARG(dy && colsum && ws_part && M > 0 && C > 0 && C % 4 == 0);
-    const int rows_per_block = 128;
+    const int rows_per_block = relu_bwd_rows_per_block(M);
     const int blocks = (int)cdivll(M, rows_per_block);
     if (y_bf16) hipLaunchKernelGGL(relu_bwd_colsum_kernel<true>, dim3(blocks, cdiv(C, 1024)), dim3(256), 0, stream, dy, add, y, g_out,
                                    g16_out, ws_part, M, C, rows_per_block);

@@ -480,11 +480,13 @@ int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, in
     p.nt_taps = k * k; p.nt_k = k; p.nt_pad = pad; p.nt_Wp = Wp; p.nt_chunks = chunks; p.nt_copy = copy;
     const long long blocks = (long long)splits * p.nt_taps * p.tilesM * p.tilesN;
     if (blocks >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;
-    // the ping-pong instance (conv_bf16_pp.hip) takes this mode too (bit-equal partials) but measured SLOWER here -- configs[4] training
-    // step 55.3 ms with it, 54.3 without (profiles/round6_mixed_train_ab.txt): the splits are short (a few chunks), its prologue is
-    // longer -- so the lock-step instance stays; CPR_BF16_NT_PP=1 switches for A/B
-    static const bool nt_pp = []() { const char* e = getenv("CPR_BF16_NT_PP"); return e && e[0] == '1'; }();
-    if (chunks >= 4 && nt_pp) conv_bf16_pp_launch(p, (unsigned)blocks, stream);
+    // the ping-pong instance (conv_bf16_pp.hip) takes this mode too (bit-equal partials).  First measured SLOWER (configs[4] training
+    // step 55.3 ms with it, 54.3 without: profiles/round6_mixed_train_ab.txt); after the backward lost its streaming passes the same
+    // A/B reads 47.7 vs 48.8 ms on configs[4] and 95.0 vs 96.9 ms on R50 640^2 B = 64 (profiles/round6_mixed_backward_ab.txt, two
+    // boxes alike): the weight gradients share the chip with fewer HBM-bound kernels of the main stream.  Default: wherever it can
+    // run (>= 4 chunks per split); CPR_BF16_NT_PP=0 keeps the lock-step instance, =n asks for splits of >= n chunks.
+    static const int nt_pp_min = []() { const char* e = getenv("CPR_BF16_NT_PP"); const int v = e ? atoi(e) : 1; return v <= 0 ? (1 << 30) : v < 4 ? 4 : v; }();
+    if (chunks >= nt_pp_min) conv_bf16_pp_launch(p, (unsigned)blocks, stream);
     else hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
     CPR_LAUNCH_STATUS();
 }

@@ -14,6 +14,10 @@
 // NT mode (256 x 256 x 64 tiles, both operands by LDS-DMA), split over the pixel axis into `splits` workgroup rows whose fp32
 // partials are summed -- and laid out as the [Cout][Cin][k][k] gradient -- by wgrad_bf16_reduce_kernel.
 #include "common.h"
+#include <type_traits>
+#include <cstdlib>
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, int N, long long rs, int k, int pad, int Wp,
                             long long copy, int splits, int chunks, hipStream_t stream);
@@ -43,7 +47,7 @@ static bool wgrad_bf16_plan(int N, int H, int W, int Cin, int Cout, int k, Wgrad
     pl->chunks = (int)((chunks_all + splits - 1) / splits);
     pl->Qk = (long long)pl->splits * pl->chunks * 64;
     pl->rs = pl->G + pl->Qk + pl->G;
-    pl->rs = (pl->rs + 63) / 64 * 64;
+    pl->rs = (pl->rs + 255) / 256 * 256;                 // (the transposing kernel writes 256 positions per workgroup)
     if (pl->rs >= (1ll << 30) || (long long)Cout * pl->rs * 2 >= (1ll << 31) || (long long)Cin * pl->rs * 2 >= (1ll << 31)) return false;
     pl->off_dy = 0;
     pl->off_x = (long long)Cout * pl->rs * 2;
@@ -53,10 +57,99 @@ static bool wgrad_bf16_plan(int N, int H, int W, int Cin, int Cout, int k, Wgrad
 }
 
 // src (N,H,W,C) NHWC (fp32 or bf16) -> NC copies dst_j[c][rs] bf16 (copy j at dst + j * copy): dst_j[c][G + q] = src at cell
-// (q + j - NC / 2), zero at border / guard cells.  One workgroup = 64 positions x 64 channels through LDS: 16-byte reads along the
-// channels, 16-byte writes along the cells; the source cells (64 + NC - 1 of them) are read once for all copies.
+// (q + j - NC / 2), zero at border / guard cells.
+//
+// Round 6 (this kernel; the round-3 one below stays for A/B, CPR_WGRAD_T64=1): one workgroup = 256 positions x 64 channels.  A
+// thread owns an 8 x 8 block -- eight 16-byte loads along the channels of eight consecutive cells (a granule: granules never
+// straddle a row of the padded grid, Wp % 8 == 0) -- transposes it in registers (one v_perm_b32 per output dword) and parks the
+// eight channel granules (8 cells x 2 bytes) in LDS as [channel][granule], the granule column XORed with twice the channel group
+// (16 lanes = 16 distinct bank quads).  The read-out runs along the cells: 32 lanes = 512 contiguous bytes of one channel row,
+// whole lines; the +-1-cell copies of the 3x3 layers are funnel shifts (v_alignbit_b32) of three neighbouring granules.  Against
+// the round-3 kernel (two-byte LDS writes and reads, 64-position tiles): 16 LDS instructions per 64 elements instead of 128.
 template <bool SRC_BF16, int NC>
 __global__ __launch_bounds__(256) void wgrad_bf16_transpose_kernel(const void* __restrict__ src, unsigned short* __restrict__ dst,
+                                                                   int N, int H, int W, int C, int pad, int Hp, int Wp, int G,
+                                                                   long long rs, long long copy) {
+    constexpr int HALO = NC > 1 ? 1 : 0, NG = 32 + 2 * HALO;         // granules per channel row of the tile (halo: one per side)
+    constexpr int ROWB = NC > 1 ? 768 : 512;                         // bytes per channel row (a multiple of 256: the swizzle's frame)
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * ROWB];
+    const long long r0 = (long long)blockIdx.x * 256;                // first position of this block (0 = start of the leading guard)
+    const int c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const long long Q = (long long)N * Hp * Wp;
+    auto swz = [](int gi, int cg) { return (gi & ~15) | ((gi ^ (2 * cg)) & 15); };
+    for (int item = tid; item < NG * 8; item += 256) {
+        const int cg = item & 7, gi = item >> 3;
+        const long long q = r0 - G + (long long)(gi - HALO) * 8;      // first cell of the granule (a multiple of 8)
+        uint4 R[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) R[r] = make_uint4(0u, 0u, 0u, 0u);
+        if (q >= 0 && q < Q) {
+            const int n = (int)(q / ((long long)Hp * Wp));
+            const int rem = (int)(q - (long long)n * Hp * Wp);
+            const int yp = rem / Wp, xp = rem - yp * Wp;
+            const int y = yp - pad;
+            if ((unsigned)y < (unsigned)H) {
+                const size_t e0 = (((size_t)n * H + y) * W) * C + c0 + cg * 8;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int x = xp + r - pad;
+                    if ((unsigned)x < (unsigned)W) {
+                        const size_t e = e0 + (size_t)x * C;
+                        if (SRC_BF16) R[r] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + e);
+                        else {
+                            const f32x4 f0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + e);
+                            const f32x4 f1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + e + 4);
+                            R[r].x = __builtin_bit_cast(unsigned, bf16x2{(__bf16)f0.x, (__bf16)f0.y});
+                            R[r].y = __builtin_bit_cast(unsigned, bf16x2{(__bf16)f0.z, (__bf16)f0.w});
+                            R[r].z = __builtin_bit_cast(unsigned, bf16x2{(__bf16)f1.x, (__bf16)f1.y});
+                            R[r].w = __builtin_bit_cast(unsigned, bf16x2{(__bf16)f1.z, (__bf16)f1.w});
+                        }
+                    }
+                }
+            }
+        }
+        // channel e of the block: dword k = (cell 2k, cell 2k + 1) = the low (e even) or high halves of dword e / 2 of rows 2k, 2k + 1
+        const unsigned* Rw = reinterpret_cast<const unsigned*>(R);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            uint4 o;
+            unsigned* ow = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                ow[k] = __builtin_amdgcn_perm(Rw[(2 * k + 1) * 4 + (e >> 1)], Rw[(2 * k) * 4 + (e >> 1)], (e & 1) ? 0x07060302u : 0x05040100u);
+            *reinterpret_cast<uint4*>(tile + (cg * 8 + e) * ROWB + swz(gi, cg) * 16) = o;
+        }
+    }
+    __syncthreads();
+    const int og = tid & 31;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = (tid >> 5) + 8 * i;
+        const unsigned char* row = tile + ch * ROWB;
+        const uint4 cur = *reinterpret_cast<const uint4*>(row + swz(og + HALO, ch >> 3) * 16);
+        unsigned short* d = dst + (size_t)(c0 + ch) * rs + r0 + og * 8;
+        if (NC == 1) {
+            *reinterpret_cast<uint4*>(d) = cur;
+        } else {
+            const uint4 prv = *reinterpret_cast<const uint4*>(row + swz(og, ch >> 3) * 16);
+            const uint4 nxt = *reinterpret_cast<const uint4*>(row + swz(og + 2, ch >> 3) * 16);
+            // copy 0 at position i shows cell i - 1, copy 2 cell i + 1: 16-bit funnel shifts over the neighbouring granules
+            const unsigned m01 = __builtin_amdgcn_alignbit(cur.y, cur.x, 16), m12 = __builtin_amdgcn_alignbit(cur.z, cur.y, 16),
+                           m23 = __builtin_amdgcn_alignbit(cur.w, cur.z, 16);
+            const uint4 lo = make_uint4(__builtin_amdgcn_alignbit(cur.x, prv.w, 16), m01, m12, m23);
+            const uint4 hi = make_uint4(m01, m12, m23, __builtin_amdgcn_alignbit(nxt.x, cur.w, 16));
+            *reinterpret_cast<uint4*>(d) = lo;
+            *reinterpret_cast<uint4*>(d + copy) = cur;
+            *reinterpret_cast<uint4*>(d + 2 * copy) = hi;
+        }
+    }
+}
+
+// The round-3 form of the kernel above (one workgroup = 64 positions x 64 channels through a two-byte-granular LDS tile): kept for
+// A/B (CPR_WGRAD_T64=1) and as the second opinion of the tests.
+template <bool SRC_BF16, int NC>
+__global__ __launch_bounds__(256) void wgrad_bf16_transpose64_kernel(const void* __restrict__ src, unsigned short* __restrict__ dst,
                                                                    int N, int H, int W, int C, int pad, int Hp, int Wp, int G,
                                                                    long long rs, long long copy) {
     constexpr int ROWS = 64 + NC - 1;
@@ -153,22 +246,25 @@ extern "C" int cpr_conv_wgrad_bf16(const void* dy, int dy_bf16, const void* x, i
     unsigned short* dyT = reinterpret_cast<unsigned short*>((char*)ws + pl.off_dy);
     unsigned short* xT = reinterpret_cast<unsigned short*>((char*)ws + pl.off_x);
     float* part = reinterpret_cast<float*>((char*)ws + pl.off_part);
-    const unsigned rows = (unsigned)(pl.rs / 64);
     const long long copy = (long long)Cin * pl.rs;
-    if (dy_bf16) hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<true, 1>), dim3(rows, Cout / 64), dim3(256), 0, stream, dy, dyT, N, H, W,
-                                    Cout, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, 0ll);
-    else hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<false, 1>), dim3(rows, Cout / 64), dim3(256), 0, stream, dy, dyT, N, H, W, Cout,
-                            pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, 0ll);
+    static const bool t64 = []() { const char* e = getenv("CPR_WGRAD_T64"); return e && e[0] == '1'; }();     // A/B: the round-3 kernel
+    auto rewrite = [&](auto bf, auto nc, const void* src, unsigned short* dst, int C, long long cp) {
+        constexpr bool B = decltype(bf)::value;
+        constexpr int NC = decltype(nc)::value;
+        if (t64) hipLaunchKernelGGL((wgrad_bf16_transpose64_kernel<B, NC>), dim3((unsigned)(pl.rs / 64), C / 64), dim3(256), 0, stream, src, dst,
+                                    N, H, W, C, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, cp);
+        else hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<B, NC>), dim3((unsigned)(pl.rs / 256), C / 64), dim3(256), 0, stream, src, dst,
+                                N, H, W, C, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, cp);
+    };
+    using std::integral_constant;
+    if (dy_bf16) rewrite(integral_constant<bool, true>{}, integral_constant<int, 1>{}, dy, dyT, Cout, 0ll);
+    else rewrite(integral_constant<bool, false>{}, integral_constant<int, 1>{}, dy, dyT, Cout, 0ll);
     if (k == 3) {
-        if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<true, 3>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H,
-                                       W, Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);
-        else hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<false, 3>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H, W,
-                                Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);
+        if (x_bf16) rewrite(integral_constant<bool, true>{}, integral_constant<int, 3>{}, x, xT, Cin, copy);
+        else rewrite(integral_constant<bool, false>{}, integral_constant<int, 3>{}, x, xT, Cin, copy);
     } else {
-        if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<true, 1>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H,
-                                       W, Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);
-        else hipLaunchKernelGGL((wgrad_bf16_transpose_kernel<false, 1>), dim3(rows, Cin / 64), dim3(256), 0, stream, x, xT, N, H, W,
-                                Cin, pl.pad, pl.Hp, pl.Wp, pl.G, pl.rs, copy);
+        if (x_bf16) rewrite(integral_constant<bool, true>{}, integral_constant<int, 1>{}, x, xT, Cin, copy);
+        else rewrite(integral_constant<bool, false>{}, integral_constant<int, 1>{}, x, xT, Cin, copy);
     }
     const int rc = conv_bf16_dma_nt_launch(dyT + pl.G, xT + pl.G, part, Cout, Cin, pl.rs, k, pl.pad, pl.Wp, copy, pl.splits, pl.chunks,
                                            stream);

@@ -1139,7 +1139,7 @@ def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None, want16=False, add=None
         colsum = torch.empty((C,), device=dy.device, dtype=torch.float32)
     g = torch.empty_like(dy) if want_g else None
     g16 = torch.empty(tuple(dy.shape), device=dy.device, dtype=torch.bfloat16) if want16 else None
-    ws = torch.empty((((M + 127) // 128 + 64) * C,), device=dy.device, dtype=torch.float32)
+    ws = torch.empty((_lib.call('cpr_relu_bwd_colsum_ws', M, C, positive=True),), device=dy.device, dtype=torch.float32)
     if y is not None:
         assert y.dtype in (torch.float32, torch.bfloat16) and y.is_contiguous() and y.numel() == dy.numel()
     if add is not None:

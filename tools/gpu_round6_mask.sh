@@ -1,14 +1,19 @@
 #!/bin/bash
-# Round-6 development visit: the mask-mode data gradient and the restructured block backward (tests, then the training A/B).
+# Round-6 development visit: the mixed-precision backward (mask mode, transposing kernel of the bf16 weight gradient, streaming pass).
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r6m
-timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_backward.py tests/test_gpu_train_step.py tests/test_gpu_autograd.py -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | tail -30 > gpurun_out/r6m/pytest.log
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_backward.py tests/test_gpu_train_step.py -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | tail -30 > gpurun_out/r6m/pytest.log
 tail -5 gpurun_out/r6m/pytest.log
-for mm in 1 0; do
-  echo "== CPR_MIXED_MASK_MODE=$mm" >> gpurun_out/r6m/train_ab.txt
-  CPR_MIXED_MASK_MODE=$mm timeout 600 python tools/bf16_ab.py --train 2>&1 | grep -v amdgpu.ids | head -2 >> gpurun_out/r6m/train_ab.txt
-  CPR_MIXED_MASK_MODE=$mm timeout 600 python tools/bf16_ab.py --train --depth 50 --size 640 --batch 64 2>&1 | grep -v amdgpu.ids | head -2 >> gpurun_out/r6m/train_ab.txt
+rm -f gpurun_out/r6m/ab.txt
+for v in "CPR_WGRAD_T64=1 CPR_BF16_NT_PP=0" "CPR_WGRAD_T64=0 CPR_BF16_NT_PP=0" "CPR_WGRAD_T64=0 CPR_BF16_NT_PP=1" "CPR_WGRAD_T64=0 CPR_BF16_NT_PP=16"; do
+  echo "== $v" >> gpurun_out/r6m/ab.txt
+  env $v timeout 600 python tools/bf16_ab.py --train --depth 50 --size 640 --batch 64 --rounds 2 2>&1 | grep -v amdgpu.ids | head -1 >> gpurun_out/r6m/ab.txt
+  env $v timeout 600 python tools/bf16_ab.py --train --rounds 2 2>&1 | grep -v amdgpu.ids | head -1 >> gpurun_out/r6m/ab.txt
 done
-cat gpurun_out/r6m/train_ab.txt
-timeout 600 python bench.py --mode train --steps 6 --warmup 2 --no-probe --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400
+cat gpurun_out/r6m/ab.txt
+( cd /tmp && CPR_TRAIN_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r6m -o r50mixed -- python $OLDPWD/bench.py --mode train --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline --no-probe > /tmp/prof_r6m.log 2>&1 )
+( cd /tmp && CPR_TRAIN_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r6m -o cfg4mixed -- python $OLDPWD/bench.py --config cfg4 --mode train --steps 3 --warmup 1 --no-cpu-baseline --no-probe > /tmp/prof_r6m2.log 2>&1 )
+find /tmp/prof_r6m -name "*kernel_stats*" -exec cp {} gpurun_out/r6m/ \;
+ls gpurun_out/r6m
