@@ -128,6 +128,14 @@ int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, const void* wgt_frag, v
  * CPR_ERR_UNSUPPORTED for relu == 2).  Reference: torch autograd's ReLU backward + conv2d input gradient + the bias-gradient row sum,
  * three kernels behind mmcv's Fp16OptimizerHook (T/mmdet/apis/train.py:116-119). */
 int cpr_conv2d_bf16_mask_slots(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int out_fp32);
+/* The block-boundary data gradient of the same backward in one launch: g = mask > 0 ? conv(in, wgt) + add32 : 0 (add32: the shortcut
+ * gradient, fp32, the output's shape), written twice -- out32 (fp32: the shortcut chain stays fp32) and out16 (its bf16 rounding, what
+ * the next weight / data gradients read) -- with the column sums of g in part (slots: cpr_conv2d_bf16_mask_slots with out_fp32 = 2;
+ * 0 = no instance for this shape, the call then returns CPR_ERR_UNSUPPORTED).  Replaces conv + fp32 store + one streaming pass
+ * (cpr_relu_bwd_colsum with add): 20 bytes per element -> 12.  wgt_frag is required (the instances are the pair-epilogue ones). */
+int cpr_conv2d_dgrad_bf16_fused(const void* in, const void* wgt, const void* wgt_frag, float* out32, void* out16, const float* add32,
+                                const void* mask, float* part, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                int pad, int Kpad, int* variant_out, void* stream);
 /* bf16 compute mode stem: conv 7x7 / stride 2 / pad 3, 3 -> 64 channels + folded BatchNorm + ReLU (resnet.py:630-636) on the
  * bf16 matrix cores.  in: layout 0 = (N,H,W,4) fp32 (4th channel ignored), layout 1 = (N,3,H,W) fp32 planes (the NCHW network input); wgt (64, 224) bf16 with k = (kh * 8 + kw) * 4 + c (kw = 7 and
  * c = 3 zero), out (N, (H-1)/2+1, (W-1)/2+1, 64) bf16.  CPR_ERR_UNSUPPORTED when the output reaches 2 GiB. */

@@ -17,6 +17,10 @@ struct ConvDmaParams {
     const float* bias;
     const unsigned short* residual;
     float* gn_part;
+    // TR instances only (round 6, the block-boundary data gradient of the mixed-precision backward): add32 = an fp32 map of the
+    // output's shape summed in BEFORE the mask (the shortcut gradient), out16 = a second, bf16 copy of the fp32 result
+    const float* add32;
+    unsigned short* out16;
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, Kpad, M, relu, out_fp32;
     // relu: 0 none, 1 ReLU behind the residual add, 2 = MASK mode (round 6, the mixed-precision backward): `residual` is the bf16 map a
     // forward ReLU produced and the result is v where that map is positive, 0 elsewhere (nothing is added); gn_part then carries
@@ -163,12 +167,69 @@ __device__ __forceinline__ void dma_epilogue(const ConvDmaParams& p, f32x16 (&ac
 // i + 1 is requested BEFORE block i is scaled and stored -- un-prefetched, every block's 16 loads are issued and awaited in
 // turn, and on the short-K bottleneck layers (1x1 256 -> 1024 + residual on 8 x 128^2: four K chunks) the epilogue is 60 % of the
 // launch (0.196 ms with, 0.076 ms without it; 0.168 with the stores dropped: profiles/round5_bf16_epilogue_ablation.txt).
-template <int MI, bool PRE = false>
+// TR (round 6): the block-boundary data gradient of the mixed-precision backward in one launch --
+//   g = mask > 0 ? acc * scale + bias + add32 : 0   -> out (fp32: the shortcut chain stays fp32) AND out16 (its bf16 rounding),
+// column sums of g into gn_part (element 0 of each slot pair).  It replaces an fp32 store + a streaming pass that read it back
+// with the shortcut gradient and the mask (20 bytes per element -> 12).
+template <int MI, bool PRE = false, bool TR = false>
 __device__ __forceinline__ void dma_epilogue_pairs(const ConvDmaParams& p, f32x16 (&acc)[MI][2], int tm, int m0, int n0, int wm,
                                                    int wn, int lane) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int l31 = lane & 31, half = lane >> 5;
     if (p.ablate & 32) return;
+    if constexpr (TR) {
+        static_assert(PRE, "the training epilogue prefetches its mask");
+        const __amdgpu_buffer_rsrc_t rs32 = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs16 = __builtin_amdgcn_make_buffer_rsrc(p.out16, 0, (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.add32), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.residual), 0, (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+        const int c0 = n0 + wn * 64 + 2 * l31;
+        const bool cok = c0 < p.Cout;
+        const int cc = cok ? c0 : p.Cout - 2;
+        const float sc0 = p.scale ? p.scale[cc] : 1.f, sc1 = p.scale ? p.scale[cc + 1] : 1.f;
+        const float bi0 = p.bias ? p.bias[cc] : 0.f, bi1 = p.bias ? p.bias[cc + 1] : 0.f;
+        float gs0 = 0.f, gs1 = 0.f;
+        unsigned msk[16];
+        u32x2 addv[16];
+        auto row_e = [&](int i, int r) { return (unsigned)((m0 + wm * (MI * 32) + i * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) * p.Cout + c0); };
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            // both operands of pixel block i are requested here and awaited below: the partner wave of the SIMD covers the wait, and
+            // prefetch sets beside the 128 accumulators spilled (61 registers with the mask of block i + 1 in flight as in PRE)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned e = row_e(i, r);
+                msk[r] = __builtin_amdgcn_raw_buffer_load_b32(rs_msk, (int)(cok ? e * 2u : 0x80000000u), 0, 0);
+                addv[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_add, (int)(cok ? e * 4u : 0x80000000u), 0, 0);
+            }
+            const int rbase = m0 + wm * (MI * 32) + i * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                const unsigned mk = msk[r];
+                float x0 = acc[i][0][r] * sc0 + bi0 + __uint_as_float(addv[r][0]);
+                float x1 = acc[i][1][r] * sc1 + bi1 + __uint_as_float(addv[r][1]);
+                // rows past M / couts past Cout read a zero mask: they add nothing to the sums and their stores are dropped
+                x0 = __uint_as_float(mk << 16) > 0.f ? x0 : 0.f;
+                x1 = __uint_as_float(mk & 0xffff0000u) > 0.f ? x1 : 0.f;
+                gs0 += x0;
+                gs1 += x1;
+                const bool ok = cok && rbase + rr < p.M;
+                const unsigned e = row_e(i, r);
+                const u32x2 v = {__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1)};
+                __builtin_amdgcn_raw_buffer_store_b64(v, rs32, (int)(ok ? e * 4u : 0x80000000u), 0, 0);
+                const bf16x2 pk = {(__bf16)x0, (__bf16)x1};
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rs16, (int)(ok ? e * 2u : 0x80000000u), 0, 0);
+            }
+        }
+        gs0 += __shfl_xor(gs0, 32, 64);
+        gs1 += __shfl_xor(gs1, 32, 64);
+        if (half == 0 && cok) {
+            const f32x4 v = {gs0, 0.f, gs1, 0.f};
+            *reinterpret_cast<f32x4*>(p.gn_part + ((size_t)(tm * 2 + wm) * p.Cout + c0) * 2) = v;
+        }
+        return;
+    }
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
         p.out, 0, (p.ablate & 16) ? 0 : (int)((size_t)p.M * p.Cout * (p.out_fp32 ? 4 : 2)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(

@@ -36,10 +36,11 @@
 // drain them with every wait): four k-steps of B fragments live in a ring of 32 registers, slot kk is re-requested for the NEXT
 // chunk one k-step after the MFMAs of k-step kk have been issued, and the loop's two waits (the barrier's vmcnt(0), one counted
 // wait in front of k-step 2) cover them.
-template <int MI, int NJ, int WN, bool BD = false, bool STAG = false>
+template <int MI, int NJ, int WN, bool BD = false, bool STAG = false, bool TR = false>
 __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) void conv_bf16_dma_kernel   // (threads, waves per SIMD)
 (ConvDmaParams p) {
     static_assert(!STAG || BD, "staggered request slots exist for the weights-direct instance");
+    static_assert(!TR || BD, "the training epilogue (dma_epilogue_pairs<.., TR>) is instantiated for the weights-direct instance");
     static_assert(!BD || (MI == 4 && NJ == 2 && WN == 4), "weights direct to registers: the 256 x 256 eight-wave instance");
     using T = DmaTile<MI, NJ, WN, BD>;
     constexpr int DBM = T::BM, DBN = T::BN, DSTAGE = T::STAGE, NM = T::NM, NF = T::NF, NP = T::NP, NPA = T::NPA, NPW = T::NPW;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 1 : MI * NJ <= 2 ? 4 : 2)) voi
             b_advance();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the requests past the last chunk must land before the LDS is released
-        dma_epilogue_pairs<MI, true>(p, acc, tm, m0, n0, wm, wn, lane);
+        dma_epilogue_pairs<MI, true, TR>(p, acc, tm, m0, n0, wm, wn, lane);
         return;
     }
     // prologue: chunk 0 -> stage 0 completely, the first C3 pieces of chunk 1 -> stage 1
@@ -415,13 +416,14 @@ void conv_bf16_pp_launch(const ConvDmaParams& p, unsigned grid, hipStream_t stre
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                          const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
-                         int ablate, int shape, const void* wfrag) {
+                         int ablate, int shape, const void* wfrag, const float* add32, void* out16) {
     const int bm = (shape == 1 || shape == 3) ? 128 : 256, bn = (shape == 2 || shape == 3) ? 128 : 256;
     if (Cout % bn != 0 || Cin % DBK != 0 || Kpad != KH * KW * Cin) return CPR_ERR_UNSUPPORTED;
     ConvDmaParams p;
     p.in = (const unsigned short*)in; p.wgt = (const unsigned short*)wgt; p.out = out; p.scale = scale; p.bias = bias;
     p.wfrag = (const unsigned short*)wfrag;
     p.residual = (const unsigned short*)residual; p.gn_part = gn_part;
+    p.add32 = add32; p.out16 = (unsigned short*)out16;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.Kpad = Kpad; p.relu = relu; p.out_fp32 = out_fp32; p.ablate = ablate;
     p.nt_taps = 0; p.nt_k = 1; p.nt_pad = 0; p.nt_Wp = 0; p.nt_chunks = 0; p.nt_copy = 0;
@@ -443,11 +445,15 @@ int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float
     // other two are bit-equal to), two-group ping-pong (conv_bf16_pp.hip: >= 4 K chunks), weights direct to registers (short K)
     if (shape == 0 && wfrag != nullptr && Kpad / DBK >= 4 && !(ablate & 512)) shape = 5;      // (ablate bit 9, measurement build: keep shape 0 off the ping-pong instance)
     const bool bd = shape == 0 && wfrag != nullptr;      // the 256 x 256 instance with the weights direct to registers
+    // the training epilogue (shortcut sum + mask + two outputs + column sums) exists for the two pair-epilogue instances
+    const bool tr = add32 != nullptr;
+    if (tr && !((bd || shape == 5) && relu == 2 && out_fp32 && out16 && gn_part && residual)) return CPR_ERR_UNSUPPORTED;
     if (variant_out) *variant_out = bm * 1000 + bn + (shape == 3 ? 1000000 : shape == 4 ? 2000000 : shape == 5 ? 5000000 : bd ? 3000000 : 0);       // 128128 alone is the register-staged <128, 128>
     const int T = p.tilesM * p.tilesN;
     const int grid = ((T + 7) / 8) * 8;
     if (shape == 1 || shape == 2) return CPR_ERR_UNSUPPORTED;      // <2, 2> and <4, 1> were measured and dropped
     if (shape == 5) conv_bf16_pp_launch(p, (unsigned)grid, stream);
+    else if (bd && tr) hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 2, 4, true, false, true>), dim3(grid), dim3(512), 0, stream, p);
     else if (shape == 3) hipLaunchKernelGGL((conv_bf16_dma_kernel<2, 1, 4>), dim3(grid), dim3(512), 0, stream, p);
 #ifdef CPR_BENCH_HOOKS   // measured 10-12 % slower than the eight-wave instance (profiles/round4_bf16_four_wave_tile.txt): measurement build only
     else if (shape == 4) hipLaunchKernelGGL((conv_bf16_dma_kernel<4, 4, 2>), dim3(grid), dim3(256), 0, stream, p);
@@ -472,7 +478,7 @@ int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, in
     if ((long long)M * rs * 2 >= (1ll << 31) || (long long)N * rs * 2 >= (1ll << 31) || rs >= (1ll << 30)) return CPR_ERR_UNSUPPORTED;
     ConvDmaParams p;
     p.in = (const unsigned short*)a; p.wgt = (const unsigned short*)b; p.wfrag = nullptr; p.out = part; p.scale = nullptr; p.bias = nullptr;
-    p.residual = nullptr; p.gn_part = nullptr;
+    p.residual = nullptr; p.gn_part = nullptr; p.add32 = nullptr; p.out16 = nullptr;
     p.N = 1; p.H = 1; p.W = M; p.Cin = (int)rs; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.Kpad = (int)rs; p.relu = 0; p.out_fp32 = 1; p.ablate = 0;
     p.OH = 1; p.OW = M; p.M = M;

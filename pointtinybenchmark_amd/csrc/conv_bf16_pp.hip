@@ -44,7 +44,7 @@ namespace {
 constexpr int PP_A_BYTES = 256 * DBK * 2;          // one stage of pixel (or cout) rows: 256 rows of 128 bytes
 }
 
-template <bool PRIO, bool PRE, int ABL = 0, bool STAMPS = false>
+template <bool PRIO, bool PRE, int ABL = 0, bool STAMPS = false, bool TR = false>
 __global__ __launch_bounds__(512, 2) void conv_bf16_pp_kernel(ConvDmaParams p) {
     constexpr int MI = 4, NJ = 2, DBM = 256, DBN = 256;
     constexpr int B_BASE = 3 * PP_A_BYTES;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pp_kernel(ConvDmaParams p) {
         dma_epilogue_pairs<MI, PRE>(q, acc, tm, m0, n0, g, wq, lane);
         return;
     }
-    dma_epilogue_pairs<MI, PRE>(p, acc, tm, m0, n0, g, wq, lane);
+    dma_epilogue_pairs<MI, PRE, TR>(p, acc, tm, m0, n0, g, wq, lane);       // (TR: the training epilogue, conv_bf16_dma.h)
     if constexpr (STAMPS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -314,5 +314,6 @@ void conv_bf16_pp_launch(const ConvDmaParams& p, unsigned grid, hipStream_t stre
     }
 #undef PP_GO
 #endif
-    hipLaunchKernelGGL((conv_bf16_pp_kernel<true, true>), dim3(grid), dim3(512), 0, stream, p);
+    if (p.add32) hipLaunchKernelGGL((conv_bf16_pp_kernel<true, true, 0, false, true>), dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_bf16_pp_kernel<true, true>), dim3(grid), dim3(512), 0, stream, p);
 }

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16_kernel(ConvParamsBf16 p
 int conv_bf16_dma_launch(const void* in, const void* wgt, void* out, const float* scale, const float* bias,
                          const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
-                         int ablate, int shape, const void* wfrag);
+                         int ablate, int shape, const void* wfrag, const float* add32, void* out16);
 #ifdef CPR_BENCH_HOOKS
 static int bf16_dma_on = 1, bf16_dma_ablate = 0, bf16_dma_force = 0, bf16_wfrag_on = 1;
 extern "C" int cpr_bf16_set_wfrag(int on) {  // measurement build: 0 = ignore the fragment-order weight image (A/B of the round-5 instance)
@@ -355,7 +355,8 @@ static int bf16_dma_shape(long long M, int Cin, int Cout, int kchunks, bool gn) 
 
 static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, const void* wfrag, void* out, const float* scale, const float* bias,
                                   const void* residual, float* gn_part, int N, int H, int W, int Cin, int Cout, int KH,
-                                  int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream) {
+                                  int KW, int stride, int pad, int Kpad, int relu, int out_fp32, int* variant_out, hipStream_t stream,
+                                  const float* add32 = nullptr, void* out16 = nullptr) {
     CPR_CHECK_ARG(in && wgt && out);
     CPR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     CPR_CHECK_ARG(Cin % BKH == 0 && Kpad == KH * KW * Cin);
@@ -380,10 +381,10 @@ static int conv2d_fwd_bf16_launch(const void* in, const void* wgt, const void* w
     if (dshape >= 0) {
         const int rc = conv_bf16_dma_launch(in, wgt, out, scale, bias, residual, gn_part, N, H, W, Cin, Cout, KH, KW, stride,
                                             pad, Kpad, relu, out_fp32, variant_out, stream, bf16_dma_ablate, dshape,
-                                            bf16_wfrag_on ? wfrag : nullptr);
+                                            bf16_wfrag_on ? wfrag : nullptr, add32, out16);
         if (rc != CPR_ERR_UNSUPPORTED) return rc;
     }
-    if (mask_mode) return CPR_ERR_UNSUPPORTED;      // (cpr_conv2d_bf16_mask_slots tells the caller beforehand)
+    if (mask_mode || add32) return CPR_ERR_UNSUPPORTED;      // (cpr_conv2d_bf16_mask_slots tells the caller beforehand)
     const long long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
     const bool big = gn_part || (Kpad / BKH >= 8 && t128 >= 4096 && Cout > 64);
     const int bm = big ? 128 : 64, bn = big ? 128 : 64;
@@ -409,9 +410,23 @@ extern "C" int cpr_conv2d_bf16_mask_slots(int N, int H, int W, int Cin, int Cout
     if (cpr_images_per_launch(N, cpr_max2((long long)H * W * Cin * 2, (long long)OH * OW * Cout * oe)) != N) return 0;
     if ((long long)N * H * W * Cin * 2 >= (1ll << 31) || (long long)Cout * KH * KW * Cin * 2 >= (1ll << 31) || M * Cout * oe >= (1ll << 31)) return 0;
     const int shape = bf16_dma_shape(M, Cin, Cout, KH * KW * Cin / BKH, false);
-    if (shape == 0 || shape == 5) return Cout % 256 == 0 ? (int)((M + 255) / 256) * 2 : 0;       // two wave rows of 128 pixels per tile
-    if (shape == 3) return Cout % 128 == 0 ? (int)((M + 127) / 128) * (out_fp32 ? 2 : 1) : 0;    // direct epilogue: per wave row; through LDS: per tile
+    if (shape == 0 || shape == 5) return Cout % 256 == 0 && (out_fp32 != 2 || bf16_wfrag_on) ? (int)((M + 255) / 256) * 2 : 0;       // two wave rows of 128 pixels per tile
+    if (shape == 3 && out_fp32 != 2) return Cout % 128 == 0 ? (int)((M + 127) / 128) * (out_fp32 ? 2 : 1) : 0;    // direct epilogue: per wave row; through LDS: per tile
     return 0;
+}
+
+// The block-boundary data gradient of the mixed-precision backward in one launch (round 6; the TR instances of the 256 x 256 tile):
+//   g = mask > 0 ? conv(in, wgt) + add32 : 0,   out32 = g (fp32), out16 = bf16(g),   part[slot][Cout][2] <- column sums of g
+// in: the bf16 gradient map, wgt / wgt_frag: the rotated, BN-scaled weights (both images), add32: the shortcut gradient (fp32, the
+// output's shape), mask: the bf16 map a forward ReLU produced (the conv's input in the forward).  Slots:
+// cpr_conv2d_bf16_mask_slots(..., out_fp32 = 2) (0 = this shape has no such instance -> CPR_ERR_UNSUPPORTED here).
+extern "C" int cpr_conv2d_dgrad_bf16_fused(const void* in, const void* wgt, const void* wgt_frag, float* out32, void* out16, const float* add32,
+                                           const void* mask, float* part, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                           int pad, int Kpad, int* variant_out, hipStream_t stream) {
+    CPR_CHECK_ARG(in && wgt && wgt_frag && out32 && out16 && add32 && mask && part);
+    if (cpr_conv2d_bf16_mask_slots(N, H, W, Cin, Cout, KH, KW, stride, pad, 2) <= 0) return CPR_ERR_UNSUPPORTED;
+    return conv2d_fwd_bf16_launch(in, wgt, wgt_frag, out32, nullptr, nullptr, mask, part, N, H, W, Cin, Cout, KH, KW, stride, pad, Kpad, 2, 1,
+                                  variant_out, stream, add32, out16);
 }
 
 // >= 2 GiB maps: balanced chunks of whole images (see cpr_images_per_launch)

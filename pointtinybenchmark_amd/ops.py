@@ -389,12 +389,41 @@ def conv2d(x, pc, scale=None, bias=None, residual=None, relu=False, in_ab=None, 
     return (out, part) if gn_part else out
 
 
-def conv2d_bf16_mask_slots(x_shape, pc, out_dtype=torch.bfloat16):
+def conv2d_bf16_mask_slots(x_shape, pc, out_dtype=torch.bfloat16, fused_add=False):
     """Column-sum slots a mask-mode launch (``conv2d(bf16 x, pc, residual=mask, res_mask=True, colsum=True)``) of this shape writes;
-    0 = the shape's kernel does not know the mode (include/cpr_hip.h, cpr_conv2d_bf16_mask_slots)."""
+    0 = the shape's kernel does not know the mode (include/cpr_hip.h, cpr_conv2d_bf16_mask_slots).  fused_add: the form with the
+    shortcut sum and two outputs (``conv2d_dgrad_bf16_fused``)."""
     N, H, W, Cin = x_shape
+    if fused_add and (not WFRAG[0] or pc.Cout % 256 != 0):
+        return 0
     return _lib.call('cpr_conv2d_bf16_mask_slots', N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding,
-                     int(out_dtype == torch.float32), positive=True)
+                     2 if fused_add else int(out_dtype == torch.float32), positive=True)
+
+
+def conv2d_dgrad_bf16_fused(g16, pc, mask, add):
+    """The block-boundary data gradient of the mixed-precision backward in one launch (include/cpr_hip.h,
+    cpr_conv2d_dgrad_bf16_fused): g = mask > 0 ? conv(g16, pc) + add : 0 -> (g fp32, g bf16, column-sum TilePartials).  g16 bf16
+    (N,H,W,Cin), pc: the rotated, BN-scaled bf16 pack, mask: bf16 map of the output's shape, add: fp32 map of the output's shape."""
+    _check(g16, ACT)
+    pack_ready(pc)
+    N, H, W, Cin = g16.shape
+    OH, OW = pc.out_hw(H, W)
+    shape = (N, OH, OW, pc.Cout)
+    assert g16.dtype == torch.bfloat16 and pc.dtype == torch.bfloat16 and Cin == pc.Cin
+    assert mask.dtype == torch.bfloat16 and add.dtype == torch.float32 and tuple(mask.shape) == shape and tuple(add.shape) == shape
+    assert mask.is_contiguous() and add.is_contiguous()
+    slots = conv2d_bf16_mask_slots(g16.shape, pc, fused_add=True)
+    assert slots > 0, 'this shape has no fused instance (ask conv2d_bf16_mask_slots(..., fused_add=True) first)'
+    out32 = torch.empty(shape, device=g16.device, dtype=torch.float32)
+    out16 = torch.empty(shape, device=g16.device, dtype=torch.bfloat16)
+    part = torch.empty((slots, pc.Cout, 2), device=g16.device, dtype=torch.float32)
+    variant = ctypes.c_int(0) if TRACE_CONV_VARIANT[0] else None
+    _lib.call('cpr_conv2d_dgrad_bf16_fused', _ptr(g16), _ptr(pc.w), _ptr(pc.frag_image()), _ptr(out32), _ptr(out16), _ptr(add), _ptr(mask),
+              _ptr(part), N, H, W, Cin, pc.Cout, pc.KH, pc.KW, pc.stride, pc.padding, pc.Kpad,
+              ctypes.byref(variant) if variant is not None else None, _stream())
+    if variant is not None:
+        TRACE_CONV_VARIANT[1] = ('bf16', variant.value)
+    return out32, out16, TilePartials(part, slots, pc.Cout)
 
 
 def conv1x1_stream(x, pc, scale=None, bias=None, residual=None, relu=False, res_mask=False):

@@ -741,6 +741,11 @@ class BackwardEngine:
                     mask.dtype == torch.bfloat16 and ops.conv2d_bf16_mask_slots(g16.shape, pc16) > 0:
                 dx16, part = ops.conv2d(g16, pc16, residual=mask, res_mask=True, colsum=True)
                 return None, part, dx16
+            if MIXED_BF16['mask_mode'] and mask is not None and add is not None and want_colsum and want16 and \
+                    mask.dtype == torch.bfloat16 and ops.conv2d_bf16_mask_slots(g16.shape, pc16, fused_add=True) > 0:
+                # the block-boundary gradient: shortcut sum, mask, both roundings and the column sums in the data gradient's epilogue
+                dx32, dx16, part = ops.conv2d_dgrad_bf16_fused(g16, pc16, mask, add)
+                return dx32, part, dx16
             return finish(ops.conv2d(g16, pc16, out_dtype=torch.float32), add)
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
                        lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))

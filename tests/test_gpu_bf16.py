@@ -417,3 +417,45 @@ def test_conv2d_bf16_mask_mode_says_which_shapes_it_takes():
     with pytest.raises(CprHipError, match='unsupported'):
         _lib.call('cpr_conv2d_fwd_bf16', x.data_ptr(), pc.w.data_ptr(), None, out.data_ptr(), None, None, x.data_ptr(), part.data_ptr(),
                   2, 16, 16, 128, 128, 3, 3, 1, 1, pc.Kpad, 2, 0, None, None)
+
+
+FUSED_CASES = [
+    # N, Cin, H, W, Cout, instance: conv1's data gradient of a bottleneck (1x1, planes -> 4 planes) on the two pair-epilogue instances
+    (13, 128, 80, 95, 512, BIG),          # layer2: two K chunks -> weights direct to registers; M = 98 800: ragged last tile
+    (16, 256, 40, 39, 1024, PP),          # layer3: four K chunks -> ping-pong; M = 24 960: ragged
+    (13, 512, 32, 32, 2048, PP),          # layer4: eight chunks
+]
+
+
+@pytest.mark.parametrize('case', FUSED_CASES, ids=lambda c: 'n%d_c%d_%dx%d_o%d_%d' % c)
+def test_conv2d_dgrad_bf16_fused_equals_conv_then_streaming_pass(case):
+    """Round 6: the block-boundary data gradient in one launch (cpr_conv2d_dgrad_bf16_fused: shortcut sum + ReLU mask + fp32 and
+    bf16 outputs + column sums in the epilogue of the 256 x 256 tile's TR instances) against what it replaces (fp32 conv output, then
+    ops.relu_bwd_colsum with add and want16): both maps BIT-equal, column sums equal up to the order of the fp32 additions."""
+    from pointtinybenchmark_amd import ops
+    N, Cin, H, W, Cout, want = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn((N, H, W, Cin), generator=g).bfloat16().cuda()
+    w = torch.randn((Cout, Cin, 1, 1), generator=g) / Cin ** 0.5
+    mask = torch.randn((N, H, W, Cout), generator=g).clamp_min(0).bfloat16().cuda()
+    add = torch.randn((N, H, W, Cout), generator=g).cuda()
+    pc = ops.PackedConv(w.cuda(), 1, 0, torch.bfloat16)
+    assert ops.conv2d_bf16_mask_slots(x.shape, pc, fused_add=True) == (N * H * W + 255) // 256 * 2
+    ops.TRACE_CONV_VARIANT[0] = True
+    try:
+        g32, g16, part = ops.conv2d_dgrad_bf16_fused(x, pc, mask, add)
+        variant = ops.TRACE_CONV_VARIANT[1]
+    finally:
+        ops.TRACE_CONV_VARIANT[0] = False
+    assert variant == ('bf16', want), variant
+    cs = part.reduce()
+    r32, cs_ref, r16 = ops.relu_bwd_colsum(ops.conv2d(x, pc, out_dtype=torch.float32), mask, want16=True, add=add)
+    torch.cuda.synchronize()
+    assert torch.equal(g32, r32), 'fp32 map differs in %d entries' % int((g32 != r32).sum())
+    assert torch.equal(g16, r16), 'bf16 map differs in %d entries' % int((g16 != r16).sum())
+    scale = float(r32.abs().sum(dim=(0, 1, 2)).max())
+    assert float((cs - cs_ref).abs().max()) <= 1e-5 * scale
+    np.testing.assert_allclose(cs.cpu().numpy(), r32.double().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=0, atol=2e-5 * scale)
+    # shapes of the 128-pixel tile have no such instance: the query says so
+    small = ops.PackedConv(torch.randn((128, 512, 1, 1)).cuda() * 0.04, 1, 0, torch.bfloat16)
+    assert ops.conv2d_bf16_mask_slots((14, 50, 50, 512), small, fused_add=True) == 0

@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round-6 development visit: the mixed-precision backward (mask mode, transposing kernel of the bf16 weight gradient, streaming pass).
+# Round-6 development visit: the mixed-precision backward (mask mode, fused block-boundary gradient, transposing kernel, streaming pass).
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r6m
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_backward.py tests/test_gpu_train_step.py -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | tail -30 > gpurun_out/r6m/pytest.log
+timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_train_step.py tests/test_gpu_autograd.py -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|Hostname\|Librccl" | tail -30 > gpurun_out/r6m/pytest.log
 tail -5 gpurun_out/r6m/pytest.log
 rm -f gpurun_out/r6m/ab.txt
-for v in "CPR_WGRAD_T64=1 CPR_BF16_NT_PP=0" "CPR_WGRAD_T64=0 CPR_BF16_NT_PP=0" "CPR_WGRAD_T64=0 CPR_BF16_NT_PP=1" "CPR_WGRAD_T64=0 CPR_BF16_NT_PP=16"; do
+for v in "CPR_MIXED_MASK_MODE=1" "CPR_MIXED_MASK_MODE=0"; do
   echo "== $v" >> gpurun_out/r6m/ab.txt
   env $v timeout 600 python tools/bf16_ab.py --train --depth 50 --size 640 --batch 64 --rounds 2 2>&1 | grep -v amdgpu.ids | head -1 >> gpurun_out/r6m/ab.txt
   env $v timeout 600 python tools/bf16_ab.py --train --rounds 2 2>&1 | grep -v amdgpu.ids | head -1 >> gpurun_out/r6m/ab.txt
