@@ -207,24 +207,44 @@ __global__ __launch_bounds__(256) void wgrad_bf16_transpose64_kernel(const void*
 }
 
 // part [splits][taps][Cout][Cin] fp32 -> grad [Cout][Cin][k][k] (the nn.Conv2d weight layout), summed over the splits: a block sums
-// 64 consecutive elements, its four 64-thread rows take every fourth split
+// 256 consecutive elements (64 threads x 4), its four 64-thread rows take every fourth split.  Round 6: 16-byte loads, four splits
+// requested before the first add (the round-3 form read 4 bytes per thread, one split at a time: 2.1 TB/s on the 64-slab layers of
+// configs[4]) -- the additions and their order are the old kernel's, so the gradients are bit for bit the same.
 __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int splits,
                                                                 int taps, int Cout, int Cin, int accumulate) {
-    __shared__ float red[4][64];
-    const long long per = (long long)Cout * Cin;
-    const long long i = (long long)blockIdx.x * 64 + (threadIdx.x & 63);      // (tap, co, ci), ci fastest; per % 64 == 0
+    __shared__ f32x4 red[4][64];
+    const long long per = (long long)Cout * Cin;                              // per % 256 == 0 (Cin % 256 == 0)
+    const long long i = ((long long)blockIdx.x * 64 + (threadIdx.x & 63)) * 4;  // (tap, co, ci), ci fastest: four consecutive ci
     const int row = threadIdx.x >> 6;
     const int tap = (int)(i / per);
     const long long r = i - (long long)tap * per;
-    float s = 0.f;
-    if (i < per * taps)
-        for (int sp = row; sp < splits; sp += 4) s += part[((long long)sp * taps + tap) * per + r];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < per * taps) {
+        const float* src = part + (long long)tap * per + r;
+        const long long step = (long long)taps * per;
+        int sp = row;
+        for (; sp + 12 < splits; sp += 16) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + sp * step), b = *reinterpret_cast<const f32x4*>(src + (sp + 4) * step);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(src + (sp + 8) * step), d = *reinterpret_cast<const f32x4*>(src + (sp + 12) * step);
+            s += a; s += b; s += c; s += d;
+        }
+        for (; sp < splits; sp += 4) s += *reinterpret_cast<const f32x4*>(src + sp * step);
+    }
     red[row][threadIdx.x & 63] = s;
     __syncthreads();
     if (row == 0 && i < per * taps) {
-        s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        float* g = grad + r * taps + tap;
-        *g = accumulate ? *g + s : s;
+        const int t = threadIdx.x;
+        s = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        if (taps == 1) {
+            f32x4* g = reinterpret_cast<f32x4*>(grad + r);
+            *g = accumulate ? *g + s : s;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* g = grad + (r + e) * taps + tap;
+                *g = accumulate ? *g + s[e] : s[e];
+            }
+        }
     }
 }
 
@@ -270,7 +290,7 @@ extern "C" int cpr_conv_wgrad_bf16(const void* dy, int dy_bf16, const void* x, i
                                            stream);
     if (rc != CPR_OK) return rc;
     const long long n = (long long)pl.taps * Cout * Cin;
-    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, part, grad, pl.splits,
+    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, grad, pl.splits,
                        pl.taps, Cout, Cin, accumulate);
     CPR_LAUNCH_STATUS();
 }

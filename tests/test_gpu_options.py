@@ -435,3 +435,59 @@ def test_cpr_options_full_size_vs_oracle(over):
     assert torch.equal(mask.cpu().bool(), nv), 'negative mask: %d entries differ' % int((mask.cpu().bool() != nv).sum())
     for k, v in ref_losses.items():
         assert abs(float(losses[k]) - float(v)) <= 5e-4 * max(abs(float(v)), 1e-6), (k, float(losses[k]), float(v))
+
+
+SWEEP_CASES = ['binary_ins', 'normed_sigmoid_p2', 'r2_merge_gt', 'r3_only_refine', 'combo_tower_binary_normed']
+
+
+@pytest.mark.parametrize('name', SWEEP_CASES)
+def test_general_loss_backward_seed_sweep_vs_oracle_autograd(name):
+    """Round 6 (advisor): the reference fixtures of test_option_backward_vs_reference_autograd sit on seeds that were PICKED (smallest
+    device-vs-oracle error among candidates), so a small error of the general loss-backward kernels could hide behind the selection.
+    Here: seeds nobody selected (fixture seed + 1000 + {1, 2, 3}), the same device step against torch autograd over the options
+    oracle (itself pinned to the reference's loss.backward() at 1e-3, tests/test_oracle_golden.py).  The classifier tensors sit right
+    behind the loss-backward kernels -- no ReLU between them and the loss -- and must agree to 1e-4 on EVERY swept seed; every other
+    tensor to 1e-2 of its norm (a ReLU boundary within fp32 conv rounding moves a tower tensor by 3e-3 .. 7e-3 in the reference's own
+    graph: oracle/gen_golden_r5.py), and the total loss to 1e-4."""
+    from oracle import cpr_options_oracle as OO
+    from oracle import cpr_oracle as O
+    from pointtinybenchmark_amd.training import CprTrainer
+    worst_cls, worst_other = 0.0, (0.0, None, None)
+    for ds in (1, 2, 3):
+        cfg = dict(grad_option_cfg(name))
+        cfg['seed'] = cfg['seed'] + 1000 + ds
+        m, batch = build_hip(cfg)
+        cb = cuda_batch(batch)
+        tr = CprTrainer(m)
+        losses = tr.forward_backward(img=cb['img'], img_metas=cb['img_metas'], gt_bboxes=cb['gt_bboxes'], gt_labels=cb['gt_labels'])
+        torch.cuda.synchronize()
+        total = float(sum(v for k, v in losses.items() if 'loss' in k))
+        got = {k: q.grad.detach().double().cpu() for k, q in m.named_parameters() if q.requires_grad and q.grad is not None}
+        del tr, m
+        sd, _ = case_inputs(cfg)
+        sd = {k: v.clone() for k, v in sd.items()}
+        for k in got:
+            sd[k].requires_grad_(True)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        feats = O.fpn_forward(sd, O.resnet_forward(sd, batch['img'], cfg['depth']), cfg['start_level'], 1)
+        cls_feat, _ = O.cpr_head_forward(sd, feats)
+        ins_feat = OO.ins_tower_forward(sd, feats)[0] if cfg.get('ins_tower') else None
+        ol, _ = OO.cpr_loss(sd, cls_feat[0], batch['gt_bboxes'], batch['gt_labels'], batch['img_metas'], cfg, ins_feat=ins_feat)
+        ot = sum(v for k, v in ol.items() if 'loss' in k)
+        assert abs(total - float(ot.detach())) <= 1e-4 * max(1.0, abs(float(ot.detach()))), (ds, total, float(ot.detach()))
+        ot.backward()
+        gmax = max(float(sd[k].grad.double().norm()) for k in got if sd[k].grad is not None)
+        for k, gr in got.items():
+            if sd[k].grad is None:
+                assert not bool(gr.any()), k
+                continue
+            ref = sd[k].grad.detach().double()
+            err = float((gr - ref).norm()) / max(float(ref.norm()), 1e-6 * gmax)
+            if k.startswith(('bbox_head.cls_out.', 'bbox_head.ins_out.')):
+                worst_cls = max(worst_cls, err)
+                assert err <= 1e-4, (name, cfg['seed'], k, err)
+            else:
+                if err > worst_other[0]:
+                    worst_other = (err, k, cfg['seed'])
+                assert err <= 1e-2, (name, cfg['seed'], k, err)
+    print('%s: classifier tensors <= %.2e, other tensors <= %.2e (%s, seed %s)' % ((name, worst_cls) + worst_other))
