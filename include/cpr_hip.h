@@ -392,6 +392,10 @@ int cpr_part_colsum(const float* part, float* out, float* ws, int tiles, int C, 
  * dgamma = inv_sigma*(<W[c],Gw[c]> - mean*colsum_g), dbeta = colsum_g (either may be NULL). */
 int cpr_bn_fold_bwd(float* Gw, const float* weight, const float* scale, const float* mean, const float* inv_sigma,
                     const float* colsum_g, float* dgamma, float* dbeta, int Cout, int K, void* stream);
+/* the same with the column sums still in a conv epilogue's partials [tiles][Cout][2] (element 0 = sum; mask mode / fused data gradients of
+ * cpr_conv2d_fwd_bf16, CPR_CONV_COLSUM of cpr_conv2d_fwd): the kernel adds each channel's column up itself (fixed order) */
+int cpr_bn_fold_bwd_part(float* Gw, const float* weight, const float* scale, const float* mean, const float* inv_sigma, const float* part,
+                         int tiles, float* dgamma, float* dbeta, int Cout, int K, void* stream);
 /* y = alpha*x + beta*y on flat fp32 buffers */
 int cpr_axpby(float* y, const float* x, float alpha, float beta, long long n, void* stream);
 /* phase decomposition of a stride-s data gradient: dst[n, s*i+py, s*j+px, :] += src[n, i+sh, j+sw, :] for all targets

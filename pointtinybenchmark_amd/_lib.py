@@ -77,6 +77,7 @@ SIGNATURES = {
     'cpr_relu_bwd_colsum_ws': [_l, _i],
     'cpr_relu_bwd_colsum': [_p, _p, _p, _i, _p, _p, _p, _p, _l, _i, _i, _p],
     'cpr_bn_fold_bwd': [_p] * 8 + [_i, _i, _p],
+    'cpr_bn_fold_bwd_part': [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p],
     'cpr_part_colsum': [_p, _p, _p, _i, _i, _p],
     'cpr_axpby': [_p, _p, _f, _f, _l, _p],
     'cpr_phase_scatter_add': [_p, _p] + [_i] * 11 + [_p],

@@ -404,13 +404,24 @@ extern "C" int cpr_part_colsum(const float* part, float* out, float* ws, int til
 //   dscale[c] = <W[c], Gw[c]> (= sum_p g*conv),  dshift[c] = colsum_g[c]
 //   dgamma = inv_sigma*(dscale - mean*dshift),  dbeta = dshift,  dW[c] = scale[c]*Gw[c]  (in place)
 // One block per output channel.
+// tiles > 0 (round 6): colsum_g is not the (C) vector but the conv epilogue's partials [tiles][C][2] (element 0 = sum; mask mode /
+// TR instances of the bf16 data gradient, the fp32 epilogue's CPR_CONV_COLSUM) -- the block adds its channel's column up itself,
+// in a fixed order, instead of one or two strided_colsum launches in front of every one of these (~115 per configs[4] step).
 __global__ void bn_fold_bwd_kernel(float* __restrict__ Gw, const float* __restrict__ Wt, const float* __restrict__ scale,
                                    const float* __restrict__ mean, const float* __restrict__ inv_sigma,
                                    const float* __restrict__ colsum_g, float* __restrict__ dgamma,
-                                   float* __restrict__ dbeta, int K) {
+                                   float* __restrict__ dbeta, int K, int tiles) {
     __shared__ double red[4];
+    __shared__ double redc[4];
     const int c = blockIdx.x;
     const float sc = scale[c];
+    double csum = 0;
+    if (tiles > 0) {
+        const int C = gridDim.x;
+        for (int t = threadIdx.x; t < tiles; t += blockDim.x) csum += (double)colsum_g[((size_t)t * C + c) * 2];
+        csum = wave_sum_d(csum);
+        if ((threadIdx.x & 63) == 0) redc[threadIdx.x >> 6] = csum;
+    }
     double dot = 0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const float gv = Gw[(size_t)c * K + k];
@@ -422,7 +433,7 @@ __global__ void bn_fold_bwd_kernel(float* __restrict__ Gw, const float* __restri
     __syncthreads();
     if (threadIdx.x == 0) {
         const double dscale = red[0] + red[1] + red[2] + red[3];
-        const double dshift = (double)colsum_g[c];
+        const double dshift = tiles > 0 ? (double)(float)(redc[0] + redc[1] + redc[2] + redc[3]) : (double)colsum_g[c];
         if (dgamma) dgamma[c] = (float)((double)inv_sigma[c] * (dscale - (double)mean[c] * dshift));
         if (dbeta) dbeta[c] = (float)dshift;
     }
@@ -432,7 +443,15 @@ extern "C" int cpr_bn_fold_bwd(float* Gw, const float* weight, const float* scal
                                hipStream_t stream) {
     CPR_CHECK_ARG(Gw && weight && scale && mean && inv_sigma && colsum_g && Cout > 0 && K > 0);
     hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(Cout), dim3(256), 0, stream, Gw, weight, scale, mean, inv_sigma, colsum_g,
-                       dgamma, dbeta, K);
+                       dgamma, dbeta, K, 0);
+    CPR_LAUNCH_STATUS();
+}
+// the same with the column sums still in the conv epilogue's partials [tiles][Cout][2] (element 0 = sum): no cpr_part_colsum in front
+extern "C" int cpr_bn_fold_bwd_part(float* Gw, const float* weight, const float* scale, const float* mean, const float* inv_sigma,
+                                    const float* part, int tiles, float* dgamma, float* dbeta, int Cout, int K, hipStream_t stream) {
+    CPR_CHECK_ARG(Gw && weight && scale && mean && inv_sigma && part && tiles > 0 && Cout > 0 && K > 0);
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(Cout), dim3(256), 0, stream, Gw, weight, scale, mean, inv_sigma, part, dgamma, dbeta, K,
+                       tiles);
     CPR_LAUNCH_STATUS();
 }
 

@@ -439,6 +439,7 @@ extern "C" int cpr_conv2d_fwd_bf16(const void* in, const void* wgt, const void* 
     const size_t oe = out_fp32 ? 4 : 2;
     const int per = cpr_images_per_launch(N, cpr_max2((long long)H * W * Cin * 2, (long long)OH * OW * Cout * (long long)oe));
     if (per <= 0) return CPR_ERR_UNSUPPORTED;
+    if (relu == 2 && per < N) return CPR_ERR_UNSUPPORTED;      // mask mode: one launch (cpr_conv2d_bf16_mask_slots reports 0 for such maps)
     for (int n0 = 0; n0 < N; n0 += per) {
         const int n = N - n0 < per ? N - n0 : per;
         const size_t rows = (size_t)n0 * OH * OW;

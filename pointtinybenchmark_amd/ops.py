@@ -1179,13 +1179,19 @@ def relu_bwd_colsum(dy, y=None, want_g=True, colsum=None, want16=False, add=None
 
 
 def bn_fold_bwd(Gw, weight, scale, mean, inv_sigma, colsum_g, want_affine=True, out_dgamma=None, out_dbeta=None):
-    """In place dW = scale*Gw; returns (dgamma, dbeta) of the folded eval BatchNorm (or (None, None))."""
+    """In place dW = scale*Gw; returns (dgamma, dbeta) of the folded eval BatchNorm (or (None, None)).  colsum_g: the (Cout,) column
+    sums of the output gradient, or the TilePartials a conv epilogue left (summed inside the kernel)."""
     Cout = Gw.shape[0]
     K = Gw.numel() // Cout
     dg, db = out_dgamma, out_dbeta
     if want_affine and dg is None:
         dg = torch.empty((Cout,), device=Gw.device, dtype=torch.float32)
         db = torch.empty((Cout,), device=Gw.device, dtype=torch.float32)
+    if isinstance(colsum_g, TilePartials):     # the conv epilogue's partials as they are: the kernel adds its channel's column up
+        assert colsum_g.C == Cout
+        _lib.call('cpr_bn_fold_bwd_part', _ptr(Gw), _ptr(_check(weight)), _ptr(scale), _ptr(mean), _ptr(inv_sigma),
+                  _ptr(colsum_g.part), colsum_g.tiles, _ptr(dg), _ptr(db), Cout, K, _stream())
+        return dg, db
     _lib.call('cpr_bn_fold_bwd', _ptr(Gw), _ptr(_check(weight)), _ptr(scale), _ptr(mean), _ptr(inv_sigma),
               _ptr(colsum_g), _ptr(dg), _ptr(db), Cout, K, _stream())
     return dg, db

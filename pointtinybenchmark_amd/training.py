@@ -702,7 +702,7 @@ class BackwardEngine:
             aff = bn.weight.requires_grad
 
             def param_grads():
-                cs = colsum.reduce() if isinstance(colsum, ops.TilePartials) else colsum
+                cs = colsum            # (TilePartials of a conv epilogue are summed inside bn_fold_bwd)
                 gw = self._g(w)
                 if w16:
                     ops.conv_wgrad_bf16(g16, x, w.shape, out=gw)    # (x: the bf16 recorded map, or a widened copy that rounds back exactly)

@@ -149,6 +149,16 @@ def test_bn_fold_relu_backward():
     _cmp('dW', Gw, w.grad, atol=2e-4 * float(w.grad.abs().max()))
     _cmp('dgamma', dg, gamma.grad, atol=2e-4 * float(gamma.grad.abs().max()))
     _cmp('dbeta', db, beta.grad, atol=2e-4 * float(beta.grad.abs().max()))
+    # round 6: the column sums handed over as a conv epilogue's partials [tiles][C][2] -- bn_fold_bwd adds the column up itself
+    parts = torch.randn((37, Cout, 2), generator=g).cuda()
+    Gw2 = ops.conv2d_wgrad(gten, _nhwc(x), w.shape, 1, 0)
+    Gw3 = Gw2.clone()
+    tp = ops.TilePartials(parts, 37, Cout)
+    dg2, db2 = ops.bn_fold_bwd(Gw2, w.detach().cuda(), scale.cuda(), rm.cuda(), inv_sigma.cuda(), tp)
+    dg3, db3 = ops.bn_fold_bwd(Gw3, w.detach().cuda(), scale.cuda(), rm.cuda(), inv_sigma.cuda(), tp.reduce())
+    assert torch.equal(Gw2, Gw3)
+    _cmp('dbeta from partials', db2, db3, atol=1e-5 * float(db3.abs().max()))
+    _cmp('dgamma from partials', dg2, dg3, atol=1e-5 * float(dg3.abs().max()))
     # colsum without a mask / without writing g, odd channel count for the thread layout (C/4 = 40)
     for C in (160, 2048, 1028):
         t = torch.randn((3, 7, 5, C), generator=g)

@@ -495,9 +495,14 @@ def test_general_loss_backward_seed_sweep_vs_oracle_autograd(name):
                 assert not bool(gr.any()), k
                 continue
             ref = sd[k].grad.detach().double()
-            err = float((gr - ref).norm()) / max(float(ref.norm()), 1e-6 * gmax)
+            if float(ref.norm()) <= 1e-6 * gmax:
+                # numerically nil (ins_out.bias under normed_sigmoid: its true gradient cancels, |g| ~ 1e-8 beside 1e3): absolute bar
+                # as in the fixture test
+                assert float((gr - ref).norm()) <= 1e-6 * gmax, (name, cfg['seed'], k, float((gr - ref).norm()), gmax)
+                continue
+            err = float((gr - ref).norm()) / float(ref.norm())
             if k.startswith(('bbox_head.cls_out.', 'bbox_head.ins_out.')):
-                kbar = max(1e-4, 3 * sens.get(k, 0.0)) if float(ref.norm()) > 1e-6 * gmax else 1e-4
+                kbar = max(1e-4, 3 * sens.get(k, 0.0))
                 worst_cls = max(worst_cls, err / kbar)
                 assert err <= kbar, (name, cfg['seed'], k, err, sens.get(k))
             else:

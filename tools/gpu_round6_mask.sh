@@ -7,7 +7,7 @@ mkdir -p gpurun_out/r6m
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_options.py -q -m gpu -x -s --tb=short -p no:cacheprovider -k "seed_sweep" 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|Hostname\|Librccl\|amdgpu.ids" | tail -30 > gpurun_out/r6m/seed_sweep.log
 tail -12 gpurun_out/r6m/seed_sweep.log
-timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_train_step.py -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|Hostname\|Librccl" | tail -12 > gpurun_out/r6m/pytest.log
+timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_backward.py tests/test_gpu_train_step.py tests/test_gpu_autograd.py tests/test_gpu_p2p.py -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|Hostname\|Librccl" | tail -12 > gpurun_out/r6m/pytest.log
 tail -3 gpurun_out/r6m/pytest.log
 rm -f gpurun_out/r6m/ab.txt
 for v in "CPR_MIXED_MASK_MODE=1"; do
