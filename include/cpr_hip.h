@@ -73,6 +73,10 @@ int cpr_conv1x1_stream_fwd(const float* in, const float* wgt, float* out, const 
 int cpr_conv_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout, int k);
 int cpr_conv_wgrad_bf16(const void* dy, int dy_bf16, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W, int Cin,
                         int Cout, int k, int accumulate, void* stream);
+/* Which kernel cpr_conv_wgrad_bf16 takes when both maps are bf16: 0 = channel-major rewrites of both maps + NT GEMM (rounds 3-6 default),
+ * 1 = the pixel-major kernel of csrc/conv_wgrad_bf16_tn.hip (round 6: reads the NHWC maps as they are through ds_read_b64_tr_b16, no
+ * rewrites).  Initial value from CPR_WGRAD_TN; on < 0 only queries.  Returns the previous value. */
+int cpr_wgrad_bf16_set_tn(int on);
 
 /* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies than
  * cpr_conv2d_fwd; same call sites: the CPR head towers cpr_head.py:1033-1043, the FPN output conv fpn.py:190-194, the 3x3 of

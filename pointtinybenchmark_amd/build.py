@@ -9,7 +9,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcprhip.so')
-SOURCES = ['conv_mfma.hip', 'conv1x1_stream.hip', 'conv_mfma_bf16.hip', 'conv_bf16_dma.hip', 'conv_bf16_pp.hip', 'stem_bf16.hip', 'stem_f32.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad.hip', 'norm_pool.hip', 'cpr_points.hip', 'assign.hip',
+SOURCES = ['conv_mfma.hip', 'conv1x1_stream.hip', 'conv_mfma_bf16.hip', 'conv_bf16_dma.hip', 'conv_bf16_pp.hip', 'stem_bf16.hip', 'stem_f32.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad_bf16_tn.hip', 'conv_wgrad.hip', 'norm_pool.hip', 'cpr_points.hip', 'assign.hip',
            'postproc.hip', 'backward.hip', 'preprocess.hip', 'pack.hip', 'project.hip', 'conv_wino.hip', 'conv_wino32.hip', 'conv_wino_wgrad.hip']
 HEADERS = ['common.h', 'conv_bf16_dma.h']
 # Kernels whose integer / mask / index outputs are held bit-exact against the reference's CPU arithmetic restate it

@@ -21,6 +21,9 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, int N, long long rs, int k, int pad, int Wp,
                             long long copy, int splits, int chunks, hipStream_t stream);
+// conv_wgrad_bf16_tn.hip: the same gradient straight from the NHWC maps (transposing LDS reads), no rewritten operands
+int wgrad_bf16_tn_launch(const void* dy, const void* x, float* part, int N, int H, int W, int Cin, int Cout, int k, int splits,
+                         int chunks, hipStream_t stream);
 
 struct WgradBf16Plan {
     int pad, Hp, Wp, G, splits, chunks, taps;
@@ -248,6 +251,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
     }
 }
 
+// which kernel takes the bf16 weight gradient when both maps are bf16: 0 = channel-major rewrites + NT GEMM, 1 = the pixel-major kernel
+// (conv_wgrad_bf16_tn.hip).  Initial value: CPR_WGRAD_TN (default 0); cpr_wgrad_bf16_set_tn switches at run time (tests, A/B tools).
+static int& wgrad_bf16_tn_mode() {
+    static int mode = []() { const char* e = getenv("CPR_WGRAD_TN"); return (e && e[0] == '1') ? 1 : 0; }();
+    return mode;
+}
+extern "C" int cpr_wgrad_bf16_set_tn(int on) {
+    const int old = wgrad_bf16_tn_mode();
+    if (on >= 0) wgrad_bf16_tn_mode() = on != 0;
+    return old;
+}
+
 // workspace size in units of 256 bytes (the byte count of a B=64 head layer does not fit the int every entry point returns)
 extern "C" int cpr_conv_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout, int k) {
     WgradBf16Plan pl;
@@ -266,6 +281,24 @@ extern "C" int cpr_conv_wgrad_bf16(const void* dy, int dy_bf16, const void* x, i
     unsigned short* dyT = reinterpret_cast<unsigned short*>((char*)ws + pl.off_dy);
     unsigned short* xT = reinterpret_cast<unsigned short*>((char*)ws + pl.off_x);
     float* part = reinterpret_cast<float*>((char*)ws + pl.off_part);
+    // CPR_WGRAD_TN=1: both maps bf16 -> the pixel-major kernel (no dyT / xT rewrites); the split count follows the same rule on the
+    // unpadded pixel count
+    const bool tn = wgrad_bf16_tn_mode() != 0;
+    if (tn && dy_bf16 && x_bf16 && Cout % 8 == 0 && Cin % 8 == 0) {
+        const long long chunks_all = ((long long)N * H * W + 63) / 64;
+        long long splits = pl.splits;
+        if (splits > chunks_all / 8 / 8 * 8) splits = chunks_all / 8 / 8 * 8;
+        if (splits < 8) splits = 8;
+        const int chunks = (int)((chunks_all + splits - 1) / splits);
+        const int rc = wgrad_bf16_tn_launch(dy, x, part, N, H, W, Cin, Cout, k, (int)splits, chunks, stream);
+        if (rc == CPR_OK) {
+            const long long n = (long long)pl.taps * Cout * Cin;
+            hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, grad, (int)splits,
+                               pl.taps, Cout, Cin, accumulate);
+            CPR_LAUNCH_STATUS();
+        }
+        if (rc != CPR_ERR_UNSUPPORTED) return rc;
+    }
     const long long copy = (long long)Cin * pl.rs;
     static const bool t64 = []() { const char* e = getenv("CPR_WGRAD_T64"); return e && e[0] == '1'; }();     // A/B: the round-3 kernel
     auto rewrite = [&](auto bf, auto nc, const void* src, unsigned short* dst, int C, long long cp) {

@@ -459,3 +459,45 @@ def test_conv2d_dgrad_bf16_fused_equals_conv_then_streaming_pass(case):
     # shapes of the 128-pixel tile have no such instance: the query says so
     small = ops.PackedConv(torch.randn((128, 512, 1, 1)).cuda() * 0.04, 1, 0, torch.bfloat16)
     assert ops.conv2d_bf16_mask_slots((14, 50, 50, 512), small, fused_add=True) == 0
+
+
+WGRAD_TN_CASES = [
+    # N, H, W, Cin, Cout, k: the pixel-major kernel reads both NHWC maps as they are (bf16)
+    (2, 24, 24, 256, 512, 1),      # 1x1 (a lateral)
+    (3, 17, 23, 256, 256, 3),      # 3x3, ragged pixel count (1173 = 18 chunks + 21), W < 64: a chunk spans rows
+    (2, 9, 7, 512, 320, 3),        # tiny map: a chunk spans more than an image's rows; Cout not a multiple of the 256-row tile
+    (1, 40, 72, 256, 64, 3),       # W > 64, one partial cout tile
+    (4, 32, 32, 1024, 256, 1),     # four cin tiles
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_TN_CASES, ids=lambda c: 'n%d_%dx%d_c%d_o%d_k%d' % c)
+def test_conv_wgrad_bf16_pixel_major_kernel_vs_fp64(case):
+    """Round 6: csrc/conv_wgrad_bf16_tn.hip -- the bf16 weight gradient straight from the NHWC maps (LDS-DMA of pixel rows,
+    ds_read_b64_tr_b16 fragments, no channel-major rewrites).  Same bars as the rewriting path: against torch's fp64 weight gradient of
+    the SAME bf16 operands only the fp32 summation order differs (2e-4 of the gradient's max); and against the rewriting path itself
+    (different split boundaries, same products) 2e-4 as well."""
+    from pointtinybenchmark_amd import _lib, ops
+    N, H, W, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, Cin, H, W), generator=g).bfloat16()
+    dy = (torch.randn((N, Cout, H, W), generator=g) * 0.1).bfloat16()
+    wz = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wz, padding=k // 2).backward(dy.double())
+    ref = wz.grad
+    xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyc = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    old = _lib.call('cpr_wgrad_bf16_set_tn', 1, positive=True)
+    try:
+        got = ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k))
+        acc = got.clone()
+        ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k), out=acc, accumulate=True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.call('cpr_wgrad_bf16_set_tn', old, positive=True)
+    err = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-4, 'pixel-major bf16 weight gradient vs fp64 on the same operands: %.3e of the max' % err
+    assert torch.equal(acc, got + got)
+    nt = ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k))
+    torch.cuda.synchronize()
+    assert float((got - nt).abs().max()) <= 2e-4 * float(ref.abs().max())
