@@ -77,6 +77,12 @@ int cpr_conv_wgrad_bf16(const void* dy, int dy_bf16, const void* x, int x_bf16, 
  * 1 = the pixel-major kernel of csrc/conv_wgrad_bf16_tn.hip (round 6: reads the NHWC maps as they are through ds_read_b64_tr_b16, no
  * rewrites).  Initial value from CPR_WGRAD_TN; on < 0 only queries.  Returns the previous value. */
 int cpr_wgrad_bf16_set_tn(int on);
+/* cpr_conv_wgrad_bf16 with a stride (1 or 2; dy is (N,OH,OW,Cout), OH = (H + 2 (k/2) - k) / stride + 1) -- the strided 3x3 / projection
+ * layers of a stage's first block.  Stride 2, Cin % 256 != 0 (Cin % 64 == 0 suffices) and 1x1 layers below 256 couts are the pixel-major
+ * kernel's alone: both maps bf16, else CPR_ERR_UNSUPPORTED.  Workspace: cpr_conv_wgrad_bf16_workspace_s (units of 256 bytes). */
+int cpr_conv_wgrad_bf16_workspace_s(int N, int H, int W, int Cin, int Cout, int k, int stride);
+int cpr_conv_wgrad_bf16_s(const void* dy, int dy_bf16, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W, int Cin,
+                          int Cout, int k, int stride, int accumulate, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies than
  * cpr_conv2d_fwd; same call sites: the CPR head towers cpr_head.py:1033-1043, the FPN output conv fpn.py:190-194, the 3x3 of

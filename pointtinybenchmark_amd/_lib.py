@@ -21,7 +21,9 @@ SIGNATURES = {
     'cpr_conv2d_dual_fwd': [_p] * 9 + [_i] * 16 + [_p, _p],
     'cpr_conv1x1_stream_fwd': [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p],
     'cpr_conv_wgrad_bf16_workspace': [_i, _i, _i, _i, _i, _i],
+    'cpr_conv_wgrad_bf16_workspace_s': [_i] * 7,
     'cpr_conv_wgrad_bf16': [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'cpr_conv_wgrad_bf16_s': [_p, _i, _p, _i, _p, _p] + [_i] * 8 + [_p],
     'cpr_wino_pack_weights': [_p, _p, _i, _i, _i, _p],
     'cpr_conv3x3_wino_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'cpr_wino32_pack_weights': [_p, _p, _i, _i, _i, _p],

@@ -22,24 +22,26 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 int conv_bf16_dma_nt_launch(const void* a, const void* b, float* part, int M, int N, long long rs, int k, int pad, int Wp,
                             long long copy, int splits, int chunks, hipStream_t stream);
 // conv_wgrad_bf16_tn.hip: the same gradient straight from the NHWC maps (transposing LDS reads), no rewritten operands
-int wgrad_bf16_tn_launch(const void* dy, const void* x, float* part, int N, int H, int W, int Cin, int Cout, int k, int splits,
+int wgrad_bf16_tn_launch(const void* dy, const void* x, float* part, int N, int H, int W, int Cin, int Cout, int k, int stride, int splits,
                          int chunks, hipStream_t stream);
 
 struct WgradBf16Plan {
     int pad, Hp, Wp, G, splits, chunks, taps;
+    bool nt_ok;                   // the rewriting path can take this shape (Cin % 256 == 0, row length within the descriptors' range)
+    int tn_splits, tn_chunks;     // the pixel-major kernel's split of the UNPADDED pixel axis
     long long Q, Qk, rs;          // real cells, cells covered by the K loop, row length (elements, guards included)
     long long off_dy, off_x, off_part, bytes;   // workspace layout
 };
 
-static bool wgrad_bf16_plan(int N, int H, int W, int Cin, int Cout, int k, WgradBf16Plan* pl) {
-    if (!(k == 1 || k == 3) || N <= 0 || H <= 0 || W <= 0 || Cin % 256 != 0 || Cout % 64 != 0) return false;
+static bool wgrad_bf16_plan(int N, int H, int W, int Cin, int Cout, int k, WgradBf16Plan* pl, int stride = 1) {
+    if (!(k == 1 || k == 3) || N <= 0 || H <= 0 || W <= 0 || Cin % 64 != 0 || Cout % 64 != 0 || !(stride == 1 || stride == 2)) return false;
     pl->pad = k / 2;
     pl->Hp = H + 2 * pl->pad;
     pl->Wp = (W + 2 * pl->pad + 7) / 8 * 8;
     pl->G = pl->Wp + 8;                                  // guard in front of and behind the cells: |shift| <= Wp + 1
     pl->Q = (long long)N * pl->Hp * pl->Wp;
     pl->taps = k * k;
-    const long long tilesMN = (long long)((Cout + 255) / 256) * (Cin / 256);
+    const long long tilesMN = (long long)((Cout + 255) / 256) * ((Cin + 255) / 256);
     const long long chunks_all = (pl->Q + 63) / 64;
     // equal workgroups: as many splits (a multiple of 8: one share per XCD) as fill four rounds of 256 CUs without starting a
     // fifth, each of at least 8 chunks
@@ -51,11 +53,24 @@ static bool wgrad_bf16_plan(int N, int H, int W, int Cin, int Cout, int k, Wgrad
     pl->Qk = (long long)pl->splits * pl->chunks * 64;
     pl->rs = pl->G + pl->Qk + pl->G;
     pl->rs = (pl->rs + 255) / 256 * 256;                 // (the transposing kernel writes 256 positions per workgroup)
-    if (pl->rs >= (1ll << 30) || (long long)Cout * pl->rs * 2 >= (1ll << 31) || (long long)Cin * pl->rs * 2 >= (1ll << 31)) return false;
+    pl->nt_ok = stride == 1 && Cin % 256 == 0 &&
+                !(pl->rs >= (1ll << 30) || (long long)Cout * pl->rs * 2 >= (1ll << 31) || (long long)Cin * pl->rs * 2 >= (1ll << 31));
+    // the pixel-major kernel (conv_wgrad_bf16_tn.hip): the same rule on the unpadded pixel count
+    const int OH = (H + 2 * pl->pad - k) / stride + 1, OW = (W + 2 * pl->pad - k) / stride + 1;      // (stride 2: the strided layers of a stage's first block)
+    if (OH <= 0 || OW <= 0) return false;
+    const long long P = (long long)N * OH * OW, pchunks = (P + 63) / 64;
+    long long ts = 1024 / (8 * pl->taps * tilesMN) * 8;
+    if (ts > pchunks / 8 / 8 * 8) ts = pchunks / 8 / 8 * 8;
+    if (ts < 8) ts = 8;
+    pl->tn_splits = (int)ts;
+    pl->tn_chunks = (int)((pchunks + ts - 1) / ts);
+    const bool tn_ok = P * Cout * 2 < (1ll << 31) && (long long)N * H * W * Cin * 2 < (1ll << 31);
+    if (!pl->nt_ok && !tn_ok) return false;
     pl->off_dy = 0;
-    pl->off_x = (long long)Cout * pl->rs * 2;
-    pl->off_part = pl->off_x + (long long)k * Cin * pl->rs * 2;
-    pl->bytes = pl->off_part + (long long)pl->splits * pl->taps * Cout * Cin * 4;
+    pl->off_x = pl->nt_ok ? (long long)Cout * pl->rs * 2 : 0;
+    pl->off_part = pl->nt_ok ? pl->off_x + (long long)k * Cin * pl->rs * 2 : 0;
+    const long long slabs = pl->splits > pl->tn_splits ? pl->splits : pl->tn_splits;
+    pl->bytes = pl->off_part + slabs * pl->taps * Cout * Cin * 4;
     return true;
 }
 
@@ -252,9 +267,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
 }
 
 // which kernel takes the bf16 weight gradient when both maps are bf16: 0 = channel-major rewrites + NT GEMM, 1 = the pixel-major kernel
-// (conv_wgrad_bf16_tn.hip).  Initial value: CPR_WGRAD_TN (default 0); cpr_wgrad_bf16_set_tn switches at run time (tests, A/B tools).
+// (conv_wgrad_bf16_tn.hip).  Initial value: CPR_WGRAD_TN (default 1); cpr_wgrad_bf16_set_tn switches at run time (tests, A/B tools).
 static int& wgrad_bf16_tn_mode() {
-    static int mode = []() { const char* e = getenv("CPR_WGRAD_TN"); return (e && e[0] == '1') ? 1 : 0; }();
+    static int mode = []() { const char* e = getenv("CPR_WGRAD_TN"); return (e && e[0] == '0') ? 0 : 1; }();
     return mode;
 }
 extern "C" int cpr_wgrad_bf16_set_tn(int on) {
@@ -264,41 +279,46 @@ extern "C" int cpr_wgrad_bf16_set_tn(int on) {
 }
 
 // workspace size in units of 256 bytes (the byte count of a B=64 head layer does not fit the int every entry point returns)
-extern "C" int cpr_conv_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout, int k) {
+extern "C" int cpr_conv_wgrad_bf16_workspace_s(int N, int H, int W, int Cin, int Cout, int k, int stride) {
     WgradBf16Plan pl;
-    if (!wgrad_bf16_plan(N, H, W, Cin, Cout, k, &pl)) return CPR_ERR_UNSUPPORTED;
+    if (!wgrad_bf16_plan(N, H, W, Cin, Cout, k, &pl, stride)) return CPR_ERR_UNSUPPORTED;
     const long long units = (pl.bytes + 255) / 256;
     return units < (1ll << 31) ? (int)units : CPR_ERR_UNSUPPORTED;
+}
+extern "C" int cpr_conv_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout, int k) {
+    return cpr_conv_wgrad_bf16_workspace_s(N, H, W, Cin, Cout, k, 1);
 }
 
 // dy (N,H,W,Cout) fp32 or bf16 (dy_bf16); x (N,H,W,Cin) fp32 or bf16 (x_bf16); grad [Cout][Cin][k][k] fp32 (accumulate: += ); ws: workspace of
 // cpr_conv_wgrad_bf16_workspace x 256 bytes, 256-byte aligned.  k in {1, 3}, stride 1, padding k / 2, Cin % 256 == 0, Cout % 64 == 0.
+// _s (round 6): + stride (1 or 2; dy is then (N,OH,OW,Cout)).  Stride 2, Cin % 256 != 0 and 1x1 layers are the pixel-major kernel's
+// alone: both maps must be bf16 (else CPR_ERR_UNSUPPORTED).
+extern "C" int cpr_conv_wgrad_bf16_s(const void* dy, int dy_bf16, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W,
+                                     int Cin, int Cout, int k, int stride, int accumulate, hipStream_t stream);
 extern "C" int cpr_conv_wgrad_bf16(const void* dy, int dy_bf16, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W,
                                    int Cin, int Cout, int k, int accumulate, hipStream_t stream) {
+    return cpr_conv_wgrad_bf16_s(dy, dy_bf16, x, x_bf16, grad, ws, N, H, W, Cin, Cout, k, 1, accumulate, stream);
+}
+extern "C" int cpr_conv_wgrad_bf16_s(const void* dy, int dy_bf16, const void* x, int x_bf16, float* grad, void* ws, int N, int H, int W,
+                                     int Cin, int Cout, int k, int stride, int accumulate, hipStream_t stream) {
     CPR_CHECK_ARG(dy && x && grad && ws);
     WgradBf16Plan pl;
-    if (!wgrad_bf16_plan(N, H, W, Cin, Cout, k, &pl)) return CPR_ERR_UNSUPPORTED;
+    if (!wgrad_bf16_plan(N, H, W, Cin, Cout, k, &pl, stride)) return CPR_ERR_UNSUPPORTED;
     unsigned short* dyT = reinterpret_cast<unsigned short*>((char*)ws + pl.off_dy);
     unsigned short* xT = reinterpret_cast<unsigned short*>((char*)ws + pl.off_x);
     float* part = reinterpret_cast<float*>((char*)ws + pl.off_part);
-    // CPR_WGRAD_TN=1: both maps bf16 -> the pixel-major kernel (no dyT / xT rewrites); the split count follows the same rule on the
-    // unpadded pixel count
-    const bool tn = wgrad_bf16_tn_mode() != 0;
-    if (tn && dy_bf16 && x_bf16 && Cout % 8 == 0 && Cin % 8 == 0) {
-        const long long chunks_all = ((long long)N * H * W + 63) / 64;
-        long long splits = pl.splits;
-        if (splits > chunks_all / 8 / 8 * 8) splits = chunks_all / 8 / 8 * 8;
-        if (splits < 8) splits = 8;
-        const int chunks = (int)((chunks_all + splits - 1) / splits);
-        const int rc = wgrad_bf16_tn_launch(dy, x, part, N, H, W, Cin, Cout, k, (int)splits, chunks, stream);
+    // both maps bf16 -> the pixel-major kernel (no dyT / xT rewrites) unless switched off (CPR_WGRAD_TN=0 / cpr_wgrad_bf16_set_tn(0))
+    if (wgrad_bf16_tn_mode() != 0 && dy_bf16 && x_bf16) {
+        const int rc = wgrad_bf16_tn_launch(dy, x, part, N, H, W, Cin, Cout, k, stride, pl.tn_splits, pl.tn_chunks, stream);
         if (rc == CPR_OK) {
             const long long n = (long long)pl.taps * Cout * Cin;
-            hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, grad, (int)splits,
+            hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, grad, pl.tn_splits,
                                pl.taps, Cout, Cin, accumulate);
             CPR_LAUNCH_STATUS();
         }
         if (rc != CPR_ERR_UNSUPPORTED) return rc;
     }
+    if (!pl.nt_ok) return CPR_ERR_UNSUPPORTED;
     const long long copy = (long long)Cin * pl.rs;
     static const bool t64 = []() { const char* e = getenv("CPR_WGRAD_T64"); return e && e[0] == '1'; }();     // A/B: the round-3 kernel
     auto rewrite = [&](auto bf, auto nc, const void* src, unsigned short* dst, int C, long long cp) {

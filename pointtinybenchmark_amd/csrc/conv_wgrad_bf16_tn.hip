@@ -2,7 +2,7 @@
 // (round 6; the mixed-precision training step, pointtinybenchmark_amd/training.py; reference analogue: torch autograd under mmcv's
 // Fp16OptimizerHook, T/mmdet/apis/train.py:116-119).
 //
-//   dW[co][kh][kw][ci] = sum over pixels q of dy[q][co] * x[q + (kh - p) W + (kw - p)][ci]
+//   dW[co][kh][kw][ci] = sum over output pixels q = (n, oy, ox) of dy[q][co] * x[n, s oy + kh - p, s ox + kw - p][ci]      (stride s = 1, 2)
 //
 // The reduction runs over PIXELS, the slow dimension of both NHWC maps, and v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per
 // lane.  conv_wgrad_bf16.hip therefore rewrites both maps channel-major (dyT, three shifted xT copies) and runs an NT GEMM -- the
@@ -29,8 +29,9 @@ struct WgradTnParams {
     const unsigned short* dy;   // (P, Cout) bf16: the gradient map, NHWC rows
     const unsigned short* x;    // (P, Cin) bf16: the recorded input map
     float* part;                // [splits][taps][Cout][Cin]
-    int H, W, Cin, Cout, k, pad;
-    int P;                      // N * H * W pixels
+    int H, W, OH, OW, Cin, Cout, k, pad, stride;
+    int P;                      // N * OH * OW output pixels (the K axis)
+    int XP;                     // N * H * W input pixels
     int tilesM, tilesN, taps, chunks;
 };
 
@@ -59,36 +60,44 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tn_kernel(WgradTnParams p) 
     const bool aok = ca < p.Cout, bok = cb < p.Cin;
     const size_t dy_addr = (size_t)p.dy, x_addr = (size_t)p.x;
     const tn_i32x4 rs_dy = {(int)(unsigned)dy_addr, (int)(unsigned)(dy_addr >> 32) & 0xffff, (int)((size_t)p.P * p.Cout * 2), 0x00020000};
-    const tn_i32x4 rs_x = {(int)(unsigned)x_addr, (int)(unsigned)(x_addr >> 32) & 0xffff, (int)((size_t)p.P * p.Cin * 2), 0x00020000};
+    const tn_i32x4 rs_x = {(int)(unsigned)x_addr, (int)(unsigned)(x_addr >> 32) & 0xffff, (int)((size_t)p.XP * p.Cin * 2), 0x00020000};
     const int dkh = kh - p.pad, dkw = kw - p.pad;
-    const int shift = dkh * p.W + dkw;                       // the tap's pixel shift inside an image
-    // pixel state of this lane's row in each of the four pieces: index, and (3x3 only) its (y, x) inside the image
-    int pq[4], py[4], px[4], voffA[4], voffB[4];
-    const int a64 = 64 / p.W, b64 = 64 - a64 * p.W;          // a chunk advances a pixel by a64 rows and b64 columns
+    const bool linear = p.k == 1 && p.stride == 1;           // the input row of output pixel q is q itself
+    const int ihw = p.H * p.W;
+    // pixel state of this lane's row in each of the four pieces: output pixel index and -- unless linear -- its (oy, ox) and the
+    // first input pixel of its image
+    int pq[4], py[4], px[4], pimg[4], voffA[4], voffB[4];
+    const int a64 = 64 / p.OW, b64 = 64 - a64 * p.OW;        // a chunk advances a pixel by a64 rows and b64 columns
     auto offsets = [&](int z) {
         const bool in = pq[z] < p.P;
         voffA[z] = (in && aok) ? (int)(((unsigned)pq[z] * (unsigned)p.Cout + (unsigned)ca) * 2u) : (int)0x80000000;
-        bool ok = in && bok;
-        if (p.k > 1) ok = ok && ((unsigned)(py[z] + dkh) < (unsigned)p.H) && ((unsigned)(px[z] + dkw) < (unsigned)p.W);
-        voffB[z] = ok ? (int)(((unsigned)(pq[z] + shift) * (unsigned)p.Cin + (unsigned)cb) * 2u) : (int)0x80000000;
+        if (linear) {
+            voffB[z] = (in && bok) ? (int)(((unsigned)pq[z] * (unsigned)p.Cin + (unsigned)cb) * 2u) : (int)0x80000000;
+        } else {
+            const int iy = py[z] * p.stride + dkh, ix = px[z] * p.stride + dkw;
+            const bool ok = in && bok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+            voffB[z] = ok ? (int)(((unsigned)(pimg[z] + iy * p.W + ix) * (unsigned)p.Cin + (unsigned)cb) * 2u) : (int)0x80000000;
+        }
     };
 #pragma unroll
     for (int z = 0; z < 4; ++z) {
         pq[z] = split * p.chunks * 64 + 16 * z + prow;
-        const int r = pq[z] / p.W;
-        px[z] = pq[z] - r * p.W;
-        py[z] = r % p.H;
+        const int r = pq[z] / p.OW;
+        px[z] = pq[z] - r * p.OW;
+        const int n = r / p.OH;
+        py[z] = r - n * p.OH;
+        pimg[z] = n * ihw;
         offsets(z);
     }
-    auto advance = [&]() {           // the rows of the next chunk: 64 pixels on
+    auto advance = [&]() {           // the rows of the next chunk: 64 output pixels on
 #pragma unroll
         for (int z = 0; z < 4; ++z) {
             pq[z] += 64;
-            if (p.k > 1) {
+            if (!linear) {
                 px[z] += b64;
                 py[z] += a64;
-                if (px[z] >= p.W) { px[z] -= p.W; py[z] += 1; }
-                while (py[z] >= p.H) py[z] -= p.H;
+                if (px[z] >= p.OW) { px[z] -= p.OW; py[z] += 1; }
+                while (py[z] >= p.OH) { py[z] -= p.OH; pimg[z] += ihw; }
             }
             offsets(z);
         }
@@ -214,16 +223,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tn_kernel(WgradTnParams p) 
         }
 }
 
-// dy (N,H,W,Cout) bf16, x (N,H,W,Cin) bf16, part [splits][k*k][Cout][Cin] fp32 (splits % 8 == 0, `chunks` 64-pixel chunks per split).
-// Both maps below 2 GiB, W >= 1; Cout % 8 == 0, Cin % 8 == 0 (16-byte channel groups).
-int wgrad_bf16_tn_launch(const void* dy, const void* x, float* part, int N, int H, int W, int Cin, int Cout, int k, int splits,
+// dy (N,OH,OW,Cout) bf16, x (N,H,W,Cin) bf16, part [splits][k*k][Cout][Cin] fp32 (splits % 8 == 0, `chunks` 64-pixel chunks per
+// split of the OUTPUT pixel axis).  k in {1, 3}, padding k / 2, stride 1 or 2 (OH = (H + 2 p - k) / s + 1).  Both maps below 2 GiB;
+// Cout % 8 == 0, Cin % 8 == 0 (16-byte channel groups).
+int wgrad_bf16_tn_launch(const void* dy, const void* x, float* part, int N, int H, int W, int Cin, int Cout, int k, int stride, int splits,
                          int chunks, hipStream_t stream) {
-    const long long P = (long long)N * H * W;
-    if (!(k == 1 || k == 3) || Cout % 8 != 0 || Cin % 8 != 0 || splits <= 0 || splits % 8 != 0 || chunks <= 0) return CPR_ERR_UNSUPPORTED;
-    if (P * Cout * 2 >= (1ll << 31) || P * Cin * 2 >= (1ll << 31) || P + 64ll * splits * chunks >= (1ll << 30)) return CPR_ERR_UNSUPPORTED;
+    if (!(k == 1 || k == 3) || !(stride == 1 || stride == 2) || Cout % 8 != 0 || Cin % 8 != 0 || splits <= 0 || splits % 8 != 0 || chunks <= 0)
+        return CPR_ERR_UNSUPPORTED;
+    const int pad = k / 2, OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    if (OH <= 0 || OW <= 0) return CPR_ERR_UNSUPPORTED;
+    const long long P = (long long)N * OH * OW, XP = (long long)N * H * W;
+    if (P * Cout * 2 >= (1ll << 31) || XP * Cin * 2 >= (1ll << 31) || P + 64ll * splits * chunks >= (1ll << 30)) return CPR_ERR_UNSUPPORTED;
     WgradTnParams p;
     p.dy = (const unsigned short*)dy; p.x = (const unsigned short*)x; p.part = part;
-    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.k = k; p.pad = k / 2; p.P = (int)P;
+    p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.Cin = Cin; p.Cout = Cout; p.k = k; p.pad = pad; p.stride = stride; p.P = (int)P; p.XP = (int)XP;
     p.tilesM = (Cout + 255) / 256; p.tilesN = (Cin + 255) / 256; p.taps = k * k; p.chunks = chunks;
     const long long blocks = (long long)splits * p.taps * p.tilesM * p.tilesN;
     if (blocks >= (1ll << 31)) return CPR_ERR_UNSUPPORTED;

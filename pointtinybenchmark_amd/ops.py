@@ -1044,31 +1044,44 @@ def conv2d_dgrad(dy, pc_t, in_hw, stride=1, mask=None, add=None, colsum=False):
     return out
 
 
-def conv_wgrad_bf16_supported(x_shape, weight_shape, stride, padding):
-    """Shapes csrc/conv_wgrad_bf16.hip takes: stride 1, 1x1 or 3x3 / padding 1, Cin % 256 == 0, Cout % 64 == 0."""
+def wgrad_tn(on=None):
+    """The kernel choice of the bf16 weight gradient for bf16 maps (include/cpr_hip.h, cpr_wgrad_bf16_set_tn): True = the pixel-major
+    kernel (csrc/conv_wgrad_bf16_tn.hip, the default), False = channel-major rewrites + NT GEMM.  Returns the value before the
+    call; on=None only queries."""
+    return bool(_lib.call('cpr_wgrad_bf16_set_tn', -1 if on is None else int(bool(on)), positive=True))      # (the previous value)
+
+
+def conv_wgrad_bf16_supported(x_shape, weight_shape, stride, padding, maps_bf16=False):
+    """Shapes the bf16 weight gradient takes: stride 1, 1x1 or 3x3 / padding 1, Cout % 64 == 0 and -- maps_bf16 (both maps are bf16:
+    the pixel-major kernel, csrc/conv_wgrad_bf16_tn.hip) Cin % 64 == 0, else (csrc/conv_wgrad_bf16.hip: channel-major rewrites + NT
+    GEMM) Cin % 256 == 0 and, for 1x1 layers, Cout >= 256."""
     Cout, Cin, KH, KW = weight_shape
-    if KH == 1 and Cout < 256:      # measured (tools/wgrad_bf16_bench.py): the two rewrites cost what the bf16 GEMM saves
+    tn = maps_bf16 and wgrad_tn()
+    if KH == 1 and Cout < 256 and not tn:      # measured (tools/wgrad_bf16_bench.py): the two rewrites cost what the bf16 GEMM saves
         return False
-    return stride == 1 and KH == KW and KH in (1, 3) and padding == KH // 2 and Cin % 256 == 0 and Cout % 64 == 0 and \
-        _lib.call('cpr_conv_wgrad_bf16_workspace', x_shape[0], x_shape[1], x_shape[2], Cin, Cout, KH, positive=True) > 0
+    if not (stride == 1 or (tn and stride == 2)):      # the strided 3x3 / projection layers: the pixel-major kernel only
+        return False
+    return KH == KW and KH in (1, 3) and padding == KH // 2 and Cin % (64 if tn else 256) == 0 and Cout % 64 == 0 and \
+        _lib.call('cpr_conv_wgrad_bf16_workspace_s', x_shape[0], x_shape[1], x_shape[2], Cin, Cout, KH, stride, positive=True) > 0
 
 
-def conv_wgrad_bf16(dy, x, weight_shape, out=None, accumulate=False):
-    """Weight gradient of a stride-1 conv on the bf16 matrix cores (mixed-precision training step): dy (N,H,W,Cout) and
-    x (N,H,W,Cin) bf16 or fp32 (rounded to bf16 on the way in) -> [Cout][Cin][k][k] fp32."""
+def conv_wgrad_bf16(dy, x, weight_shape, out=None, accumulate=False, stride=1):
+    """Weight gradient of a conv (1x1 or 3x3 / padding 1) on the bf16 matrix cores (mixed-precision training step): dy (N,OH,OW,Cout)
+    and x (N,H,W,Cin) bf16 or fp32 (rounded to bf16 on the way in) -> [Cout][Cin][k][k] fp32.  stride 2 needs both maps in bf16."""
     N, H, W, Cin = x.shape
     Cout, Cin_w, KH, KW = weight_shape
-    assert Cin_w == Cin and tuple(dy.shape) == (N, H, W, Cout) and KH == KW
+    OH, OW = (H + 2 * (KH // 2) - KH) // stride + 1, (W + 2 * (KH // 2) - KH) // stride + 1
+    assert Cin_w == Cin and tuple(dy.shape) == (N, OH, OW, Cout) and KH == KW, (tuple(dy.shape), (N, OH, OW, Cout))
     assert x.dtype in (torch.float32, torch.bfloat16) and dy.dtype in (torch.float32, torch.bfloat16)
     assert x.is_contiguous() and dy.is_contiguous()
-    units = _lib.call('cpr_conv_wgrad_bf16_workspace', N, H, W, Cin, Cout, KH, positive=True)
+    units = _lib.call('cpr_conv_wgrad_bf16_workspace_s', N, H, W, Cin, Cout, KH, stride, positive=True)
     ws = torch.empty((units * 256,), device=x.device, dtype=torch.uint8)
     if out is None:
         assert not accumulate
         out = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
     assert tuple(out.shape) == tuple(weight_shape) and out.is_contiguous() and out.dtype == torch.float32
-    _lib.call('cpr_conv_wgrad_bf16', _ptr(dy), int(dy.dtype == torch.bfloat16), _ptr(x), int(x.dtype == torch.bfloat16), _ptr(out),
-              _ptr(ws), N, H, W, Cin, Cout, KH, int(accumulate), _stream())
+    _lib.call('cpr_conv_wgrad_bf16_s', _ptr(dy), int(dy.dtype == torch.bfloat16), _ptr(x), int(x.dtype == torch.bfloat16), _ptr(out),
+              _ptr(ws), N, H, W, Cin, Cout, KH, stride, int(accumulate), _stream())
     return out
 
 

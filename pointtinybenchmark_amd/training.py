@@ -365,7 +365,7 @@ class BackwardEngine:
         dgrad16 = need_dx and MIXED_BF16['dgrad'] and rec['raw'].dtype == torch.bfloat16 and cm.conv.stride[0] == 1 and \
             w.shape[0] % 64 == 0
         wgrad16 = MIXED_BF16['wgrad'] and rec['x'].dtype == torch.bfloat16 and rec['in_ab'] is None and ops.conv_wgrad_bf16_supported(
-            rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0])
+            rec['x'].shape, w.shape, cm.conv.stride[0], cm.conv.padding[0], maps_bf16=True)
         if rec['raw'].dtype == torch.bfloat16 and FUSED_CAST:
             # the GroupNorm backward reads the bf16 recorded map as it is and writes the bf16 rounding of its result itself (and the
             # fp32 map only when a fp32 kernel still reads it): no widening / narrowing passes around it
@@ -668,7 +668,8 @@ class BackwardEngine:
         w = conv.weight
         k = conv.kernel_size[0]
         w16 = not w.requires_grad or (MIXED_BF16['wgrad'] and
-                                      ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0]))
+                                      ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0],
+                                                                    maps_bf16=x.dtype == torch.bfloat16))
         d16 = not need_dx or (MIXED_BF16['dgrad'] and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and
                               (k == 3 and not has_add or k == 1 and MIXED_BF16['dgrad1x1'] and w.shape[1] % 64 == 0))
         return bool(w16 and d16)
@@ -693,7 +694,7 @@ class BackwardEngine:
         # mixed precision: ONE bf16 copy of the gradient map feeds the bf16 weight gradient and the bf16 data gradient (round 6: the
         # stride-1 1x1 layers too -- their fp32 form was 13 % of the step's kernel time, profiles/round5_train_cfg4_kernel_stats.csv)
         w16 = w.requires_grad and self._mixed and MIXED_BF16['wgrad'] and \
-            ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0])
+            ops.conv_wgrad_bf16_supported(x.shape, w.shape, conv.stride[0], conv.padding[0], maps_bf16=x.dtype == torch.bfloat16)
         d16 = need_dx and self._mixed and MIXED_BF16['dgrad'] and conv.stride[0] == 1 and w.shape[0] % 64 == 0 and \
             (k == 3 and add is None or k == 1 and MIXED_BF16['dgrad1x1'] and w.shape[1] % 64 == 0)
         if g16 is None and (w16 or d16):
@@ -705,7 +706,7 @@ class BackwardEngine:
                 cs = colsum            # (TilePartials of a conv epilogue are summed inside bn_fold_bwd)
                 gw = self._g(w)
                 if w16:
-                    ops.conv_wgrad_bf16(g16, x, w.shape, out=gw)    # (x: the bf16 recorded map, or a widened copy that rounds back exactly)
+                    ops.conv_wgrad_bf16(g16, x, w.shape, out=gw, stride=conv.stride[0])    # (x: the bf16 recorded map, or a widened copy that rounds back exactly)
                 else:
                     ops.conv2d_wgrad(g, self._f32(x), w.shape, conv.stride[0], conv.padding[0], out=gw)
                 ops.bn_fold_bwd(gw, w, scale, bn.running_mean, inv_sigma, cs,

@@ -462,42 +462,55 @@ def test_conv2d_dgrad_bf16_fused_equals_conv_then_streaming_pass(case):
 
 
 WGRAD_TN_CASES = [
-    # N, H, W, Cin, Cout, k: the pixel-major kernel reads both NHWC maps as they are (bf16)
-    (2, 24, 24, 256, 512, 1),      # 1x1 (a lateral)
-    (3, 17, 23, 256, 256, 3),      # 3x3, ragged pixel count (1173 = 18 chunks + 21), W < 64: a chunk spans rows
-    (2, 9, 7, 512, 320, 3),        # tiny map: a chunk spans more than an image's rows; Cout not a multiple of the 256-row tile
-    (1, 40, 72, 256, 64, 3),       # W > 64, one partial cout tile
-    (4, 32, 32, 1024, 256, 1),     # four cin tiles
+    # N, H, W, Cin, Cout, k, stride: the pixel-major kernel reads both NHWC maps as they are (bf16)
+    (2, 24, 24, 256, 512, 1, 1),      # 1x1 (a lateral)
+    (3, 17, 23, 256, 256, 3, 1),      # 3x3, ragged pixel count (1173 = 18 chunks + 21), W < 64: a chunk spans rows
+    (2, 9, 7, 512, 320, 3, 1),        # tiny map: a chunk spans more than an image's rows; Cout not a multiple of the 256-row tile
+    (1, 40, 72, 256, 64, 3, 1),       # W > 64, one partial cout tile
+    (4, 32, 32, 1024, 256, 1, 1),     # four cin tiles
+    (2, 16, 16, 128, 256, 3, 1),      # Cin = 128: half a cin tile (only this kernel takes the shape)
+    (3, 20, 20, 512, 128, 1, 1),      # 1x1 with Cout < 256 (the rewriting path declines it: its rewrites cost what its GEMM saves)
+    (3, 34, 30, 128, 128, 3, 2),      # conv2 of a stage's first block: 3x3 / stride 2 (17 x 15 outputs)
+    (2, 33, 31, 256, 512, 1, 2),      # its projection shortcut: 1x1 / stride 2, odd map (17 x 16 outputs)
+    (5, 9, 11, 256, 256, 3, 2),       # stride 2 on a tiny map: a chunk spans images
 ]
 
 
-@pytest.mark.parametrize('case', WGRAD_TN_CASES, ids=lambda c: 'n%d_%dx%d_c%d_o%d_k%d' % c)
+@pytest.mark.parametrize('case', WGRAD_TN_CASES, ids=lambda c: 'n%d_%dx%d_c%d_o%d_k%d_s%d' % c)
 def test_conv_wgrad_bf16_pixel_major_kernel_vs_fp64(case):
     """Round 6: csrc/conv_wgrad_bf16_tn.hip -- the bf16 weight gradient straight from the NHWC maps (LDS-DMA of pixel rows,
     ds_read_b64_tr_b16 fragments, no channel-major rewrites).  Same bars as the rewriting path: against torch's fp64 weight gradient of
     the SAME bf16 operands only the fp32 summation order differs (2e-4 of the gradient's max); and against the rewriting path itself
     (different split boundaries, same products) 2e-4 as well."""
     from pointtinybenchmark_amd import _lib, ops
-    N, H, W, Cin, Cout, k = case
+    N, H, W, Cin, Cout, k, stride = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn((N, Cin, H, W), generator=g).bfloat16()
-    dy = (torch.randn((N, Cout, H, W), generator=g) * 0.1).bfloat16()
+    OH, OW = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    dy = (torch.randn((N, Cout, OH, OW), generator=g) * 0.1).bfloat16()
     wz = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
-    F.conv2d(x.double(), wz, padding=k // 2).backward(dy.double())
+    F.conv2d(x.double(), wz, stride=stride, padding=k // 2).backward(dy.double())
     ref = wz.grad
     xc = x.permute(0, 2, 3, 1).contiguous().cuda()
     dyc = dy.permute(0, 2, 3, 1).contiguous().cuda()
-    old = _lib.call('cpr_wgrad_bf16_set_tn', 1, positive=True)
+    old = ops.wgrad_tn(True)
     try:
-        got = ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k))
+        got = ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k), stride=stride)
         acc = got.clone()
-        ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k), out=acc, accumulate=True)
+        ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k), out=acc, accumulate=True, stride=stride)
         torch.cuda.synchronize()
     finally:
-        _lib.call('cpr_wgrad_bf16_set_tn', old, positive=True)
+        ops.wgrad_tn(old)
     err = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
     assert err <= 2e-4, 'pixel-major bf16 weight gradient vs fp64 on the same operands: %.3e of the max' % err
     assert torch.equal(acc, got + got)
-    nt = ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k))
-    torch.cuda.synchronize()
-    assert float((got - nt).abs().max()) <= 2e-4 * float(ref.abs().max())
+    assert ops.conv_wgrad_bf16_supported((N, H, W, Cin), (Cout, Cin, k, k), stride, k // 2, maps_bf16=True)
+    assert not ops.conv_wgrad_bf16_supported((N, H, W, Cin), (Cout, Cin, k, k), stride, k // 2) or (stride == 1 and Cin % 256 == 0)
+    if Cin % 256 == 0 and stride == 1:
+        old = ops.wgrad_tn(False)
+        try:
+            nt = ops.conv_wgrad_bf16(dyc, xc, (Cout, Cin, k, k))
+            torch.cuda.synchronize()
+        finally:
+            ops.wgrad_tn(old)
+        assert float((got - nt).abs().max()) <= 2e-4 * float(ref.abs().max())
