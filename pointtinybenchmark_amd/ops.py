@@ -133,16 +133,17 @@ class PackedConv:
         self._packed()
 
     @classmethod
-    def for_dgrad_bf16(cls, weight, padding, scale=None):
+    def for_dgrad_bf16(cls, weight, padding, scale=None, pad_override=None):
         """The bf16 pack of the stride-1 conv over dy that yields the data gradient of a stride-1 conv (mixed-precision step): in / out
         channels swapped, taps flipped, the forward conv's folded-BN ``scale`` multiplied in (fp32) before the rounding, padding
-        K-1-p.  The same bits as PackedConv((w * scale).flip(2, 3).permute(1, 0, 2, 3), 1, K-1-p, bf16), one launch."""
+        K-1-p (``pad_override``: explicit padding, used by the per-parity sub-kernels of a strided conv, which need not be square).
+        The same bits as PackedConv((w * scale).flip(2, 3).permute(1, 0, 2, 3), 1, K-1-p, bf16), one launch."""
         Cout, Cin, KH, KW = weight.shape
-        assert KH == KW and weight.is_cuda and Cout % 64 == 0
+        assert (KH == KW or pad_override is not None) and weight.is_cuda and Cout % 64 == 0
         self = cls.__new__(cls)
         self.dtype = torch.bfloat16
         self.Cout, self.Cin, self.KH, self.KW, self.Kpad = Cin, Cout, KH, KW, KH * KW * Cout
-        self.stride, self.padding = 1, KH - 1 - padding
+        self.stride, self.padding = 1, (KH - 1 - padding if pad_override is None else pad_override)
         self._pack_bf16(weight, scale, 1)
         return self
 
@@ -963,14 +964,15 @@ def match_cost(pred, logits, gt, labels, cls_terms, reg_terms):
 
 
 # ------------------------------------------------------------------------------------------------ backward / optimizer
-def dgrad_pack(weight, stride, padding, scale=None):
+def dgrad_pack(weight, stride, padding, scale=None, dtype=torch.float32):
     """PackedConv that computes the data gradient of ``conv2d(x, weight, stride, padding)`` as a stride-1 forward conv
     over dy (zero-inserted first when stride > 1): channels swapped, taps flipped, padding K-1-p; ``scale`` (Cout,) is
     the forward conv's folded-BatchNorm scale, multiplied into the weights.  Stride-2 convs with k in {1, 3} and
     padding k//2 (every strided conv of the ResNet body) get the phase-decomposed form (PhasedDgrad)."""
     if stride == 2 and weight.shape[2] == weight.shape[3] and weight.shape[2] in (1, 3) and padding == weight.shape[2] // 2 \
             and _PHASED[0]:
-        return PhasedDgrad(weight, stride, padding, scale)
+        return PhasedDgrad(weight, stride, padding, scale, dtype)
+    assert dtype == torch.float32, 'bf16: PackedConv.for_dgrad_bf16 (stride 1) or the phase-decomposed form (stride 2)'
     return PackedConv.for_dgrad(weight, padding, scale)
 
 
@@ -982,10 +984,10 @@ class PhasedDgrad:
     over dy per output-parity class (py, px) using only the taps that can reach that class (1+2+2+4 = 9 of the 9 taps
     instead of 4 x 9 over a dilated gradient), scattered to the strided positions."""
 
-    def __init__(self, weight, stride, padding, scale=None):
+    def __init__(self, weight, stride, padding, scale=None, dtype=torch.float32):
         Cout, Cin, KH, KW = weight.shape
         assert stride == 2 and KH == KW and KH in (1, 3) and padding == KH // 2 and weight.is_cuda
-        self.Cin, self.stride, self.classes = Cin, stride, []
+        self.Cin, self.stride, self.classes, self.dtype = Cin, stride, [], dtype      # bf16 (round 6): the sub-convolutions on the bf16 pipe, fp32 out
         for py in range(2):
             khs = [kh for kh in range(KH) if (py + padding - kh) % 2 == 0]
             for px in range(2):
@@ -997,7 +999,8 @@ class PhasedDgrad:
                 dw = [(px + padding - kw) // 2 for kw in kws]
                 P = max(0, max(dh), max(dw), -min(dh), -min(dw))
                 sub = weight.detach()[:, :, khs][:, :, :, kws].contiguous()    # ascending kh/kw; for_dgrad flips the taps
-                pc = PackedConv.for_dgrad(sub, 0, scale, pad_override=P)
+                pc = PackedConv.for_dgrad(sub, 0, scale, pad_override=P) if dtype == torch.float32 else \
+                    PackedConv.for_dgrad_bf16(sub, 0, scale, pad_override=P)
                 # flipped tap t <-> descending kh <-> offset dmin + t, conv offset t - P  =>  out row i' = i + dmin + P
                 self.classes.append((py, px, pc, min(dh) + P, min(dw) + P))
 
@@ -1005,8 +1008,9 @@ class PhasedDgrad:
         N = dy.shape[0]
         H, W = in_hw
         dx = add.clone() if add is not None else torch.zeros((N, H, W, self.Cin), device=dy.device, dtype=torch.float32)
+        assert dy.dtype == self.dtype
         for py, px, pc, sh, sw in self.classes:
-            o = conv2d(dy, pc)
+            o = conv2d(dy, pc, out_dtype=torch.float32)
             _lib.call('cpr_phase_scatter_add', _ptr(o), _ptr(dx), N, o.shape[1], o.shape[2], self.Cin, H, W, py, px, sh, sw,
                       self.stride, _stream())
         return dx

@@ -222,6 +222,7 @@ FUSED_CAST = os.environ.get('CPR_MIXED_FUSED_CAST', '1') != '0'
 # data gradients of the mixed-precision step on the fp32 kernels; force = bf16 backward rules behind an fp32 recorded forward
 MIXED_BF16 = dict(wgrad=os.environ.get('CPR_MIXED_WGRAD', 'bf16') != 'fp32', dgrad=os.environ.get('CPR_MIXED_DGRAD', 'bf16') != 'fp32',
                   dgrad1x1=os.environ.get('CPR_MIXED_DGRAD_1X1', 'bf16') != 'fp32',
+                  dgrad_s2=os.environ.get('CPR_MIXED_DGRAD_S2', 'bf16') != 'fp32',
                   mask_mode=os.environ.get('CPR_MIXED_MASK_MODE', '1') != '0', force=False)
 
 
@@ -748,6 +749,15 @@ class BackwardEngine:
                 dx32, dx16, part = ops.conv2d_dgrad_bf16_fused(g16, pc16, mask, add)
                 return dx32, part, dx16
             return finish(ops.conv2d(g16, pc16, out_dtype=torch.float32), add)
+        if need_dx and self._mixed and MIXED_BF16['dgrad'] and MIXED_BF16['dgrad_s2'] and conv.stride[0] == 2 and k in (1, 3) and \
+                conv.padding[0] == k // 2 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and ops._PHASED[0]:
+            # mixed precision, the strided layers of a stage's first block (round 6): the four parity sub-convolutions of the phase-
+            # decomposed data gradient on the bf16 pipe (fp32 out, scattered / summed in fp32 as before)
+            pt16 = cache.get(('dgrad16s2', id(conv)), [w, bn.weight, bn.running_var],
+                             lambda: ops.dgrad_pack(w, 2, conv.padding[0], scale=scale, dtype=torch.bfloat16))
+            if g16 is None:
+                g16 = g.to(torch.bfloat16)
+            return finish(pt16(g16, (x.shape[1], x.shape[2]), add=add))
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
                        lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
         if WINO_DGRAD[0] and k == 3 and conv.stride[0] == 1 and add is None and \

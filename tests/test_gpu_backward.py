@@ -255,3 +255,36 @@ def test_strided_dgrad_phased_equals_zero_insertion(case):
     sc = float(x.grad.abs().max())
     _cmp('phased', _nchw(outs[0]), x.grad, atol=2e-4 * sc)
     _cmp('zero-insert', _nchw(outs[1]), x.grad, atol=2e-4 * sc)
+
+
+@pytest.mark.parametrize('case', [(2, 128, 34, 30, 128, 3, 2, 1), (2, 256, 28, 28, 512, 1, 2, 0), (3, 64, 18, 24, 64, 3, 2, 1)],
+                         ids=lambda c: 'n%d_c%d_%dx%d_o%d_k%d_s%d_p%d' % c)
+def test_strided_dgrad_phased_bf16_vs_fp64(case):
+    """Round 6 (mixed-precision step): the four parity sub-convolutions of the stride-2 data gradient on the bf16 matrix pipe
+    (PhasedDgrad(dtype=bf16): bf16 gradient map, bf16 sub-kernel packs with the folded-BN scale multiplied in before the rounding,
+    fp32 accumulators and fp32 scatter).  Against torch's fp64 data gradient of the SAME bf16 operands only the fp32 summation
+    order differs (2e-4 of the max); against the unrounded operands bf16's 8 bits show (3e-2 relative L2).  With ``add``."""
+    ops = _ops()
+    N, Cin, H, W, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    ws = (w * scale[:, None, None, None])
+    x = torch.zeros((N, Cin, H, W), dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, ws.bfloat16().double(), None, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.bfloat16().double())
+    ref = x.grad
+    pt = ops.dgrad_pack(w.cuda(), stride, pad, scale=scale.cuda(), dtype=torch.bfloat16)
+    assert isinstance(pt, ops.PhasedDgrad) and pt.dtype == torch.bfloat16
+    other = torch.randn((N, H, W, Cin), generator=g).cuda()
+    got = pt(_nhwc(dy).bfloat16(), (H, W))
+    got2 = pt(_nhwc(dy).bfloat16(), (H, W), add=other)
+    torch.cuda.synchronize()
+    sc = float(ref.abs().max())
+    _cmp('bf16 phased vs fp64 on the rounded operands', _nchw(got).double(), ref, atol=2e-4 * sc)
+    assert float((got2 - other - got).abs().max()) <= 1e-5 * sc
+    x2 = torch.zeros((N, Cin, H, W), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x2, ws.double(), None, stride, pad).backward(dy.double())
+    rel = float((_nchw(got).double().cpu() - x2.grad).norm() / x2.grad.norm())
+    assert rel <= 3e-2, rel

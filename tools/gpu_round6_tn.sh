@@ -1,22 +1,18 @@
 #!/bin/bash
-# Round-6 development visit: the pixel-major bf16 weight-gradient kernel (csrc/conv_wgrad_bf16_tn.hip) -- tests, then the training A/B.
+# Round-6 development visit: pixel-major bf16 weight gradient / bf16 strided data gradient -- tests, then the training A/B.
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r6t
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_train_step.py tests/test_gpu_autograd.py tests/test_gpu_fullsize_grads.py tests/test_gpu_p2p.py -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|Hostname\|Librccl" | tail -25 > gpurun_out/r6t/pytest.log
+timeout 1200 python -m pytest tests/test_gpu_backward.py tests/test_gpu_bf16.py tests/test_gpu_train_step.py tests/test_gpu_autograd.py tests/test_gpu_fullsize_grads.py -q -m gpu -x --tb=short -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|Hostname\|Librccl" | tail -25 > gpurun_out/r6t/pytest.log
 tail -8 gpurun_out/r6t/pytest.log
 rm -f gpurun_out/r6t/ab.txt
-for v in "CPR_WGRAD_TN=0" "CPR_WGRAD_TN=1"; do
+for v in "CPR_MIXED_DGRAD_S2=fp32" "CPR_MIXED_DGRAD_S2=bf16"; do
   echo "== $v" >> gpurun_out/r6t/ab.txt
   env $v timeout 600 python tools/bf16_ab.py --train --depth 50 --size 640 --batch 64 --rounds 2 2>&1 | grep -v amdgpu.ids | head -1 >> gpurun_out/r6t/ab.txt
   env $v timeout 600 python tools/bf16_ab.py --train --rounds 2 2>&1 | grep -v amdgpu.ids | head -1 >> gpurun_out/r6t/ab.txt
 done
 cat gpurun_out/r6t/ab.txt
-( cd /tmp && CPR_TRAIN_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r6t -o cfg4tn -- python $OLDPWD/bench.py --config cfg4 --mode train --steps 3 --warmup 1 --no-cpu-baseline --no-probe > /tmp/prof_r6t.log 2>&1 )
-( cd /tmp && CPR_TRAIN_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r6t -o r50tn -- python $OLDPWD/bench.py --mode train --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline --no-probe > /tmp/prof_r6t2.log 2>&1 )
-find /tmp/prof_r6t -name "*kernel_stats*" -exec cp {} gpurun_out/r6t/ \;
-head -14 gpurun_out/r6t/cfg4tn_kernel_stats.csv | cut -c1-150
 timeout 600 python bench.py --config cfg4 --mode train --steps 6 --warmup 2 --no-probe 2>/dev/null | tail -1 > gpurun_out/r6t/bench_train_cfg4.json
 python - <<P
 import json
