@@ -59,7 +59,9 @@ static bool wgrad_bf16_plan(int N, int H, int W, int Cin, int Cout, int k, Wgrad
     const int OH = (H + 2 * pl->pad - k) / stride + 1, OW = (W + 2 * pl->pad - k) / stride + 1;      // (stride 2: the strided layers of a stage's first block)
     if (OH <= 0 || OW <= 0) return false;
     const long long P = (long long)N * OH * OW, pchunks = (P + 63) / 64;
-    long long ts = 1024 / (8 * pl->taps * tilesMN) * 8;
+    // (CPR_WGRAD_TN_WGS: the workgroup budget of the rule, default 768 = three rounds of 256 CUs: R50 640^2 B = 64 69.6 ms against 70.8 at 1024 and 72.7 at 2048 -- fewer slabs to write and sum; profiles/round6_wgrad_tn_splits_ab.txt)
+    static const long long tn_wgs = []() { const char* e = getenv("CPR_WGRAD_TN_WGS"); const long long v = e ? atoll(e) : 0; return v >= 64 ? v : 768; }();
+    long long ts = tn_wgs / (8 * pl->taps * tilesMN) * 8;
     if (ts > pchunks / 8 / 8 * 8) ts = pchunks / 8 / 8 * 8;
     if (ts < 8) ts = 8;
     pl->tn_splits = (int)ts;
