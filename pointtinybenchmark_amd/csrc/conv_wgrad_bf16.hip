@@ -2,6 +2,10 @@
 // training step (pointtinybenchmark_amd/training.py; reference analogue: torch autograd under mmcv's Fp16OptimizerHook,
 // T/mmdet/apis/train.py:116-119).
 //
+// Since round 6 this file is the SECOND choice: with both maps in bf16 the entry point runs the pixel-major kernel of
+// conv_wgrad_bf16_tn.hip (no rewritten operands; stride 2, Cin % 64, small 1x1 layers included) and the rewriting path below takes
+// what is left -- an fp32 map among the two (rounded on the way in), or CPR_WGRAD_TN=0 / cpr_wgrad_bf16_set_tn(0).
+//
 //   dW[co][kh][kw][ci] = sum over pixels of dy[n, y, x, co] * x[n, y + kh - p, x + kw - p, ci]
 //
 // is a GEMM whose reduction runs over PIXELS, the slow dimension of both NHWC operands, while v_mfma_f32_32x32x16_bf16 wants 8
@@ -59,8 +63,8 @@ static bool wgrad_bf16_plan(int N, int H, int W, int Cin, int Cout, int k, Wgrad
     const int OH = (H + 2 * pl->pad - k) / stride + 1, OW = (W + 2 * pl->pad - k) / stride + 1;      // (stride 2: the strided layers of a stage's first block)
     if (OH <= 0 || OW <= 0) return false;
     const long long P = (long long)N * OH * OW, pchunks = (P + 63) / 64;
-    // (CPR_WGRAD_TN_WGS: the workgroup budget of the rule, default 768 = three rounds of 256 CUs: R50 640^2 B = 64 69.6 ms against 70.8 at 1024 and 72.7 at 2048 -- fewer slabs to write and sum; profiles/round6_wgrad_tn_splits_ab.txt)
-    static const long long tn_wgs = []() { const char* e = getenv("CPR_WGRAD_TN_WGS"); const long long v = e ? atoll(e) : 0; return v >= 64 ? v : 768; }();
+    // (CPR_WGRAD_TN_WGS: the workgroup budget of the rule, default 512 = two rounds of 256 CUs: R50 640^2 B = 64 69.2 - 69.7 ms against 70.8 at 1024 and 72.7 at 2048, the configs[4] training line under torchrun 198 img/s against 196 (768) and 195 (1024) -- fewer slabs to write and sum; profiles/round6_wgrad_tn_splits_ab.txt)
+    static const long long tn_wgs = []() { const char* e = getenv("CPR_WGRAD_TN_WGS"); const long long v = e ? atoll(e) : 0; return v >= 64 ? v : 512; }();
     long long ts = tn_wgs / (8 * pl->taps * tilesMN) * 8;
     if (ts > pchunks / 8 / 8 * 8) ts = pchunks / 8 / 8 * 8;
     if (ts < 8) ts = 8;
