@@ -106,6 +106,24 @@ def main():
     print('%-16s %-58s %3s %8s %7s' % ('op', 'shape', 'cnt', 'ms', 'TF/s'))
     for (name, shp), (cnt, ms, fl) in rows[:args.top]:
         print('%-16s %-58s %3d %8.3f %7.1f' % (name, shp, cnt, ms, fl / ms / 1e9 if ms > 0 else 0))
+    # Round 6 (verdict item 5): what would the step be if EVERY matrix-pipe op ran at the fraction of the fp32-MFMA peak the dominant
+    # forward kernel reaches (0.785 of 157.3 TFLOP/s = 123.5 executed; a Winograd-eligible 3x3 / stride-1 op executes 1 / 2.25 of its
+    # algorithmic flops, i.e. 277.8 TFLOP/s algorithmic), everything else unchanged?
+    peak, frac = 157.3, 0.785
+    conv_ms = bound_ms = 0.0
+    for (name, shp), (cnt, ms, fl) in rows:
+        if name not in ('conv2d', 'conv2d_wgrad', 'conv2d_dgrad') or fl <= 0:
+            continue
+        wino = (' k3 s1' in shp)
+        rate = peak * frac * (2.25 if wino else 1.0)
+        conv_ms += ms
+        bound_ms += fl / rate / 1e9
+    other = step_ms - conv_ms
+    print()
+    print('model: matrix-pipe ops %.1f ms of the %.1f ms step (%.0f %%); at %.3f of the fp32-MFMA peak everywhere (Winograd 3x3: x2.25) they would take '
+          '%.1f ms -> step %.1f ms = %.0f img/s (measured %.0f img/s); the rest of the step (%.1f ms) is HBM-bound passes, the loss and launches'
+          % (conv_ms, step_ms, 100 * conv_ms / step_ms, frac, bound_ms, other + bound_ms, args.batch / (other + bound_ms) * 1e3,
+             args.batch / step_ms * 1e3, other))
 
 
 if __name__ == '__main__':
