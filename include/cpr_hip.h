@@ -383,6 +383,10 @@ int cpr_gn_bwd(const float* x, const float* dz, const float* a, const float* b, 
 int cpr_gn_bwd_bf16(const void* x_bf16, const float* dz, const float* a, const float* b, const float* mean, const float* rstd,
                     const float* gamma, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* ws_part, float* ws_k, int N,
                     int HW, int C, int G, int P, int relu, int accumulate, void* stream);
+/* ... with the upstream gradient dz in bf16 as well (round 6: the bf16 data gradient of the layer above writes it in bf16) */
+int cpr_gn_bwd_bf16_dz16(const void* x_bf16, const void* dz_bf16, const float* a, const float* b, const float* mean, const float* rstd,
+                         const float* gamma, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* ws_part, float* ws_k,
+                         int N, int HW, int C, int G, int P, int relu, int accumulate, void* stream);
 /* FPN top-down path backward (fpn.py:176-185): dcoarse (N,UH,UW,C) (+)= sum over the nearest-upsample children of dfine */
 int cpr_upsample_add_bwd(const float* dfine, float* dcoarse, int N, int H, int W, int UH, int UW, int C, int accumulate,
                          void* stream);

@@ -76,6 +76,7 @@ SIGNATURES = {
     'cpr_conv2d_wgrad': [_p] * 6 + [_i] * 11 + [_p],
     'cpr_gn_bwd': [_p] * 12 + [_i] * 7 + [_p],
     'cpr_gn_bwd_bf16': [_p] * 13 + [_i] * 7 + [_p],
+    'cpr_gn_bwd_bf16_dz16': [_p] * 13 + [_i] * 7 + [_p],
     'cpr_upsample_add_bwd': [_p, _p] + [_i] * 7 + [_p],
     'cpr_relu_bwd_colsum_ws': [_l, _i],
     'cpr_relu_bwd_colsum': [_p, _p, _p, _i, _p, _p, _p, _p, _l, _i, _i, _p],

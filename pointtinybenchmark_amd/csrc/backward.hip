@@ -28,8 +28,10 @@ template <bool XB> __device__ __forceinline__ f32x4 gnb_load4(const void* __rest
         return *reinterpret_cast<const f32x4*>(static_cast<const float*>(x) + o);
     }
 }
-template <bool XB>
-__global__ void gn_bwd_stats_kernel(const void* __restrict__ x, const float* __restrict__ dz,
+// DZB (round 6): the upstream gradient dz is a bf16 map too (the bf16 data gradient of the layer above wrote it in bf16: 2 bytes
+// less per element in its store and in both passes here); widened exactly on load.
+template <bool XB, bool DZB = false>
+__global__ void gn_bwd_stats_kernel(const void* __restrict__ x, const void* __restrict__ dz,
                                     const float* __restrict__ a, const float* __restrict__ b,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     float* __restrict__ part, int HW, int C, int G, int P, int relu) {
@@ -53,7 +55,7 @@ __global__ void gn_bwd_stats_kernel(const void* __restrict__ x, const float* __r
     for (int p = p0 + pl; p < p1; p += PP) {
         const size_t o = ((size_t)n * HW + p) * C + q * 4;
         const f32x4 xv = gnb_load4<XB>(x, o);
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dz + o);
+        const f32x4 dv = gnb_load4<DZB>(dz, o);
         const f32x4 y = xv * av + bv;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -131,8 +133,8 @@ __global__ void gn_bwd_params_kernel(const float* __restrict__ dgb_part, float* 
 }
 
 // pass 2: dx = dy*a + x*k2 + k3   (dx and / or its bf16 rounding dx16: whichever pointer is given)
-template <bool XB>
-__global__ void gn_bwd_apply_kernel(const void* __restrict__ x, const float* __restrict__ dz,
+template <bool XB, bool DZB = false>
+__global__ void gn_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ dz,
                                     const float* __restrict__ a, const float* __restrict__ b,
                                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
                                     unsigned short* __restrict__ dx16, int N, int HW, int C4, int G, int relu) {
@@ -143,7 +145,7 @@ __global__ void gn_bwd_apply_kernel(const void* __restrict__ x, const float* __r
         const int c = (int)(i % C4);
         const int n = (int)(i / ((long long)HW * C4));
         const f32x4 xv = gnb_load4<XB>(x, (size_t)i * 4);
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dz + i * 4);
+        const f32x4 dv = gnb_load4<DZB>(dz, (size_t)i * 4);
         const f32x4 av = *reinterpret_cast<const f32x4*>(a + ((size_t)n * C4 + c) * 4);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(b + ((size_t)n * C4 + c) * 4);
         const f32x4 y = xv * av + bv;
@@ -165,8 +167,8 @@ __global__ void gn_bwd_apply_kernel(const void* __restrict__ x, const float* __r
     }
 }
 
-template <bool XB>
-static int gn_bwd_launch(const void* x, const float* dz, const float* a, const float* b, const float* mean, const float* rstd,
+template <bool XB, bool DZB = false>
+static int gn_bwd_launch(const void* x, const void* dz, const float* a, const float* b, const float* mean, const float* rstd,
                          const float* gamma, float* dx, unsigned short* dx16, float* dgamma, float* dbeta, float* ws_part,
                          float* ws_k, int N, int HW, int C, int G, int P, int relu, int accumulate, hipStream_t stream) {
     // ws_part: N*P*C*2 floats; ws_k: 2*N*G + 2*N*C floats (k2 | k3 | per-image dgamma/dbeta contributions)
@@ -176,7 +178,7 @@ static int gn_bwd_launch(const void* x, const float* dz, const float* a, const f
     float* k2 = ws_k;
     float* k3 = ws_k + (size_t)N * G;
     float* dgb = ws_k + (size_t)2 * N * G;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<XB>, dim3(P, N), dim3(256), 0, stream, x, dz, a, b, mean, rstd, ws_part, HW, C, G,
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<XB, DZB>), dim3(P, N), dim3(256), 0, stream, x, dz, a, b, mean, rstd, ws_part, HW, C, G,
                        P, relu);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), (size_t)2 * C * sizeof(double), stream, ws_part, gamma,
                        mean, rstd, k2, k3, dgb, P, C, G, (double)HW * (C / G));
@@ -184,7 +186,7 @@ static int gn_bwd_launch(const void* x, const float* dz, const float* a, const f
                        accumulate);
     const long long total = (long long)N * HW * (C / 4);
     const int grid = (int)(cdivll(total, 256) < 32768 ? cdivll(total, 256) : 32768);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<XB>, dim3(grid), dim3(256), 0, stream, x, dz, a, b, k2, k3, dx, dx16, N, HW, C / 4, G,
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<XB, DZB>), dim3(grid), dim3(256), 0, stream, x, dz, a, b, k2, k3, dx, dx16, N, HW, C / 4, G,
                        relu);
     CPR_LAUNCH_STATUS();
 }
@@ -203,6 +205,14 @@ extern "C" int cpr_gn_bwd_bf16(const void* x_bf16, const float* dz, const float*
                                hipStream_t stream) {
     return gn_bwd_launch<true>(x_bf16, dz, a, b, mean, rstd, gamma, dx, (unsigned short*)dx_bf16, dgamma, dbeta, ws_part, ws_k, N,
                                HW, C, G, P, relu, accumulate, stream);
+}
+// ... and with the upstream gradient dz in bf16 as well (round 6)
+extern "C" int cpr_gn_bwd_bf16_dz16(const void* x_bf16, const void* dz_bf16, const float* a, const float* b, const float* mean,
+                                    const float* rstd, const float* gamma, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
+                                    float* ws_part, float* ws_k, int N, int HW, int C, int G, int P, int relu, int accumulate,
+                                    hipStream_t stream) {
+    return gn_bwd_launch<true, true>(x_bf16, dz_bf16, a, b, mean, rstd, gamma, dx, (unsigned short*)dx_bf16, dgamma, dbeta, ws_part,
+                                     ws_k, N, HW, C, G, P, relu, accumulate, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ FPN top-down add

@@ -1151,7 +1151,8 @@ def gn_bwd(x, dz, a, b, mean, rstd, gamma, relu, dgamma=None, dbeta=None, slots=
         assert want16 or want32
         dx = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32) if want32 else None
         dx16 = torch.empty_like(x) if want16 else None
-        _lib.call('cpr_gn_bwd_bf16', _ptr(x), _ptr(_check(dz)), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(_check(gamma)),
+        assert dz.dtype in (torch.float32, torch.bfloat16) and dz.is_contiguous()
+        _lib.call('cpr_gn_bwd_bf16_dz16' if dz.dtype == torch.bfloat16 else 'cpr_gn_bwd_bf16', _ptr(x), _ptr(dz), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(_check(gamma)),
                   _ptr(dx), _ptr(dx16), _ptr(dgamma), _ptr(dbeta), _ptr(ws_part), _ptr(ws_k), N, HW, C, G, slots, int(relu),
                   int(acc), _stream())
         return dx, dgamma, dbeta, dx16

@@ -201,6 +201,12 @@ def test_gn_backward_reads_the_bf16_map_and_writes_its_own_bf16_rounding():
         assert dx16.dtype == torch.bfloat16 and torch.equal(dx16, ref.to(torch.bfloat16))
         none32, _, _, only16 = ops.gn_bwd(x16, dz, a, b, mean, rstd, gamma, relu, want16=True, want32=False)
         assert none32 is None and torch.equal(only16, dx16)
+        # round 6: the upstream gradient in bf16 as well (cpr_gn_bwd_bf16_dz16) -- the widening is exact, so it must give bit for
+        # bit what the fp32 kernel gives on the widened gradient map
+        dz16 = dz.to(torch.bfloat16)
+        ref2, dg2, db2 = ops.gn_bwd(x16.float(), dz16.float(), a, b, mean, rstd, gamma, relu)
+        dx2, dgb, dbb, dx2h = ops.gn_bwd(x16, dz16, a, b, mean, rstd, gamma, relu, want16=True, want32=True)
+        assert torch.equal(dx2, ref2) and torch.equal(dgb, dg2) and torch.equal(dbb, db2) and torch.equal(dx2h, ref2.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize('name', ['cpr_r18_c3_128', 'cpr_r50_c1_160_spread'])
@@ -214,6 +220,8 @@ def test_mixed_precision_fused_casts_change_no_bit(name):
                                       cfg['seed'], cfg.get('ragged', False))
     cb = to_cuda(batch)
     runs = []
+    dz16 = training.MIXED_BF16['dz16']
+    training.MIXED_BF16['dz16'] = False        # (round 6: bf16 gradient maps between the tower's layers ROUND; this test is about the casts that do not)
     try:
         for fused in (True, False):
             training.FUSED_CAST = fused
@@ -225,6 +233,7 @@ def test_mixed_precision_fused_casts_change_no_bit(name):
             runs.append(({k: float(v) for k, v in losses.items()}, tr.flat_g.clone()))
     finally:
         training.FUSED_CAST = True
+        training.MIXED_BF16['dz16'] = dz16
     assert runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][1], runs[1][1]), 'fused casts changed %d gradient entries' % int((runs[0][1] != runs[1][1]).sum())
 
