@@ -315,6 +315,18 @@ def test_conv_wgrad_bf16_head_layer_shape_vs_fp32_kernel():
     torch.cuda.synchronize()
     rel = float((got - ref).norm() / ref.norm())
     assert rel <= 1e-2, rel
+    # round 6: the pixel-major kernel on the same maps in bf16 (its splits and chunk boundaries differ from the rewriting path's, the
+    # products are the same): against the rewriting path on the SAME bf16 operands only fp32 summation order differs
+    dy16, x16 = dy.bfloat16(), x.bfloat16()
+    old = ops.wgrad_tn(True)
+    try:
+        tn = ops.conv_wgrad_bf16(dy16, x16, (C, C, 3, 3))
+        ops.wgrad_tn(False)
+        nt = ops.conv_wgrad_bf16(dy16, x16, (C, C, 3, 3))
+        torch.cuda.synchronize()
+    finally:
+        ops.wgrad_tn(old)
+    assert float((tn - nt).abs().max()) <= 1e-4 * float(nt.abs().max()), float((tn - nt).abs().max() / nt.abs().max())
 
 
 @pytest.mark.parametrize('shape', [(256, 256, 3), (512, 128, 1), (64, 64, 3), (1024, 256, 1)])
