@@ -478,6 +478,14 @@ int cpr_spin(long long ticks, void* stream);
  * inv_sigma (optional) = 1/sqrt(var+eps) */
 int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
                 float* shift, float* inv_sigma, int C, void* stream);
+/* Multi-tensor forms of cpr_bn_fold and cpr_pack_weights_bf16 (round 6; the per-step refresh of the mixed-precision / fp32 training
+ * step, layers._PackCache.refresh_all): one launch over a DEVICE table of 64-byte jobs --
+ *   fold job: { const float *gamma, *beta, *mean, *var; float *scale, *shift, *inv (each may be NULL); int C; float eps; }
+ *   pack job: { const float* w; const float* scale; void* out; void* frag; int O, I, KH, KW, transpose, block0, nblocks, pad; }
+ * (pack jobs in ascending block0; job j owns workgroups [block0, block0 + nblocks) of the total_blocks launched).  Results are
+ * bit for bit the single-tensor entries'. */
+int cpr_bn_fold_multi(const void* jobs_dev, int n, int max_c, void* stream);
+int cpr_pack_weights_bf16_multi(const void* jobs_dev, int n, int total_blocks, void* stream);
 /* gradient of sum_b (loss_cls[b] + loss_pts[b]) of cpr_p2p_loss wrt the class logits (B*M, C) and the regression output
  * (p2p_head.py:220-248; sigmoid focal loss with its un-detached focal weight, SmoothL1 through
  * pred = anchor + (point_anchor + reg*gamma_p)*stride).  npos: device scalar, positives in the batch.  dcls (B*M, Cp),

@@ -44,14 +44,15 @@ extern "C" int cpr_pack_weights(const float* w, const float* scale, float* out, 
 // conv_bf16_dma_kernel<4, 2, 4, true> by the same thread: frag[rows / 64][K / 16][j][h][l][8] = out[64 g + 2 l + j][16 ks + 8 h ..].
 // The mixed-precision step re-packs every bf16 layer after each optimizer update: ~330 tiny launches per configs[4] step before.
 typedef __attribute__((ext_vector_type(2))) __bf16 pk_bf16x2_t;
-__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                         unsigned short* __restrict__ out, unsigned short* __restrict__ frag, int O, int I, int KH,
-                                         int KW, int transpose) {
+// (the body is shared with the multi-tensor launch below: `block` of `nblocks` workgroups walks the pack)
+__device__ __forceinline__ void pack_weights_bf16_body(const float* __restrict__ w, const float* __restrict__ scale,
+                                                       unsigned short* __restrict__ out, unsigned short* __restrict__ frag, int O, int I,
+                                                       int KH, int KW, int transpose, int block, int nblocks) {
     const int rows = transpose ? I : O, cols = transpose ? O : I;
     const int K = KH * KW * cols, KS = K >> 4;
     const long long total = (long long)rows * (K >> 1);          // two consecutive k per thread (cols is even)
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)nblocks * blockDim.x) {
         const int r = (int)(idx / (K >> 1));
         const int k = (int)(idx - (long long)r * (K >> 1)) * 2;
         float v[2];
@@ -72,6 +73,35 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const floa
             *reinterpret_cast<unsigned*>(frag + ((((((size_t)g * KS + ks) * 2 + j) * 2 + h) * 32 + l) << 3) + e) = bits;
         }
     }
+}
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                         unsigned short* __restrict__ out, unsigned short* __restrict__ frag, int O, int I, int KH,
+                                         int KW, int transpose) {
+    pack_weights_bf16_body(w, scale, out, frag, O, I, KH, KW, transpose, blockIdx.x, gridDim.x);
+}
+
+// Multi-tensor forms (round 6): the mixed-precision step re-folds every BatchNorm and re-packs every bf16 layer after each
+// optimizer update -- ~320 five-microsecond launches per configs[4] step, and with the host-side work around them 4.3 ms of a
+// 37 ms step (tools/diag/stale_packs_ab.sh: the step with stale packs, profiles/round6_stale_packs_ab.txt).  One launch per kind
+// over a table of jobs that lives on the device (the pointers are stable: parameters are views of the trainer's flat buffer, the
+// outputs are refreshed in place).  Bit for bit the single-tensor kernels' results (the same bodies).
+struct PackJob {        // 64 bytes; layers._PackCache builds the table
+    const float* w; const float* scale; unsigned short* out; unsigned short* frag;
+    int O, I, KH, KW, transpose, block0, nblocks, pad;
+};
+__global__ void pack_weights_bf16_multi_kernel(const PackJob* __restrict__ jobs, int n) {
+    int lo = 0, hi = n - 1;                       // the job whose block range holds blockIdx.x (block0 ascending)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    pack_weights_bf16_body(j.w, j.scale, j.out, j.frag, j.O, j.I, j.KH, j.KW, j.transpose, (int)blockIdx.x - j.block0, j.nblocks);
+}
+extern "C" int cpr_pack_weights_bf16_multi(const void* jobs_dev, int n, int total_blocks, hipStream_t stream) {
+    CPR_CHECK_ARG(jobs_dev && n > 0 && total_blocks > 0);
+    hipLaunchKernelGGL(pack_weights_bf16_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, (const PackJob*)jobs_dev, n);
+    CPR_LAUNCH_STATUS();
 }
 extern "C" int cpr_pack_weights_bf16(const float* w, const float* scale, void* out, void* frag, int O, int I, int KH, int KW,
                                      int transpose, hipStream_t stream) {
@@ -109,6 +139,24 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
     scale[c] = sc;
     shift[c] = __fsub_rn(beta[c], __fmul_rn(mean[c], sc));
     if (inv_sigma) inv_sigma[c] = __fdiv_rn(1.f, sd);
+}
+struct FoldJob {        // 64 bytes; scale / shift / inv may each be null
+    const float *gamma, *beta, *mean, *var; float *scale, *shift, *inv; int C; float eps;
+};
+__global__ void bn_fold_multi_kernel(const FoldJob* __restrict__ jobs) {
+    const FoldJob j = jobs[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= j.C) return;
+    const float sd = __fsqrt_rn(__fadd_rn(j.var[c], j.eps));
+    const float sc = __fdiv_rn(j.gamma[c], sd);
+    if (j.scale) j.scale[c] = sc;
+    if (j.shift) j.shift[c] = __fsub_rn(j.beta[c], __fmul_rn(j.mean[c], sc));
+    if (j.inv) j.inv[c] = __fdiv_rn(1.f, sd);
+}
+extern "C" int cpr_bn_fold_multi(const void* jobs_dev, int n, int max_c, hipStream_t stream) {
+    CPR_CHECK_ARG(jobs_dev && n > 0 && max_c > 0);
+    hipLaunchKernelGGL(bn_fold_multi_kernel, dim3(cdiv(max_c, 256), n), dim3(256), 0, stream, (const FoldJob*)jobs_dev);
+    CPR_LAUNCH_STATUS();
 }
 extern "C" int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                            float* scale, float* shift, float* inv_sigma, int C, hipStream_t stream) {

@@ -12,11 +12,14 @@ from . import ops
 
 
 _WEIGHT_EPOCH = [0]
+_STALE_PACKS = __import__('os').environ.get('CPR_EXPERIMENT_STALE_PACKS', '0') == '1'
 
 
 def bump_weight_epoch():
     """Called by the native optimizer: its kernels update parameters through raw pointers, which torch's version counter
     does not see."""
+    if _STALE_PACKS:       # measurement only (CPR_EXPERIMENT_STALE_PACKS=1: WRONG results): what the per-step re-packs and re-folds cost
+        return
     _WEIGHT_EPOCH[0] += 1
 
 
@@ -25,16 +28,34 @@ class _PackCache:
 
     def __init__(self):
         self._d = {}
+        self._jobs = {}          # key -> (tensors, job): entries the native trainer refreshes IN PLACE after its optimizer step
+        self._tables = None      # device job tables of refresh_all (rebuilt when a job is registered or a pointer moved)
 
-    def get(self, key, tensors, make):
+    @staticmethod
+    def _ver(tensors):
         ver = tuple((t.data_ptr(), t._version) for t in tensors)
         if any(t.requires_grad for t in tensors):
             ver = ver + (_WEIGHT_EPOCH[0],)
+        return ver
+
+    def get(self, key, tensors, make, refresh=None):
+        """refresh (optional): val -> job, how the native trainer re-computes ``val`` IN PLACE after an optimizer step instead of
+        letting the entry lapse (refresh_all): ('fold', bn, scale | None, shift | None, inv | None) or
+        ('pack', weight, key of the fold entry whose scale is multiplied in | None, packed_conv, transpose)."""
+        ver = self._ver(tensors)
         hit = self._d.get(key)
         if hit is not None and hit[0] == ver:
             self._order_behind(hit)
             return hit[1]
         val = make()
+        if refresh is not None and REFRESH_IN_PLACE[0]:
+            job = refresh(val)
+            if job is not None:
+                self._jobs[key] = (list(tensors), job)
+                self._tables = None
+        elif key in self._jobs:
+            del self._jobs[key]
+            self._tables = None
         # whatever make() enqueued (pack kernels, torch ops building a bf16 pack / a folded norm / a bias vector) ran on the
         # CURRENT stream: a reader on another stream (sub-batches of CPR_STREAMS > 1, the trainer's side stream) must order
         # itself behind it -- the event lives with the entry until it has completed
@@ -44,6 +65,82 @@ class _PackCache:
             ev.record()
         self._d[key] = [ver, val, ev, torch.cuda.current_stream().cuda_stream if ev is not None else None]
         return val
+
+    def refresh_all(self):
+        """Called by the native trainer right after its optimizer step (the parameters changed through raw pointers, the weight epoch
+        was bumped): every registered fold / bf16 pack is recomputed in place by ONE multi-tensor launch per kind (csrc/pack.hip,
+        cpr_bn_fold_multi / cpr_pack_weights_bf16_multi: bit for bit the single-tensor kernels) and its entry re-stamped with the
+        current version, instead of ~320 lazy rebuilds -- launches, allocations and Python -- spread over the next step (4.3 of the
+        37 ms of a configs[4] step, profiles/round6_stale_packs_ab.txt).  Entries without a job lapse and rebuild as before."""
+        import numpy as np
+        from . import _lib
+        live = []
+        for k, (t, j) in self._jobs.items():
+            if k not in self._d:
+                continue
+            if j[0] == 'pack' and j[2] is not None:
+                # a data-gradient pack multiplies a folded-BN scale in: only while that fold is refreshed in place too (else this
+                # entry lapses with the epoch like any other and is rebuilt from the new fold)
+                if j[2] not in self._jobs or j[2] not in self._d:
+                    continue
+            live.append((k, t, j))
+        if not live:
+            return
+
+        def scale_of(j):
+            return None if j[2] is None else self._d[j[2]][1][0]
+        ptrs = tuple(x.data_ptr() for _, t, _ in live for x in t) + \
+            tuple((0 if scale_of(j) is None else scale_of(j).data_ptr(), j[3].w.data_ptr(), 0 if j[3].wfrag is None else j[3].wfrag.data_ptr())
+                  for _, _, j in live if j[0] == 'pack')
+        if self._tables is None or self._tables[0] != ptrs:
+            folds, packs, blocks, max_c = [], [], 0, 1
+            for k, t, j in live:
+                if j[0] == 'fold':
+                    _, bn, sc, sh, inv = j
+                    C = bn.weight.numel()
+                    max_c = max(max_c, C)
+                    folds.append((bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                  0 if sc is None else sc.data_ptr(), 0 if sh is None else sh.data_ptr(),
+                                  0 if inv is None else inv.data_ptr(), C, float(bn.eps)))
+            # folds first: the data-gradient packs multiply the refreshed scale in
+            for k, t, j in live:
+                if j[0] == 'pack':
+                    _, w, _, pc, transpose = j
+                    sc = scale_of(j)
+                    O, I, KH, KW = w.shape
+                    rows, cols = (I, O) if transpose else (O, I)
+                    nb = max(1, min(64, (rows * (KH * KW * cols // 2) + 255) // 256))
+                    packs.append((w.data_ptr(), 0 if sc is None else sc.data_ptr(), pc.w.data_ptr(),
+                                  0 if pc.wfrag is None else pc.wfrag.data_ptr(), O, I, KH, KW, int(transpose), blocks, nb, 0))
+                    blocks += nb
+            dev = live[0][1][0].device
+            fdt = np.dtype([('p', '<u8', (7,)), ('C', '<i4'), ('eps', '<f4')])
+            pdt = np.dtype([('p', '<u8', (4,)), ('i', '<i4', (8,))])
+            ft = pt = None
+            if folds:
+                fa = np.zeros((len(folds),), dtype=fdt)
+                for i, f in enumerate(folds):
+                    fa[i] = (f[:7], f[7], f[8])
+                ft = torch.from_numpy(fa.view(np.uint8).reshape(-1).copy()).to(dev)
+            if packs:
+                pa = np.zeros((len(packs),), dtype=pdt)
+                for i, q in enumerate(packs):
+                    pa[i] = (q[:4], q[4:])
+                pt = torch.from_numpy(pa.view(np.uint8).reshape(-1).copy()).to(dev)
+            self._tables = (ptrs, ft, len(folds), max_c, pt, len(packs), blocks)
+        _, ft, nf, max_c, pt, npk, blocks = self._tables
+        stream = torch.cuda.current_stream().cuda_stream
+        if ft is not None:
+            _lib.call('cpr_bn_fold_multi', ft.data_ptr(), nf, max_c, stream)
+        if pt is not None:
+            _lib.call('cpr_pack_weights_bf16_multi', pt.data_ptr(), npk, blocks, stream)
+        ev = torch.cuda.Event()
+        ev.record()
+        for k, t, j in live:
+            hit = self._d[k]
+            hit[0], hit[2], hit[3] = self._ver(t), ev, stream
+            if j[0] == 'pack':
+                j[3].ready = ev
 
     @staticmethod
     def _order_behind(entry):
@@ -56,9 +153,18 @@ class _PackCache:
             torch.cuda.current_stream().wait_event(ev)
 
 
+# CPR_REFRESH_IN_PLACE=0: every fold / pack lapses with the weight epoch and is rebuilt lazily (rounds 3-5; A/B switch)
+REFRESH_IN_PLACE = [__import__('os').environ.get('CPR_REFRESH_IN_PLACE', '1') != '0']
+
+
 def packed_conv(cache, conv, dtype=torch.float32):
+    def job(pc):        # the bf16 pack kernel's outputs can be refreshed in place; the fp32 / Winograd packs lapse as before
+        if dtype == torch.bfloat16 and conv.weight.is_cuda and ops.PACK_BF16_KERNEL[0] and conv.weight.dtype == torch.float32 \
+                and conv.weight.is_contiguous():
+            return ('pack', conv.weight, None, pc, 0)
+        return None
     return cache.get(('pc', id(conv), dtype), [conv.weight],
-                     lambda: ops.PackedConv(conv.weight, conv.stride[0], conv.padding[0], dtype))
+                     lambda: ops.PackedConv(conv.weight, conv.stride[0], conv.padding[0], dtype), refresh=job)
 
 
 def folded_bn(cache, bn):
@@ -71,7 +177,11 @@ def folded_bn(cache, bn):
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
             shift = (bn.bias - bn.running_mean * scale).float().contiguous()
         return scale, shift
-    return cache.get(('bn', id(bn)), [bn.weight, bn.bias, bn.running_mean, bn.running_var], make)
+    def job(val):
+        ok = bn.weight.is_cuda and all(t.dtype == torch.float32 and t.is_contiguous()
+                                       for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var, val[0], val[1]))
+        return ('fold', bn, val[0], val[1], None) if ok else None
+    return cache.get(('bn', id(bn)), [bn.weight, bn.bias, bn.running_mean, bn.running_var], make, refresh=job)
 
 
 class ConvModule(nn.Module):

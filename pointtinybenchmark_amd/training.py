@@ -746,7 +746,8 @@ class BackwardEngine:
                     return ops.PackedConv.for_dgrad_bf16(w, conv.padding[0], scale=scale)
                 wt = (w.detach() * scale[:, None, None, None]).flip(2, 3).permute(1, 0, 2, 3)
                 return ops.PackedConv(wt, 1, k - 1 - conv.padding[0], torch.bfloat16)
-            pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16)
+            pc16 = cache.get(('dgrad16', id(conv)), [w, bn.weight, bn.running_var], pack16,
+                             refresh=(lambda pc: ('pack', w, ('bn', id(bn)), pc, 1)) if ops.PACK_BF16_KERNEL[0] else None)
             if MIXED_BF16['mask_mode'] and not need32 and mask is not None and add is None and want_colsum and want16 and \
                     mask.dtype == torch.bfloat16 and ops.conv2d_bf16_mask_slots(g16.shape, pc16) > 0:
                 dx16, part = ops.conv2d(g16, pc16, residual=mask, res_mask=True, colsum=True)
@@ -864,6 +865,7 @@ class CprTrainer(BackwardEngine):
                                                          max(1, int(min_bucket_mb * mb)), max(1, int(tail_bucket_mb * mb))))
         self.norm2 = torch.zeros((1,), device=dev, dtype=torch.float64)
         self._ws = torch.empty((1024,), device=dev, dtype=torch.float64)
+        self._pack_caches = None
         self.steps = 0
         self.group = group
         self.sync_initial_state()
@@ -988,6 +990,12 @@ class CprTrainer(BackwardEngine):
                      self.weight_decay, self.max_norm or 0.0, grad_scale, first=self.steps == 0)
         self.steps += 1
         bump_weight_epoch()
+        # the folds / bf16 packs the last step registered are recomputed in place now, in two launches, instead of lapsing (round 6)
+        if self._pack_caches is None:
+            from .layers import _PackCache
+            self._pack_caches = [m._cache for m in self.model.modules() if isinstance(getattr(m, '_cache', None), _PackCache)]
+        for c in self._pack_caches:
+            c.refresh_all()
 
     def grad_norm(self):
         """Global L2 norm of the (rank-averaged) gradient the last ``step`` clipped with (host sync: logging only)."""

@@ -276,6 +276,59 @@ def test_mixed_precision_mask_mode_changes_only_the_column_sum_order():
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_in_place_refresh_of_folds_and_packs_changes_no_bit(mode):
+    """Round 6: after its optimizer step the native trainer recomputes every BatchNorm fold and bf16 weight pack the last step used IN
+    PLACE with two multi-tensor launches (layers._PackCache.refresh_all, cpr_bn_fold_multi / cpr_pack_weights_bf16_multi) instead of
+    letting ~320 cache entries lapse and rebuild one by one.  Four training steps with and without it (CPR_REFRESH_IN_PLACE) must give
+    the same losses and the same parameters BIT for bit; and after the last step every refreshed buffer must equal a fresh
+    single-tensor fold / pack of the current parameters."""
+    from pointtinybenchmark_amd import layers, ops, training
+    cfg = CPR_CASES['cpr_r50_c1_160_spread']
+    batch = synthetic.synthetic_batch(cfg['batch'], cfg['height'], cfg['width'], cfg['num_gts'], cfg['num_classes'], cfg['seed'],
+                                      cfg.get('ragged', False))
+    cb = to_cuda(batch)
+    runs = []
+    try:
+        for inplace in (True, False):
+            layers.REFRESH_IN_PLACE[0] = inplace
+            m, _ = build_hip_locator(cfg)
+            if mode == 'bf16':
+                m.set_compute_dtype('bf16')
+            tr = training.CprTrainer(m, lr=0.01)
+            hist = []
+            for _ in range(4):
+                losses = tr.forward_backward(cb['img'], cb['img_metas'], cb['gt_bboxes'], cb['gt_labels'])
+                tr.step()
+                hist.append({k: float(v) for k, v in losses.items()})
+            torch.cuda.synchronize()
+            runs.append((hist, tr.flat_p.clone()))
+            if inplace:
+                n_fold = n_pack = 0
+                for c in tr._pack_caches:
+                    for key, (tensors, job) in c._jobs.items():
+                        val = c._d[key][1]
+                        if job[0] == 'fold':
+                            bn = job[1]
+                            sc, sh, _ = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+                            assert torch.equal(val[0], sc) and torch.equal(val[1], sh), key
+                            n_fold += 1
+                        else:
+                            _, w, skey, pc, transpose = job
+                            if transpose:
+                                fresh = ops.PackedConv.for_dgrad_bf16(w, pc.KH - 1 - pc.padding, scale=c._d[skey][1][0])
+                            else:
+                                fresh = ops.PackedConv(w, pc.stride, pc.padding, torch.bfloat16)
+                            assert torch.equal(fresh.w, pc.w), key
+                            assert (fresh.wfrag is None) == (pc.wfrag is None) and (pc.wfrag is None or torch.equal(fresh.wfrag, pc.wfrag)), key
+                            n_pack += 1
+                assert n_fold >= 30 and (mode == 'fp32' or n_pack >= 40), (n_fold, n_pack)
+    finally:
+        layers.REFRESH_IN_PLACE[0] = True
+    assert runs[0][0] == runs[1][0], 'losses differ'
+    assert torch.equal(runs[0][1], runs[1][1]), 'parameters differ in %d entries' % int((runs[0][1] != runs[1][1]).sum())
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 def test_two_stream_step_is_bit_repeatable_under_allocator_pressure(mode):
     """The parameter-gradient work runs on a side stream and reads maps the main stream frees right afterwards -- in the
     mixed-precision step these are widened fp32 TEMPORARIES of the recorded bf16 maps (round-3 advisor finding: a missing
