@@ -485,6 +485,9 @@ int cpr_bn_fold(const float* gamma, const float* beta, const float* mean, const 
  * (pack jobs in ascending block0; job j owns workgroups [block0, block0 + nblocks) of the total_blocks launched).  Results are
  * bit for bit the single-tensor entries'. */
 int cpr_bn_fold_multi(const void* jobs_dev, int n, int max_c, void* stream);
+/* ... and of cpr_pack_weights (fp32 packs): job { const float* w; const float* scale; float* out; int nblocks, pad;
+ * int O, I, KH, KW, colsp, Kpad, transpose, block0; } */
+int cpr_pack_weights_multi(const void* jobs_dev, int n, int total_blocks, void* stream);
 int cpr_pack_weights_bf16_multi(const void* jobs_dev, int n, int total_blocks, void* stream);
 /* gradient of sum_b (loss_cls[b] + loss_pts[b]) of cpr_p2p_loss wrt the class logits (B*M, C) and the regression output
  * (p2p_head.py:220-248; sigmoid focal loss with its un-detached focal weight, SmoothL1 through

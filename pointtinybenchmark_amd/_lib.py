@@ -36,6 +36,7 @@ SIGNATURES = {
     'cpr_conv2d_bf16_mask_slots': [_i] * 10,
     'cpr_wgrad_bf16_set_tn': [_i],
     'cpr_bn_fold_multi': [_p, _i, _i, _p],
+    'cpr_pack_weights_multi': [_p, _i, _i, _p],
     'cpr_pack_weights_bf16_multi': [_p, _i, _i, _p],
     'cpr_conv2d_dgrad_bf16_fused': [_p] * 8 + [_i] * 10 + [_p, _p],
     'cpr_stem7x7s2_bf16': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -6,12 +6,13 @@
 //   forward pack  (transpose = 0): rows = O, cols = I,  out[o][kh][kw][i]  = w[o][i][kh][kw]
 //   dgrad pack    (transpose = 1): rows = I, cols = O,  out[i][kh][kw][o]  = w[o][i][KH-1-kh][KW-1-kw] * scale[o]
 // colsp = cols padded (4 for the 3-channel stem, else cols); one thread per output element.
-__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
-                                    int O, int I, int KH, int KW, int colsp, int Kpad, int transpose) {
+// (the body is shared with the multi-tensor launch: `block` of `nblocks` workgroups walks the pack)
+__device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                                  int O, int I, int KH, int KW, int colsp, int Kpad, int transpose, int block, int nblocks) {
     const int rows = transpose ? I : O, cols = transpose ? O : I;
     const long long total = (long long)rows * Kpad;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)nblocks * blockDim.x) {
         const int r = (int)(idx / Kpad);
         const int k = (int)(idx - (long long)r * Kpad);
         float v = 0.f;
@@ -26,6 +27,29 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
         }
         out[idx] = v;
     }
+}
+__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                    int O, int I, int KH, int KW, int colsp, int Kpad, int transpose) {
+    pack_weights_body(w, scale, out, O, I, KH, KW, colsp, Kpad, transpose, blockIdx.x, gridDim.x);
+}
+// multi-tensor form (round 6, see the bf16 one below): jobs in ascending block0
+struct Pack32Job {      // 64 bytes
+    const float* w; const float* scale; float* out; int nblocks, pad;
+    int O, I, KH, KW, colsp, Kpad, transpose, block0;
+};
+__global__ void pack_weights_multi_kernel(const Pack32Job* __restrict__ jobs, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const Pack32Job j = jobs[lo];
+    pack_weights_body(j.w, j.scale, j.out, j.O, j.I, j.KH, j.KW, j.colsp, j.Kpad, j.transpose, (int)blockIdx.x - j.block0, j.nblocks);
+}
+extern "C" int cpr_pack_weights_multi(const void* jobs_dev, int n, int total_blocks, hipStream_t stream) {
+    CPR_CHECK_ARG(jobs_dev && n > 0 && total_blocks > 0);
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, (const Pack32Job*)jobs_dev, n);
+    CPR_LAUNCH_STATUS();
 }
 extern "C" int cpr_pack_weights(const float* w, const float* scale, float* out, int O, int I, int KH, int KW, int colsp,
                                 int Kpad, int transpose, hipStream_t stream) {

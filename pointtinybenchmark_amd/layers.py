@@ -41,7 +41,7 @@ class _PackCache:
     def get(self, key, tensors, make, refresh=None):
         """refresh (optional): val -> job, how the native trainer re-computes ``val`` IN PLACE after an optimizer step instead of
         letting the entry lapse (refresh_all): ('fold', bn, scale | None, shift | None, inv | None) or
-        ('pack', weight, key of the fold entry whose scale is multiplied in | None, packed_conv, transpose)."""
+        ('pack' | 'pack32', weight, key of the fold entry whose scale is multiplied in | None, packed_conv, transpose) (bf16 / fp32 pack)."""
         ver = self._ver(tensors)
         hit = self._d.get(key)
         if hit is not None and hit[0] == ver:
@@ -78,7 +78,7 @@ class _PackCache:
         for k, (t, j) in self._jobs.items():
             if k not in self._d:
                 continue
-            if j[0] == 'pack' and j[2] is not None:
+            if j[0] in ('pack', 'pack32') and j[2] is not None:
                 # a data-gradient pack multiplies a folded-BN scale in: only while that fold is refreshed in place too (else this
                 # entry lapses with the epoch like any other and is rebuilt from the new fold)
                 if j[2] not in self._jobs or j[2] not in self._d:
@@ -90,10 +90,10 @@ class _PackCache:
         def scale_of(j):
             return None if j[2] is None else self._d[j[2]][1][0]
         ptrs = tuple(x.data_ptr() for _, t, _ in live for x in t) + \
-            tuple((0 if scale_of(j) is None else scale_of(j).data_ptr(), j[3].w.data_ptr(), 0 if j[3].wfrag is None else j[3].wfrag.data_ptr())
-                  for _, _, j in live if j[0] == 'pack')
+            tuple((0 if scale_of(j) is None else scale_of(j).data_ptr(), j[3].w.data_ptr(),
+                   0 if getattr(j[3], 'wfrag', None) is None else j[3].wfrag.data_ptr()) for _, _, j in live if j[0] in ('pack', 'pack32'))
         if self._tables is None or self._tables[0] != ptrs:
-            folds, packs, blocks, max_c = [], [], 0, 1
+            folds, packs, packs32, blocks, blocks32, max_c = [], [], [], 0, 0, 1
             for k, t, j in live:
                 if j[0] == 'fold':
                     _, bn, sc, sh, inv = j
@@ -113,10 +113,25 @@ class _PackCache:
                     packs.append((w.data_ptr(), 0 if sc is None else sc.data_ptr(), pc.w.data_ptr(),
                                   0 if pc.wfrag is None else pc.wfrag.data_ptr(), O, I, KH, KW, int(transpose), blocks, nb, 0))
                     blocks += nb
+                elif j[0] == 'pack32':          # the fp32 implicit-GEMM pack [rows][Kpad] (forward: colsp = padded Cin, dgrad: padded Cout)
+                    _, w, _, pc, transpose = j
+                    sc = scale_of(j)
+                    O, I, KH, KW = w.shape
+                    rows = I if transpose else O
+                    nb = max(1, min(64, (rows * pc.Kpad + 255) // 256))
+                    packs32.append((w.data_ptr(), 0 if sc is None else sc.data_ptr(), pc.w.data_ptr(), nb, 0,
+                                    O, I, KH, KW, pc.Cin, pc.Kpad, int(transpose), blocks32))
+                    blocks32 += nb
             dev = live[0][1][0].device
             fdt = np.dtype([('p', '<u8', (7,)), ('C', '<i4'), ('eps', '<f4')])
             pdt = np.dtype([('p', '<u8', (4,)), ('i', '<i4', (8,))])
-            ft = pt = None
+            p32dt = np.dtype([('p', '<u8', (3,)), ('i', '<i4', (10,))])
+            ft = pt = p32t = None
+            if packs32:
+                qa = np.zeros((len(packs32),), dtype=p32dt)
+                for i, q in enumerate(packs32):
+                    qa[i] = (q[:3], q[3:])
+                p32t = torch.from_numpy(qa.view(np.uint8).reshape(-1).copy()).to(dev)
             if folds:
                 fa = np.zeros((len(folds),), dtype=fdt)
                 for i, f in enumerate(folds):
@@ -127,19 +142,28 @@ class _PackCache:
                 for i, q in enumerate(packs):
                     pa[i] = (q[:4], q[4:])
                 pt = torch.from_numpy(pa.view(np.uint8).reshape(-1).copy()).to(dev)
-            self._tables = (ptrs, ft, len(folds), max_c, pt, len(packs), blocks)
-        _, ft, nf, max_c, pt, npk, blocks = self._tables
+            self._tables = (ptrs, ft, len(folds), max_c, pt, len(packs), blocks, p32t, len(packs32), blocks32)
+        _, ft, nf, max_c, pt, npk, blocks, p32t, np32, blocks32 = self._tables
         stream = torch.cuda.current_stream().cuda_stream
         if ft is not None:
             _lib.call('cpr_bn_fold_multi', ft.data_ptr(), nf, max_c, stream)
         if pt is not None:
             _lib.call('cpr_pack_weights_bf16_multi', pt.data_ptr(), npk, blocks, stream)
+        if p32t is not None:
+            _lib.call('cpr_pack_weights_multi', p32t.data_ptr(), np32, blocks32, stream)
+            for k, t, j in live:        # the Winograd images of a refreshed fp32 pack: G g G^T again, in place (one launch each)
+                if j[0] == 'pack32':
+                    pc = j[3]
+                    for attr, fn in (('wino', 'cpr_wino_pack_weights'), ('wino32', 'cpr_wino32_pack_weights')):
+                        img = getattr(pc, attr, None)
+                        if img is not None:
+                            _lib.call(fn, pc.w.data_ptr(), img.data_ptr(), pc.Cin, pc.Cout, pc.Kpad, stream)
         ev = torch.cuda.Event()
         ev.record()
         for k, t, j in live:
             hit = self._d[k]
             hit[0], hit[2], hit[3] = self._ver(t), ev, stream
-            if j[0] == 'pack':
+            if j[0] in ('pack', 'pack32'):
                 j[3].ready = ev
 
     @staticmethod
@@ -162,6 +186,8 @@ def packed_conv(cache, conv, dtype=torch.float32):
         if dtype == torch.bfloat16 and conv.weight.is_cuda and ops.PACK_BF16_KERNEL[0] and conv.weight.dtype == torch.float32 \
                 and conv.weight.is_contiguous():
             return ('pack', conv.weight, None, pc, 0)
+        if dtype == torch.float32 and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and conv.weight.is_contiguous():
+            return ('pack32', conv.weight, None, pc, 0)
         return None
     return cache.get(('pc', id(conv), dtype), [conv.weight],
                      lambda: ops.PackedConv(conv.weight, conv.stride[0], conv.padding[0], dtype), refresh=job)

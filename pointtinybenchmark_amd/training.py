@@ -768,7 +768,9 @@ class BackwardEngine:
                 g16 = g.to(torch.bfloat16)
             return finish(pt16(g16, (x.shape[1], x.shape[2]), add=add))
         pt = cache.get(('dgrad', id(conv)), [w, bn.weight, bn.running_var],
-                       lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale))
+                       lambda: ops.dgrad_pack(w, conv.stride[0], conv.padding[0], scale=scale),
+                       refresh=lambda q: ('pack32', w, ('bn', id(bn)), q, 1) if isinstance(q, ops.PackedConv) and
+                       q.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous() else None)
         if WINO_DGRAD[0] and k == 3 and conv.stride[0] == 1 and add is None and \
                 (mask is not None or want_colsum) and ops.wino_eligible(pt, x.shape[1], x.shape[2], torch.float32):
             # a 3x3 stride-1 data gradient with a mask / column-sum epilogue would run the direct kernel (2.25x the multiplies of

@@ -303,7 +303,7 @@ def test_in_place_refresh_of_folds_and_packs_changes_no_bit(mode):
             torch.cuda.synchronize()
             runs.append((hist, tr.flat_p.clone()))
             if inplace:
-                n_fold = n_pack = 0
+                n_fold = n_pack = n_pack32 = 0
                 for c in tr._pack_caches:
                     for key, (tensors, job) in c._jobs.items():
                         val = c._d[key][1]
@@ -312,6 +312,14 @@ def test_in_place_refresh_of_folds_and_packs_changes_no_bit(mode):
                             sc, sh, _ = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
                             assert torch.equal(val[0], sc) and torch.equal(val[1], sh), key
                             n_fold += 1
+                        elif job[0] == 'pack32':
+                            _, w, skey, pc, transpose = job
+                            if transpose:
+                                fresh = ops.PackedConv.for_dgrad(w, pc.KH - 1 - pc.padding, c._d[skey][1][0])
+                            else:
+                                fresh = ops.PackedConv(w, pc.stride, pc.padding, torch.float32)
+                            assert torch.equal(fresh.w, pc.w), key
+                            n_pack32 += 1
                         else:
                             _, w, skey, pc, transpose = job
                             if transpose:
@@ -321,7 +329,7 @@ def test_in_place_refresh_of_folds_and_packs_changes_no_bit(mode):
                             assert torch.equal(fresh.w, pc.w), key
                             assert (fresh.wfrag is None) == (pc.wfrag is None) and (pc.wfrag is None or torch.equal(fresh.wfrag, pc.wfrag)), key
                             n_pack += 1
-                assert n_fold >= 30 and (mode == 'fp32' or n_pack >= 40), (n_fold, n_pack)
+                assert n_fold >= 30 and (n_pack32 >= 40 if mode == 'fp32' else n_pack >= 40), (n_fold, n_pack, n_pack32)
     finally:
         layers.REFRESH_IN_PLACE[0] = True
     assert runs[0][0] == runs[1][0], 'losses differ'
